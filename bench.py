@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X JPEG block-transform path.
+
+Workload (BASELINE.json configs[1]): 1080p 4:2:0 baseline frames, synthetic
+*valid* coefficient blocks (Huffman bypassed), resident in HBM; one "step" is
+one pass of the decode hot path (dequantise -> inverse zig-zag -> Chen-Wang
+IDCT -> clip/level shift -> plane store) over one batch of frames through the
+C ABI (hvc_decode_frames).  Metric: Mpixel/s decoded (cropped 1920x1080 luma
+pixels per frame).
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by the driver with torch.distributed.run (one rank per GPU);
+the path shards as independent frame batches: no data-path collective, weak
+scaling (per-GPU batch fixed).  The barrier / max-over-ranks reduction below is
+timing closure only.
+
+The JSON line also carries
+  roofline      achieved algorithmic GB/s of the dominant kernel (k_decode_fast:
+                192 B per 8x8 block = 128 B int16 coefficients read + 64 B pixels
+                written) over its HIP-event-timed duration, against 8 TB/s HBM;
+  cpu_baseline  the CPU oracle (oracle/hvc_oracle.c, the restated model path,
+                scalar, 1 thread) timed on this host on a bounded sample of the
+                same workload.  It is the checker, timed as a baseline only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H = 1920, 1080
+# Decoder.init geometry (decoder.ml:304-345) for 4:2:0: rounded to 16 -> 1920x1088
+PLANES = [(240, 136, 0), (120, 68, 1), (120, 68, 1)]  # (blocks_w, blocks_h, qtab)
+BLOCKS_PER_FRAME = sum(bw * bh for bw, bh, _ in PLANES)  # 48960
+ALGO_BYTES_PER_BLOCK = 192  # 128 B read + 64 B written
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def make_distinct_frames(n_distinct, seed):
+    """Coefficient records of n_distinct synthetic frames (valid, encoder-producible):
+    synthetic pixels -> the CPU oracle's forward path at quality 75."""
+    from oracle import orc
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import synth_pixels
+    ql = orc.quant_scale(orc.quant_luma(), 75).astype(np.uint16)
+    qc = orc.quant_scale(orc.quant_chroma(), 75).astype(np.uint16)
+    frames = []
+    for f in range(n_distinct):
+        rec = []
+        for ci, (bw, bh, qt) in enumerate(PLANES):
+            pix = synth_pixels(seed + 16 * f + ci, bh * 8, bw * 8)
+            rec.append(orc.fdct_quant(pix, ql if qt == 0 else qc, bw, bh))
+        frames.append(np.concatenate(rec))
+    return np.stack(frames), np.stack([ql, qc])
+
+
+def cpu_baseline(frames, qtabs, min_seconds=10.0):
+    """Oracle block stage (scalar C, int64, one block at a time) on the same frames."""
+    from oracle import orc
+    done, t0 = 0, time.perf_counter()
+    while True:
+        rec = frames[done % len(frames)]
+        off = 0
+        for bw, bh, qt in PLANES:
+            n = bw * bh * 64
+            orc.dequant_idct_recon(rec[off:off + n], qtabs[qt], bw, bh)
+            off += n
+        done += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds:
+            break
+    return {"value": round(done * W * H / dt / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": "port",
+            "sample": "%d frames of the same 1080p 4:2:0 workload, %.1f s, oracle/hvc_oracle.c "
+                      "orc_dequant_idct_recon, 1 thread" % (done, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames (replicated to --frames)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--check", action="store_true", help="verify the GPU output of the batch against the oracle")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import video_coding_amd as hvc
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    frames, qtabs = make_distinct_frames(args.distinct, seed=0x4A504547 + 1000 * rank)
+    specs, cfs, pfs = hvc.hvc.frame_layout(PLANES)
+    reps = (args.frames + args.distinct - 1) // args.distinct
+    d_coefs = torch.from_numpy(frames).cuda().repeat(reps, 1)[:args.frames].contiguous()
+    d_pix = torch.zeros((args.frames, pfs), dtype=torch.uint8, device="cuda")
+    comps = hvc.hvc.components(specs)
+
+    ctx = hvc.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_profiling(True)
+
+    def step():
+        ctx.decode_frames(d_coefs, cfs, qtabs, comps, args.frames, d_pix, pfs)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # HIP events recorded around k_decode_fast inside the timed region (one pair per step)
+    kernel_ms = ctx.kernel_ms_history(min(args.steps, 64))
+    wide = ctx.last_wide_blocks()
+    if args.check:
+        from oracle import orc
+        got = d_pix[:args.distinct].cpu().numpy()
+        for f in range(args.distinct):
+            off = 0
+            for (bw, bh, qt), s in zip(PLANES, specs):
+                n = bw * bh * 64
+                want = orc.dequant_idct_recon(frames[f][off:off + n], qtabs[qt], bw, bh)
+                assert np.array_equal(got[f][s["plane_offset"]:s["plane_offset"] + n], want), (f, bw)
+                off += n
+
+    if rank == 0:
+        k_ms = float(np.mean(kernel_ms))
+        algo_bytes = args.frames * BLOCKS_PER_FRAME * ALGO_BYTES_PER_BLOCK
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mpixel/s decoded (1080p 4:2:0 batch)",
+            "value": round(world * args.frames * args.steps * W * H / dt / 1e6, 1),
+            "unit": "Mpixel/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32 (24-bit multiplies; int64 fix-up kernel), int16 in / u8 out",
+            "data": "synthetic",
+            "config": {"workload": "1080p 4:2:0 baseline, synthetic valid coefficient blocks (Huffman bypassed), "
+                                   "HBM-resident, %d frames/GPU/step" % args.frames,
+                       "frames_per_gpu_per_step": args.frames, "blocks_per_frame": BLOCKS_PER_FRAME,
+                       "parallelism": "independent frame batch per GPU, no collective",
+                       "wide_path_blocks": int(wide)},
+            "roofline": {"bound": "hbm", "kernel": "k_decode_fast", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": None, "kernel_ms": round(k_ms, 4),
+                         "algorithmic_bytes_per_launch": algo_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames, qtabs, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,169 @@
+/*
+ * hvc_jpeg.h -- C ABI of libhvc_jpeg.so: the MI355X (gfx950) JPEG block-transform
+ * path that drops in behind hardcamls/video-coding's `jpeg/model` Decoder /
+ * Encoder API.
+ *
+ * The reference has no FFI layer; this header is the
+ * boundary a maintainer binds at the seam `jpeg/model/src/decoder.ml:347-360`
+ * (decode_block) and `jpeg/model/src/encoder.ml:195-205` (encode_block).  Each
+ * entry point cites the reference code it replaces (paths relative to the
+ * reference root).  INTEGRATION.md shows the OCaml ctypes binding.
+ *
+ * Conventions
+ *  - plain C, no exceptions cross the boundary; every function returns
+ *    HVC_OK (0) or a negative hvc_status; hvc_strerror() gives a static string.
+ *    The OCaml wrapper maps a non-zero code to `raise_s [%message "hvc" ...]`,
+ *    the model's own error style (decoder.ml:67, 92, 101, 136).
+ *  - the caller owns every buffer it passes; the library never retains a
+ *    caller pointer after the call returns (after hvc_synchronize for device
+ *    pointers).  Device scratch and streams live inside hvc_ctx.
+ *  - an hvc_ctx is bound to ONE GPU and is NOT thread-safe: one per host
+ *    thread / GPU.  There is no CPU backend: hvc_create fails with
+ *    HVC_E_NO_DEVICE when no gfx950 device is usable.
+ *  - all results are bit-exact to the OCaml model for every input the model
+ *    accepts (int16 coefficients, 8- or 16-bit quantiser entries).
+ *
+ * Data layouts
+ *  - coefficients: int16, [plane][blocks_h][blocks_w][64], each block in
+ *    ZIG-ZAG order exactly as the model's `coefs` array holds them after
+ *    Huffman decoding (decoder.ml:118-140) but with the DC predictor already
+ *    added (decoder.ml:143 is a sequential dependency and stays on the host).
+ *  - quantiser tables: 64 x uint16 in zig-zag order = Markers.Dqt.elements
+ *    (markers.ml:153-167), indexed like `qnt_tab.(i)` at decoder.ml:146.
+ *  - pixel planes: row-major uint8, `stride` bytes per row = the model's
+ *    Plane.t (common/src/plane.ml:4-17); a Base_bigstring's data pointer can be
+ *    passed as is.
+ */
+#ifndef HVC_JPEG_H
+#define HVC_JPEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HVC_API __attribute__((visibility("default")))
+
+typedef struct hvc_ctx hvc_ctx; /* opaque: device, stream, scratch, fix-up list */
+
+typedef enum hvc_status {
+    HVC_OK = 0,
+    HVC_E_INVALID_ARG = -1,  /* null pointer, non-positive size, bad enum */
+    HVC_E_NO_DEVICE = -2,    /* no usable gfx950 GPU / HIP runtime error at create */
+    HVC_E_HIP = -3,          /* a HIP call failed; hvc_last_hip_error() has the code */
+    HVC_E_ALIGNMENT = -4,    /* plane pointer/stride not 8-byte aligned, coefs not 16-byte aligned */
+    HVC_E_RANGE = -5,        /* quantiser entry 0, or encoder output outside int16 */
+    HVC_E_OUT_OF_MEMORY = -6,
+    HVC_E_TOO_LARGE = -7     /* plane geometry beyond the kernel's index range */
+} hvc_status;
+
+/* where the data pointers of a call live */
+typedef enum hvc_mem {
+    HVC_MEM_HOST = 0,   /* host memory: staged through device scratch; call blocks until done */
+    HVC_MEM_DEVICE = 1  /* device memory of ctx's GPU: enqueued on ctx's stream, returns at once */
+} hvc_mem;
+
+HVC_API int hvc_create(hvc_ctx **out, int device);
+HVC_API void hvc_destroy(hvc_ctx *ctx);
+HVC_API const char *hvc_strerror(int code);
+HVC_API int hvc_last_hip_error(const hvc_ctx *ctx);
+HVC_API const char *hvc_version(void);
+
+/* Use an existing HIP stream (hipStream_t passed as void*; NULL = ctx's own
+ * stream).  Lets a host runtime order this library's kernels with its own
+ * copies; torch.cuda.current_stream().cuda_stream is such a handle. */
+HVC_API int hvc_set_stream(hvc_ctx *ctx, void *hip_stream);
+HVC_API int hvc_synchronize(hvc_ctx *ctx);
+
+/* HIP-event timer on ctx's stream (for benchmarks): begin, enqueue work, end. */
+HVC_API int hvc_timer_begin(hvc_ctx *ctx);
+HVC_API int hvc_timer_end(hvc_ctx *ctx, float *elapsed_ms);
+
+/* Per-kernel timing: when enabled, every decode/encode call brackets its
+ * dominant kernel (K1 / K3 -- not the memset or the fix-up kernel) with HIP
+ * events on ctx's stream (device-memory calls only); hvc_last_kernel_ms waits
+ * for that kernel and returns its duration.  bench.py's roofline figure comes
+ * from here. */
+HVC_API int hvc_set_profiling(hvc_ctx *ctx, int enabled);
+HVC_API int hvc_last_kernel_ms(hvc_ctx *ctx, float *elapsed_ms);
+/* durations of the last n (<= 64) profiled calls, oldest first; does not
+ * serialise the calls themselves (one event pair per call, ring of 64) */
+HVC_API int hvc_kernel_ms_history(hvc_ctx *ctx, float *elapsed_ms, int n);
+
+/* ------------------------------------------------------------------------- */
+/* Decode side.
+ *
+ * hvc_dequant_idct_recon: for every 8x8 block of `n_planes` equally sized
+ * component planes computes
+ *     dequantize + inverse zig-zag   decoder.ml:142-149 (dc_pred = 0, DC absolute)
+ *     Dct.Chen.inverse_8x8           dct.ml:11-107
+ *     clip, +128, plane store        decoder.ml:213-224
+ * i.e. the body of Decoder.decode_block (decoder.ml:347-360) minus the Huffman
+ * part.  Block (bx,by) of plane p reads coefs + p*coef_plane_stride +
+ * (by*blocks_w+bx)*64 and writes the 8x8 pixels at plane + p*plane_stride +
+ * (by*8+j)*stride + bx*8+i.
+ * coef_plane_stride is in int16 elements (0 = blocks_w*blocks_h*64);
+ * plane_stride in bytes (0 = stride*blocks_h*8). */
+HVC_API int hvc_dequant_idct_recon(hvc_ctx *ctx, const int16_t *coefs, size_t coef_plane_stride,
+                                   const uint16_t *qtab, int blocks_w, int blocks_h, int n_planes,
+                                   uint8_t *plane, size_t stride, size_t plane_stride, int where);
+
+/* A frame batch in one launch: every frame has the same `n_comp` components
+ * (Decoder.Component.t, decoder.ml:167-187; geometry of Decoder.init,
+ * decoder.ml:304-345). */
+typedef struct hvc_component {
+    int blocks_w, blocks_h; /* decoded_width/8, decoded_height/8 */
+    int qtab;               /* index into qtabs[] */
+    int reserved;
+    size_t coef_offset;     /* int16 elements from the frame's coefficient record */
+    size_t plane_offset;    /* bytes from the frame's pixel record */
+    size_t stride;          /* bytes per pixel row (>= blocks_w*8, multiple of 8) */
+} hvc_component;
+
+/* coefs + f*coef_frame_stride + comp.coef_offset -> pixels + f*pixel_frame_stride
+ * + comp.plane_offset, for f < n_frames.  qtabs: [n_qtabs][64] uint16 (host
+ * memory always; tiny).  Same arithmetic as hvc_dequant_idct_recon. */
+HVC_API int hvc_decode_frames(hvc_ctx *ctx, const int16_t *coefs, size_t coef_frame_stride,
+                              const uint16_t *qtabs, int n_qtabs, const hvc_component *comps,
+                              int n_comp, int n_frames, uint8_t *pixels,
+                              size_t pixel_frame_stride, int where);
+
+/* Number of blocks the last decode call on ctx routed through the wide
+ * (64-bit) fix-up kernel (diagnostic; synchronises the stream). */
+HVC_API int hvc_last_wide_blocks(hvc_ctx *ctx, uint64_t *count);
+
+/* ------------------------------------------------------------------------- */
+/* Encode side (mirror): level shift, Dct.Chen.forward_8x8, quantise, zig-zag
+ *     Encoder.level_shifted_input_block  encoder.ml:81-90
+ *     Dct.Chen.forward_8x8               dct.ml:109-196
+ *     Encoder.quant / quant_and_scale    encoder.ml:98-108
+ * Output coefficients in zig-zag order, DC absolute (the DC difference of
+ * encoder.ml:138-140 stays on the host with the RLE/Huffman writer). */
+HVC_API int hvc_fdct_quant(hvc_ctx *ctx, const uint8_t *plane, size_t stride, size_t plane_stride,
+                           const uint16_t *qtab, int blocks_w, int blocks_h, int n_planes,
+                           int16_t *coefs, size_t coef_plane_stride, int where);
+
+HVC_API int hvc_encode_frames(hvc_ctx *ctx, const uint8_t *pixels, size_t pixel_frame_stride,
+                              const uint16_t *qtabs, int n_qtabs, const hvc_component *comps,
+                              int n_comp, int n_frames, int16_t *coefs, size_t coef_frame_stride,
+                              int where);
+
+/* ------------------------------------------------------------------------- */
+/* 4:2:0 -> 4:4:4 chroma upsample, tools/src/planar_444.ml:82-103
+ * (supersample_hv2 over all rows, :122-131): src cw x ch -> dst 2cw x 2ch. */
+HVC_API int hvc_upsample420(hvc_ctx *ctx, const uint8_t *src, int cw, int ch, size_t src_stride,
+                            uint8_t *dst, size_t dst_stride, int n_planes, size_t src_plane_stride,
+                            size_t dst_plane_stride, int where);
+
+/* Device memory helpers so that a binding needs no HIP of its own. */
+HVC_API int hvc_device_alloc(hvc_ctx *ctx, size_t bytes, void **out);
+HVC_API int hvc_device_free(hvc_ctx *ctx, void *p);
+HVC_API int hvc_memcpy_h2d(hvc_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+HVC_API int hvc_memcpy_d2h(hvc_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HVC_JPEG_H */

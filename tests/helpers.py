@@ -1,0 +1,53 @@
+"""Shared test helpers (CPU side).  The oracle is the checker."""
+import numpy as np
+
+from oracle import orc
+
+
+def coef_planes_from_jpeg(data):
+    """Run the oracle's Sequenced decoder over a JPEG and collect, per component,
+    the quantised coefficients in the C-ABI layout ([bh][bw][64] int16, zig-zag,
+    DC absolute), the quantiser table and the decoded (padded) plane."""
+    d = orc.Decoder(data)
+    dims = [d.info(i) for i in range(d.ncomp)]
+    coefs = [np.zeros((dims[i]["decoded_height"] // 8, dims[i]["decoded_width"] // 8, 64), dtype=np.int16)
+             for i in range(d.ncomp)]
+    while True:
+        ci = d.next_block()
+        if ci is None:
+            break
+        inf = d.info(ci)
+        c = d.array(ci, "coefs").copy()
+        c[0] = inf["dc_pred"]
+        coefs[ci][inf["y"] // 8, inf["x"] // 8] = c
+    return [dict(coefs=coefs[i], qtab=d.array(i, "quant_table").astype(np.uint16), plane=d.plane(i), info=dims[i])
+            for i in range(d.ncomp)], d
+
+
+def pcg32(seed, n):
+    """Small deterministic generator (numpy PCG64 seeded) -> uint32 array."""
+    return np.random.Generator(np.random.PCG64(seed)).integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+
+
+def synth_pixels(seed, h, w):
+    """Synthetic pixel plane (h, w multiples of 8): per 8x8 block either a smooth
+    ramp with low noise or uniform random bytes."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    bh, bw = h // 8, w // 8
+    kind = rng.integers(0, 2, size=(bh, bw))
+    yy, xx = np.mgrid[0:8, 0:8]
+    gx = rng.integers(-12, 13, size=(bh, bw))
+    gy = rng.integers(-12, 13, size=(bh, bw))
+    base = rng.integers(0, 256, size=(bh, bw))
+    ramp = (base[:, :, None, None] + gx[:, :, None, None] * xx + gy[:, :, None, None] * yy
+            + rng.integers(-3, 4, size=(bh, bw, 8, 8)))
+    noise = rng.integers(0, 256, size=(bh, bw, 8, 8))
+    blk = np.where(kind[:, :, None, None] == 0, ramp, noise)
+    blk = np.clip(blk, 0, 255).astype(np.uint8)
+    return blk.transpose(0, 2, 1, 3).reshape(h, w)
+
+
+def synth_coefs(seed, bh, bw, qtab):
+    """Valid (encoder-producible) coefficient plane [bh][bw][64] via the oracle's forward path."""
+    pix = synth_pixels(seed, bh * 8, bw * 8)
+    return orc.fdct_quant(pix, qtab, bw, bh).reshape(bh, bw, 64), pix

@@ -1,0 +1,172 @@
+"""GPU parity tests of the decode path (K1) through the C ABI, against the CPU
+oracle on the same inputs.  Bit-exact (integer work)."""
+import numpy as np
+import pytest
+
+from conftest import golden_bytes, golden_json
+from helpers import coef_planes_from_jpeg, synth_coefs
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import video_coding_amd as hvc
+    c = hvc.Context(0)
+    yield c
+    c.close()
+
+
+def gpu_decode_plane(ctx, coefs, qtab, stride=None, fill=0):
+    bh, bw = coefs.shape[:2]
+    stride = stride or bw * 8
+    out = np.full((bh * 8, stride), fill, dtype=np.uint8)
+    ctx.dequant_idct_recon(np.ascontiguousarray(coefs), qtab, bw, bh, 1, out, stride=stride)
+    return out
+
+
+def test_g2_mouse480_blocks(ctx):
+    """The six golden blocks of Mouse480 (test_decoder_accelerator.ml:209-376)."""
+    g = golden_json("g2_mouse480_blocks.json")
+    hdr = golden_json("mouse480_header.json")
+    tabs = {t["table_identifier"]: np.array(t["elements"], dtype=np.uint16) for t in hdr["quant_tables"]}
+    tq = {c[0]: c[3] for c in hdr["components_id_h_v_tq"]}
+    s12 = lambda v: np.where(np.array(v) >= 2048, np.array(v) - 4096, np.array(v))
+    prev = {}
+    for blk in g["blocks"]:
+        c = s12(blk["coefs_lo12"]).astype(np.int16)
+        c[0] = blk["dc_pred_after"]  # absolute DC
+        out = gpu_decode_plane(ctx, c.reshape(1, 1, 64), tabs[tq[blk["identifier"]]])
+        assert out.reshape(64).tolist() == blk["recon"], blk["block_number"]
+
+
+@pytest.mark.parametrize("fn", ["mini.jpg", "Mouse480.jpg"])
+def test_real_jpeg_planes(ctx, fn):
+    comps, _ = coef_planes_from_jpeg(golden_bytes(fn))
+    for i, c in enumerate(comps):
+        out = gpu_decode_plane(ctx, c["coefs"], c["qtab"])
+        assert np.array_equal(out, c["plane"]), (fn, i)
+    assert ctx.last_wide_blocks() == 0
+
+
+def test_frame_batch_api_420(ctx):
+    """hvc_decode_frames: 3 components, 2 tables, several frames in one launch."""
+    import video_coding_amd as hvc
+    comps, _ = coef_planes_from_jpeg(golden_bytes("Mouse480.jpg"))
+    specs, cfs, pfs = hvc.hvc.frame_layout([(c["coefs"].shape[1], c["coefs"].shape[0], min(i, 1))
+                                            for i, c in enumerate(comps)])
+    n_frames = 3
+    coefs = np.zeros(n_frames * cfs, dtype=np.int16)
+    for f in range(n_frames):
+        for s, c in zip(specs, comps):
+            blk = c["coefs"] if f != 1 else c["coefs"][::-1, ::-1]  # frame 1: blocks permuted
+            coefs[f * cfs + s["coef_offset"]: f * cfs + s["coef_offset"] + blk.size] = blk.reshape(-1)
+    qtabs = np.stack([comps[0]["qtab"], comps[1]["qtab"]])
+    pixels = np.zeros(n_frames * pfs, dtype=np.uint8)
+    ctx.decode_frames(coefs, cfs, qtabs, specs, n_frames, pixels, pfs)
+    for f in range(n_frames):
+        for s, c in zip(specs, comps):
+            bw, bh = s["blocks_w"], s["blocks_h"]
+            got = pixels[f * pfs + s["plane_offset"]: f * pfs + s["plane_offset"] + bw * bh * 64].reshape(bh * 8, bw * 8)
+            if f != 1:
+                want = c["plane"]
+            else:
+                want = orc.dequant_idct_recon(c["coefs"][::-1, ::-1], c["qtab"], bw, bh).reshape(bh * 8, bw * 8)
+            assert np.array_equal(got, want), (f, s)
+
+
+@pytest.mark.parametrize("bw,bh", [(1, 1), (1, 7), (3, 5), (17, 31), (240, 136), (255, 3)])
+def test_ragged_sizes_valid_data(ctx, bw, bh):
+    q = orc.quant_scale(orc.quant_luma(), 75).astype(np.uint16)
+    coefs, _ = synth_coefs(1234 + bw * 1000 + bh, bh, bw, q)
+    want = orc.dequant_idct_recon(coefs, q, bw, bh).reshape(bh * 8, bw * 8)
+    got = gpu_decode_plane(ctx, coefs, q)
+    assert np.array_equal(got, want)
+    assert ctx.last_wide_blocks() == 0  # encoder-producible data never needs the 64-bit kernel
+
+
+def test_padded_stride_keeps_padding(ctx):
+    q = orc.quant_scale(orc.quant_chroma(), 50).astype(np.uint16)
+    bw, bh = 5, 4
+    coefs, _ = synth_coefs(99, bh, bw, q)
+    stride = bw * 8 + 24
+    got = gpu_decode_plane(ctx, coefs, q, stride=stride, fill=0xA5)
+    want = orc.dequant_idct_recon(coefs, q, bw, bh).reshape(bh * 8, bw * 8)
+    assert np.array_equal(got[:, :bw * 8], want)
+    assert (got[:, bw * 8:] == 0xA5).all()
+
+
+@pytest.mark.parametrize("seed,qmax,amp", [(1, 255, 32767), (2, 255, 2047), (3, 16, 32767), (4, 1, 32767),
+                                           (5, 255, 300), (6, 100, 1200)])
+def test_adversarial_coefficients_take_wide_path_and_stay_exact(ctx, seed, qmax, amp):
+    """Arbitrary int16 coefficients (far outside what an encoder can produce):
+    the int32 kernel's guard must route what it cannot prove safe to the int64
+    kernel; output equals the int64 oracle everywhere."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    bw, bh = 37, 9
+    coefs = rng.integers(-amp, amp + 1, size=(bh, bw, 64)).astype(np.int16)
+    coefs[0, 0, :] = 32767
+    coefs[0, 1, :] = -32768
+    coefs[0, 2, :] = 0
+    coefs[0, 2, 0] = -32768
+    q = rng.integers(1, qmax + 1, size=64).astype(np.uint16)
+    q[0] = qmax
+    want = orc.dequant_idct_recon(coefs, q, bw, bh).reshape(bh * 8, bw * 8)
+    got = gpu_decode_plane(ctx, coefs, q)
+    assert np.array_equal(got, want)
+
+
+def test_guard_boundary_sweep(ctx):
+    """Scale one dense block up until the guard trips: exact on both sides."""
+    rng = np.random.Generator(np.random.PCG64(7))
+    base = rng.integers(-1, 2, size=64)
+    q = np.ones(64, dtype=np.uint16)
+    n = 400
+    coefs = np.zeros((1, n, 64), dtype=np.int16)
+    for i in range(n):
+        coefs[0, i] = np.clip(base * (i * 8), -32768, 32767)
+    want = orc.dequant_idct_recon(coefs, q, n, 1).reshape(8, n * 8)
+    got = gpu_decode_plane(ctx, coefs, q)
+    assert np.array_equal(got, want)
+    assert 0 < ctx.last_wide_blocks() < n
+
+
+def test_sixteen_bit_quant_table_goes_wide(ctx):
+    rng = np.random.Generator(np.random.PCG64(8))
+    coefs = rng.integers(-50, 51, size=(2, 3, 64)).astype(np.int16)
+    q = rng.integers(1, 65536, size=64).astype(np.uint16)
+    want = orc.dequant_idct_recon(coefs, q, 3, 2).reshape(16, 24)
+    assert np.array_equal(gpu_decode_plane(ctx, coefs, q), want)
+
+
+def test_device_memory_path_torch(ctx):
+    import torch
+    q = orc.quant_scale(orc.quant_luma(), 75).astype(np.uint16)
+    bw, bh, n = 30, 17, 4
+    coefs = np.stack([synth_coefs(50 + i, bh, bw, q)[0] for i in range(n)])
+    want = orc.dequant_idct_recon(coefs, q, bw, bh, n_planes=n).reshape(n, bh * 8, bw * 8)
+    d_coefs = torch.from_numpy(coefs).cuda()
+    d_pix = torch.zeros((n, bh * 8, bw * 8), dtype=torch.uint8, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.dequant_idct_recon(d_coefs, q, bw, bh, n, d_pix)
+    ctx.synchronize()
+    ctx.set_stream(0)
+    assert np.array_equal(d_pix.cpu().numpy(), want)
+
+
+def test_errors(ctx):
+    import video_coding_amd as hvc
+    q = np.ones(64, dtype=np.uint16)
+    c = np.zeros((1, 1, 64), dtype=np.int16)
+    out = np.zeros((8, 8), dtype=np.uint8)
+    with pytest.raises(hvc.HvcError) as e:
+        q0 = q.copy(); q0[5] = 0
+        ctx.dequant_idct_recon(c, q0, 1, 1, 1, out)
+    assert e.value.code == -5
+    with pytest.raises(hvc.HvcError) as e:
+        ctx.dequant_idct_recon(c, q, 1, 1, 1, out, stride=12)
+    assert e.value.code == -4
+    with pytest.raises(hvc.HvcError) as e:
+        ctx.dequant_idct_recon(c, q, 0, 1, 1, out)
+    assert e.value.code == -1

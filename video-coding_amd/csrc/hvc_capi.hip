@@ -1,0 +1,396 @@
+// hvc_capi.hip -- the C ABI of include/hvc_jpeg.h over the gfx950 kernels.
+// Host-side plumbing only: argument checking, geometry -> kernel parameter
+// blocks, staging for host-memory callers, streams and events.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/hvc_jpeg.h"
+#include "hvc_kernels.h"
+
+#define HVC_PROF_RING 64
+
+struct hvc_ctx {
+    int device = -1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // ring of event pairs around the dominant kernel of the last HVC_PROF_RING profiled calls
+    hipEvent_t k0[HVC_PROF_RING] = {}, k1[HVC_PROF_RING] = {};
+    unsigned long long k_calls = 0;
+    bool profiling = false;
+    unsigned *d_fix_count = nullptr;
+    unsigned *d_fix_list = nullptr;
+    size_t fix_cap = 0; // entries
+    void *d_in = nullptr, *d_out = nullptr;
+    size_t in_cap = 0, out_cap = 0;
+    int last_hip = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+int fail_hip(hvc_ctx *c, hipError_t e) {
+    c->last_hip = (int)e;
+    return HVC_E_HIP;
+}
+#define HIPCHK(c, call)                                 \
+    do {                                                \
+        hipError_t e_ = (call);                         \
+        if (e_ != hipSuccess) return fail_hip((c), e_); \
+    } while (0)
+
+int grow(hvc_ctx *c, void **p, size_t *cap, size_t need) {
+    if (need <= *cap) return HVC_OK;
+    if (*p) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(*p));
+        *p = nullptr;
+        *cap = 0;
+    }
+    size_t want = need + need / 4 + 4096;
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) {
+        *p = nullptr;
+        c->last_hip = (int)e;
+        return HVC_E_OUT_OF_MEMORY;
+    }
+    *cap = want;
+    return HVC_OK;
+}
+
+// Geometry of one call -> CompK[]; shared by decode and encode.
+struct Layout {
+    hvc::CompK comp[HVC_MAX_COMP];
+    int n_comp = 0, tiles_per_frame = 0;
+    size_t coef_span = 0;  // elements covered by one frame record
+    size_t pixel_span = 0; // bytes covered by one frame record
+    unsigned long long blocks_per_frame = 0;
+};
+
+int make_layout(const hvc_component *comps, int n_comp, int n_qtabs, Layout &L) {
+    if (!comps || n_comp < 1 || n_comp > HVC_MAX_COMP) return HVC_E_INVALID_ARG;
+    L.n_comp = n_comp;
+    int tile = 0;
+    for (int i = 0; i < n_comp; i++) {
+        const hvc_component &c = comps[i];
+        if (c.blocks_w < 1 || c.blocks_h < 1 || c.qtab < 0 || c.qtab >= n_qtabs) return HVC_E_INVALID_ARG;
+        if (c.stride < (size_t)c.blocks_w * 8) return HVC_E_INVALID_ARG;
+        if ((c.stride & 7) || (c.plane_offset & 7) || (c.coef_offset & 7)) return HVC_E_ALIGNMENT;
+        unsigned long long nblk = (unsigned long long)c.blocks_w * (unsigned long long)c.blocks_h;
+        if (nblk * (unsigned long long)c.blocks_w >= (1ull << 32) || nblk >= (1ull << 31)) return HVC_E_TOO_LARGE;
+        hvc::CompK &k = L.comp[i];
+        k.bw = c.blocks_w;
+        k.bh = c.blocks_h;
+        k.nblk = (int)nblk;
+        k.tile0 = tile;
+        k.magic = c.blocks_w == 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)c.blocks_w - 1) / (unsigned)c.blocks_w);
+        k.qtab = c.qtab;
+        k.coef_off = c.coef_offset;
+        k.plane_off = c.plane_offset;
+        k.stride = c.stride;
+        tile += (int)((nblk + HVC_TILE - 1) / HVC_TILE);
+        size_t ce = c.coef_offset + (size_t)nblk * 64;
+        size_t pe = c.plane_offset + ((size_t)c.blocks_h * 8 - 1) * c.stride + (size_t)c.blocks_w * 8;
+        if (ce > L.coef_span) L.coef_span = ce;
+        if (pe > L.pixel_span) L.pixel_span = pe;
+        L.blocks_per_frame += nblk;
+    }
+    L.tiles_per_frame = tile;
+    return HVC_OK;
+}
+
+int check_qtabs(const uint16_t *qtabs, int n_qtabs) {
+    if (!qtabs || n_qtabs < 1 || n_qtabs > HVC_MAX_QTABS) return HVC_E_INVALID_ARG;
+    for (int i = 0; i < n_qtabs * 64; i++)
+        if (qtabs[i] == 0) return HVC_E_RANGE;
+    return HVC_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *hvc_version(void) { return "hvc_jpeg 0.1 (gfx950)"; }
+
+const char *hvc_strerror(int code) {
+    switch (code) {
+    case HVC_OK: return "ok";
+    case HVC_E_INVALID_ARG: return "invalid argument";
+    case HVC_E_NO_DEVICE: return "no usable gfx950 device";
+    case HVC_E_HIP: return "HIP runtime error";
+    case HVC_E_ALIGNMENT: return "pointer, offset or stride not aligned";
+    case HVC_E_RANGE: return "value out of range";
+    case HVC_E_OUT_OF_MEMORY: return "out of device memory";
+    case HVC_E_TOO_LARGE: return "plane geometry too large";
+    default: return "unknown hvc error";
+    }
+}
+
+int hvc_create(hvc_ctx **out, int device) {
+    if (!out) return HVC_E_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return HVC_E_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return HVC_E_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return HVC_E_NO_DEVICE; // gfx950 code objects only
+    hvc_ctx *c = new (std::nothrow) hvc_ctx();
+    if (!c) return HVC_E_OUT_OF_MEMORY;
+    c->device = device;
+    DeviceGuard g(device);
+    bool ok = g.ok && hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
+              [&] {
+                  for (int i = 0; i < HVC_PROF_RING; i++)
+                      if (hipEventCreate(&c->k0[i]) != hipSuccess || hipEventCreate(&c->k1[i]) != hipSuccess) return false;
+                  return true;
+              }() &&
+              hipMalloc((void **)&c->d_fix_count, sizeof(unsigned)) == hipSuccess;
+    if (!ok) {
+        hvc_destroy(c);
+        return HVC_E_NO_DEVICE;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return HVC_OK;
+}
+
+void hvc_destroy(hvc_ctx *c) {
+    if (!c) return;
+    DeviceGuard g(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_fix_count) (void)hipFree(c->d_fix_count);
+    if (c->d_fix_list) (void)hipFree(c->d_fix_list);
+    if (c->d_in) (void)hipFree(c->d_in);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (int i = 0; i < HVC_PROF_RING; i++) {
+        if (c->k0[i]) (void)hipEventDestroy(c->k0[i]);
+        if (c->k1[i]) (void)hipEventDestroy(c->k1[i]);
+    }
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int hvc_last_hip_error(const hvc_ctx *c) { return c ? c->last_hip : 0; }
+
+int hvc_set_stream(hvc_ctx *c, void *s) {
+    if (!c) return HVC_E_INVALID_ARG;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return HVC_OK;
+}
+
+int hvc_synchronize(hvc_ctx *c) {
+    if (!c) return HVC_E_INVALID_ARG;
+    DeviceGuard g(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HVC_OK;
+}
+
+int hvc_timer_begin(hvc_ctx *c) {
+    if (!c) return HVC_E_INVALID_ARG;
+    DeviceGuard g(c->device);
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    return HVC_OK;
+}
+
+int hvc_timer_end(hvc_ctx *c, float *ms) {
+    if (!c || !ms) return HVC_E_INVALID_ARG;
+    DeviceGuard g(c->device);
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return HVC_OK;
+}
+
+int hvc_set_profiling(hvc_ctx *c, int enabled) {
+    if (!c) return HVC_E_INVALID_ARG;
+    c->profiling = enabled != 0;
+    c->k_calls = 0;
+    return HVC_OK;
+}
+
+int hvc_kernel_ms_history(hvc_ctx *c, float *ms, int n) {
+    if (!c || !ms || n < 1 || n > HVC_PROF_RING || (unsigned long long)n > c->k_calls) return HVC_E_INVALID_ARG;
+    DeviceGuard g(c->device);
+    for (int i = 0; i < n; i++) { // ms[0] = oldest of the last n profiled calls
+        int slot = (int)((c->k_calls - (unsigned long long)n + (unsigned long long)i) % HVC_PROF_RING);
+        HIPCHK(c, hipEventSynchronize(c->k1[slot]));
+        HIPCHK(c, hipEventElapsedTime(&ms[i], c->k0[slot], c->k1[slot]));
+    }
+    return HVC_OK;
+}
+
+int hvc_last_kernel_ms(hvc_ctx *c, float *ms) { return hvc_kernel_ms_history(c, ms, 1); }
+
+int hvc_device_alloc(hvc_ctx *c, size_t bytes, void **out) {
+    if (!c || !out) return HVC_E_INVALID_ARG;
+    DeviceGuard g(c->device);
+    hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        c->last_hip = (int)e;
+        *out = nullptr;
+        return HVC_E_OUT_OF_MEMORY;
+    }
+    return HVC_OK;
+}
+
+int hvc_device_free(hvc_ctx *c, void *p) {
+    if (!c) return HVC_E_INVALID_ARG;
+    DeviceGuard g(c->device);
+    HIPCHK(c, hipFree(p));
+    return HVC_OK;
+}
+
+int hvc_memcpy_h2d(hvc_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!c || (!dst && bytes) || (!src && bytes)) return HVC_E_INVALID_ARG;
+    DeviceGuard g(c->device);
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HVC_OK;
+}
+
+int hvc_memcpy_d2h(hvc_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!c || (!dst && bytes) || (!src && bytes)) return HVC_E_INVALID_ARG;
+    DeviceGuard g(c->device);
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HVC_OK;
+}
+
+int hvc_last_wide_blocks(hvc_ctx *c, uint64_t *count) {
+    if (!c || !count) return HVC_E_INVALID_ARG;
+    DeviceGuard g(c->device);
+    unsigned v = 0;
+    HIPCHK(c, hipMemcpyAsync(&v, c->d_fix_count, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *count = v;
+    return HVC_OK;
+}
+
+// ---------------------------------------------------------------------------
+int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const uint16_t *qtabs, int n_qtabs,
+                      const hvc_component *comps, int n_comp, int n_frames, uint8_t *pixels, size_t pixel_fs,
+                      int where) {
+    if (!c || !coefs || !pixels || n_frames < 0) return HVC_E_INVALID_ARG;
+    if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
+    int r = check_qtabs(qtabs, n_qtabs);
+    if (r) return r;
+    Layout L;
+    r = make_layout(comps, n_comp, n_qtabs, L);
+    if (r) return r;
+    if (n_frames == 0) return HVC_OK;
+    if (n_frames > 65535) return HVC_E_TOO_LARGE;
+    if (n_frames > 1 && (coef_fs < L.coef_span || pixel_fs < L.pixel_span)) return HVC_E_INVALID_ARG;
+    if ((coef_fs & 7) || (pixel_fs & 7)) return HVC_E_ALIGNMENT;
+    unsigned long long ids = (unsigned long long)n_frames * L.tiles_per_frame * HVC_TILE;
+    if (ids >= (1ull << 32)) return HVC_E_TOO_LARGE;
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
+
+    // fix-up list: one entry per block at most
+    size_t need = (size_t)ids;
+    if (need > c->fix_cap) {
+        void *p = c->d_fix_list;
+        size_t cap = c->fix_cap * sizeof(unsigned);
+        r = grow(c, &p, &cap, need * sizeof(unsigned));
+        c->d_fix_list = (unsigned *)p;
+        c->fix_cap = cap / sizeof(unsigned);
+        if (r) return r;
+    }
+
+    hvc::DecodeParams P;
+    std::memset(&P, 0, sizeof P);
+    P.coef_fs = coef_fs;
+    P.pixel_fs = pixel_fs;
+    P.n_frames = n_frames;
+    P.n_comp = L.n_comp;
+    P.tiles_per_frame = L.tiles_per_frame;
+    for (int i = 0; i < L.n_comp; i++) P.comp[i] = L.comp[i];
+    for (int i = 0; i < n_qtabs * 64; i++) P.qt[i] = (int)qtabs[i];
+    P.fix_count = c->d_fix_count;
+    P.fix_list = c->d_fix_list;
+
+    // 16-bit quantiser entries above 255 leave the fast kernel's proven range
+    // (|coef * q| must stay below 2^23): such planes go straight to the wide kernel.
+    bool wide_only = false;
+    for (int i = 0; i < n_qtabs * 64; i++) wide_only |= qtabs[i] > 255;
+
+    if (where == HVC_MEM_DEVICE) {
+        if (((uintptr_t)coefs & 15) || ((uintptr_t)pixels & 7)) return HVC_E_ALIGNMENT;
+        P.coefs = coefs;
+        P.pixels = pixels;
+        const bool prof = c->profiling && !wide_only;
+        const int slot = (int)(c->k_calls % HVC_PROF_RING);
+        HIPCHK(c, wide_only ? hvc::launch_decode_wide_only(P, c->stream)
+                            : hvc::launch_decode(P, c->stream, prof ? c->k0[slot] : nullptr,
+                                                 prof ? c->k1[slot] : nullptr));
+        if (prof) c->k_calls++;
+        return HVC_OK;
+    }
+
+    // host memory: mirror the caller's record layout on the device
+    size_t cbytes = ((size_t)(n_frames - 1) * coef_fs + L.coef_span) * sizeof(int16_t);
+    size_t pbytes = (size_t)(n_frames - 1) * pixel_fs + L.pixel_span;
+    r = grow(c, &c->d_in, &c->in_cap, cbytes);
+    if (r) return r;
+    r = grow(c, &c->d_out, &c->out_cap, pbytes);
+    if (r) return r;
+    HIPCHK(c, hipMemcpyAsync(c->d_in, coefs, cbytes, hipMemcpyHostToDevice, c->stream));
+    P.coefs = (const int16_t *)c->d_in;
+    P.pixels = (uint8_t *)c->d_out;
+    HIPCHK(c, wide_only ? hvc::launch_decode_wide_only(P, c->stream) : hvc::launch_decode(P, c->stream));
+    // copy back only the pixels the kernels wrote (the caller's padding stays untouched)
+    for (int f = 0; f < n_frames; f++)
+        for (int i = 0; i < n_comp; i++) {
+            size_t off = (size_t)f * pixel_fs + comps[i].plane_offset;
+            HIPCHK(c, hipMemcpy2DAsync(pixels + off, comps[i].stride, (uint8_t *)c->d_out + off, comps[i].stride,
+                                       (size_t)comps[i].blocks_w * 8, (size_t)comps[i].blocks_h * 8,
+                                       hipMemcpyDeviceToHost, c->stream));
+        }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HVC_OK;
+}
+
+int hvc_dequant_idct_recon(hvc_ctx *c, const int16_t *coefs, size_t coef_plane_stride, const uint16_t *qtab,
+                           int blocks_w, int blocks_h, int n_planes, uint8_t *plane, size_t stride,
+                           size_t plane_stride, int where) {
+    if (blocks_w < 1 || blocks_h < 1) return HVC_E_INVALID_ARG;
+    hvc_component comp;
+    std::memset(&comp, 0, sizeof comp);
+    comp.blocks_w = blocks_w;
+    comp.blocks_h = blocks_h;
+    comp.qtab = 0;
+    comp.stride = stride;
+    if (!coef_plane_stride) coef_plane_stride = (size_t)blocks_w * blocks_h * 64;
+    if (!plane_stride) plane_stride = stride * (size_t)blocks_h * 8;
+    // planes are "frames" of one component; split batches beyond the grid.y limit
+    int done = 0;
+    while (done < n_planes) {
+        int n = n_planes - done > 65535 ? 65535 : n_planes - done;
+        int r = hvc_decode_frames(c, coefs + (size_t)done * coef_plane_stride, coef_plane_stride, qtab, 1, &comp, 1,
+                                  n, plane + (size_t)done * plane_stride, plane_stride, where);
+        if (r) return r;
+        done += n;
+    }
+    return n_planes < 0 ? HVC_E_INVALID_ARG : HVC_OK;
+}
+
+} // extern "C"

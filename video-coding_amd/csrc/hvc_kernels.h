@@ -1,0 +1,63 @@
+// hvc_kernels.h -- kernel parameter blocks and launcher prototypes (internal).
+#ifndef HVC_KERNELS_H
+#define HVC_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define HVC_MAX_COMP 4
+#define HVC_MAX_QTABS 4
+#define HVC_TILE 256 /* blocks per workgroup = threads per workgroup (one block per lane) */
+
+namespace hvc {
+
+// One component plane of a frame as the kernels see it (Decoder.Component.t,
+// jpeg/model/src/decoder.ml:167-187, reduced to geometry).
+struct CompK {
+    int bw, bh;        // plane size in 8x8 blocks
+    int nblk;          // bw * bh
+    int tile0;         // first tile (of HVC_TILE blocks) of this component inside a frame
+    unsigned magic;    // ceil(2^32 / bw): by = umulhi(b, magic) for b < nblk (bw*bw*bh < 2^32)
+    int qtab;          // table index
+    size_t coef_off;   // int16 elements from the frame's coefficient record
+    size_t plane_off;  // bytes from the frame's pixel record
+    size_t stride;     // bytes per pixel row
+};
+
+struct DecodeParams {
+    const int16_t *coefs;
+    uint8_t *pixels;
+    size_t coef_fs;   // int16 elements between frames
+    size_t pixel_fs;  // bytes between frames
+    int n_frames, n_comp, tiles_per_frame, pad;
+    CompK comp[HVC_MAX_COMP];
+    int qt[HVC_MAX_QTABS * 64];  // quantiser tables, zig-zag order (kernarg segment -> scalar loads)
+    unsigned *fix_count;  // device: number of entries in fix_list
+    unsigned *fix_list;   // device: global block ids needing the wide kernel
+};
+
+struct EncodeParams {
+    const uint8_t *pixels;
+    int16_t *coefs;
+    size_t coef_fs, pixel_fs;
+    int n_frames, n_comp, tiles_per_frame, pad;
+    CompK comp[HVC_MAX_COMP];
+    const float *qrcp;  // device: [n_qtabs][64] float 1/(4*q), zig-zag order
+};
+
+struct UpsampleParams {
+    const uint8_t *src;
+    uint8_t *dst;
+    int cw, ch, n_planes, pad;
+    size_t src_stride, dst_stride, src_ps, dst_ps;
+};
+
+// k0/k1 (optional): events recorded right before / after the dominant kernel.
+hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr);
+hipError_t launch_decode_wide_only(const DecodeParams &P, hipStream_t s);
+hipError_t launch_encode(const EncodeParams &P, hipStream_t s);
+hipError_t launch_upsample420(const UpsampleParams &P, hipStream_t s);
+
+} // namespace hvc
+#endif

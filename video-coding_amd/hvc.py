@@ -1,0 +1,215 @@
+"""ctypes binding of libhvc_jpeg.so (include/hvc_jpeg.h)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_DIR, "libhvc_jpeg.so")
+_LIB = None
+
+HVC_MEM_HOST, HVC_MEM_DEVICE = 0, 1
+
+# every symbol include/hvc_jpeg.h declares
+SYMBOLS = [
+    "hvc_create", "hvc_destroy", "hvc_strerror", "hvc_last_hip_error", "hvc_version", "hvc_set_stream",
+    "hvc_synchronize", "hvc_timer_begin", "hvc_timer_end", "hvc_set_profiling", "hvc_last_kernel_ms", "hvc_kernel_ms_history", "hvc_dequant_idct_recon", "hvc_decode_frames",
+    "hvc_last_wide_blocks", "hvc_fdct_quant", "hvc_encode_frames", "hvc_upsample420", "hvc_device_alloc",
+    "hvc_device_free", "hvc_memcpy_h2d", "hvc_memcpy_d2h",
+]
+
+
+class HvcError(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = code
+        msg = lib().hvc_strerror(code).decode() if _LIB is not None else str(code)
+        super().__init__("hvc error %d (%s) %s" % (code, msg, what))
+
+
+class Component(C.Structure):
+    """struct hvc_component"""
+    _fields_ = [("blocks_w", C.c_int), ("blocks_h", C.c_int), ("qtab", C.c_int), ("reserved", C.c_int),
+                ("coef_offset", C.c_size_t), ("plane_offset", C.c_size_t), ("stride", C.c_size_t)]
+
+
+def build(force=False):
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_DIR, "csrc", f) for f in os.listdir(os.path.join(_DIR, "csrc"))]
+    srcs.append(os.path.join(os.path.dirname(_DIR), "include", "hvc_jpeg.h"))
+    stale = not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_DIR, "csrc")] + (["-B"] if force else []))
+    return _SO
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_SO):
+            raise ImportError("libhvc_jpeg.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or `make -C video-coding_amd/csrc` (there is no CPU fallback)")
+        L = C.CDLL(_SO)
+        vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
+        L.hvc_strerror.restype = C.c_char_p
+        L.hvc_strerror.argtypes = [i]
+        L.hvc_version.restype = C.c_char_p
+        L.hvc_create.argtypes = [C.POINTER(vp), i]
+        L.hvc_destroy.argtypes = [vp]
+        L.hvc_destroy.restype = None
+        L.hvc_last_hip_error.argtypes = [vp]
+        L.hvc_set_stream.argtypes = [vp, vp]
+        L.hvc_synchronize.argtypes = [vp]
+        L.hvc_timer_begin.argtypes = [vp]
+        L.hvc_timer_end.argtypes = [vp, C.POINTER(C.c_float)]
+        L.hvc_set_profiling.argtypes = [vp, i]
+        L.hvc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.hvc_kernel_ms_history.argtypes = [vp, C.POINTER(C.c_float), i]
+        L.hvc_dequant_idct_recon.argtypes = [vp, vp, sz, vp, i, i, i, vp, sz, sz, i]
+        L.hvc_decode_frames.argtypes = [vp, vp, sz, vp, i, C.POINTER(Component), i, i, vp, sz, i]
+        L.hvc_last_wide_blocks.argtypes = [vp, C.POINTER(C.c_uint64)]
+        if hasattr(L, "hvc_fdct_quant"):
+            L.hvc_fdct_quant.argtypes = [vp, vp, sz, sz, vp, i, i, i, vp, sz, i]
+            L.hvc_encode_frames.argtypes = [vp, vp, sz, vp, i, C.POINTER(Component), i, i, vp, sz, i]
+            L.hvc_upsample420.argtypes = [vp, vp, i, i, sz, vp, sz, i, sz, sz, i]
+        L.hvc_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+        L.hvc_device_free.argtypes = [vp, vp]
+        L.hvc_memcpy_h2d.argtypes = [vp, vp, vp, sz]
+        L.hvc_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+        _LIB = L
+    return _LIB
+
+
+def _chk(code, what=""):
+    if code != 0:
+        raise HvcError(code, what)
+
+
+def _addr(x):
+    """host numpy array or device torch tensor / raw int address -> (address, where)"""
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data, HVC_MEM_HOST
+    if isinstance(x, int):
+        return x, HVC_MEM_DEVICE
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr(), (HVC_MEM_DEVICE if x.is_cuda else HVC_MEM_HOST)
+    raise TypeError(type(x))
+
+
+def components(specs):
+    """specs: list of dicts(blocks_w, blocks_h, qtab, coef_offset, plane_offset, stride)"""
+    arr = (Component * len(specs))()
+    for a, s in zip(arr, specs):
+        a.blocks_w, a.blocks_h, a.qtab = s["blocks_w"], s["blocks_h"], s.get("qtab", 0)
+        a.coef_offset, a.plane_offset = s.get("coef_offset", 0), s.get("plane_offset", 0)
+        a.stride = s.get("stride", s["blocks_w"] * 8)
+    return arr
+
+
+def frame_layout(planes_bw_bh_qtab):
+    """Tight frame record: component planes back to back.  Returns (specs,
+    coef elements per frame, pixel bytes per frame)."""
+    specs, co, po = [], 0, 0
+    for bw, bh, qt in planes_bw_bh_qtab:
+        specs.append(dict(blocks_w=bw, blocks_h=bh, qtab=qt, coef_offset=co, plane_offset=po, stride=bw * 8))
+        co += bw * bh * 64
+        po += bw * bh * 64
+    return specs, co, po
+
+
+class Context:
+    """hvc_ctx: one per GPU / host thread."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _chk(lib().hvc_create(C.byref(self._h), device), "hvc_create(device=%d)" % device)
+
+    def close(self):
+        if self._h:
+            lib().hvc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, handle):
+        _chk(lib().hvc_set_stream(self._h, C.c_void_p(handle)))
+
+    def synchronize(self):
+        _chk(lib().hvc_synchronize(self._h))
+
+    def timer_begin(self):
+        _chk(lib().hvc_timer_begin(self._h))
+
+    def timer_end(self):
+        ms = C.c_float()
+        _chk(lib().hvc_timer_end(self._h, C.byref(ms)))
+        return ms.value
+
+    def set_profiling(self, on=True):
+        _chk(lib().hvc_set_profiling(self._h, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        _chk(lib().hvc_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def kernel_ms_history(self, n):
+        arr = (C.c_float * n)()
+        _chk(lib().hvc_kernel_ms_history(self._h, arr, n))
+        return list(arr)
+
+    def last_wide_blocks(self):
+        n = C.c_uint64()
+        _chk(lib().hvc_last_wide_blocks(self._h, C.byref(n)))
+        return n.value
+
+    # -- decode -------------------------------------------------------------
+    def dequant_idct_recon(self, coefs, qtab, blocks_w, blocks_h, n_planes, plane, stride=None,
+                           coef_plane_stride=0, plane_stride=0):
+        ca, w1 = _addr(coefs)
+        pa, w2 = _addr(plane)
+        assert w1 == w2, "coefs and plane must live in the same memory space"
+        q = np.ascontiguousarray(qtab, dtype=np.uint16)
+        assert q.size == 64
+        _chk(lib().hvc_dequant_idct_recon(self._h, ca, coef_plane_stride, q.ctypes.data, blocks_w, blocks_h,
+                                          n_planes, pa, stride or blocks_w * 8, plane_stride, w1))
+
+    def decode_frames(self, coefs, coef_frame_stride, qtabs, comps, n_frames, pixels, pixel_frame_stride):
+        ca, w1 = _addr(coefs)
+        pa, w2 = _addr(pixels)
+        assert w1 == w2
+        q = np.ascontiguousarray(qtabs, dtype=np.uint16).reshape(-1, 64)
+        arr = comps if not isinstance(comps, list) else components(comps)
+        _chk(lib().hvc_decode_frames(self._h, ca, coef_frame_stride, q.ctypes.data, q.shape[0], arr, len(arr),
+                                     n_frames, pa, pixel_frame_stride, w1))
+
+    # -- encode -------------------------------------------------------------
+    def fdct_quant(self, plane, qtab, blocks_w, blocks_h, n_planes, coefs, stride=None, plane_stride=0,
+                   coef_plane_stride=0):
+        pa, w1 = _addr(plane)
+        ca, w2 = _addr(coefs)
+        assert w1 == w2
+        q = np.ascontiguousarray(qtab, dtype=np.uint16)
+        _chk(lib().hvc_fdct_quant(self._h, pa, stride or blocks_w * 8, plane_stride, q.ctypes.data, blocks_w,
+                                  blocks_h, n_planes, ca, coef_plane_stride, w1))
+
+    def encode_frames(self, pixels, pixel_frame_stride, qtabs, comps, n_frames, coefs, coef_frame_stride):
+        pa, w1 = _addr(pixels)
+        ca, w2 = _addr(coefs)
+        assert w1 == w2
+        q = np.ascontiguousarray(qtabs, dtype=np.uint16).reshape(-1, 64)
+        arr = comps if not isinstance(comps, list) else components(comps)
+        _chk(lib().hvc_encode_frames(self._h, pa, pixel_frame_stride, q.ctypes.data, q.shape[0], arr, len(arr),
+                                     n_frames, ca, coef_frame_stride, w1))
+
+    def upsample420(self, src, cw, ch, dst, n_planes=1, src_stride=None, dst_stride=None, src_plane_stride=0,
+                    dst_plane_stride=0):
+        sa, w1 = _addr(src)
+        da, w2 = _addr(dst)
+        assert w1 == w2
+        _chk(lib().hvc_upsample420(self._h, sa, cw, ch, src_stride or cw, da, dst_stride or 2 * cw, n_planes,
+                                   src_plane_stride, dst_plane_stride, w1))
