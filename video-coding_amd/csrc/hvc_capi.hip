@@ -393,4 +393,138 @@ int hvc_dequant_idct_recon(hvc_ctx *c, const int16_t *coefs, size_t coef_plane_s
     return n_planes < 0 ? HVC_E_INVALID_ARG : HVC_OK;
 }
 
+// ---------------------------------------------------------------------------
+int hvc_encode_frames(hvc_ctx *c, const uint8_t *pixels, size_t pixel_fs, const uint16_t *qtabs, int n_qtabs,
+                      const hvc_component *comps, int n_comp, int n_frames, int16_t *coefs, size_t coef_fs,
+                      int where) {
+    if (!c || !coefs || !pixels || n_frames < 0) return HVC_E_INVALID_ARG;
+    if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
+    int r = check_qtabs(qtabs, n_qtabs);
+    if (r) return r;
+    // Encoder tables are 8-bit (Markers.Dqt element_precision = 8, encoder.ml:224-229;
+    // Quant_tables.scale clips to 1..255, quant_tables.ml:139-147).
+    for (int i = 0; i < n_qtabs * 64; i++)
+        if (qtabs[i] > 255) return HVC_E_RANGE;
+    Layout L;
+    r = make_layout(comps, n_comp, n_qtabs, L);
+    if (r) return r;
+    if (n_frames == 0) return HVC_OK;
+    if (n_frames > 65535) return HVC_E_TOO_LARGE;
+    if (n_frames > 1 && (coef_fs < L.coef_span || pixel_fs < L.pixel_span)) return HVC_E_INVALID_ARG;
+    if ((coef_fs & 7) || (pixel_fs & 7)) return HVC_E_ALIGNMENT;
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
+
+    hvc::EncodeParams P;
+    std::memset(&P, 0, sizeof P);
+    P.coef_fs = coef_fs;
+    P.pixel_fs = pixel_fs;
+    P.n_frames = n_frames;
+    P.n_comp = L.n_comp;
+    P.tiles_per_frame = L.tiles_per_frame;
+    for (int i = 0; i < L.n_comp; i++) P.comp[i] = L.comp[i];
+    for (int i = 0; i < n_qtabs * 64; i++) {
+        const float d = 4.0f * (float)qtabs[i];
+        P.qrcp[i] = 1.0f / d;           // correctly rounded fl(1/(4t))
+        P.qhalf[i] = 0.5f + 0.5f / d;   // 0.5 + 1/(8t)
+    }
+
+    if (where == HVC_MEM_DEVICE) {
+        if (((uintptr_t)coefs & 15) || ((uintptr_t)pixels & 7)) return HVC_E_ALIGNMENT;
+        P.coefs = coefs;
+        P.pixels = pixels;
+        const bool prof = c->profiling;
+        const int slot = (int)(c->k_calls % HVC_PROF_RING);
+        HIPCHK(c, hvc::launch_encode(P, c->stream, prof ? c->k0[slot] : nullptr, prof ? c->k1[slot] : nullptr));
+        if (prof) c->k_calls++;
+        return HVC_OK;
+    }
+
+    size_t cbytes = ((size_t)(n_frames - 1) * coef_fs + L.coef_span) * sizeof(int16_t);
+    size_t pbytes = (size_t)(n_frames - 1) * pixel_fs + L.pixel_span;
+    r = grow(c, &c->d_in, &c->in_cap, pbytes);
+    if (r) return r;
+    r = grow(c, &c->d_out, &c->out_cap, cbytes);
+    if (r) return r;
+    HIPCHK(c, hipMemcpyAsync(c->d_in, pixels, pbytes, hipMemcpyHostToDevice, c->stream));
+    P.pixels = (const uint8_t *)c->d_in;
+    P.coefs = (int16_t *)c->d_out;
+    HIPCHK(c, hvc::launch_encode(P, c->stream));
+    // copy back only the coefficient planes (gaps in the caller's records stay untouched)
+    for (int f = 0; f < n_frames; f++)
+        for (int i = 0; i < n_comp; i++) {
+            size_t off = (size_t)f * coef_fs + comps[i].coef_offset;
+            size_t n = (size_t)comps[i].blocks_w * comps[i].blocks_h * 64;
+            HIPCHK(c, hipMemcpyAsync(coefs + off, (int16_t *)c->d_out + off, n * sizeof(int16_t),
+                                     hipMemcpyDeviceToHost, c->stream));
+        }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HVC_OK;
+}
+
+int hvc_fdct_quant(hvc_ctx *c, const uint8_t *plane, size_t stride, size_t plane_stride, const uint16_t *qtab,
+                   int blocks_w, int blocks_h, int n_planes, int16_t *coefs, size_t coef_plane_stride, int where) {
+    if (blocks_w < 1 || blocks_h < 1 || n_planes < 0) return HVC_E_INVALID_ARG;
+    hvc_component comp;
+    std::memset(&comp, 0, sizeof comp);
+    comp.blocks_w = blocks_w;
+    comp.blocks_h = blocks_h;
+    comp.qtab = 0;
+    comp.stride = stride;
+    if (!coef_plane_stride) coef_plane_stride = (size_t)blocks_w * blocks_h * 64;
+    if (!plane_stride) plane_stride = stride * (size_t)blocks_h * 8;
+    int done = 0;
+    while (done < n_planes) {
+        int n = n_planes - done > 65535 ? 65535 : n_planes - done;
+        int r = hvc_encode_frames(c, plane + (size_t)done * plane_stride, plane_stride, qtab, 1, &comp, 1, n,
+                                  coefs + (size_t)done * coef_plane_stride, coef_plane_stride, where);
+        if (r) return r;
+        done += n;
+    }
+    return HVC_OK;
+}
+
+int hvc_upsample420(hvc_ctx *c, const uint8_t *src, int cw, int ch, size_t src_stride, uint8_t *dst,
+                    size_t dst_stride, int n_planes, size_t src_ps, size_t dst_ps, int where) {
+    if (!c || !src || !dst || cw < 1 || ch < 1 || n_planes < 0) return HVC_E_INVALID_ARG;
+    if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
+    if (src_stride < (size_t)cw || dst_stride < (size_t)cw * 2) return HVC_E_INVALID_ARG;
+    if (n_planes == 0) return HVC_OK;
+    if (n_planes > 65535) return HVC_E_TOO_LARGE;
+    if (!src_ps) src_ps = src_stride * (size_t)ch;
+    if (!dst_ps) dst_ps = dst_stride * (size_t)ch * 2;
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
+    hvc::UpsampleParams P;
+    std::memset(&P, 0, sizeof P);
+    P.cw = cw;
+    P.ch = ch;
+    P.n_planes = n_planes;
+    P.src_stride = src_stride;
+    P.dst_stride = dst_stride;
+    P.src_ps = src_ps;
+    P.dst_ps = dst_ps;
+    if (where == HVC_MEM_DEVICE) {
+        P.src = src;
+        P.dst = dst;
+        HIPCHK(c, hvc::launch_upsample420(P, c->stream));
+        return HVC_OK;
+    }
+    size_t sbytes = (size_t)(n_planes - 1) * src_ps + (size_t)(ch - 1) * src_stride + (size_t)cw;
+    size_t dbytes = (size_t)(n_planes - 1) * dst_ps + (size_t)(2 * ch - 1) * dst_stride + (size_t)cw * 2;
+    int r = grow(c, &c->d_in, &c->in_cap, sbytes);
+    if (r) return r;
+    r = grow(c, &c->d_out, &c->out_cap, dbytes);
+    if (r) return r;
+    HIPCHK(c, hipMemcpyAsync(c->d_in, src, sbytes, hipMemcpyHostToDevice, c->stream));
+    P.src = (const uint8_t *)c->d_in;
+    P.dst = (uint8_t *)c->d_out;
+    HIPCHK(c, hvc::launch_upsample420(P, c->stream));
+    for (int p = 0; p < n_planes; p++)
+        HIPCHK(c, hipMemcpy2DAsync(dst + (size_t)p * dst_ps, dst_stride, (uint8_t *)c->d_out + (size_t)p * dst_ps,
+                                   dst_stride, (size_t)cw * 2, (size_t)ch * 2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HVC_OK;
+}
+
 } // extern "C"

@@ -43,7 +43,8 @@ struct EncodeParams {
     size_t coef_fs, pixel_fs;
     int n_frames, n_comp, tiles_per_frame, pad;
     CompK comp[HVC_MAX_COMP];
-    const float *qrcp;  // device: [n_qtabs][64] float 1/(4*q), zig-zag order
+    float qrcp[HVC_MAX_QTABS * 64];   // fl(1/(4*q)), zig-zag order (kernarg segment)
+    float qhalf[HVC_MAX_QTABS * 64];  // 0.5 + 1/(8*q)
 };
 
 struct UpsampleParams {
@@ -56,7 +57,7 @@ struct UpsampleParams {
 // k0/k1 (optional): events recorded right before / after the dominant kernel.
 hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr);
 hipError_t launch_decode_wide_only(const DecodeParams &P, hipStream_t s);
-hipError_t launch_encode(const EncodeParams &P, hipStream_t s);
+hipError_t launch_encode(const EncodeParams &P, hipStream_t s, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr);
 hipError_t launch_upsample420(const UpsampleParams &P, hipStream_t s);
 
 } // namespace hvc
