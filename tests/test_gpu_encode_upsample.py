@@ -1,0 +1,123 @@
+"""GPU parity tests of the encode path (K3: level shift + forward DCT + quantise +
+zig-zag) and the 4:2:0 -> 4:4:4 upsample (K2) through the C ABI, against the
+CPU oracle.  Bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import golden_bytes, golden_json
+from helpers import synth_pixels
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import video_coding_amd as hvc
+    c = hvc.Context(0)
+    yield c
+    c.close()
+
+
+def gpu_fdct_quant(ctx, plane, q, stride=None):
+    h, w = plane.shape
+    bw, bh = (stride and (w // 8) or w // 8), h // 8
+    out = np.zeros((bh, bw, 64), dtype=np.int16)
+    ctx.fdct_quant(np.ascontiguousarray(plane), q, bw, bh, 1, out)
+    return out
+
+
+def test_g1_chen_forward_kat(ctx):
+    """test_chen_dct.ml:47-87 input block: q=1 turns quant_and_scale into the test's
+    own '/4 rounded' (x>0 ? (x+2)/4 : (x-2)/4), in zig-zag order."""
+    g = golden_json("g1_chen_dct.json")
+    pix = (np.array(g["input"]) + 128).astype(np.uint8).reshape(8, 8)
+    got = gpu_fdct_quant(ctx, pix, np.ones(64, dtype=np.uint16)).reshape(64)
+    zi = orc.zigzag_inverse()
+    assert [int(got[k]) for k in range(64)] == [g["fdct_div4_rounded"][zi[k]] for k in range(64)]
+
+
+@pytest.mark.parametrize("fn,chroma", [("mini64x64.420", 420), ("mini64x64.422", 422), ("mini64x64.444", 444)])
+@pytest.mark.parametrize("quality", [1, 30, 75, 95, 100])
+def test_reference_frames_all_qualities(ctx, fn, chroma, quality):
+    y, u, v = orc.split_yuv(golden_bytes(fn), 64, 64, chroma)
+    _, coefs = orc.encode_yuv(y, u, v, 64, 64, chroma, quality, want_coefs=True)
+    ql = orc.quant_scale(orc.quant_luma(), quality).astype(np.uint16)
+    qc = orc.quant_scale(orc.quant_chroma(), quality).astype(np.uint16)
+    for plane, q, want in ((y, ql, coefs[0]), (u, qc, coefs[1]), (v, qc, coefs[2])):
+        assert np.array_equal(gpu_fdct_quant(ctx, plane, q), want)
+
+
+@pytest.mark.parametrize("bw,bh", [(1, 1), (3, 5), (33, 9), (240, 135), (257, 2)])
+def test_ragged_sizes_and_extreme_pixels(ctx, bw, bh):
+    rng = np.random.Generator(np.random.PCG64(bw * 131 + bh))
+    pix = synth_pixels(bw * 7 + bh, bh * 8, bw * 8)
+    pix[:8, :8] = 255
+    if bw > 1:
+        pix[:8, 8:16] = 0
+    if bh > 1:
+        yy, xx = np.mgrid[0:8, 0:8]
+        pix[8:16, :8] = np.where((yy + xx) % 2 == 0, 255, 0)  # checkerboard: largest AC energy
+    q = rng.integers(1, 256, size=64).astype(np.uint16)
+    want = orc.fdct_quant(pix, q, bw, bh).reshape(bh, bw, 64)
+    assert np.array_equal(gpu_fdct_quant(ctx, pix, q), want)
+
+
+def test_frame_batch_encode_then_decode_roundtrip(ctx):
+    """encode -> decode of a 4:2:0 frame batch on the GPU equals the oracle's
+    encode -> decode (both directions exact => identical pixels)."""
+    import video_coding_amd as hvc
+    planes = [(6, 4, 0), (3, 2, 1), (3, 2, 1)]
+    specs, cfs, pfs = hvc.hvc.frame_layout(planes)
+    n_frames = 5
+    ql = orc.quant_scale(orc.quant_luma(), 60).astype(np.uint16)
+    qc = orc.quant_scale(orc.quant_chroma(), 60).astype(np.uint16)
+    qtabs = np.stack([ql, qc])
+    pixels = np.zeros(n_frames * pfs, dtype=np.uint8)
+    for f in range(n_frames):
+        for s in specs:
+            n = s["blocks_w"] * s["blocks_h"] * 64
+            pixels[f * pfs + s["plane_offset"]:f * pfs + s["plane_offset"] + n] = synth_pixels(
+                f * 10 + s["blocks_w"], s["blocks_h"] * 8, s["blocks_w"] * 8).reshape(-1)
+    coefs = np.zeros(n_frames * cfs, dtype=np.int16)
+    ctx.encode_frames(pixels, pfs, qtabs, specs, n_frames, coefs, cfs)
+    recon = np.zeros_like(pixels)
+    ctx.decode_frames(coefs, cfs, qtabs, specs, n_frames, recon, pfs)
+    for f in range(n_frames):
+        for s in specs:
+            bw, bh = s["blocks_w"], s["blocks_h"]
+            n = bw * bh * 64
+            src = pixels[f * pfs + s["plane_offset"]:f * pfs + s["plane_offset"] + n].reshape(bh * 8, bw * 8)
+            wc = orc.fdct_quant(src, qtabs[s["qtab"]], bw, bh)
+            assert np.array_equal(coefs[f * cfs + s["coef_offset"]:f * cfs + s["coef_offset"] + n], wc)
+            wp = orc.dequant_idct_recon(wc, qtabs[s["qtab"]], bw, bh)
+            assert np.array_equal(recon[f * pfs + s["plane_offset"]:f * pfs + s["plane_offset"] + n], wp)
+
+
+def test_g7_upsample_kat(ctx):
+    g = golden_json("g7_upsample.json")["cases"]["444<->420"]
+    f420, back = g[1], g[2]
+    for rows, want in ((f420[4:6], back[4:8]), (f420[6:8], back[8:12])):
+        src = np.array(rows, dtype=np.uint8)
+        dst = np.zeros((4, 4), dtype=np.uint8)
+        ctx.upsample420(src, 2, 2, dst)
+        assert dst.tolist() == want
+
+
+@pytest.mark.parametrize("cw,ch", [(1, 1), (2, 3), (5, 7), (26, 22), (960, 540), (33, 2)])
+def test_upsample_sizes(ctx, cw, ch):
+    rng = np.random.Generator(np.random.PCG64(cw * 1000 + ch))
+    n = 3
+    src = rng.integers(0, 256, size=(n, ch, cw)).astype(np.uint8)
+    dst = np.zeros((n, 2 * ch, 2 * cw), dtype=np.uint8)
+    ctx.upsample420(src, cw, ch, dst, n_planes=n)
+    for p in range(n):
+        assert np.array_equal(dst[p], orc.supersample_hv2(src[p])), p
+
+
+def test_encoder_rejects_wide_tables(ctx):
+    import video_coding_amd as hvc
+    q = np.full(64, 256, dtype=np.uint16)
+    with pytest.raises(hvc.HvcError) as e:
+        ctx.fdct_quant(np.zeros((8, 8), dtype=np.uint8), q, 1, 1, 1, np.zeros(64, dtype=np.int16))
+    assert e.value.code == -5

@@ -1,0 +1,165 @@
+"""Interval-arithmetic proofs for the int32 / 24-bit-multiply fast kernels
+(video-coding_amd/csrc/hvc_kernels.hip).  CPU only.
+
+Every operation of idct_1d_fast / fdct_1d is replayed on intervals.  The tests
+show: under the kernel's range guard (GUARD_D, GUARD_R, GUARD_Y) no int32
+operation can wrap and every v_mul_i32_i24 / v_mad_i32_i24 operand lies in
+[-2^23, 2^23); and the encoder needs no guard at all because its inputs are
+8-bit pixels.  Intervals ignore correlations, so the bounds are conservative.
+"""
+import re
+import os
+
+I32 = (-(1 << 31), (1 << 31) - 1)
+I24 = (-(1 << 23), (1 << 23) - 1)
+
+W1, W2, W3, W5, W6, W7 = 2841, 2676, 2408, 1609, 1108, 565
+
+
+class Iv:
+    """closed integer interval that asserts it fits int32 on construction"""
+
+    def __init__(self, lo, hi, what=""):
+        assert lo <= hi
+        assert I32[0] <= lo and hi <= I32[1], "int32 overflow possible in %s: [%d, %d]" % (what, lo, hi)
+        self.lo, self.hi = lo, hi
+
+    def __add__(self, o):
+        o = o if isinstance(o, Iv) else Iv(o, o)
+        return Iv(self.lo + o.lo, self.hi + o.hi, "add")
+
+    def __sub__(self, o):
+        o = o if isinstance(o, Iv) else Iv(o, o)
+        return Iv(self.lo - o.hi, self.hi - o.lo, "sub")
+
+    def __neg__(self):
+        return Iv(-self.hi, -self.lo)
+
+    def shl(self, k):
+        return Iv(self.lo << k, self.hi << k, "shl")
+
+    def asr(self, k):
+        return Iv(self.lo >> k, self.hi >> k)
+
+    def clampto(self, lo, hi):
+        """guard: the kernel only continues when the value is inside [lo, hi]"""
+        return Iv(max(self.lo, lo), min(self.hi, hi))
+
+    def absmax(self):
+        return max(abs(self.lo), abs(self.hi))
+
+
+def mul24(c, x):
+    assert I24[0] <= c <= I24[1]
+    assert I24[0] <= x.lo and x.hi <= I24[1], "mul24 operand outside 24 bits: [%d, %d]" % (x.lo, x.hi)
+    a, b = c * x.lo, c * x.hi
+    return Iv(min(a, b), max(a, b), "mul24")
+
+
+def mad24(c, x, acc):
+    acc = acc if isinstance(acc, Iv) else Iv(acc, acc)
+    return mul24(c, x) + acc
+
+
+def kernel_constants():
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-coding_amd",
+                            "csrc", "hvc_kernels.hip")).read()
+    out = {}
+    for name in ("GUARD_D", "GUARD_R", "GUARD_Y"):
+        m = re.search(r"constexpr int %s = \(1 << (\d+)\) - 1;" % name, src)
+        out[name] = (1 << int(m.group(1))) - 1
+    return out
+
+
+def idct_1d_fast(b, col, bias, guard_y):
+    """mirror of idct_1d_fast<COL, BIAS>; returns the 8 outputs (column pass: unshifted)"""
+    R = 4 if col else 0
+    x0 = b[0].shl(8) + (8192 + bias) if col else b[0].shl(11) + 128
+    x1 = b[4].shl(8) if col else b[4].shl(11)
+    x2, x3, x4, x5, x6, x7 = b[6], b[2], b[1], b[7], b[5], b[3]
+    n4 = mad24(W7, x5, mad24(W1, x4, R))
+    n5 = mad24(-W1, x5, mad24(W7, x4, R))
+    n6 = mad24(W3, x7, mad24(W5, x6, R))
+    n7 = mad24(-W5, x7, mad24(W3, x6, R))
+    n3 = mad24(W6, x2, mad24(W2, x3, R))
+    n2 = mad24(-W2, x2, mad24(W6, x3, R))
+    if col:
+        n4, n5, n6, n7, n3, n2 = (v.asr(3) for v in (n4, n5, n6, n7, n3, n2))
+    x8 = x0 + x1
+    x0 = x0 - x1
+    x1 = n4 + n6
+    x4 = n4 - n6
+    x6 = n5 + n7
+    x5 = n5 - n7
+    x7 = x8 + n3
+    x8 = x8 - n3
+    x3 = x0 + n2
+    x0 = x0 - n2
+    ys = (x4 + x5).clampto(-guard_y, guard_y)   # g.y2(ys, yd): outside -> wide kernel
+    yd = (x4 - x5).clampto(-guard_y, guard_y)
+    x2 = mad24(181, ys, 128).asr(8)
+    x4 = mad24(181, yd, 128).asr(8)
+    S = 0 if col else 8
+    outs = [x7 + x1, x3 + x2, x0 + x4, x8 + x6, x8 - x6, x0 - x4, x3 - x2, x7 - x1]
+    return [o.asr(S) for o in outs]
+
+
+def test_decode_fast_path_cannot_overflow_under_its_guard():
+    k = kernel_constants()
+    d = Iv(-k["GUARD_D"], k["GUARD_D"])
+    # dequantisation: int16 coefficient x 8-bit table entry through v_mul_i32_i24
+    assert 32768 * 255 <= I24[1], "coefficient * q must fit the 24-bit multiplier"
+    rows = idct_1d_fast([d] * 8, col=False, bias=0, guard_y=k["GUARD_Y"])
+    r = Iv(-k["GUARD_R"], k["GUARD_R"])          # g.r2(): row outputs outside -> wide kernel
+    rows = [x.clampto(r.lo, r.hi) for x in rows]
+    cols = idct_1d_fast([r] * 8, col=True, bias=128 << 14, guard_y=k["GUARD_Y"])
+    for c in cols:   # consumed by v_ashr_pk_u8_i32 (arithmetic shift of an int32): any int32 is fine
+        assert I32[0] <= c.lo and c.hi <= I32[1]
+
+
+def test_guard_is_not_vacuous_and_has_headroom_for_real_data():
+    """Encoder-producible blocks peak far below the guard: |dequant| <= ~1.1k*q-rounding,
+    row outputs <= ~3e4, 181-arguments <= ~7.8e6 < GUARD_Y = 8388607."""
+    k = kernel_constants()
+    assert k["GUARD_D"] >= 16 * 2048 and k["GUARD_R"] >= 4 * 32768 and k["GUARD_Y"] == (1 << 23) - 1
+
+
+def fdct_1d(p):
+    def c4(f, g):
+        return mul24(362, f + g).asr(9)
+
+    def c4m(f, g):
+        return mul24(362, f - g).asr(9)
+
+    def c62(f, g):
+        return mad24(473, g, mul24(196, f)).asr(9)
+
+    def c71(f, g):
+        return mad24(502, g, mul24(100, f)).asr(9)
+
+    def c35(f, g):
+        return mad24(284, g, mul24(426, f)).asr(9)
+
+    a0, c3 = p[0] + p[7], p[0] - p[7]
+    a1, c2 = p[1] + p[6], p[1] - p[6]
+    a2, c1 = p[2] + p[5], p[2] - p[5]
+    a3, c0 = p[3] + p[4], p[3] - p[4]
+    b0, b1, b2, b3 = a0 + a3, a1 + a2, a1 - a2, a0 - a3
+    o = [None] * 8
+    o[0], o[4], o[2], o[6] = c4(b0, b1), c4m(b0, b1), c62(b2, b3), c62(b3, -b2)
+    b0, b1 = c4m(c2, c1), c4(c2, c1)
+    a0, a1, a2, a3 = c0 + b0, c0 - b0, c3 - b1, c3 + b1
+    o[1], o[5], o[3], o[7] = c71(a0, a3), c35(a1, a2), c35(a2, -a1), c71(a3, -a0)
+    return o
+
+
+def test_encode_path_needs_no_guard():
+    p = Iv(-128, 127)
+    cols = fdct_1d([p] * 8)
+    m1 = max(c.absmax() for c in cols)
+    rows = fdct_1d([Iv(-m1, m1)] * 8)
+    m2 = max(c.absmax() for c in rows)
+    # the quantiser's float path is verified exhaustively for |f| <= 2^15 (test_quant_division.py)
+    assert m2 <= 1 << 15, m2
+    # quantised values fit int16 trivially
+    assert (m2 + 2) // 4 + 1 < 32768

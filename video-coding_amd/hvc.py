@@ -2,6 +2,7 @@
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -49,6 +50,15 @@ def lib():
         if not os.path.exists(_SO):
             raise ImportError("libhvc_jpeg.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "or `make -C video-coding_amd/csrc` (there is no CPU fallback)")
+        if "torch" not in sys.modules:
+            # A process that also uses PyTorch-ROCm must run ONE HIP runtime: torch bundles
+            # its own libamdhip64 (same SONAME as /opt/rocm's).  Loading torch first makes the
+            # dynamic linker resolve this library's dependency to the copy torch already
+            # mapped; the other order leaves torch without a usable device.
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(_SO)
         vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
         L.hvc_strerror.restype = C.c_char_p
