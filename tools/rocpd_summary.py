@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 (rocpd sqlite) outputs of tools/gpu_profile.sh into a
+small text file for profiles/.
+
+    python tools/rocpd_summary.py gpurun_out/prof_<tag> > profiles/<name>.txt
+"""
+import glob
+import os
+import sqlite3
+import sys
+
+
+def q(db, sql):
+    return list(sqlite3.connect(db).execute(sql))
+
+
+def main(d):
+    print("# rocprofv3 summary of %s" % d)
+    tr = glob.glob(os.path.join(d, "trace", "*.db"))
+    if tr:
+        print("\n## --kernel-trace --stats  (durations in ns)")
+        print("%-60s %8s %14s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
+        for name, calls, total, avg, pct in q(tr[0], "select name,total_calls,total_duration,average,percentage from top_kernels"):
+            print("%-60s %8d %14.0f %12.1f %7.2f" % (name[:60], calls, total * 1e3 if total < 1e6 else total, avg * 1e3 if avg < 1e5 else avg, pct))
+        rows = q(tr[0], "select name, duration, vgpr_count, sgpr_count, grid_x, grid_y, workgroup_x from kernels "
+                        "where name like 'hvc::%' order by start")
+        print("\nper-dispatch (hvc kernels): name duration_ns vgpr sgpr grid wg")
+        for r in rows:
+            print("  %-48s %9d vgpr=%d sgpr=%d grid=%dx%d wg=%d" % (r[0][:48], r[1], r[2], r[3], r[4], r[5], r[6]))
+    print("\n## --pmc passes (average per dispatch of each hvc kernel)")
+    for sub in sorted(glob.glob(os.path.join(d, "pmc_*"))):
+        dbs = glob.glob(os.path.join(sub, "*.db"))
+        if not dbs:
+            continue
+        for kn, cn, avg, n in q(dbs[0], "select kernel_name, counter_name, avg(value), count(*) from counters_collection "
+                                        "where kernel_name like 'hvc::%' group by kernel_name, counter_name"):
+            extra = ""
+            if cn == "FETCH_SIZE":
+                extra = "  KB -> x1024 x2 (gfx950 16B/lane read correction) = %.1f MB" % (avg * 1024 * 2 / 1e6)
+            if cn == "WRITE_SIZE":
+                extra = "  KB -> x1024 = %.1f MB" % (avg * 1024 / 1e6)
+            print("  %-40s %-22s %16.1f  (n=%d)%s" % (kn[:40], cn, avg, n, extra))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
