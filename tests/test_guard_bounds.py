@@ -62,12 +62,16 @@ def mad24(c, x, acc):
 
 
 def kernel_constants():
-    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-coding_amd",
-                            "csrc", "hvc_kernels.hip")).read()
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-coding_amd", "csrc")
+    src = open(os.path.join(csrc, "hvc_kernels.hip")).read()
+    hdr = open(os.path.join(csrc, "hvc_kernels.h")).read()
     out = {}
-    for name in ("GUARD_D", "GUARD_R", "GUARD_Y"):
+    for name in ("GUARD_R", "GUARD_Y"):
         m = re.search(r"constexpr int %s = \(1 << (\d+)\) - 1;" % name, src)
         out[name] = (1 << int(m.group(1))) - 1
+    m = re.search(r"#define HVC_GUARD_D \(\(1 << (\d+)\) - 1\)", hdr)
+    out["GUARD_D"] = (1 << int(m.group(1))) - 1
+    assert "constexpr int GUARD_D = HVC_GUARD_D;" in src
     return out
 
 
@@ -115,6 +119,22 @@ def test_decode_fast_path_cannot_overflow_under_its_guard():
     cols = idct_1d_fast([r] * 8, col=True, bias=128 << 14, guard_y=k["GUARD_Y"])
     for c in cols:   # consumed by v_ashr_pk_u8_i32 (arithmetic shift of an int32): any int32 is fine
         assert I32[0] <= c.lo and c.hi <= I32[1]
+
+
+def test_energy_threshold_bounds_every_dequantised_coefficient():
+    """hvc_capi.hip: ethr = min((GUARD_D / qmax)^2, 2^31 - 2) and the kernel flags E > ethr
+    (E saturates at 2^31 - 1).  So an accepted block has max|c| <= sqrt(E) <= GUARD_D / qmax,
+    hence |c * q| <= GUARD_D; when ethr is capped, qmax <= 2 and 32768 * qmax <= GUARD_D anyway."""
+    k = kernel_constants()
+    import math
+    for qmax in list(range(1, 256)) + [256, 1000, 65535]:
+        m = k["GUARD_D"] // qmax
+        thr = min(m * m, 0x7FFFFFFE)
+        if thr == m * m:
+            cmax = math.isqrt(thr)            # largest |c| with c^2 <= thr
+            assert cmax * qmax <= k["GUARD_D"]
+        else:
+            assert 32768 * qmax <= k["GUARD_D"]
 
 
 def test_guard_is_not_vacuous_and_has_headroom_for_real_data():

@@ -325,6 +325,14 @@ int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const ui
     P.tiles_per_frame = L.tiles_per_frame;
     for (int i = 0; i < L.n_comp; i++) P.comp[i] = L.comp[i];
     for (int i = 0; i < n_qtabs * 64; i++) P.qt[i] = (int)qtabs[i];
+    for (int t = 0; t < n_qtabs; t++) {
+        // every |coef * q| <= qmax * sqrt(E): the fast kernel accepts E up to (HVC_GUARD_D / qmax)^2
+        unsigned qmax = 1;
+        for (int i = 0; i < 64; i++) qmax = qtabs[t * 64 + i] > qmax ? qtabs[t * 64 + i] : qmax;
+        unsigned long long m = HVC_GUARD_D / qmax;
+        unsigned long long thr = m * m;
+        P.ethr[t] = thr > 0x7ffffffeull ? 0x7ffffffe : (int)thr;
+    }
     P.fix_count = c->d_fix_count;
     P.fix_list = c->d_fix_list;
 

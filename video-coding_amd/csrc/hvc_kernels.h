@@ -8,6 +8,7 @@
 
 #define HVC_MAX_COMP 4
 #define HVC_MAX_QTABS 4
+#define HVC_GUARD_D ((1 << 17) - 1) /* fast kernel: largest |dequantised coefficient| it is proved for */
 #define HVC_TILE 256 /* blocks per workgroup = threads per workgroup (one block per lane) */
 
 namespace hvc {
@@ -33,6 +34,7 @@ struct DecodeParams {
     int n_frames, n_comp, tiles_per_frame, pad;
     CompK comp[HVC_MAX_COMP];
     int qt[HVC_MAX_QTABS * 64];  // quantiser tables, zig-zag order (kernarg segment -> scalar loads)
+    int ethr[HVC_MAX_QTABS];     // per table: largest coefficient energy the int32 kernel accepts
     unsigned *fix_count;  // device: number of entries in fix_list
     unsigned *fix_list;   // device: global block ids needing the wide kernel
 };

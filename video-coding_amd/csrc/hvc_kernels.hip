@@ -25,6 +25,10 @@
 
 #include "hvc_kernels.h"
 
+#ifndef HVC_FAST_LB
+#define HVC_FAST_LB HVC_TILE /* experiments: -DHVC_FAST_LB="HVC_TILE,6" forces 6 waves per SIMD */
+#endif
+
 namespace hvc {
 
 // jpeg/model/src/zigzag.ml:3-69  inverse[zz] = raster
@@ -46,25 +50,47 @@ constexpr int W1 = 2841, W2 = 2676, W3 = 2408, W5 = 1609, W6 = 1108, W7 = 565;
 // ---------------------------------------------------------------------------
 // Range guard of the int32 fast path (proved by tests/test_guard_bounds.py with
 // interval arithmetic over exactly the operations below):
-//   |dequantised coefficient|        <= GUARD_D
+//   |dequantised coefficient|        <= GUARD_D   (via the coefficient energy, below)
 //   |row-pass output|                <= GUARD_R
 //   |argument of a 181*y product|    <= GUARD_Y   (row and column pass)
 // imply that no int32 operation wraps and every v_mul_i32_i24 / v_mad_i32_i24
 // operand lies in [-2^23, 2^23).
-constexpr int GUARD_D = (1 << 17) - 1;
+constexpr int GUARD_D = HVC_GUARD_D;
 constexpr int GUARD_R = (1 << 18) - 1;
 constexpr int GUARD_Y = (1 << 23) - 1;
 
 struct Guard {
-    int dmax = 0, dmin = 0, rmax = 0, rmin = 0, ymax = 0, ymin = 0;
-    __device__ __forceinline__ void d2(int a, int b) { dmax = max(max(dmax, a), b); dmin = min(min(dmin, a), b); }
+    // |dequantised coefficient| is bounded a priori: every |c[k] * q[k]| <= qmax * sqrt(E) with
+    // E = sum c[k]^2 accumulated by v_dot2_i32_i16 (saturating) straight from the packed
+    // coefficient dwords; the host passes ethr = (GUARD_D / qmax)^2 per table.
+    int energy = 0;
+    int rmax = 0, rmin = 0, ymax = 0, ymin = 0;
+    __device__ __forceinline__ void e2(unsigned packed_pair) {
+        typedef short short2v __attribute__((ext_vector_type(2)));
+        short2v pr = __builtin_bit_cast(short2v, packed_pair);
+        energy = __builtin_amdgcn_sdot2(pr, pr, energy, true);
+    }
     __device__ __forceinline__ void r2(int a, int b) { rmax = max(max(rmax, a), b); rmin = min(min(rmin, a), b); }
     __device__ __forceinline__ void y2(int a, int b) { ymax = max(max(ymax, a), b); ymin = min(min(ymin, a), b); }
-    __device__ __forceinline__ bool bad() const {
-        return (dmax > GUARD_D) | (dmin < -GUARD_D) | (rmax > GUARD_R) | (rmin < -GUARD_R) |
-               (ymax > GUARD_Y) | (ymin < -GUARD_Y);
+    __device__ __forceinline__ bool bad(int ethr) const {
+        return (energy > ethr) | (rmax > GUARD_R) | (rmin < -GUARD_R) | (ymax > GUARD_Y) | (ymin < -GUARD_Y);
     }
 };
+
+// dequantise one half of a packed coefficient pair: the sign extension of the int16 half rides in
+// the SDWA source selector of the 24-bit multiply (one instruction, no unpack).  q is wave-uniform.
+__device__ __forceinline__ int dequant_lo(unsigned pair, int q) {
+    int d;
+    asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD"
+        : "=v"(d) : "v"(pair), "s"(q));
+    return d;
+}
+__device__ __forceinline__ int dequant_hi(unsigned pair, int q) {
+    int d;
+    asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+        : "=v"(d) : "v"(pair), "s"(q));
+    return d;
+}
 
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 __device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
@@ -206,7 +232,7 @@ __device__ __forceinline__ bool locate(const Params &P, int frame, int tile, int
 
 // ---------------------------------------------------------------------------
 // K1 fast: int32 / mul24.
-__global__ __launch_bounds__(HVC_TILE) void k_decode_fast(DecodeParams P) {
+__global__ __launch_bounds__(HVC_FAST_LB) void k_decode_fast(DecodeParams P) {
     BlockRef br;
     const int lane = threadIdx.x;
     const bool active = locate(P, blockIdx.y, blockIdx.x, lane, br);
@@ -228,13 +254,9 @@ __global__ __launch_bounds__(HVC_TILE) void k_decode_fast(DecodeParams P) {
 #pragma unroll
         for (int h = 0; h < 4; h++) {
             const int k = j * 8 + h * 2;
-            int lo = (int)(short)(w[h] & 0xffffu);
-            int hi = ((int)w[h]) >> 16;
-            int d0 = mul24(lo, q[k]);
-            int d1 = mul24(hi, q[k + 1]);
-            g.d2(d0, d1);
-            v[ZI[k]] = d0;
-            v[ZI[k + 1]] = d1;
+            g.e2(w[h]);
+            v[ZI[k]] = dequant_lo(w[h], q[k]);
+            v[ZI[k + 1]] = dequant_hi(w[h], q[k + 1]);
         }
     }
 
@@ -257,7 +279,7 @@ __global__ __launch_bounds__(HVC_TILE) void k_decode_fast(DecodeParams P) {
 
     // clip (decoder.ml:213) on the shifted value: clamp(x,-128,127)+128 == clamp(x+128,0,255),
     // done together with the column pass's >> 14 by the saturating pack.
-    const bool bad = g.bad();
+    const bool bad = g.bad(P.ethr[br.qtab]);
     if (active && !bad) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {

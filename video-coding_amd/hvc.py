@@ -7,7 +7,7 @@ import sys
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_DIR, "libhvc_jpeg.so")
+_SO = os.environ.get("HVC_JPEG_LIB") or os.path.join(_DIR, "libhvc_jpeg.so")  # env override: A/B experiments only
 _LIB = None
 
 HVC_MEM_HOST, HVC_MEM_DEVICE = 0, 1
