@@ -80,6 +80,56 @@ def cpu_baseline(frames, qtabs, min_seconds=10.0):
                       "orc_dequant_idct_recon, 1 thread" % (done, dt)}
 
 
+def dist_env():
+    """RANK / WORLD_SIZE / LOCAL_RANK as torch.distributed.run exports them (1 process = 1 GPU)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def dist_init(world, backend, device=None):
+    """Process group for timing closure only (barrier + MAX of the elapsed time): the data path
+    has no collective.  backend: "nccl" (= RCCL, one rank per GPU) or "gloo" (CPU rehearsal)."""
+    import torch.distributed as dist
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend, **kw)
+    return dist
+
+
+def timed_steps(step, steps, warmup, sync, world, dist=None):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + sync on both sides."""
+    for _ in range(warmup):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    return time.perf_counter() - t0
+
+
+def max_over_ranks(dt, world, dist=None, device="cpu"):
+    if world == 1:
+        return dt
+    import torch
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def whole_job_mpixels(world, frames_per_gpu, steps, dt):
+    """value = units ALL ranks processed / max-over-ranks time (weak scaling: per-GPU batch fixed)."""
+    return world * frames_per_gpu * steps * W * H / dt / 1e6
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,18 +143,13 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
     import video_coding_amd as hvc
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local_rank = dist_env()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dist = dist_init(world, "nccl", torch.device("cuda", local_rank))
 
     frames, qtabs = make_distinct_frames(args.distinct, seed=0x4A504547 + 1000 * rank)
     specs, cfs, pfs = hvc.hvc.frame_layout(PLANES)
@@ -120,24 +165,8 @@ def main():
     def step():
         ctx.decode_frames(d_coefs, cfs, qtabs, comps, args.frames, d_pix, pfs)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, world, dist)
+    dt = max_over_ranks(dt, world, dist, "cuda")
 
     # HIP events recorded around k_decode_fast inside the timed region (one pair per step)
     kernel_ms = ctx.kernel_ms_history(min(args.steps, 64))
@@ -159,7 +188,7 @@ def main():
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "Mpixel/s decoded (1080p 4:2:0 batch)",
-            "value": round(world * args.frames * args.steps * W * H / dt / 1e6, 1),
+            "value": round(whole_job_mpixels(world, args.frames, args.steps, dt), 1),
             "unit": "Mpixel/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),

@@ -22,7 +22,9 @@ struct hvc_ctx {
     hipEvent_t k0[HVC_PROF_RING] = {}, k1[HVC_PROF_RING] = {};
     unsigned long long k_calls = 0;
     bool profiling = false;
-    unsigned *d_fix_count = nullptr;
+    unsigned *d_fix_count = nullptr; // two counters, used alternately (see k_decode_wide)
+    int fix_phase = 0;               // index of the counter the NEXT decode call appends to
+    int fix_last = 0;                // index of the counter the last decode call used
     unsigned *d_fix_list = nullptr;
     size_t fix_cap = 0; // entries
     void *d_in = nullptr, *d_out = nullptr;
@@ -161,7 +163,8 @@ int hvc_create(hvc_ctx **out, int device) {
                       if (hipEventCreate(&c->k0[i]) != hipSuccess || hipEventCreate(&c->k1[i]) != hipSuccess) return false;
                   return true;
               }() &&
-              hipMalloc((void **)&c->d_fix_count, sizeof(unsigned)) == hipSuccess;
+              hipMalloc((void **)&c->d_fix_count, 2 * sizeof(unsigned)) == hipSuccess &&
+              hipMemset(c->d_fix_count, 0, 2 * sizeof(unsigned)) == hipSuccess;
     if (!ok) {
         hvc_destroy(c);
         return HVC_E_NO_DEVICE;
@@ -279,7 +282,7 @@ int hvc_last_wide_blocks(hvc_ctx *c, uint64_t *count) {
     if (!c || !count) return HVC_E_INVALID_ARG;
     DeviceGuard g(c->device);
     unsigned v = 0;
-    HIPCHK(c, hipMemcpyAsync(&v, c->d_fix_count, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&v, c->d_fix_count + c->fix_last, sizeof v, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *count = v;
     return HVC_OK;
@@ -333,13 +336,18 @@ int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const ui
         unsigned long long thr = m * m;
         P.ethr[t] = thr > 0x7ffffffeull ? 0x7ffffffe : (int)thr;
     }
-    P.fix_count = c->d_fix_count;
+    P.fix_count = c->d_fix_count + c->fix_phase;
+    P.fix_count_next = c->d_fix_count + (c->fix_phase ^ 1);
     P.fix_list = c->d_fix_list;
 
     // 16-bit quantiser entries above 255 leave the fast kernel's proven range
     // (|coef * q| must stay below 2^23): such planes go straight to the wide kernel.
     bool wide_only = false;
     for (int i = 0; i < n_qtabs * 64; i++) wide_only |= qtabs[i] > 255;
+    if (!wide_only) { // this call consumes counter fix_phase; its wide kernel clears the other one
+        c->fix_last = c->fix_phase;
+        c->fix_phase ^= 1;
+    }
 
     if (where == HVC_MEM_DEVICE) {
         if (((uintptr_t)coefs & 15) || ((uintptr_t)pixels & 7)) return HVC_E_ALIGNMENT;

@@ -35,7 +35,8 @@ struct DecodeParams {
     CompK comp[HVC_MAX_COMP];
     int qt[HVC_MAX_QTABS * 64];  // quantiser tables, zig-zag order (kernarg segment -> scalar loads)
     int ethr[HVC_MAX_QTABS];     // per table: largest coefficient energy the int32 kernel accepts
-    unsigned *fix_count;  // device: number of entries in fix_list
+    unsigned *fix_count;       // device: number of entries in fix_list (this call's counter)
+    unsigned *fix_count_next;  // device: the next call's counter, cleared by this call's wide kernel
     unsigned *fix_list;   // device: global block ids needing the wide kernel
 };
 

@@ -309,6 +309,9 @@ __global__ __launch_bounds__(HVC_FAST_LB) void k_decode_fast(DecodeParams P) {
 __global__ __launch_bounds__(64) void k_decode_wide(DecodeParams P, const unsigned *count, const unsigned *list,
                                                     unsigned long long total) {
     unsigned long long n = list ? (unsigned long long)*count : total;
+    // The two fix-up counters alternate between calls: this launch reads the
+    // current one and clears the other for the next call (no memset node).
+    if (blockIdx.x == 0 && threadIdx.x == 0 && P.fix_count_next) *P.fix_count_next = 0;
     for (unsigned long long i = (unsigned long long)blockIdx.x * 64 + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * 64) {
         unsigned long long id = list ? list[i] : i;
@@ -469,8 +472,7 @@ __global__ __launch_bounds__(256) void k_upsample420(UpsampleParams P) {
 // launchers (host)
 hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0, hipEvent_t k1) {
     if (P.n_frames <= 0 || P.tiles_per_frame <= 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(P.fix_count, 0, sizeof(unsigned), s);
-    if (e != hipSuccess) return e;
+    hipError_t e;
     dim3 grid((unsigned)P.tiles_per_frame, (unsigned)P.n_frames, 1);
     if (k0 && (e = hipEventRecord(k0, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_decode_fast, grid, dim3(HVC_TILE), 0, s, P);
@@ -479,7 +481,7 @@ hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0, hi
     if (k1 && (e = hipEventRecord(k1, s)) != hipSuccess) return e;
     // Fixed small grid; every thread strides over the (normally empty) list and
     // exits as soon as its index passes *fix_count.
-    hipLaunchKernelGGL(k_decode_wide, dim3(1024), dim3(64), 0, s, P, P.fix_count, P.fix_list, 0ull);
+    hipLaunchKernelGGL(k_decode_wide, dim3(256), dim3(64), 0, s, P, P.fix_count, P.fix_list, 0ull);
     return hipGetLastError();
 }
 
