@@ -80,6 +80,19 @@ def cpu_baseline(frames, qtabs, min_seconds=10.0):
                       "orc_dequant_idct_recon, 1 thread" % (done, dt)}
 
 
+def measured_traffic(frames):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate --pmc runs of this very
+    command and corrected as MI355X_MICROARCH.md prescribes).  bench.py cannot collect counters
+    itself; None when the profile is absent or was taken at another batch size."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        return round(t["hbm_bytes"]) if t.get("frames_per_launch") == frames else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def dist_env():
     """RANK / WORLD_SIZE / LOCAL_RANK as torch.distributed.run exports them (1 process = 1 GPU)."""
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
@@ -193,17 +206,19 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32 (24-bit multiplies; int64 fix-up kernel), int16 in / u8 out",
+            "dtype": "int32",
             "data": "synthetic",
             "config": {"workload": "1080p 4:2:0 baseline, synthetic valid coefficient blocks (Huffman bypassed), "
                                    "HBM-resident, %d frames/GPU/step" % args.frames,
                        "frames_per_gpu_per_step": args.frames, "blocks_per_frame": BLOCKS_PER_FRAME,
                        "parallelism": "independent frame batch per GPU, no collective",
                        "wide_path_blocks": int(wide)},
-            "roofline": {"bound": "hbm", "kernel": "k_decode_fast", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": "k_decode_packed", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": None, "kernel_ms": round(k_ms, 4),
-                         "algorithmic_bytes_per_launch": algo_bytes},
+                         "traffic": measured_traffic(args.frames), "kernel_ms": round(k_ms, 4),
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "arithmetic": "int32 with int16-pair dot products (v_dot2_i32_i16); int64 fix-up kernel "
+                                       "for blocks outside the proven range"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, qtabs, args.cpu_seconds)

@@ -183,3 +183,73 @@ def test_encode_path_needs_no_guard():
     assert m2 <= 1 << 15, m2
     # quantised values fit int16 trivially
     assert (m2 + 2) // 4 + 1 < 32768
+
+
+# ---------------------------------------------------------------------------
+# k_decode_packed: int16 operand pairs + v_dot2_i32_i16
+I16 = (-32768, 32767)
+
+
+def dot2(pair, k, add=0):
+    """v_dot2_i32_i16: both halves must be genuine int16 values; the sum must fit int32."""
+    (a, b), (ka, kb) = pair, k
+    for x in (a, b):
+        assert I16[0] <= x.lo and x.hi <= I16[1], "dot2 operand outside int16: [%d, %d]" % (x.lo, x.hi)
+    assert all(I16[0] <= c <= I16[1] for c in (ka, kb))
+    pa = sorted((ka * a.lo, ka * a.hi))
+    pb = sorted((kb * b.lo, kb * b.hi))
+    return Iv(pa[0] + pb[0] + add, pa[1] + pb[1] + add, "dot2")
+
+
+def idct_1d_packed(A, B, C, Z, col, guard_y):
+    s, rnd, add0 = (256, 4, 8192 + (128 << 14)) if col else (2048, 0, 128)
+    rs = 3 if col else 0
+    n4, n5 = dot2(A, (W1, W7), rnd).asr(rs), dot2(A, (W7, -W1), rnd).asr(rs)
+    n6, n7 = dot2(B, (W5, W3), rnd).asr(rs), dot2(B, (W3, -W5), rnd).asr(rs)
+    n3, n2 = dot2(C, (W2, W6), rnd).asr(rs), dot2(C, (W6, -W2), rnd).asr(rs)
+    x8, x0 = dot2(Z, (s, s), add0), dot2(Z, (s, -s), add0)
+    x1, x6 = n4 + n6, n5 + n7
+    x4, x5 = n4 - n6, n5 - n7
+    x7 = x8 + n3
+    x8 = x8 - n3
+    x3 = x0 + n2
+    x0 = x0 - n2
+    ys = (x4 + x5).clampto(-guard_y, guard_y)
+    yd = (x4 - x5).clampto(-guard_y, guard_y)
+    x2 = mad24(181, ys, 128).asr(8)
+    x4 = mad24(181, yd, 128).asr(8)
+    S = 0 if col else 8
+    return [o.asr(S) for o in (x7 + x1, x3 + x2, x0 + x4, x8 + x6, x8 - x6, x0 - x4, x3 - x2, x7 - x1)]
+
+
+def test_packed_kernel_cannot_overflow_under_its_guard():
+    """E <= (32767/qmax)^2 => every dequantised coefficient is an exact int16 (v_pk_mul_lo_u16 keeps
+    the low 16 bits of c*q, which are the value itself when it fits); the row outputs may be anything
+    in int32 (they are saturate-packed), and the row-energy guard renergy < 32767^2 -- computed on
+    the saturated values, so one clipped value alone reaches it -- leaves |r| < 32767: exact pairs."""
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-coding_amd", "csrc")
+    src = open(os.path.join(csrc, "hvc_kernels.hip")).read()
+    hdr = open(os.path.join(csrc, "hvc_kernels.h")).read()
+    assert "#define HVC_GUARD_D_PACKED 32767" in hdr and "constexpr int GUARD_RE = 32767 * 32767;" in src
+    gy = kernel_constants()["GUARD_Y"]
+    d = Iv(-32767, 32767)
+    rows = idct_1d_packed((d, d), (d, d), (d, d), (d, d), col=False, guard_y=gy)
+    for o in rows:  # v_cvt_pk_i16_i32 saturates any int32
+        assert I32[0] <= o.lo and o.hi <= I32[1]
+    # a saturated half is +-32767/-32768 and contributes >= 32767^2 to renergy: flagged
+    assert 32767 * 32767 >= 32767 * 32767 and 32768 * 32768 >= 32767 * 32767
+    r = Iv(-32766, 32766)
+    cols = idct_1d_packed((r, r), (r, r), (r, r), (r, r), col=True, guard_y=gy)
+    for o in cols:  # consumed by v_ashr_pk_u8_i32
+        assert I32[0] <= o.lo and o.hi <= I32[1]
+
+
+def test_packed_energy_thresholds():
+    import math
+    for qmax in range(1, 256):
+        m = 32767 // qmax
+        thr = min(m * m, 0x7FFFFFFE)
+        assert math.isqrt(thr) * qmax <= 32767
+    # real-data headroom: a full-amplitude block has sum(pixel^2) <= 64 * 128^2, its row outputs
+    # carry energy ~ 511x that (22.6^2): about half of the 32767^2 threshold.
+    assert 511 * 64 * 128 * 128 < 32767 * 32767

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 2 --no-cpu-baseline $@"
+ARGS="--steps 40 --warmup 10 --no-cpu-baseline $@"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python3 $ROOT/bench.py $ARGS > $OUT/trace_bench.log 2>&1
 # PMC passes (own runs; no trace domains)
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python3 $ROOT/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1

@@ -335,6 +335,16 @@ int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const ui
         unsigned long long m = HVC_GUARD_D / qmax;
         unsigned long long thr = m * m;
         P.ethr[t] = thr > 0x7ffffffeull ? 0x7ffffffe : (int)thr;
+        m = HVC_GUARD_D_PACKED / qmax;
+        thr = m * m;
+        P.ethr_packed[t] = thr > 0x7ffffffeull ? 0x7ffffffe : (int)thr;
+        static const int PAIRS[4][2] = {{1, 7}, {5, 3}, {2, 6}, {0, 4}};
+        for (int r = 0; r < 8; r++)
+            for (int k = 0; k < 4; k++) {
+                unsigned lo = qtabs[t * 64 + hvc::HVC_ZF[8 * r + PAIRS[k][0]]];
+                unsigned hi = qtabs[t * 64 + hvc::HVC_ZF[8 * r + PAIRS[k][1]]];
+                P.qpair[t * 32 + r * 4 + k] = (lo & 0xffffu) | (hi << 16);
+            }
     }
     P.fix_count = c->d_fix_count + c->fix_phase;
     P.fix_count_next = c->d_fix_count + (c->fix_phase ^ 1);

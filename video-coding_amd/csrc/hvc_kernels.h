@@ -11,7 +11,15 @@
 #define HVC_GUARD_D ((1 << 17) - 1) /* fast kernel: largest |dequantised coefficient| it is proved for */
 #define HVC_TILE 256 /* blocks per workgroup = threads per workgroup (one block per lane) */
 
+#define HVC_GUARD_D_PACKED 32767 /* packed kernel: |dequantised coefficient| must fit int16 */
+
 namespace hvc {
+
+// jpeg/model/src/zigzag.ml:71-137  forward[raster] = zz  (host-side copy for table preparation)
+static const unsigned char HVC_ZF[64] = {
+    0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30,
+    41, 43, 9,  11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38,
+    46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
 
 // One component plane of a frame as the kernels see it (Decoder.Component.t,
 // jpeg/model/src/decoder.ml:167-187, reduced to geometry).
@@ -34,7 +42,11 @@ struct DecodeParams {
     int n_frames, n_comp, tiles_per_frame, pad;
     CompK comp[HVC_MAX_COMP];
     int qt[HVC_MAX_QTABS * 64];  // quantiser tables, zig-zag order (kernarg segment -> scalar loads)
-    int ethr[HVC_MAX_QTABS];     // per table: largest coefficient energy the int32 kernel accepts
+    int ethr[HVC_MAX_QTABS];     // per table: largest coefficient energy k_decode_fast accepts
+    // k_decode_packed: per table and row r, the quantiser entries of the row's operand pairs
+    // (raster 8r+1, 8r+7) (8r+5, 8r+3) (8r+2, 8r+6) (8r+0, 8r+4) as lo | hi << 16
+    unsigned qpair[HVC_MAX_QTABS * 32];
+    int ethr_packed[HVC_MAX_QTABS];  // largest coefficient energy k_decode_packed accepts
     unsigned *fix_count;       // device: number of entries in fix_list (this call's counter)
     unsigned *fix_count_next;  // device: the next call's counter, cleared by this call's wide kernel
     unsigned *fix_list;   // device: global block ids needing the wide kernel

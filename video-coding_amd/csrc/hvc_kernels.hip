@@ -22,6 +22,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "hvc_kernels.h"
 
@@ -152,6 +153,23 @@ __device__ __forceinline__ void idct_1d_fast(int &b0, int &b1, int &b2, int &b3,
 // hardware; so the kernel never leaves that pattern to the compiler and issues
 // the instruction itself, once per destination half: 4 pixels = 2 instructions
 // for shift + clamp + pack.)
+// 8 pixels of one block row.  The pixels are written once and never re-read by this kernel: a
+// non-temporal store (HVC_NT_STORES, default) measured +2.6 % on the kernel's traffic shape
+// (profiles/r01_mem_ubench.txt: 5.76 -> 5.91 TB/s); non-temporal LOADS would halve it (they bypass
+// the L1 that merges a lane's eight 16-byte reads of its 128-byte line).
+#ifndef HVC_NT_STORES
+#define HVC_NT_STORES 1
+#endif
+__device__ __forceinline__ void store_row8(uint8_t *p, unsigned lo, unsigned hi) {
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    u2v t = {lo, hi};
+#if HVC_NT_STORES
+    __builtin_nontemporal_store(t, reinterpret_cast<u2v *>(p));
+#else
+    *reinterpret_cast<u2v *>(p) = t;
+#endif
+}
+
 __device__ __forceinline__ unsigned ashr14_sat_pack4(int a, int b, int c, int d) {
     unsigned r;
     asm("v_ashr_pk_u8_i32 %0, %1, %2, 14" : "=v"(r) : "v"(a), "v"(b));
@@ -286,10 +304,250 @@ __global__ __launch_bounds__(HVC_FAST_LB) void k_decode_fast(DecodeParams P) {
             uint2 o;
             o.x = ashr14_sat_pack4(v[j * 8 + 0], v[j * 8 + 1], v[j * 8 + 2], v[j * 8 + 3]);
             o.y = ashr14_sat_pack4(v[j * 8 + 4], v[j * 8 + 5], v[j * 8 + 6], v[j * 8 + 7]);
-            *reinterpret_cast<uint2 *>(P.pixels + br.pix_idx + (size_t)j * br.stride) = o;
+            store_row8(P.pixels + br.pix_idx + (size_t)j * br.stride, o.x, o.y);
         }
     }
     // fix-up list: one atomic per wave
+    const bool flag = active && bad;
+    const unsigned long long m = __ballot(flag);
+    if (m) {
+        const int wl = lane & 63;
+        unsigned base = 0;
+        if (wl == 0) base = atomicAdd(P.fix_count, (unsigned)__popcll(m));
+        base = __shfl(base, 0);
+        if (flag) {
+            unsigned idx = base + (unsigned)__popcll(m & ((1ull << wl) - 1ull));
+            P.fix_list[idx] = ((unsigned)blockIdx.y * (unsigned)P.tiles_per_frame + blockIdx.x) * HVC_TILE + lane;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1 packed: the same block-per-lane mapping with PACKED int16 operands.
+//
+// Measured issue costs (profiles/r01_valu_ubench.txt) make integer multiplies the
+// expensive part of the butterfly (mul/mad ~1.7x an add).  v_dot2_i32_i16
+// (d = a.lo*b.lo + a.hi*b.hi + c, same ~1.7x cost) computes one whole rotation
+// output  W1*x4 + W7*x5 (+ rounding)  per instruction when (x4, x5) sit in one
+// register as an int16 pair, and the pair x8 = (b0 + b4) << s + r,
+// x0 - x1 = (b0 - b4) << s + r the same way.  So:
+//   * the coefficient dwords are byte-permuted (v_perm_b32) into the four
+//     operand pairs of each row -- (b1,b7) (b5,b3) (b2,b6) (b0,b4) -- and
+//     dequantised two at a time (v_pk_mul_lo_u16, exact while |c*q| < 2^15);
+//   * a row pass is 8 v_dot2 + adds; its outputs are saturate-packed
+//     (v_cvt_pk_i16_i32) across ROWS into the column passes' operand pairs
+//     (r1,r7) (r5,r3) (r2,r6) (r0,r4): 32 VGPRs instead of 64 for the transposed
+//     intermediate;
+//   * a column pass is again 8 v_dot2 + adds, finished two columns at a time by
+//     v_ashr_pk_u8_i32 (>> 14, clip, byte pack).
+// Guard (tests/test_guard_bounds.py): coefficient energy E <= (32767/qmax)^2 =>
+// every |c*q| <= 32767; row-output energy sum r^2 < 32767^2 computed on the
+// SATURATED packed values (a clipped value alone reaches the threshold) => every
+// |r| < 32767 and the pack was exact; |y| < 2^23 for the two 181*y products of
+// every pass.  Anything else goes to the int64 kernel via the fix-up list.
+typedef short short2v __attribute__((ext_vector_type(2)));
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+
+// d = pair.lo * k.lo + pair.hi * k.hi + ADD with the three-operand (VOP3P) encoding: the constant pair
+// sits in an SGPR and a small addend is an inline constant, so no v_mov is spent on the accumulator
+// (the builtin lowers to the two-operand v_dot2c form, which needs d preloaded).
+template <int ADD>
+__device__ __forceinline__ int dot2(unsigned pair, unsigned k) {
+    static_assert(ADD == 0 || ADD == 4, "inline constants only");
+    int d;
+    if (ADD == 0)
+        asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(pair), "s"(k));
+    else
+        asm("v_dot2_i32_i16 %0, %1, %2, 4" : "=v"(d) : "v"(pair), "s"(k));
+    return d;
+}
+// same with a (wave-uniform) addend that is not an inline constant: it lives in a VGPR
+__device__ __forceinline__ int dot2v(unsigned pair, unsigned k, int add) {
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(pair), "s"(k), "v"(add));
+    return d;
+}
+__device__ __forceinline__ int dot2_sat(unsigned pair, unsigned k, int acc) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, pair), __builtin_bit_cast(short2v, k), acc, true);
+}
+constexpr unsigned pk(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
+
+// position of raster coefficient p inside the 32 loaded dwords: dword ZF[p] / 2, half ZF[p] & 1
+template <int PA, int PB>
+__device__ __forceinline__ unsigned gather_pair(const unsigned (&w)[32]) {
+    constexpr int za = ZF[PA], zb = ZF[PB];
+    constexpr int ha = za & 1, hb = zb & 1;
+    // v_perm_b32 D = bytes of {S0 (bytes 4-7), S1 (bytes 0-3)} chosen by the selector
+    constexpr unsigned sel = ((unsigned)(4 + 2 * hb + 1) << 24) | ((unsigned)(4 + 2 * hb) << 16) |
+                             ((unsigned)(2 * ha + 1) << 8) | (unsigned)(2 * ha);
+    return __builtin_amdgcn_perm(w[zb >> 1], w[za >> 1], sel);
+}
+__device__ __forceinline__ unsigned pk_mul_lo(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, (ushort2v)(__builtin_bit_cast(ushort2v, a) * __builtin_bit_cast(ushort2v, b)));
+}
+
+struct PackedGuard {
+    int energy = 0;   // sum of squared quantised coefficients (saturating)
+    int renergy = 0;  // sum of squared (saturated) row outputs (saturating)
+    int ymax = 0, ymin = 0;
+    int k128 = 128, kcol = 8192 + (128 << 14); // wave-uniform addends of the (b0, b4) dot products, kept in VGPRs
+    __device__ __forceinline__ void y2(int a, int b) { ymax = max(max(ymax, a), b); ymin = min(min(ymin, a), b); }
+};
+constexpr int GUARD_RE = 32767 * 32767; // renergy >= this  <=>  some |r| may have reached 32767
+
+// Row pass (dct.ml:11-54) of row R from the coefficient dwords; the eight outputs (>> 8) are returned
+// in o[0..7].  qp = the row's four packed quantiser pairs, in the order (1,7) (5,3) (2,6) (0,4).
+template <int R>
+__device__ __forceinline__ void idct_row_packed(const unsigned (&w)[32], const unsigned *__restrict__ qp, int (&o)[8],
+                                                PackedGuard &g) {
+    const unsigned A = pk_mul_lo(gather_pair<8 * R + 1, 8 * R + 7>(w), qp[0]); // (x4, x5)
+    const unsigned B = pk_mul_lo(gather_pair<8 * R + 5, 8 * R + 3>(w), qp[1]); // (x6, x7)
+    const unsigned C = pk_mul_lo(gather_pair<8 * R + 2, 8 * R + 6>(w), qp[2]); // (x3, x2)
+    const unsigned Z = pk_mul_lo(gather_pair<8 * R + 0, 8 * R + 4>(w), qp[3]); // (b0, b4)
+    const int n4 = dot2<0>(A, pk(W1, W7)), n5 = dot2<0>(A, pk(W7, -W1));
+    const int n6 = dot2<0>(B, pk(W5, W3)), n7 = dot2<0>(B, pk(W3, -W5));
+    const int n3 = dot2<0>(C, pk(W2, W6)), n2 = dot2<0>(C, pk(W6, -W2));
+    int x8 = dot2v(Z, pk(2048, 2048), g.k128);  // x0 + x1
+    int x0 = dot2v(Z, pk(2048, -2048), g.k128); // x0 - x1
+    const int x1 = n4 + n6, x6 = n5 + n7;
+    int x4 = n4 - n6, x5 = n5 - n7;
+    const int x7 = x8 + n3;
+    x8 = x8 - n3;
+    const int x3 = x0 + n2;
+    x0 = x0 - n2;
+    const int ys = x4 + x5, yd = x4 - x5;
+    g.y2(ys, yd);
+    const int x2 = mad24(181, ys, 128) >> 8;
+    x4 = mad24(181, yd, 128) >> 8;
+    o[0] = (x7 + x1) >> 8;
+    o[1] = (x3 + x2) >> 8;
+    o[2] = (x0 + x4) >> 8;
+    o[3] = (x8 + x6) >> 8;
+    o[4] = (x8 - x6) >> 8;
+    o[5] = (x0 - x4) >> 8;
+    o[6] = (x3 - x2) >> 8;
+    o[7] = (x7 - x1) >> 8;
+}
+
+// saturating pack of two row outputs into one column-pass operand pair + its share of the energy
+__device__ __forceinline__ unsigned pack_rows(int lo, int hi, PackedGuard &g) {
+    const unsigned p = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(lo, hi));
+    g.renergy = dot2_sat(p, p, g.renergy);
+    return p;
+}
+
+// Column pass (dct.ml:56-98) from the four operand pairs of one column; outputs unshifted, with the
+// +128 level shift of recon folded into the rounding constant (see k_decode_fast).
+__device__ __forceinline__ void idct_col_packed(unsigned A, unsigned B, unsigned C, unsigned Z, int (&o)[8],
+                                                PackedGuard &g) {
+    const int n4 = dot2<4>(A, pk(W1, W7)) >> 3, n5 = dot2<4>(A, pk(W7, -W1)) >> 3;
+    const int n6 = dot2<4>(B, pk(W5, W3)) >> 3, n7 = dot2<4>(B, pk(W3, -W5)) >> 3;
+    const int n3 = dot2<4>(C, pk(W2, W6)) >> 3, n2 = dot2<4>(C, pk(W6, -W2)) >> 3;
+    int x8 = dot2v(Z, pk(256, 256), g.kcol);
+    int x0 = dot2v(Z, pk(256, -256), g.kcol);
+    const int x1 = n4 + n6, x6 = n5 + n7;
+    int x4 = n4 - n6, x5 = n5 - n7;
+    const int x7 = x8 + n3;
+    x8 = x8 - n3;
+    const int x3 = x0 + n2;
+    x0 = x0 - n2;
+    const int ys = x4 + x5, yd = x4 - x5;
+    g.y2(ys, yd);
+    const int x2 = mad24(181, ys, 128) >> 8;
+    x4 = mad24(181, yd, 128) >> 8;
+    o[0] = x7 + x1;
+    o[1] = x3 + x2;
+    o[2] = x0 + x4;
+    o[3] = x8 + x6;
+    o[4] = x8 - x6;
+    o[5] = x0 - x4;
+    o[6] = x3 - x2;
+    o[7] = x7 - x1;
+}
+
+// two adjacent pixels of a row: sat_u8(a >> 14) | sat_u8(b >> 14) << 8 into one half of dst
+template <int HALF>
+__device__ __forceinline__ void ashr14_sat_pack2(unsigned &dst, int a, int b) {
+    if (HALF == 0)
+        asm("v_ashr_pk_u8_i32 %0, %1, %2, 14" : "=v"(dst) : "v"(a), "v"(b));
+    else
+        asm("v_ashr_pk_u8_i32 %0, %1, %2, 14 op_sel:[0,0,0,1]" : "+v"(dst) : "v"(a), "v"(b));
+}
+
+#ifndef HVC_PACKED_LB
+// Occupancy A/B on MI355X (same box, 40 steps, 256 frames): asking for 7 waves/SIMD makes the
+// scheduler stay within 72 VGPRs (66, no spill) and runs 0.453 ms; 5-6 waves 0.436-0.438 ms; left
+// free (<= 4 waves: 116 VGPRs, rows interleaved for ILP) 0.432 ms; 8 waves needs spills, 0.476 ms.
+// The kernel is HBM-bound (mem_ubench ceiling for this traffic shape 0.407 ms), so fewer, longer
+// waves with bursty memory phases win.
+#define HVC_PACKED_LB HVC_TILE, 4
+#endif
+__global__ __launch_bounds__(HVC_PACKED_LB) void k_decode_packed(DecodeParams P) {
+    BlockRef br;
+    const int lane = threadIdx.x;
+    const bool active = locate(P, blockIdx.y, blockIdx.x, lane, br);
+
+    const uint4 *src = reinterpret_cast<const uint4 *>(P.coefs + br.coef_idx);
+    unsigned w[32];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint4 t = src[j];
+        w[4 * j + 0] = t.x;
+        w[4 * j + 1] = t.y;
+        w[4 * j + 2] = t.z;
+        w[4 * j + 3] = t.w;
+    }
+    PackedGuard g;
+#pragma unroll
+    for (int d = 0; d < 32; d++) g.energy = dot2_sat(w[d], w[d], g.energy);
+
+    const unsigned *__restrict__ qp = P.qpair + br.qtab * 32; // wave-uniform, kernarg segment
+
+    // rows in the order that completes one column operand pair per two rows
+    unsigned cA[8], cB[8], cC[8], cZ[8];
+    {
+        int ra[8], rb[8];
+        idct_row_packed<1>(w, qp + 4 * 1, ra, g);
+        idct_row_packed<7>(w, qp + 4 * 7, rb, g);
+#pragma unroll
+        for (int c = 0; c < 8; c++) cA[c] = pack_rows(ra[c], rb[c], g); // (x4, x5) = (r1, r7)
+        idct_row_packed<5>(w, qp + 4 * 5, ra, g);
+        idct_row_packed<3>(w, qp + 4 * 3, rb, g);
+#pragma unroll
+        for (int c = 0; c < 8; c++) cB[c] = pack_rows(ra[c], rb[c], g); // (x6, x7) = (r5, r3)
+        idct_row_packed<2>(w, qp + 4 * 2, ra, g);
+        idct_row_packed<6>(w, qp + 4 * 6, rb, g);
+#pragma unroll
+        for (int c = 0; c < 8; c++) cC[c] = pack_rows(ra[c], rb[c], g); // (x3, x2) = (r2, r6)
+        idct_row_packed<0>(w, qp + 4 * 0, ra, g);
+        idct_row_packed<4>(w, qp + 4 * 4, rb, g);
+#pragma unroll
+        for (int c = 0; c < 8; c++) cZ[c] = pack_rows(ra[c], rb[c], g); // (b0, b4) = (r0, r4)
+    }
+
+    // columns two at a time: 16 results -> 8 row halves of the output dwords
+    unsigned out[8][2];
+#pragma unroll
+    for (int c = 0; c < 8; c += 2) {
+        int ca[8], cb[8];
+        idct_col_packed(cA[c], cB[c], cC[c], cZ[c], ca, g);
+        idct_col_packed(cA[c + 1], cB[c + 1], cC[c + 1], cZ[c + 1], cb, g);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if ((c & 2) == 0)
+                ashr14_sat_pack2<0>(out[j][c >> 2], ca[j], cb[j]);
+            else
+                ashr14_sat_pack2<1>(out[j][c >> 2], ca[j], cb[j]);
+        }
+    }
+
+    const bool bad = (g.energy > P.ethr_packed[br.qtab]) | (g.renergy >= GUARD_RE) | (g.ymax > GUARD_Y) |
+                     (g.ymin < -GUARD_Y);
+    if (active && !bad) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            store_row8(P.pixels + br.pix_idx + (size_t)j * br.stride, out[j][0], out[j][1]);
+    }
     const bool flag = active && bad;
     const unsigned long long m = __ballot(flag);
     if (m) {
@@ -475,7 +733,12 @@ hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0, hi
     hipError_t e;
     dim3 grid((unsigned)P.tiles_per_frame, (unsigned)P.n_frames, 1);
     if (k0 && (e = hipEventRecord(k0, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_decode_fast, grid, dim3(HVC_TILE), 0, s, P);
+    // HVC_DECODE_KERNEL=v2 selects the unpacked int32 kernel (A/B measurements only)
+    static const bool use_v2 = [] { const char *v = getenv("HVC_DECODE_KERNEL"); return v && v[0] == 'v' && v[1] == '2'; }();
+    if (use_v2)
+        hipLaunchKernelGGL(k_decode_fast, grid, dim3(HVC_TILE), 0, s, P);
+    else
+        hipLaunchKernelGGL(k_decode_packed, grid, dim3(HVC_TILE), 0, s, P);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (k1 && (e = hipEventRecord(k1, s)) != hipSuccess) return e;
