@@ -56,7 +56,10 @@ typedef enum hvc_status {
     HVC_E_ALIGNMENT = -4,    /* plane pointer/stride not 8-byte aligned, coefs not 16-byte aligned */
     HVC_E_RANGE = -5,        /* quantiser entry 0, or encoder output outside int16 */
     HVC_E_OUT_OF_MEMORY = -6,
-    HVC_E_TOO_LARGE = -7     /* plane geometry beyond the kernel's index range */
+    HVC_E_TOO_LARGE = -7,    /* plane geometry beyond the kernel's index range */
+    HVC_E_BAD_JPEG = -8,     /* the model would raise: missing frame/scan/table, invalid Huffman code,
+                                coefficient index out of range (decoder.ml:92, 101, 136, 228-243, 291) */
+    HVC_E_UNSUPPORTED_MARKER = -9 /* "unsupported marker code" (decoder.ml:67) */
 } hvc_status;
 
 /* where the data pointers of a call live */
@@ -156,6 +159,69 @@ HVC_API int hvc_encode_frames(hvc_ctx *ctx, const uint8_t *pixels, size_t pixel_
 HVC_API int hvc_upsample420(hvc_ctx *ctx, const uint8_t *src, int cw, int ch, size_t src_stride,
                             uint8_t *dst, size_t dst_stride, int n_planes, size_t src_plane_stride,
                             size_t dst_plane_stride, int where);
+
+/* ------------------------------------------------------------------------- */
+/* Host front end / back end around the block stage:
+ * the callers and data formats either side of the hot path.  Host C++ only. */
+
+typedef struct hvc_jpeg_component { /* Decoder.Component.t geometry, decoder.ml:167-187, 304-345 */
+    int identifier, hscale, vscale;
+    int decoded_width, decoded_height; /* padded plane: rounded to the MCU */
+    int actual_width, actual_height;   /* cropped size of get_yuv_frame */
+    int dc_table, ac_table;            /* Huffman table selectors of the scan */
+} hvc_jpeg_component;
+
+typedef struct hvc_jpeg_info {
+    int width, height, n_comp;     /* Markers.Sof / Sos; components in scan order */
+    int n_qtabs;
+    hvc_jpeg_component comp[4];
+    hvc_component layout[4];       /* tight frame record: planes / coefficient planes back to back */
+    uint16_t qtabs[4][64];         /* tables layout[].qtab refers to (Markers.Dqt.elements order) */
+    size_t coef_count;             /* int16 elements of one frame's coefficient record */
+    size_t pixel_bytes;            /* bytes of one frame's padded pixel record */
+    size_t ecs_offset;             /* byte offset of the entropy-coded segment */
+} hvc_jpeg_info;
+
+/* Decoder.Header.decode (decoder.ml:36-70) + the geometry of Decoder.init (:294-345). */
+HVC_API int hvc_jpeg_read_header(const uint8_t *jpeg, size_t n, hvc_jpeg_info *info);
+/* The Huffman + DC-prediction half of Decoder.decode in decode_seq order (decoder.ml:118-140, 143,
+ * 261-281, 362-395) into one frame's coefficient record (host memory, info->coef_count int16). */
+HVC_API int hvc_jpeg_entropy_decode(const uint8_t *jpeg, size_t n, const hvc_jpeg_info *info, int16_t *coefs);
+/* Decoder.get_yuv_frame (decoder.ml:403-420): cropped planes back to back (Frame.output order). */
+HVC_API int hvc_jpeg_get_yuv_frame(const hvc_jpeg_info *info, const uint8_t *pixels, uint8_t *out, size_t cap,
+                                   size_t *out_len);
+/* Decoder.decode_a_frame minus the crop (decoder.ml:422-427): header, host entropy decode, GPU block
+ * stage; `pixels` (host, info->pixel_bytes) receives the padded planes = get_decoded_planes. */
+HVC_API int hvc_jpeg_decode(hvc_ctx *ctx, const uint8_t *jpeg, size_t n, hvc_jpeg_info *info, uint8_t *pixels,
+                            size_t pixel_cap);
+
+/* BASELINE config 3: a batch of baseline JPEGs of identical geometry and tables.  `threads` host
+ * threads run the entropy decode into pinned chunk buffers; each finished chunk goes to the GPU with
+ * hipMemcpyAsync on a copy stream while the block-stage kernel of the previous chunk runs on the
+ * compute stream and the host decodes the next one.  pixels: n padded pixel records
+ * (pixel_frame_stride bytes apart; `where` says host or device memory). */
+typedef struct hvc_batch_stats {
+    double wall_ms, entropy_ms_sum, h2d_ms_sum, kernel_ms_sum, d2h_ms_sum; /* sums over chunks */
+    int chunks, threads, frames_per_chunk;
+    uint64_t coef_bytes;
+} hvc_batch_stats;
+HVC_API int hvc_jpeg_decode_batch(hvc_ctx *ctx, const uint8_t *const *jpegs, const size_t *sizes, int n_frames,
+                                  int threads, int frames_per_chunk, uint8_t *pixels, size_t pixel_frame_stride,
+                                  int where, hvc_batch_stats *stats);
+
+/* Quant_tables.scale Quant_tables.luma/chroma quality (quant_tables.ml:139-147). */
+HVC_API int hvc_quant_table(int chroma_table, int quality, uint16_t *out64);
+/* Encoder.Parameters.c420/c422/c444 + Encoder.create geometry (encoder.ml:287-349, 437-472): chroma is
+ * 420, 422 or 444.  Fills the padded plane layout (zero padding, plane.ml:11-17) and the tables. */
+HVC_API int hvc_jpeg_encoder_layout(int width, int height, int chroma, int quality, hvc_jpeg_info *info);
+/* Encoder.write_headers + rle + write_bits + EOI over a coefficient record (encoder.ml:127-193,
+ * 371-418, 476-510): byte-identical to Model.Encoder's output. */
+HVC_API int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uint8_t *out, size_t cap,
+                                    size_t *out_len);
+/* Encoder.encode_420/422/444 ~frame ~quality (encoder.ml:512-541): y/u/v are the tight planes of the
+ * frame (Frame.create sizes); padding, GPU forward stage and host entropy coding inside. */
+HVC_API int hvc_jpeg_encode(hvc_ctx *ctx, const uint8_t *y, const uint8_t *u, const uint8_t *v, int width,
+                            int height, int chroma, int quality, uint8_t *out, size_t cap, size_t *out_len);
 
 /* Device memory helpers so that a binding needs no HIP of its own. */
 HVC_API int hvc_device_alloc(hvc_ctx *ctx, size_t bytes, void **out);

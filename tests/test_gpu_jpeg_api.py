@@ -1,0 +1,128 @@
+"""End-to-end entry points through the C ABI on the GPU: whole-file decode
+(Decoder.decode_a_frame), whole-frame encode (Encoder.encode_4xx) and the batch
+pipeline of BASELINE config 3, against the CPU oracle and the reference's golden
+files / PSNR pins."""
+import numpy as np
+import pytest
+
+from conftest import golden_bytes, golden_json
+from helpers import synth_pixels
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import video_coding_amd as hvc
+    c = hvc.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("fn", ["mini.jpg", "Mouse480.jpg"])
+def test_decode_a_frame(ctx, fn):
+    import video_coding_amd as hvc
+    data = golden_bytes(fn)
+    info, pixels = ctx.jpeg_decode(data)
+    d = orc.Decoder(data)
+    d.decode()
+    for i, plane in enumerate(info.planes(pixels)):
+        assert np.array_equal(plane, d.plane(i)), (fn, i)          # get_decoded_planes
+    want = np.concatenate([p.reshape(-1) for p in d.get_yuv_frame()])
+    assert np.array_equal(hvc.hvc.jpeg_get_yuv_frame(info, pixels), want)  # get_yuv_frame
+
+
+@pytest.mark.parametrize("idx", range(5))
+def test_g4_psnr_pins_through_the_product_path(ctx, idx):
+    """jpeg/test/model-encode-and-decode.t with BOTH directions on the GPU path: encode the reference
+    frame, decode it, PSNR against the source printed like `oyuv compare psnr` -- equals the pin."""
+    import video_coding_amd as hvc
+    c = golden_json("g4_psnr_pins.json")["cases"][idx]
+    w, h, chroma = c["width"], c["height"], c["chroma"]
+    y, u, v = orc.split_yuv(golden_bytes(c["file"]), w, h, chroma)
+    jpg = ctx.jpeg_encode(y, u, v, w, h, chroma, c["quality"])
+    assert jpg == orc.encode_yuv(y, u, v, w, h, chroma, c["quality"])
+    info, pixels = ctx.jpeg_decode(jpg)
+    frame = hvc.hvc.jpeg_get_yuv_frame(info, pixels)
+    planes, off = [], 0
+    for i in range(3):
+        n = info.comp[i].actual_width * info.comp[i].actual_height
+        planes.append(frame[off:off + n].reshape(info.comp[i].actual_height, info.comp[i].actual_width))
+        off += n
+    got = [orc.ocaml_float_to_string(orc.psnr(a, b)) for a, b in zip((y, u, v), planes)]
+    assert got == c["psnr"]
+
+
+def test_g3_encode_mini_jpg_byte_exact(ctx):
+    y, u, v = orc.split_yuv(golden_bytes("mini64x64.420"), 64, 64, 420)
+    assert ctx.jpeg_encode(y, u, v, 64, 64, 420, 75) == golden_bytes("mini.jpg")
+
+
+@pytest.mark.parametrize("w,h,chroma,q", [(52, 44, 420, 95), (130, 70, 422, 40), (33, 17, 444, 80), (1920, 1080, 420, 75)])
+def test_encode_decode_various_sizes(ctx, w, h, chroma, q):
+    cw, ch = orc.chroma_dims(chroma, w, h)
+    r8 = lambda x: (x + 7) // 8 * 8
+    y = synth_pixels(1 + w, r8(h), r8(w))[:h, :w]
+    u = synth_pixels(2 + w, r8(ch), r8(cw))[:ch, :cw]
+    v = synth_pixels(3 + w, r8(ch), r8(cw))[:ch, :cw]
+    jpg = ctx.jpeg_encode(y, u, v, w, h, chroma, q)
+    assert jpg == orc.encode_yuv(y, u, v, w, h, chroma, q)
+    info, pixels = ctx.jpeg_decode(jpg)
+    d = orc.Decoder(jpg)
+    d.decode()
+    for i, plane in enumerate(info.planes(pixels)):
+        assert np.array_equal(plane, d.plane(i))
+
+
+def _make_jpegs(n, w, h, q=75):
+    out = []
+    for f in range(n):
+        y = synth_pixels(100 + f, h, w)
+        u = synth_pixels(200 + f, h // 2, w // 2)
+        v = synth_pixels(300 + f, h // 2, w // 2)
+        out.append(orc.encode_yuv(y, u, v, w, h, 420, q))
+    return out
+
+
+@pytest.mark.parametrize("threads,chunk", [(1, 1), (4, 3), (8, 32)])
+def test_batch_pipeline_host_output(ctx, threads, chunk):
+    import video_coding_amd as hvc
+    jpegs = _make_jpegs(11, 96, 64)
+    info = hvc.hvc.jpeg_read_header(jpegs[0])
+    stride = info.pixel_bytes
+    pixels = np.zeros(len(jpegs) * stride, dtype=np.uint8)
+    st = ctx.jpeg_decode_batch(jpegs, pixels, stride, threads=threads, frames_per_chunk=chunk)
+    assert st.chunks == (len(jpegs) + min(chunk, len(jpegs)) - 1) // min(chunk, len(jpegs))
+    for f, j in enumerate(jpegs):
+        d = orc.Decoder(j)
+        d.decode()
+        for i, plane in enumerate(info.planes(pixels[f * stride:(f + 1) * stride])):
+            assert np.array_equal(plane, d.plane(i)), (f, i)
+
+
+def test_batch_pipeline_device_output_and_reuse(ctx):
+    import torch
+    import video_coding_amd as hvc
+    jpegs = _make_jpegs(9, 64, 48, q=50)
+    info = hvc.hvc.jpeg_read_header(jpegs[0])
+    stride = info.pixel_bytes
+    for rep in range(2):  # second call reuses the pinned ring
+        d_pix = torch.zeros(len(jpegs) * stride, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ctx.jpeg_decode_batch(jpegs, d_pix, stride, threads=3, frames_per_chunk=4)
+        got = d_pix.cpu().numpy()
+        for f, j in enumerate(jpegs):
+            d = orc.Decoder(j)
+            d.decode()
+            for i, plane in enumerate(info.planes(got[f * stride:(f + 1) * stride])):
+                assert np.array_equal(plane, d.plane(i)), (rep, f, i)
+
+
+def test_batch_rejects_mixed_geometry(ctx):
+    import video_coding_amd as hvc
+    jpegs = _make_jpegs(2, 64, 48) + _make_jpegs(1, 32, 32)
+    info = hvc.hvc.jpeg_read_header(jpegs[0])
+    pixels = np.zeros(3 * info.pixel_bytes, dtype=np.uint8)
+    with pytest.raises(hvc.HvcError):
+        ctx.jpeg_decode_batch(jpegs, pixels, info.pixel_bytes, threads=2, frames_per_chunk=2)

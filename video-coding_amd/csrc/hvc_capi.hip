@@ -3,10 +3,16 @@
 // blocks, staging for host-memory callers, streams and events.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <thread>
+#include <vector>
 
 #include "../../include/hvc_jpeg.h"
 #include "hvc_kernels.h"
@@ -30,6 +36,12 @@ struct hvc_ctx {
     void *d_in = nullptr, *d_out = nullptr;
     size_t in_cap = 0, out_cap = 0;
     int last_hip = 0;
+    // hvc_jpeg_decode_batch: copy stream + ring of pinned host / device coefficient chunks
+    static constexpr int RING = 3;
+    hipStream_t copy_stream = nullptr;
+    void *h_ring[RING] = {}, *d_ring[RING] = {}, *d_oring[RING] = {};
+    size_t ring_bytes = 0, oring_bytes = 0;
+    hipEvent_t ev_h2d[RING] = {}, ev_kern[RING] = {}, ev_t[4] = {};
 };
 
 namespace {
@@ -140,6 +152,8 @@ const char *hvc_strerror(int code) {
     case HVC_E_RANGE: return "value out of range";
     case HVC_E_OUT_OF_MEMORY: return "out of device memory";
     case HVC_E_TOO_LARGE: return "plane geometry too large";
+    case HVC_E_BAD_JPEG: return "malformed or unsupported JPEG stream";
+    case HVC_E_UNSUPPORTED_MARKER: return "unsupported marker code";
     default: return "unknown hvc error";
     }
 }
@@ -188,6 +202,16 @@ void hvc_destroy(hvc_ctx *c) {
         if (c->k0[i]) (void)hipEventDestroy(c->k0[i]);
         if (c->k1[i]) (void)hipEventDestroy(c->k1[i]);
     }
+    for (int i = 0; i < hvc_ctx::RING; i++) {
+        if (c->h_ring[i]) (void)hipHostFree(c->h_ring[i]);
+        if (c->d_ring[i]) (void)hipFree(c->d_ring[i]);
+        if (c->d_oring[i]) (void)hipFree(c->d_oring[i]);
+        if (c->ev_h2d[i]) (void)hipEventDestroy(c->ev_h2d[i]);
+        if (c->ev_kern[i]) (void)hipEventDestroy(c->ev_kern[i]);
+    }
+    for (int i = 0; i < 4; i++)
+        if (c->ev_t[i]) (void)hipEventDestroy(c->ev_t[i]);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -551,6 +575,242 @@ int hvc_upsample420(hvc_ctx *c, const uint8_t *src, int cw, int ch, size_t src_s
                                    dst_stride, (size_t)cw * 2, (size_t)ch * 2, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HVC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// single-frame conveniences (host memory)
+
+// Decoder.decode_a_frame minus the crop (decoder.ml:422-427)
+int hvc_jpeg_decode(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_info *info, uint8_t *pixels, size_t pixel_cap) {
+    if (!c || !jpeg || !info || !pixels) return HVC_E_INVALID_ARG;
+    int r = hvc_jpeg_read_header(jpeg, n, info);
+    if (r) return r;
+    if (pixel_cap < info->pixel_bytes) return HVC_E_INVALID_ARG;
+    std::vector<int16_t> coefs;
+    try {
+        coefs.resize(info->coef_count);
+    } catch (const std::bad_alloc &) {
+        return HVC_E_OUT_OF_MEMORY;
+    }
+    r = hvc_jpeg_entropy_decode(jpeg, n, info, coefs.data());
+    if (r) return r;
+    return hvc_decode_frames(c, coefs.data(), info->coef_count, &info->qtabs[0][0], info->n_qtabs, info->layout,
+                             info->n_comp, 1, pixels, info->pixel_bytes, HVC_MEM_HOST);
+}
+
+// Encoder.encode_420/422/444 (encoder.ml:512-541)
+int hvc_jpeg_encode(hvc_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v, int width, int height, int chroma,
+                    int quality, uint8_t *out, size_t cap, size_t *out_len) {
+    if (!c || !y || !u || !v || !out_len) return HVC_E_INVALID_ARG;
+    hvc_jpeg_info info;
+    int r = hvc_jpeg_encoder_layout(width, height, chroma, quality, &info);
+    if (r) return r;
+    std::vector<uint8_t> planes;
+    std::vector<int16_t> coefs;
+    try {
+        planes.assign(info.pixel_bytes, 0); // Plane.create is zero-filled (plane.ml:11-17)
+        coefs.resize(info.coef_count);
+    } catch (const std::bad_alloc &) {
+        return HVC_E_OUT_OF_MEMORY;
+    }
+    // Plane.blit_available of the frame's planes into the padded ones (encoder.ml:514-516; frame.ml:10-41)
+    const uint8_t *src[3] = {y, u, v};
+    const int cw = chroma == 444 ? width : width / 2, ch = chroma == 420 ? height / 2 : height;
+    const int sw[3] = {width, cw, cw}, sh[3] = {height, ch, ch};
+    for (int i = 0; i < 3; i++) {
+        const int bw = sw[i] < info.comp[i].decoded_width ? sw[i] : info.comp[i].decoded_width;
+        const int bh = sh[i] < info.comp[i].decoded_height ? sh[i] : info.comp[i].decoded_height;
+        for (int row = 0; row < bh; row++)
+            std::memcpy(planes.data() + info.layout[i].plane_offset + (size_t)row * info.layout[i].stride,
+                        src[i] + (size_t)row * sw[i], (size_t)bw);
+    }
+    r = hvc_encode_frames(c, planes.data(), info.pixel_bytes, &info.qtabs[0][0], info.n_qtabs, info.layout, 3, 1,
+                          coefs.data(), info.coef_count, HVC_MEM_HOST);
+    if (r) return r;
+    return hvc_jpeg_entropy_encode(&info, coefs.data(), out, cap, out_len);
+}
+
+// ---------------------------------------------------------------------------
+// BASELINE config 3: host Huffman || hipMemcpyAsync (copy stream) || block-stage kernel (compute stream)
+int hvc_jpeg_decode_batch(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *sizes, int n_frames, int threads,
+                          int frames_per_chunk, uint8_t *pixels, size_t pixel_fs, int where, hvc_batch_stats *stats) {
+    if (!c || !jpegs || !sizes || !pixels || n_frames < 0) return HVC_E_INVALID_ARG;
+    if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (n_frames == 0) return HVC_OK;
+    hvc_jpeg_info info0;
+    int r = hvc_jpeg_read_header(jpegs[0], sizes[0], &info0);
+    if (r) return r;
+    if (pixel_fs < info0.pixel_bytes || (pixel_fs & 7)) return HVC_E_INVALID_ARG;
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    if (frames_per_chunk < 1) frames_per_chunk = 32;
+    if (frames_per_chunk > n_frames) frames_per_chunk = n_frames;
+    const int C = frames_per_chunk, NB = hvc_ctx::RING;
+    const int n_chunks = (n_frames + C - 1) / C;
+    const size_t frame_coef_bytes = info0.coef_count * sizeof(int16_t);
+    const size_t ring_bytes = frame_coef_bytes * (size_t)C;
+    const size_t oring_bytes = where == HVC_MEM_HOST ? info0.pixel_bytes * (size_t)C : 0;
+
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
+    if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < NB; i++) {
+        if (!c->ev_h2d[i]) HIPCHK(c, hipEventCreate(&c->ev_h2d[i]));
+        if (!c->ev_kern[i]) HIPCHK(c, hipEventCreate(&c->ev_kern[i]));
+    }
+    for (int i = 0; i < 4; i++)
+        if (!c->ev_t[i]) HIPCHK(c, hipEventCreate(&c->ev_t[i]));
+    if (ring_bytes > c->ring_bytes) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+        for (int i = 0; i < NB; i++) {
+            if (c->h_ring[i]) (void)hipHostFree(c->h_ring[i]);
+            if (c->d_ring[i]) (void)hipFree(c->d_ring[i]);
+            c->h_ring[i] = c->d_ring[i] = nullptr;
+        }
+        c->ring_bytes = 0;
+        for (int i = 0; i < NB; i++) {
+            if (hipHostMalloc(&c->h_ring[i], ring_bytes, hipHostMallocDefault) != hipSuccess ||
+                hipMalloc(&c->d_ring[i], ring_bytes) != hipSuccess)
+                return HVC_E_OUT_OF_MEMORY;
+        }
+        c->ring_bytes = ring_bytes;
+    }
+    if (oring_bytes > c->oring_bytes) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < NB; i++) {
+            if (c->d_oring[i]) (void)hipFree(c->d_oring[i]);
+            c->d_oring[i] = nullptr;
+        }
+        c->oring_bytes = 0;
+        for (int i = 0; i < NB; i++)
+            if (hipMalloc(&c->d_oring[i], oring_bytes) != hipSuccess) return HVC_E_OUT_OF_MEMORY;
+        c->oring_bytes = oring_bytes;
+    }
+
+    // worker threads pull frames in order; a frame's chunk slot must have been released (its previous
+    // occupant uploaded) before they write into it
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<int> next_frame{0};
+    std::atomic<int> error{0};
+    std::vector<int> done_in_chunk((size_t)n_chunks, 0);
+    int released_upto = NB - 1; // chunks 0..NB-1 may be written at once
+    std::atomic<long long> entropy_ns{0};
+    auto worker = [&]() {
+        for (;;) {
+            const int f = next_frame.fetch_add(1);
+            if (f >= n_frames || error.load()) return;
+            const int k = f / C, slot = k % NB;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return k <= released_upto || error.load(); });
+            }
+            if (error.load()) return;
+            const auto t0 = std::chrono::steady_clock::now();
+            hvc_jpeg_info fi;
+            int e = hvc_jpeg_read_header(jpegs[f], sizes[f], &fi);
+            if (!e && (fi.n_comp != info0.n_comp || fi.n_qtabs != info0.n_qtabs || fi.coef_count != info0.coef_count ||
+                       std::memcmp(fi.layout, info0.layout, sizeof fi.layout) ||
+                       std::memcmp(fi.qtabs, info0.qtabs, sizeof fi.qtabs)))
+                e = HVC_E_INVALID_ARG; // a batch shares one geometry and one set of tables
+            if (!e)
+                e = hvc_jpeg_entropy_decode(jpegs[f], sizes[f], &fi,
+                                            (int16_t *)c->h_ring[slot] + (size_t)(f - k * C) * info0.coef_count);
+            entropy_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            std::lock_guard<std::mutex> lk(mu);
+            if (e) error.store(e);
+            done_in_chunk[(size_t)k]++;
+            cv.notify_all();
+        }
+    };
+    const auto wall0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++) pool.emplace_back(worker);
+
+    int rc = HVC_OK;
+    double h2d_ms = 0, k_ms = 0, d2h_ms = 0;
+    hipStream_t compute = c->stream;
+    for (int k = 0; k < n_chunks && rc == HVC_OK; k++) {
+        const int slot = k % NB, first = k * C, cnt = (first + C <= n_frames) ? C : n_frames - first;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return done_in_chunk[(size_t)k] == cnt || error.load(); });
+        }
+        if (error.load()) { rc = error.load(); break; }
+        hipError_t he = hipSuccess;
+        uint8_t *dst = where == HVC_MEM_DEVICE ? pixels + (size_t)first * pixel_fs : (uint8_t *)c->d_oring[slot];
+        const size_t dst_fs = where == HVC_MEM_DEVICE ? pixel_fs : info0.pixel_bytes;
+        // the device chunk (and output ring slot) is reused every NB chunks: its previous kernel must be done
+        if (k >= NB) he = hipStreamWaitEvent(c->copy_stream, c->ev_kern[slot], 0);
+        if (he == hipSuccess) he = hipEventRecord(c->ev_t[0], c->copy_stream);
+        if (he == hipSuccess)
+            he = hipMemcpyAsync(c->d_ring[slot], c->h_ring[slot], frame_coef_bytes * (size_t)cnt, hipMemcpyHostToDevice,
+                                c->copy_stream);
+        if (he == hipSuccess) he = hipEventRecord(c->ev_h2d[slot], c->copy_stream);
+        if (he == hipSuccess) he = hipStreamWaitEvent(compute, c->ev_h2d[slot], 0);
+        if (he != hipSuccess) { rc = fail_hip(c, he); break; }
+        const bool prof_saved = c->profiling;
+        c->profiling = false;
+        he = hipEventRecord(c->ev_t[1], compute);
+        rc = hvc_decode_frames(c, (const int16_t *)c->d_ring[slot], info0.coef_count, &info0.qtabs[0][0], info0.n_qtabs,
+                               info0.layout, info0.n_comp, cnt, dst, dst_fs, HVC_MEM_DEVICE);
+        c->profiling = prof_saved;
+        if (rc) break;
+        if (he == hipSuccess) he = hipEventRecord(c->ev_t[2], compute);
+        if (he == hipSuccess && where == HVC_MEM_HOST) {
+            for (int f = 0; f < cnt && he == hipSuccess; f++)
+                he = hipMemcpyAsync(pixels + (size_t)(first + f) * pixel_fs, dst + (size_t)f * dst_fs, info0.pixel_bytes,
+                                    hipMemcpyDeviceToHost, compute);
+        }
+        if (he == hipSuccess) he = hipEventRecord(c->ev_kern[slot], compute);
+        if (he == hipSuccess) he = hipEventRecord(c->ev_t[3], compute);
+        // wait for this chunk's upload, then hand the pinned slot to chunk k + NB
+        if (he == hipSuccess) he = hipEventSynchronize(c->ev_h2d[slot]);
+        if (he != hipSuccess) { rc = fail_hip(c, he); break; }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            released_upto = k + NB;
+            cv.notify_all();
+        }
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev_t[0], c->ev_h2d[slot]) == hipSuccess) h2d_ms += ms;
+        // kernel / d2h times of this chunk are read once it has finished; keep the loop asynchronous by
+        // reading them only for the chunk that just left the ring (below) or at the end
+        if (k == n_chunks - 1 || true) {
+            if (hipEventSynchronize(c->ev_t[3]) == hipSuccess) {
+                if (hipEventElapsedTime(&ms, c->ev_t[1], c->ev_t[2]) == hipSuccess) k_ms += ms;
+                if (hipEventElapsedTime(&ms, c->ev_t[2], c->ev_t[3]) == hipSuccess) d2h_ms += ms;
+            }
+        }
+    }
+    if (rc != HVC_OK) {
+        std::lock_guard<std::mutex> lk(mu);
+        error.store(rc);
+        cv.notify_all();
+    }
+    for (auto &t : pool) t.join();
+    if (rc == HVC_OK) {
+        hipError_t he = hipStreamSynchronize(compute);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->copy_stream);
+        if (he != hipSuccess) rc = fail_hip(c, he);
+    } else {
+        (void)hipStreamSynchronize(compute);
+        (void)hipStreamSynchronize(c->copy_stream);
+    }
+    if (stats) {
+        stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        stats->entropy_ms_sum = (double)entropy_ns.load() * 1e-6;
+        stats->h2d_ms_sum = h2d_ms;
+        stats->kernel_ms_sum = k_ms;
+        stats->d2h_ms_sum = d2h_ms;
+        stats->chunks = n_chunks;
+        stats->threads = threads;
+        stats->frames_per_chunk = C;
+        stats->coef_bytes = (uint64_t)frame_coef_bytes * (uint64_t)n_frames;
+    }
+    return rc;
 }
 
 } // extern "C"

@@ -1,0 +1,612 @@
+// hvc_entropy.cpp -- host side of the JPEG model around the GPU block stage:
+//   * front end:  Decoder.Header.decode + Decoder.init geometry + the Huffman /
+//     DC-prediction half of Decoder.decode_block, producing the coefficient
+//     records the kernels consume            (jpeg/model/src/decoder.ml:5-140, 226-345, 362-395)
+//   * back end:   Encoder.write_headers + rle + write_bits over the coefficient
+//     planes the encode kernel produces      (jpeg/model/src/encoder.ml:127-193, 207-264, 371-418, 476-510)
+// Plain C++ (no HIP): the sequential entropy coding stays on the host by design
+// (BASELINE.json north_star); it is written for throughput (64-bit bit buffer,
+// one table lookup per symbol, frames decoded in parallel by the caller's
+// threads), not as a transliteration.  Behaviour follows the model, including its
+// quirks: one table per DQT/DHT segment, the entropy-coded segment ends at the
+// first marker (restart markers unsupported), reads past the end yield zero bits.
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/hvc_jpeg.h"
+#include "hvc_kernels.h"
+
+namespace {
+
+using hvc::HVC_ZF;
+
+// ---------------------------------------------------------------------------
+// header parsing (Decoder.Header.decode, decoder.ml:24-70; Markers.*.decode, markers.ml)
+struct ByteReader {
+    const uint8_t *p;
+    size_t n, pos = 0;
+    int get8() { return pos < n ? p[pos++] : (pos++, 0); } // Bits.get past the end reads zeros
+    int get16() { int a = get8(); return (a << 8) | get8(); }
+};
+
+struct HuffSpec {
+    int lengths[16];
+    int values[256];
+    int total = 0;
+};
+struct DhtSeg { int tclass, id; HuffSpec spec; };
+struct DqtSeg { int id; uint16_t q[64]; };
+
+struct Header {
+    int width = 0, height = 0, ncomp_frame = 0;
+    int cid[4], ch[4], cv[4], ctq[4];
+    int ncomp_scan = 0;
+    int ssel[4], sdc[4], sac[4];
+    std::vector<DqtSeg> dqt; // in file order; lookups take the LAST match like the model's cons-list
+    std::vector<DhtSeg> dht;
+    bool have_frame = false, have_scan = false;
+    size_t ecs_pos = 0; // byte position right after the SOS header
+};
+
+int parse_header(const uint8_t *data, size_t n, Header &h) {
+    ByteReader r{data, n};
+    for (;;) {
+        // find_marker (decoder.ml:24-29): skip bytes until 0xff
+        for (;;) {
+            if (r.pos > n + 8) return HVC_E_BAD_JPEG;
+            if (r.get8() == 0xff) break;
+        }
+        const int mc = r.get8();
+        if (mc == 0xc0) { // SOF0, markers.ml:49-59
+            (void)r.get16();
+            (void)r.get8();
+            h.height = r.get16();
+            h.width = r.get16();
+            h.ncomp_frame = r.get8();
+            if (h.ncomp_frame > 4) return HVC_E_BAD_JPEG;
+            for (int i = 0; i < h.ncomp_frame; i++) {
+                h.cid[i] = r.get8();
+                const int hv = r.get8();
+                h.ch[i] = hv >> 4;
+                h.cv[i] = hv & 15;
+                h.ctq[i] = r.get8();
+            }
+            h.have_frame = true;
+        } else if (mc == 0xda) { // SOS, markers.ml:111-129
+            (void)r.get16();
+            h.ncomp_scan = r.get8();
+            if (h.ncomp_scan > 4) return HVC_E_BAD_JPEG;
+            for (int i = 0; i < h.ncomp_scan; i++) {
+                h.ssel[i] = r.get8();
+                const int t = r.get8();
+                h.sdc[i] = t >> 4;
+                h.sac[i] = t & 15;
+            }
+            (void)r.get8();
+            (void)r.get8();
+            (void)r.get8();
+            h.have_scan = true;
+            h.ecs_pos = r.pos;
+            return HVC_OK;
+        } else if (mc == 0xdb) { // DQT, markers.ml:162-167: ONE table per segment
+            (void)r.get16();
+            const int pq = r.get8();
+            DqtSeg s;
+            s.id = pq & 15;
+            const bool wide = (pq >> 4) != 0; // element_precision = 8 lsl (pq >> 4)
+            if ((pq >> 4) > 1) return HVC_E_BAD_JPEG;
+            for (int i = 0; i < 64; i++) s.q[i] = (uint16_t)(wide ? r.get16() : r.get8());
+            h.dqt.push_back(s);
+        } else if (mc == 0xc4) { // DHT, markers.ml:209-217: ONE table per segment
+            (void)r.get16();
+            const int tc = r.get8();
+            DhtSeg s;
+            s.tclass = tc >> 4;
+            s.id = tc & 15;
+            int total = 0;
+            for (int i = 0; i < 16; i++) total += (s.spec.lengths[i] = r.get8());
+            if (total > 256) return HVC_E_BAD_JPEG;
+            for (int i = 0; i < total; i++) s.spec.values[i] = r.get8();
+            s.spec.total = total;
+            h.dht.push_back(s);
+        } else if (mc == 0xdd) { // DRI: parsed and ignored, like the model (decoder.ml:56-59)
+            (void)r.get16();
+            (void)r.get16();
+        } else if (mc == 0xd8) { // SOI
+        } else if ((mc >= 0xe0 && mc <= 0xef) || mc == 0xfe) { // APPn / COM: skip (decoder.ml:31-34)
+            // Bits.show 16 then advance len*8: the length field itself is part of the skipped bytes
+            const size_t at = r.pos;
+            const int len = r.get16();
+            r.pos = at + (size_t)len;
+        } else {
+            return HVC_E_UNSUPPORTED_MARKER; // decoder.ml:67
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Huffman decode tables (Tables.Specification.create_code_table, tables.ml:27-45; Tables.Lut.create :490-501)
+struct Lut {
+    int max_bits = 0;
+    std::vector<uint16_t> e; // (length << 8) | data ; 0 = no code
+    bool build(const HuffSpec &s) {
+        int maxb = 0;
+        for (int i = 0; i < 16; i++)
+            if (s.lengths[i]) maxb = i + 1;
+        max_bits = maxb;
+        e.assign((size_t)1 << maxb, 0);
+        unsigned code = 0;
+        int k = 0;
+        for (int len = 1; len <= 16; len++) {
+            for (int i = 0; i < s.lengths[len - 1]; i++, k++) {
+                if (len > maxb) return false;
+                const unsigned first = (code + (unsigned)i) << (maxb - len);
+                const unsigned count = 1u << (maxb - len);
+                if (first + count > e.size()) return false; // over-subscribed table
+                for (unsigned j = 0; j < count; j++) e[first + j] = (uint16_t)((len << 8) | s.values[k]);
+            }
+            code = (code + (unsigned)s.lengths[len - 1]) << 1;
+        }
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// bit reader over the extracted entropy-coded segment (stuffing already removed)
+struct BitReader {
+    const uint8_t *p;
+    size_t n, pos = 0;
+    uint64_t buf = 0; // MSB-aligned
+    int cnt = 0;
+    inline void refill() {
+        while (cnt <= 56) {
+            const uint64_t b = pos < n ? p[pos] : 0; // past the end: zero bits (bitstream_reader.ml:19-22)
+            pos++;
+            buf |= b << (56 - cnt);
+            cnt += 8;
+        }
+    }
+    inline unsigned peek(int k) const { return k ? (unsigned)(buf >> (64 - k)) : 0u; }
+    inline void skip(int k) { buf <<= k; cnt -= k; }
+};
+
+// decoder.ml:73-79 mag'
+inline int extend(int cat, unsigned code) {
+    return (code & (1u << (cat - 1))) ? (int)code : (int)code - (int)((1u << cat) - 1);
+}
+
+} // namespace
+
+// ===========================================================================
+extern "C" {
+
+// Decoder.Header.decode + the geometry of Decoder.init (decoder.ml:294-345)
+int hvc_jpeg_read_header(const uint8_t *data, size_t n, hvc_jpeg_info *info) {
+    if (!data || !info) return HVC_E_INVALID_ARG;
+    std::memset(info, 0, sizeof *info);
+    Header h;
+    int r = parse_header(data, n, h);
+    if (r) return r;
+    if (!h.have_frame || !h.have_scan) return HVC_E_BAD_JPEG; // decoder.ml:283-292
+    int max_h = 0, max_v = 0;
+    for (int i = 0; i < h.ncomp_frame; i++) {
+        if (h.ch[i] > max_h) max_h = h.ch[i];
+        if (h.cv[i] > max_v) max_v = h.cv[i];
+    }
+    if (max_h == 0 || max_v == 0 || h.ncomp_scan == 0) return HVC_E_BAD_JPEG;
+    const long rw = ((long)h.width + max_h * 8 - 1) / (max_h * 8) * (max_h * 8);
+    const long rh = ((long)h.height + max_v * 8 - 1) / (max_v * 8) * (max_v * 8);
+    info->width = h.width;
+    info->height = h.height;
+    info->n_comp = h.ncomp_scan;
+    info->ecs_offset = h.ecs_pos;
+    size_t coef_off = 0, pix_off = 0;
+    for (int i = 0; i < h.ncomp_scan; i++) {
+        int f = -1; // find_component (decoder.ml:226-230): first match
+        for (int k = 0; k < h.ncomp_frame; k++)
+            if (h.cid[k] == h.ssel[i]) { f = k; break; }
+        if (f < 0) return HVC_E_BAD_JPEG;
+        hvc_jpeg_component &c = info->comp[i];
+        c.identifier = h.cid[f];
+        c.hscale = h.ch[f];
+        c.vscale = h.cv[f];
+        c.decoded_width = (int)(rw * h.ch[f] / max_h);
+        c.decoded_height = (int)(rh * h.cv[f] / max_v);
+        c.actual_width = h.width * h.ch[f] / max_h;
+        c.actual_height = h.height * h.cv[f] / max_v;
+        if (c.decoded_width < 8 || c.decoded_height < 8 || (c.decoded_width & 7) || (c.decoded_height & 7))
+            return HVC_E_BAD_JPEG;
+        // find_quant_table (decoder.ml:232-236): newest table with that id
+        int qi = -1;
+        for (int k = (int)h.dqt.size() - 1; k >= 0; k--)
+            if (h.dqt[k].id == h.ctq[f]) { qi = k; break; }
+        if (qi < 0) return HVC_E_BAD_JPEG;
+        int slot = -1; // de-duplicate into at most 4 table slots
+        for (int k = 0; k < info->n_qtabs; k++)
+            if (!std::memcmp(info->qtabs[k], h.dqt[qi].q, sizeof info->qtabs[k])) slot = k;
+        if (slot < 0) {
+            if (info->n_qtabs == 4) return HVC_E_BAD_JPEG;
+            slot = info->n_qtabs++;
+            std::memcpy(info->qtabs[slot], h.dqt[qi].q, sizeof info->qtabs[slot]);
+        }
+        c.dc_table = h.sdc[i];
+        c.ac_table = h.sac[i];
+        hvc_component &L = info->layout[i];
+        L.blocks_w = c.decoded_width / 8;
+        L.blocks_h = c.decoded_height / 8;
+        L.qtab = slot;
+        L.coef_offset = coef_off;
+        L.plane_offset = pix_off;
+        L.stride = (size_t)c.decoded_width;
+        coef_off += (size_t)L.blocks_w * L.blocks_h * 64;
+        pix_off += (size_t)c.decoded_width * c.decoded_height;
+    }
+    info->coef_count = coef_off;
+    info->pixel_bytes = pix_off;
+    return HVC_OK;
+}
+
+// The Huffman half of Decoder.decode (decode_seq order, decoder.ml:362-395; huffman_decode :118-140;
+// the DC predictor add of :143) into one frame's coefficient record: int16, zig-zag order, DC absolute,
+// block (bx,by) of component i at coefs + layout[i].coef_offset + (by*blocks_w + bx)*64.
+int hvc_jpeg_entropy_decode(const uint8_t *data, size_t n, const hvc_jpeg_info *info, int16_t *coefs) {
+    if (!data || !info || !coefs) return HVC_E_INVALID_ARG;
+    Header h;
+    int r = parse_header(data, n, h);
+    if (r) return r;
+    Lut dc[4], ac[4];
+    for (int i = 0; i < info->n_comp; i++) {
+        int di = -1, ai = -1; // find_huffman_table (decoder.ml:238-259): newest match
+        for (int k = (int)h.dht.size() - 1; k >= 0; k--) {
+            if (di < 0 && h.dht[k].tclass == 0 && h.dht[k].id == info->comp[i].dc_table) di = k;
+            if (ai < 0 && h.dht[k].tclass == 1 && h.dht[k].id == info->comp[i].ac_table) ai = k;
+        }
+        if (di < 0 || ai < 0) return HVC_E_BAD_JPEG;
+        if (!dc[i].build(h.dht[di].spec) || !ac[i].build(h.dht[ai].spec)) return HVC_E_BAD_JPEG;
+    }
+    // extract_entropy_coded_bits (decoder.ml:261-281): up to the first marker, 0xff00 -> 0xff
+    std::vector<uint8_t> ecs;
+    {
+        size_t pos = h.ecs_pos;
+        ecs.reserve(n > pos ? n - pos : 0);
+        while (pos < n) {
+            const uint8_t *ff = (const uint8_t *)std::memchr(data + pos, 0xff, n - pos);
+            const size_t stop = ff ? (size_t)(ff - data) : n;
+            ecs.insert(ecs.end(), data + pos, data + stop);
+            if (!ff) break; // the model would spin on zero bytes here; a missing EOI just ends the segment
+            const int next = stop + 1 < n ? data[stop + 1] : 0; // past the end reads as 0x00 = stuffing
+            if (next != 0x00) break;
+            ecs.push_back(0xff);
+            pos = stop + 2;
+        }
+    }
+    std::memset(coefs, 0, info->coef_count * sizeof(int16_t)); // clear_block for every block
+    BitReader br{ecs.data(), ecs.size()};
+    int dc_pred[4] = {0, 0, 0, 0};
+    const hvc_jpeg_component &c0 = info->comp[0];
+    const int mbs_wide = c0.decoded_width / (8 * c0.hscale), mbs_high = c0.decoded_height / (8 * c0.vscale);
+    for (int my = 0; my < mbs_high; my++)
+        for (int mx = 0; mx < mbs_wide; mx++)
+            for (int i = 0; i < info->n_comp; i++) {
+                const hvc_jpeg_component &c = info->comp[i];
+                const hvc_component &L = info->layout[i];
+                const uint16_t *dct = dc[i].e.data(), *act = ac[i].e.data();
+                const int dmax = dc[i].max_bits, amax = ac[i].max_bits;
+                for (int sy = 0; sy < c.vscale; sy++)
+                    for (int sx = 0; sx < c.hscale; sx++) {
+                        const int bx = mx * c.hscale + sx, by = my * c.vscale + sy;
+                        if (bx >= L.blocks_w || by >= L.blocks_h) return HVC_E_BAD_JPEG; // Plane.set out of bounds
+                        int16_t *blk = coefs + L.coef_offset + ((size_t)by * L.blocks_w + bx) * 64;
+                        br.refill();
+                        unsigned e = dct[br.peek(dmax)];
+                        if (!e) return HVC_E_BAD_JPEG; // "Can't find dc code"
+                        br.skip(e >> 8);
+                        int cat = e & 0xff, diff = 0;
+                        if (cat) {
+                            if (cat > 16) return HVC_E_BAD_JPEG;
+                            br.refill();
+                            diff = extend(cat, br.peek(cat));
+                            br.skip(cat);
+                        }
+                        const int dcv = diff + dc_pred[i];
+                        dc_pred[i] = dcv;
+                        if (dcv < -32768 || dcv > 32767) return HVC_E_RANGE;
+                        blk[0] = (int16_t)dcv;
+                        int k = 1;
+                        while (k < 64) {
+                            br.refill();
+                            e = act[br.peek(amax)];
+                            if (!e) return HVC_E_BAD_JPEG; // "Can't find ac code"
+                            br.skip(e >> 8);
+                            const int run = (e >> 4) & 15, size = e & 15;
+                            int mag = 0;
+                            if (size) {
+                                mag = extend(size, br.peek(size));
+                                br.skip(size);
+                            }
+                            if (mag == 0 && run == 0) break; // decoder.ml:131-132 (EOB, or a zero-size code)
+                            k += run;
+                            if (k >= 64) return HVC_E_BAD_JPEG; // "coefficient index out of range"
+                            blk[k++] = (int16_t)mag;
+                        }
+                    }
+            }
+    return HVC_OK;
+}
+
+// Decoder.crop / get_yuv_frame (decoder.ml:403-420): the actual_w x actual_h top-left part of every
+// padded plane, planes back to back (the layout Frame.output writes, common/src/frame.ml:66-70).
+int hvc_jpeg_get_yuv_frame(const hvc_jpeg_info *info, const uint8_t *pixels, uint8_t *out, size_t cap, size_t *out_len) {
+    if (!info || !pixels || !out) return HVC_E_INVALID_ARG;
+    size_t need = 0;
+    for (int i = 0; i < info->n_comp; i++) need += (size_t)info->comp[i].actual_width * info->comp[i].actual_height;
+    if (out_len) *out_len = need;
+    if (need > cap) return HVC_E_INVALID_ARG;
+    uint8_t *o = out;
+    for (int i = 0; i < info->n_comp; i++) {
+        const hvc_jpeg_component &c = info->comp[i];
+        const uint8_t *p = pixels + info->layout[i].plane_offset;
+        for (int y = 0; y < c.actual_height; y++, o += c.actual_width)
+            std::memcpy(o, p + (size_t)y * info->layout[i].stride, (size_t)c.actual_width);
+    }
+    return HVC_OK;
+}
+
+} // extern "C"
+
+// ===========================================================================
+// Encoder back end
+namespace {
+
+// ITU-T T.81 Annex K.3 tables = Tables.Default (tables.ml:54-476), BITS / HUFFVAL form
+const uint8_t K_DC_LUMA_BITS[16] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+const uint8_t K_DC_CHROMA_BITS[16] = {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+const uint8_t K_DC_VALS[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+const uint8_t K_AC_LUMA_BITS[16] = {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d};
+const uint8_t K_AC_CHROMA_BITS[16] = {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77};
+const uint8_t K_AC_LUMA_VALS[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71,
+    0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72,
+    0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37,
+    0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59,
+    0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83,
+    0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3,
+    0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3,
+    0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2,
+    0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+const uint8_t K_AC_CHROMA_VALS[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22,
+    0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1,
+    0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36,
+    0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58,
+    0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a,
+    0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a,
+    0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba,
+    0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda,
+    0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+
+// jpeg/model/src/quant_tables.ml:3-137 (Annex K numbers in array order, used as zig-zag order)
+const uint8_t K_Q_LUMA[64] = {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,
+                              14, 13, 16, 24, 40,  57,  69,  56,  14, 17, 22, 29, 51,  87,  80,  62,
+                              18, 22, 37, 56, 68,  109, 103, 77,  24, 35, 55, 64, 81,  104, 113, 92,
+                              49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+const uint8_t K_Q_CHROMA[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99,
+                                99, 99, 47, 66, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                                99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+
+struct EncCode { uint16_t bits; uint8_t len; };
+struct EncTable { EncCode dc[16]; EncCode ac[256]; }; // ac indexed by (run << 4) | size
+
+void build_enc(EncTable &t, const uint8_t *dc_bits, const uint8_t *dc_vals, const uint8_t *ac_bits, const uint8_t *ac_vals) {
+    std::memset(&t, 0, sizeof t);
+    unsigned code = 0;
+    int k = 0;
+    for (int len = 1; len <= 16; len++) { // canonical code assignment, tables.ml:27-45
+        for (int i = 0; i < dc_bits[len - 1]; i++, k++) t.dc[dc_vals[k]] = EncCode{(uint16_t)(code + i), (uint8_t)len};
+        code = (code + dc_bits[len - 1]) << 1;
+    }
+    code = 0;
+    k = 0;
+    for (int len = 1; len <= 16; len++) {
+        for (int i = 0; i < ac_bits[len - 1]; i++, k++) t.ac[ac_vals[k]] = EncCode{(uint16_t)(code + i), (uint8_t)len};
+        code = (code + ac_bits[len - 1]) << 1;
+    }
+}
+
+// Bitstream_writer (common/src/bitstream_writer.ml): MSB first, 0xff -> 0xff00 stuffing
+struct BitWriter {
+    std::vector<uint8_t> &out;
+    uint64_t acc = 0;
+    int nbits = 0;
+    explicit BitWriter(std::vector<uint8_t> &o) : out(o) {}
+    inline void put(unsigned value, int bits) {
+        if (!bits) return;
+        acc = (acc << bits) | (value & ((1u << bits) - 1u));
+        nbits += bits;
+        while (nbits >= 8) {
+            const uint8_t d = (uint8_t)(acc >> (nbits - 8));
+            out.push_back(d);
+            if (d == 0xff) out.push_back(0);
+            nbits -= 8;
+        }
+    }
+    void flush_with_1s() { // bitstream_writer.ml:45-49
+        while (nbits & 7) put(1, 1);
+    }
+};
+
+inline int bit_size(int v) { // encoder.ml:143
+    unsigned a = (unsigned)(v < 0 ? -v : v);
+    int n = 0;
+    while (a) { n++; a >>= 1; }
+    return n;
+}
+
+void put_marker(std::vector<uint8_t> &o, int code) { o.push_back(0xff); o.push_back((uint8_t)code); }
+void put16(std::vector<uint8_t> &o, int v) { o.push_back((uint8_t)(v >> 8)); o.push_back((uint8_t)v); }
+
+void write_dht(std::vector<uint8_t> &o, int tclass, int id, const uint8_t *bits, const uint8_t *vals) {
+    int total = 0;
+    for (int i = 0; i < 16; i++) total += bits[i];
+    put_marker(o, 0xc4);
+    put16(o, 3 + 16 + total);
+    o.push_back((uint8_t)((tclass << 4) | id));
+    o.insert(o.end(), bits, bits + 16);
+    o.insert(o.end(), vals, vals + total);
+}
+
+} // namespace
+
+extern "C" {
+
+// Quant_tables.scale (quant_tables.ml:139-147)
+int hvc_quant_table(int chroma_table, int quality, uint16_t *out) {
+    if (!out) return HVC_E_INVALID_ARG;
+    int q = quality < 1 ? 1 : (quality > 100 ? 100 : quality);
+    const int s = q < 50 ? 5000 / q : 200 - 2 * q;
+    const uint8_t *t = chroma_table ? K_Q_CHROMA : K_Q_LUMA;
+    for (int i = 0; i < 64; i++) {
+        int d = (t[i] * s + 50) / 100;
+        out[i] = (uint16_t)(d < 1 ? 1 : (d > 255 ? 255 : d));
+    }
+    return HVC_OK;
+}
+
+// Encoder.Parameters.c420/c422/c444 (encoder.ml:347-349) + Encoder.create plane geometry (:437-472):
+// the padded plane layout the encode kernel reads and the coefficient record it writes.
+int hvc_jpeg_encoder_layout(int width, int height, int chroma, int quality, hvc_jpeg_info *info) {
+    if (!info || width < 1 || height < 1 || width > 65535 || height > 65535) return HVC_E_INVALID_ARG;
+    static const int S420[6] = {2, 2, 1, 1, 1, 1}, S422[6] = {2, 2, 1, 2, 1, 2}, S444[6] = {1, 1, 1, 1, 1, 1};
+    const int *s = chroma == 420 ? S420 : chroma == 422 ? S422 : chroma == 444 ? S444 : nullptr;
+    if (!s) return HVC_E_INVALID_ARG;
+    std::memset(info, 0, sizeof *info);
+    info->width = width;
+    info->height = height;
+    info->n_comp = 3;
+    info->n_qtabs = 2;
+    hvc_quant_table(0, quality, info->qtabs[0]);
+    hvc_quant_table(1, quality, info->qtabs[1]);
+    const int max_h = s[0], max_v = s[1]; // luma carries the maxima in all three parameter sets
+    size_t coef_off = 0, pix_off = 0;
+    for (int i = 0; i < 3; i++) {
+        hvc_jpeg_component &c = info->comp[i];
+        c.identifier = i + 1;
+        c.hscale = s[2 * i];
+        c.vscale = s[2 * i + 1];
+        c.actual_width = width * c.hscale / max_h;
+        c.actual_height = height * c.vscale / max_v;
+        c.decoded_width = (c.actual_width + 8 * c.hscale - 1) / (8 * c.hscale) * (8 * c.hscale);
+        c.decoded_height = (c.actual_height + 8 * c.vscale - 1) / (8 * c.vscale) * (8 * c.vscale);
+        c.dc_table = c.ac_table = i ? 1 : 0;
+        hvc_component &L = info->layout[i];
+        L.blocks_w = c.decoded_width / 8;
+        L.blocks_h = c.decoded_height / 8;
+        L.qtab = i ? 1 : 0;
+        L.coef_offset = coef_off;
+        L.plane_offset = pix_off;
+        L.stride = (size_t)c.decoded_width;
+        coef_off += (size_t)L.blocks_w * L.blocks_h * 64;
+        pix_off += (size_t)c.decoded_width * c.decoded_height;
+    }
+    info->coef_count = coef_off;
+    info->pixel_bytes = pix_off;
+    return HVC_OK;
+}
+
+// Encoder.write_headers (encoder.ml:371-418) + encode_seq's rle / write_bits (:127-193, 476-505) +
+// complete_and_write_eoi (:507-510) over one frame's quantised coefficient record (zig-zag, DC absolute).
+int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uint8_t *out, size_t cap, size_t *out_len) {
+    if (!info || !coefs || !out_len || info->n_comp != 3) return HVC_E_INVALID_ARG;
+    std::vector<uint8_t> o;
+    o.reserve(info->coef_count / 4 + 1024);
+    put_marker(o, 0xd8);
+    { // write_app0 "Hardcaml JPEG."
+        static const char tag[] = "Hardcaml JPEG.";
+        put_marker(o, 0xe0);
+        put16(o, 2 + (int)sizeof(tag) - 1);
+        o.insert(o.end(), tag, tag + sizeof(tag) - 1);
+    }
+    for (int t = 0; t < 2; t++) { // write_dqt, element_precision 8
+        put_marker(o, 0xdb);
+        put16(o, 3 + 64);
+        o.push_back((uint8_t)t);
+        for (int i = 0; i < 64; i++) o.push_back((uint8_t)info->qtabs[t][i]);
+    }
+    put_marker(o, 0xc0); // write_sof
+    put16(o, 2 + 6 + 3 * 3);
+    o.push_back(8);
+    put16(o, info->height);
+    put16(o, info->width);
+    o.push_back(3);
+    for (int i = 0; i < 3; i++) {
+        o.push_back((uint8_t)info->comp[i].identifier);
+        o.push_back((uint8_t)((info->comp[i].hscale << 4) | info->comp[i].vscale));
+        o.push_back((uint8_t)info->layout[i].qtab);
+    }
+    write_dht(o, 0, 0, K_DC_LUMA_BITS, K_DC_VALS);
+    write_dht(o, 0, 1, K_DC_CHROMA_BITS, K_DC_VALS);
+    write_dht(o, 1, 0, K_AC_LUMA_BITS, K_AC_LUMA_VALS);
+    write_dht(o, 1, 1, K_AC_CHROMA_BITS, K_AC_CHROMA_VALS);
+    put_marker(o, 0xda); // write_sos
+    put16(o, 2 + 4 + 3 * 2);
+    o.push_back(3);
+    for (int i = 0; i < 3; i++) {
+        o.push_back((uint8_t)info->comp[i].identifier);
+        o.push_back((uint8_t)((info->comp[i].dc_table << 4) | info->comp[i].ac_table));
+    }
+    o.push_back(0);
+    o.push_back(63);
+    o.push_back(0);
+
+    EncTable et[2];
+    build_enc(et[0], K_DC_LUMA_BITS, K_DC_VALS, K_AC_LUMA_BITS, K_AC_LUMA_VALS);
+    build_enc(et[1], K_DC_CHROMA_BITS, K_DC_VALS, K_AC_CHROMA_BITS, K_AC_CHROMA_VALS);
+    BitWriter bw(o);
+    int dc_pred[3] = {0, 0, 0};
+    const hvc_jpeg_component &c0 = info->comp[0];
+    const int mbs_wide = c0.decoded_width / (8 * c0.hscale), mbs_high = c0.decoded_height / (8 * c0.vscale);
+    for (int my = 0; my < mbs_high; my++)
+        for (int mx = 0; mx < mbs_wide; mx++)
+            for (int i = 0; i < 3; i++) {
+                const hvc_jpeg_component &c = info->comp[i];
+                const hvc_component &L = info->layout[i];
+                const EncTable &t = et[c.dc_table];
+                for (int sy = 0; sy < c.vscale; sy++)
+                    for (int sx = 0; sx < c.hscale; sx++) {
+                        const int bx = mx * c.hscale + sx, by = my * c.vscale + sy;
+                        const int16_t *q = coefs + L.coef_offset + ((size_t)by * L.blocks_w + bx) * 64;
+                        // DC: difference to the predictor (encoder.ml:138-140), size + magnitude (:155-160)
+                        const int diff = q[0] - dc_pred[i];
+                        dc_pred[i] = q[0];
+                        int size = bit_size(diff);
+                        if (size > 11) return HVC_E_RANGE; // no code in the default DC tables
+                        bw.put(t.dc[size].bits, t.dc[size].len);
+                        bw.put((unsigned)(diff >= 0 ? diff : diff - 1), size);
+                        // AC: runs of zeros, ZRL for runs >= 16, EOB when the tail is zero (:127-141, 162-187)
+                        int run = 0;
+                        for (int k = 1; k < 64; k++) {
+                            const int v = q[k];
+                            if (v == 0) { run++; continue; }
+                            while (run >= 16) { bw.put(t.ac[0xf0].bits, t.ac[0xf0].len); run -= 16; }
+                            size = bit_size(v);
+                            if (size > 10) return HVC_E_RANGE; // no code in the default AC tables
+                            const EncCode e = t.ac[(run << 4) | size];
+                            bw.put(e.bits, e.len);
+                            bw.put((unsigned)(v >= 0 ? v : v - 1), size);
+                            run = 0;
+                        }
+                        if (run) bw.put(t.ac[0].bits, t.ac[0].len);
+                    }
+            }
+    bw.flush_with_1s();
+    put_marker(o, 0xd9);
+    *out_len = o.size();
+    if (!out || o.size() > cap) return HVC_E_INVALID_ARG;
+    std::memcpy(out, o.data(), o.size());
+    return HVC_OK;
+}
+
+} // extern "C"

@@ -18,6 +18,9 @@ SYMBOLS = [
     "hvc_synchronize", "hvc_timer_begin", "hvc_timer_end", "hvc_set_profiling", "hvc_last_kernel_ms", "hvc_kernel_ms_history", "hvc_dequant_idct_recon", "hvc_decode_frames",
     "hvc_last_wide_blocks", "hvc_fdct_quant", "hvc_encode_frames", "hvc_upsample420", "hvc_device_alloc",
     "hvc_device_free", "hvc_memcpy_h2d", "hvc_memcpy_d2h",
+    "hvc_jpeg_read_header", "hvc_jpeg_entropy_decode", "hvc_jpeg_get_yuv_frame", "hvc_jpeg_decode",
+    "hvc_jpeg_decode_batch", "hvc_quant_table", "hvc_jpeg_encoder_layout", "hvc_jpeg_entropy_encode",
+    "hvc_jpeg_encode",
 ]
 
 
@@ -32,6 +35,38 @@ class Component(C.Structure):
     """struct hvc_component"""
     _fields_ = [("blocks_w", C.c_int), ("blocks_h", C.c_int), ("qtab", C.c_int), ("reserved", C.c_int),
                 ("coef_offset", C.c_size_t), ("plane_offset", C.c_size_t), ("stride", C.c_size_t)]
+
+
+class JpegComponent(C.Structure):
+    """struct hvc_jpeg_component"""
+    _fields_ = [(n, C.c_int) for n in ("identifier", "hscale", "vscale", "decoded_width", "decoded_height",
+                                       "actual_width", "actual_height", "dc_table", "ac_table")]
+
+
+class JpegInfo(C.Structure):
+    """struct hvc_jpeg_info"""
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("n_comp", C.c_int), ("n_qtabs", C.c_int),
+                ("comp", JpegComponent * 4), ("layout", Component * 4), ("qtabs", (C.c_uint16 * 64) * 4),
+                ("coef_count", C.c_size_t), ("pixel_bytes", C.c_size_t), ("ecs_offset", C.c_size_t)]
+
+    def qtab_array(self):
+        return np.array([[self.qtabs[t][i] for i in range(64)] for t in range(self.n_qtabs)], dtype=np.uint16)
+
+    def planes(self, pixels):
+        """views of the padded planes inside a frame's pixel record (numpy uint8)"""
+        out = []
+        for i in range(self.n_comp):
+            c, L = self.comp[i], self.layout[i]
+            out.append(pixels[L.plane_offset:L.plane_offset + c.decoded_width * c.decoded_height].reshape(
+                c.decoded_height, c.decoded_width))
+        return out
+
+
+class BatchStats(C.Structure):
+    """struct hvc_batch_stats"""
+    _fields_ = [("wall_ms", C.c_double), ("entropy_ms_sum", C.c_double), ("h2d_ms_sum", C.c_double),
+                ("kernel_ms_sum", C.c_double), ("d2h_ms_sum", C.c_double), ("chunks", C.c_int), ("threads", C.c_int),
+                ("frames_per_chunk", C.c_int), ("coef_bytes", C.c_uint64)]
 
 
 def build(force=False):
@@ -82,6 +117,17 @@ def lib():
             L.hvc_fdct_quant.argtypes = [vp, vp, sz, sz, vp, i, i, i, vp, sz, i]
             L.hvc_encode_frames.argtypes = [vp, vp, sz, vp, i, C.POINTER(Component), i, i, vp, sz, i]
             L.hvc_upsample420.argtypes = [vp, vp, i, i, sz, vp, sz, i, sz, sz, i]
+        ip = C.POINTER(JpegInfo)
+        L.hvc_jpeg_read_header.argtypes = [vp, sz, ip]
+        L.hvc_jpeg_entropy_decode.argtypes = [vp, sz, ip, vp]
+        L.hvc_jpeg_get_yuv_frame.argtypes = [ip, vp, vp, sz, C.POINTER(sz)]
+        L.hvc_jpeg_decode.argtypes = [vp, vp, sz, ip, vp, sz]
+        L.hvc_jpeg_decode_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), i, i, i, vp, sz, i,
+                                            C.POINTER(BatchStats)]
+        L.hvc_quant_table.argtypes = [i, i, vp]
+        L.hvc_jpeg_encoder_layout.argtypes = [i, i, i, i, ip]
+        L.hvc_jpeg_entropy_encode.argtypes = [ip, vp, vp, sz, C.POINTER(sz)]
+        L.hvc_jpeg_encode.argtypes = [vp, vp, vp, vp, i, i, i, i, vp, sz, C.POINTER(sz)]
         L.hvc_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
         L.hvc_device_free.argtypes = [vp, vp]
         L.hvc_memcpy_h2d.argtypes = [vp, vp, vp, sz]
@@ -125,6 +171,54 @@ def frame_layout(planes_bw_bh_qtab):
         co += bw * bh * 64
         po += bw * bh * 64
     return specs, co, po
+
+
+# -- host front end / back end (no GPU needed) ------------------------------------------------
+def jpeg_read_header(data: bytes):
+    """Decoder.Header.decode + Decoder.init geometry -> JpegInfo"""
+    info = JpegInfo()
+    _chk(lib().hvc_jpeg_read_header(data, len(data), C.byref(info)), "hvc_jpeg_read_header")
+    return info
+
+
+def jpeg_entropy_decode(data: bytes, info=None):
+    """Huffman + DC prediction of one frame -> (info, int16 coefficient record)"""
+    info = info or jpeg_read_header(data)
+    coefs = np.empty(info.coef_count, dtype=np.int16)
+    _chk(lib().hvc_jpeg_entropy_decode(data, len(data), C.byref(info), coefs.ctypes.data), "hvc_jpeg_entropy_decode")
+    return info, coefs
+
+
+def jpeg_get_yuv_frame(info, pixels):
+    pixels = np.ascontiguousarray(pixels, dtype=np.uint8)
+    need = sum(info.comp[i].actual_width * info.comp[i].actual_height for i in range(info.n_comp))
+    out = np.empty(need, dtype=np.uint8)
+    n = C.c_size_t()
+    _chk(lib().hvc_jpeg_get_yuv_frame(C.byref(info), pixels.ctypes.data, out.ctypes.data, need, C.byref(n)))
+    return out
+
+
+def quant_table(chroma_table, quality):
+    out = np.empty(64, dtype=np.uint16)
+    _chk(lib().hvc_quant_table(1 if chroma_table else 0, quality, out.ctypes.data))
+    return out
+
+
+def jpeg_encoder_layout(width, height, chroma, quality):
+    info = JpegInfo()
+    _chk(lib().hvc_jpeg_encoder_layout(width, height, chroma, quality, C.byref(info)), "hvc_jpeg_encoder_layout")
+    return info
+
+
+def jpeg_entropy_encode(info, coefs):
+    coefs = np.ascontiguousarray(coefs, dtype=np.int16)
+    assert coefs.size == info.coef_count
+    cap = 2 * coefs.size + 4096
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t()
+    _chk(lib().hvc_jpeg_entropy_encode(C.byref(info), coefs.ctypes.data, out.ctypes.data, cap, C.byref(n)),
+         "hvc_jpeg_entropy_encode")
+    return out[:n.value].tobytes()
 
 
 class Context:
@@ -196,6 +290,35 @@ class Context:
         arr = comps if not isinstance(comps, list) else components(comps)
         _chk(lib().hvc_decode_frames(self._h, ca, coef_frame_stride, q.ctypes.data, q.shape[0], arr, len(arr),
                                      n_frames, pa, pixel_frame_stride, w1))
+
+    def jpeg_decode(self, data: bytes):
+        """Decoder.decode_a_frame minus the crop: (info, padded pixel record as numpy uint8)"""
+        info = jpeg_read_header(data)
+        pixels = np.zeros(info.pixel_bytes, dtype=np.uint8)
+        _chk(lib().hvc_jpeg_decode(self._h, data, len(data), C.byref(info), pixels.ctypes.data, pixels.size),
+             "hvc_jpeg_decode")
+        return info, pixels
+
+    def jpeg_decode_batch(self, jpegs, pixels, pixel_frame_stride, threads=8, frames_per_chunk=32):
+        """config 3 pipeline.  jpegs: list of bytes; pixels: numpy (host) or torch cuda tensor."""
+        n = len(jpegs)
+        ptrs = (C.c_void_p * n)(*[C.cast(C.c_char_p(j), C.c_void_p) for j in jpegs])
+        sizes = (C.c_size_t * n)(*[len(j) for j in jpegs])
+        pa, where = _addr(pixels)
+        st = BatchStats()
+        _chk(lib().hvc_jpeg_decode_batch(self._h, ptrs, sizes, n, threads, frames_per_chunk, pa, pixel_frame_stride,
+                                         where, C.byref(st)), "hvc_jpeg_decode_batch")
+        return st
+
+    def jpeg_encode(self, y, u, v, width, height, chroma=420, quality=75):
+        """Encoder.encode_420/422/444 ~frame ~quality -> jpeg bytes"""
+        y, u, v = (np.ascontiguousarray(p, dtype=np.uint8) for p in (y, u, v))
+        cap = 4 * width * height + 65536
+        out = np.empty(cap, dtype=np.uint8)
+        n = C.c_size_t()
+        _chk(lib().hvc_jpeg_encode(self._h, y.ctypes.data, u.ctypes.data, v.ctypes.data, width, height, chroma, quality,
+                                   out.ctypes.data, cap, C.byref(n)), "hvc_jpeg_encode")
+        return out[:n.value].tobytes()
 
     # -- encode -------------------------------------------------------------
     def fdct_quant(self, plane, qtab, blocks_w, blocks_h, n_planes, coefs, stride=None, plane_stride=0,
