@@ -473,11 +473,8 @@ int hvc_encode_frames(hvc_ctx *c, const uint8_t *pixels, size_t pixel_fs, const 
     P.n_comp = L.n_comp;
     P.tiles_per_frame = L.tiles_per_frame;
     for (int i = 0; i < L.n_comp; i++) P.comp[i] = L.comp[i];
-    for (int i = 0; i < n_qtabs * 64; i++) {
-        const float d = 4.0f * (float)qtabs[i];
-        P.qrcp[i] = 1.0f / d;           // correctly rounded fl(1/(4t))
-        P.qhalf[i] = 0.5f + 0.5f / d;   // 0.5 + 1/(8t)
-    }
+    for (int i = 0; i < n_qtabs * 64; i++) // fl((1 + 2^-16) / (4t)): see quant1 in hvc_kernels.hip
+        P.qrcp[i] = (float)((1.0 + 1.0 / 65536.0) / (4.0 * (double)qtabs[i]));
 
     if (where == HVC_MEM_DEVICE) {
         if (((uintptr_t)coefs & 15) || ((uintptr_t)pixels & 7)) return HVC_E_ALIGNMENT;

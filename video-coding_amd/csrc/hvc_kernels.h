@@ -58,8 +58,7 @@ struct EncodeParams {
     size_t coef_fs, pixel_fs;
     int n_frames, n_comp, tiles_per_frame, pad;
     CompK comp[HVC_MAX_COMP];
-    float qrcp[HVC_MAX_QTABS * 64];   // fl(1/(4*q)), zig-zag order (kernarg segment)
-    float qhalf[HVC_MAX_QTABS * 64];  // 0.5 + 1/(8*q)
+    float qrcp[HVC_MAX_QTABS * 64];   // fl((1 + 2^-16) / (4*q)), zig-zag order (kernarg segment)
 };
 
 struct UpsampleParams {

@@ -227,6 +227,9 @@ struct BlockRef {
     size_t pix_idx;  // byte index of this block's top-left pixel
     size_t stride;
     int qtab;
+    size_t plane_coef_idx; // int16 element index of the plane's first coefficient
+    int tile_b0;           // block index (inside the plane) of lane 0 of this workgroup
+    int nblk;              // blocks in the plane
 };
 
 template <class Params>
@@ -245,6 +248,9 @@ __device__ __forceinline__ bool locate(const Params &P, int frame, int tile, int
     br.pix_idx = (size_t)frame * P.pixel_fs + K.plane_off + (size_t)by * 8 * K.stride + (size_t)bx * 8;
     br.stride = K.stride;
     br.qtab = K.qtab;
+    br.plane_coef_idx = (size_t)frame * P.coef_fs + K.coef_off;
+    br.tile_b0 = (tile - K.tile0) * HVC_TILE;
+    br.nblk = K.nblk;
     return active;
 }
 
@@ -602,23 +608,40 @@ __global__ __launch_bounds__(64) void k_decode_wide(DecodeParams P, const unsign
 // with 24-bit multiplies is exact, no guard and no wide kernel.
 
 // dct.ml:109-112
-__device__ __forceinline__ int c4(int f, int g) { return mul24(362, f + g) >> 9; }
-__device__ __forceinline__ int c4m(int f, int g) { return mul24(362, f - g) >> 9; }
-__device__ __forceinline__ int c62(int f, int g) { return mad24(473, g, mul24(196, f)) >> 9; }
-__device__ __forceinline__ int c71(int f, int g) { return mad24(502, g, mul24(100, f)) >> 9; }
-__device__ __forceinline__ int c35(int f, int g) { return mad24(284, g, mul24(426, f)) >> 9; }
+// The multiplies are issued explicitly: left to hipcc 7.2, constants folded through the 24-bit
+// intrinsics come back as explicit 24-bit sign extensions (shift pairs / v_bfe_i32, +150 VALU ops per
+// block), and plain 32-bit forms become v_mad_u64_u32.  Constant in an SGPR, operands < 2^15.
+__device__ __forceinline__ int vmul24(int k, int x) {
+    int d;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "s"(k), "v"(x));
+    return d;
+}
+__device__ __forceinline__ int vmad24(int k, int x, int acc) {
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "s"(k), "v"(x), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ int c4(int f, int g) { return vmul24(362, f + g) >> 9; }
+__device__ __forceinline__ int c4m(int f, int g) { return vmul24(362, f - g) >> 9; }
+__device__ __forceinline__ int c62(int f, int g) { return vmad24(473, g, vmul24(196, f)) >> 9; }
+__device__ __forceinline__ int c71(int f, int g) { return vmad24(502, g, vmul24(100, f)) >> 9; }
+__device__ __forceinline__ int c35(int f, int g) { return vmad24(284, g, vmul24(426, f)) >> 9; }
+// c62 b3 (-b2), c35 a2 (-a1), c71 a3 (-a0): the negation rides in the constant
+__device__ __forceinline__ int c62n(int f, int g) { return vmad24(-473, g, vmul24(196, f)) >> 9; }
+__device__ __forceinline__ int c71n(int f, int g) { return vmad24(-502, g, vmul24(100, f)) >> 9; }
+__device__ __forceinline__ int c35n(int f, int g) { return vmad24(-284, g, vmul24(426, f)) >> 9; }
 
-// dct.ml:114-149 (dct_col) / :151-187 (dct_row): one butterfly, 8 values in place
-__device__ __forceinline__ void fdct_1d(int &p0, int &p1, int &p2, int &p3, int &p4, int &p5, int &p6, int &p7) {
-    int a0 = p0 + p7, c3 = p0 - p7;
-    int a1 = p1 + p6, c2 = p1 - p6;
-    int a2 = p2 + p5, c1 = p2 - p5;
-    int a3 = p3 + p4, c0 = p3 - p4;
-    int b0 = a0 + a3, b1 = a1 + a2, b2 = a1 - a2, b3 = a0 - a3;
+// dct.ml:114-149 (dct_col) / :151-187 (dct_row) share one butterfly.
+// The butterfly after its first stage: from the sums a0..a3 and differences c0..c3.  LS = the
+// sums still carry the +256 of two un-shifted pixels (see k_encode): only b0 and b1 see it.
+template <bool LS>
+__device__ __forceinline__ void fdct_tail(int a0, int a1, int a2, int a3, int c0, int c1, int c2, int c3, int &p0,
+                                          int &p1, int &p2, int &p3, int &p4, int &p5, int &p6, int &p7) {
+    int b0 = LS ? a0 + a3 - 512 : a0 + a3, b1 = LS ? a1 + a2 - 512 : a1 + a2, b2 = a1 - a2, b3 = a0 - a3;
     p0 = c4(b0, b1);
     p4 = c4m(b0, b1);      // c4 b0 (-b1)
     p2 = c62(b2, b3);
-    p6 = c62(b3, -b2);
+    p6 = c62n(b3, b2);     // c62 b3 (-b2)
     b0 = c4m(c2, c1);      // c4 c2 (-c1)
     b1 = c4(c2, c1);
     a0 = c0 + b0;
@@ -627,63 +650,124 @@ __device__ __forceinline__ void fdct_1d(int &p0, int &p1, int &p2, int &p3, int 
     a3 = c3 + b1;
     p1 = c71(a0, a3);
     p5 = c35(a1, a2);
-    p3 = c35(a2, -a1);
-    p7 = c71(a3, -a0);
+    p3 = c35n(a2, a1);     // c35 a2 (-a1)
+    p7 = c71n(a3, a0);     // c71 a3 (-a0)
 }
 
-// Encoder.quant_and_scale (encoder.ml:98-101): trunc((f +- 2t) / (4t)), i.e.
-// f/(4t) rounded half away from zero.  Evaluated as trunc(|f| * r + h) with
-// r = fl(1/(4t)) and h = 0.5 + 1/(8t): the exact quotients are multiples of
-// 1/(4t), the bias centres them between float errors (< 2^-9 / (4t) for
-// |f| < 2^14), so the truncation is exact -- verified exhaustively for every
-// t in 1..255 and every |f| <= 2^15 by tests/test_quant_division.py.
-__device__ __forceinline__ int quant1(int f, float r, float h) {
-    float ff = (float)f;
-    float x = __builtin_fmaf(__builtin_fabsf(ff), r, h);
-    x = __builtin_copysignf(x, ff);
-    return (int)x; // v_cvt_i32_f32 truncates toward zero
+// byte BYTE of a  +/-  byte BYTE of b: the unpacking of the pixel bytes rides in the SDWA source
+// selectors of the first butterfly stage (zero-extended bytes, one instruction each)
+template <int BYTE>
+__device__ __forceinline__ int add_bytes(unsigned a, unsigned b) {
+    int d;
+    if (BYTE == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(d) : "v"(a), "v"(b));
+    if (BYTE == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(d) : "v"(a), "v"(b));
+    if (BYTE == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2" : "=v"(d) : "v"(a), "v"(b));
+    if (BYTE == 3) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+template <int BYTE>
+__device__ __forceinline__ int sub_bytes(unsigned a, unsigned b) {
+    int d;
+    if (BYTE == 0) asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(d) : "v"(a), "v"(b));
+    if (BYTE == 1) asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(d) : "v"(a), "v"(b));
+    if (BYTE == 2) asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2" : "=v"(d) : "v"(a), "v"(b));
+    if (BYTE == 3) asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(d) : "v"(a), "v"(b));
+    return d;
 }
 
-__global__ __launch_bounds__(HVC_TILE) void k_encode(EncodeParams P) {
+// Column pass (dct.ml:114-149) of column C from the eight packed pixel rows (two dwords each).
+// level_shifted_input_block (encoder.ml:87) subtracts 128 from every pixel: differences of two
+// pixels do not see it, sums carry +256, and past the first stage only b0 = a0 + a3 and b1 = a1 + a2
+// use sums -- so the shift is two "- 512" (fdct_tail<true>) instead of 64 subtractions.
+template <int C>
+__device__ __forceinline__ void fdct_col_bytes(const unsigned (&px)[8][2], int (&v)[64]) {
+    constexpr int D = C >> 2, B = C & 3;
+    const int a0 = add_bytes<B>(px[0][D], px[7][D]), c3 = sub_bytes<B>(px[0][D], px[7][D]);
+    const int a1 = add_bytes<B>(px[1][D], px[6][D]), c2 = sub_bytes<B>(px[1][D], px[6][D]);
+    const int a2 = add_bytes<B>(px[2][D], px[5][D]), c1 = sub_bytes<B>(px[2][D], px[5][D]);
+    const int a3 = add_bytes<B>(px[3][D], px[4][D]), c0 = sub_bytes<B>(px[3][D], px[4][D]);
+    fdct_tail<true>(a0, a1, a2, a3, c0, c1, c2, c3, v[C], v[8 + C], v[16 + C], v[24 + C], v[32 + C], v[40 + C],
+                    v[48 + C], v[56 + C]);
+}
+
+// Encoder.quant_and_scale (encoder.ml:98-101): trunc((f +- 2t) / (4t)) = f/(4t) rounded to the
+// nearest integer, halves away from zero.  Evaluated as floor(f * r + 0.5) (v_cvt_rpi_i32_f32) with
+// r = fl((1 + 2^-16) / (4t)): the exact quotients are multiples of 1/(4t), so a non-tie is at
+// least 1/(8t) from a rounding boundary while the relative bias moves it by < 2^-16 * 2^11; a tie
+// (k + 1/2) is pushed just past the boundary, away from zero, for either sign.  Exhaustively equal
+// to the model for every t in 1..255 and |f| <= 2^15 (tests/test_quant_division.py).
+__device__ __forceinline__ int quant1(int f, float r) {
+    int q;
+    const float x = (float)f * r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(x));
+    return q;
+}
+
+#ifndef HVC_ENCODE_LB
+#define HVC_ENCODE_LB HVC_TILE
+#endif
+__global__ __launch_bounds__(HVC_ENCODE_LB) void k_encode(EncodeParams P) {
     BlockRef br;
     const int lane = threadIdx.x;
     const bool active = locate(P, blockIdx.y, blockIdx.x, lane, br);
     const uint8_t *pix = P.pixels + br.pix_idx;
-    int v[64];
-    // level_shifted_input_block (encoder.ml:81-90): 8 rows x 8 B per lane; a
-    // wave's row loads are 512 contiguous bytes of a pixel row.
+    // 8 rows x 8 B per lane; a wave's row loads are 512 contiguous bytes of a pixel row.
+    unsigned px[8][2];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        uint2 w = *reinterpret_cast<const uint2 *>(pix + (size_t)j * br.stride);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            v[j * 8 + i] = (int)((w.x >> (8 * i)) & 0xffu) - 128;
-            v[j * 8 + 4 + i] = (int)((w.y >> (8 * i)) & 0xffu) - 128;
-        }
+        const uint2 w = *reinterpret_cast<const uint2 *>(pix + (size_t)j * br.stride);
+        px[j][0] = w.x;
+        px[j][1] = w.y;
     }
     // Dct.Chen.forward_8x8 (dct.ml:189-196): columns first, then rows
+    int v[64];
+    fdct_col_bytes<0>(px, v);
+    fdct_col_bytes<1>(px, v);
+    fdct_col_bytes<2>(px, v);
+    fdct_col_bytes<3>(px, v);
+    fdct_col_bytes<4>(px, v);
+    fdct_col_bytes<5>(px, v);
+    fdct_col_bytes<6>(px, v);
+    fdct_col_bytes<7>(px, v);
 #pragma unroll
-    for (int c = 0; c < 8; c++)
-        fdct_1d(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
-#pragma unroll
-    for (int r = 0; r < 8; r++)
-        fdct_1d(v[r * 8 + 0], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6],
-                v[r * 8 + 7]);
+    for (int r = 0; r < 8; r++) {
+        int *p = v + r * 8;
+        fdct_tail<false>(p[0] + p[7], p[1] + p[6], p[2] + p[5], p[3] + p[4], p[3] - p[4], p[2] - p[5], p[1] - p[6],
+                         p[0] - p[7], p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
+    }
     // Encoder.quant (encoder.ml:103-108): quant[zz] = quant_and_scale fdct[ZI[zz]] table[zz]
     const float *__restrict__ qr = P.qrcp + br.qtab * 64;
-    const float *__restrict__ qh = P.qhalf + br.qtab * 64;
-    uint4 *dst = reinterpret_cast<uint4 *>(P.coefs + br.coef_idx);
+    // A lane holds its block's 128 output bytes; storing them as eight 16-byte pieces 128 bytes apart
+    // across lanes makes every piece its own L2 write request (TCC requests 8x, 4.5 TB/s ceiling in
+    // tools/ubench/store_ubench; non-temporal: 5x slower still).  So each wave transposes its 8 KiB
+    // through LDS -- XOR-swizzled 16-byte slots, conflict-free for both the ds_write_b128 (lane l
+    // writes slot 8l + (c ^ (l & 7))) and the ds_read_b128 -- and stores whole 1 KiB runs
+    // (lane i of store j writes byte 1024 j + 16 i of the wave's coefficient run).
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    __shared__ u4v lds[HVC_TILE / 64][512];
+    const int wv = lane >> 6, l = lane & 63;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         unsigned w[4];
 #pragma unroll
         for (int h = 0; h < 4; h++) {
             const int k = j * 8 + h * 2;
-            int lo = quant1(v[ZI[k]], qr[k], qh[k]);
-            int hi = quant1(v[ZI[k + 1]], qr[k + 1], qh[k + 1]);
-            w[h] = ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16);
+            const int lo = quant1(v[ZI[k]], qr[k]);
+            const int hi = quant1(v[ZI[k + 1]], qr[k + 1]);
+            w[h] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(lo, hi)); // |q| <= 2^13: no saturation
         }
-        if (active) dst[j] = make_uint4(w[0], w[1], w[2], w[3]);
+        const u4v t = {w[0], w[1], w[2], w[3]};
+        lds[wv][l * 8 + (j ^ (l & 7))] = t;
+    }
+    // (wave-private LDS region: the wave's own ds ops are ordered, no barrier needed)
+    const int wave_b0 = br.tile_b0 + (lane & ~63);
+    u4v *dst = reinterpret_cast<u4v *>(P.coefs + br.plane_coef_idx + (size_t)wave_b0 * 64);
+    (void)active;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int blk = 8 * j + (l >> 3), ch = l & 7;
+        const u4v t = lds[wv][blk * 8 + (ch ^ (blk & 7))];
+        if (wave_b0 + blk < br.nblk) dst[j * 64 + l] = t;
     }
 }
 
