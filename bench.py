@@ -146,9 +146,9 @@ def whole_job_mpixels(world, frames_per_gpu, steps, dt):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)  # the first launches after idle run off-clock (DVFS)
+    ap.add_argument("--frames", type=int, default=1024, help="frames per GPU per step (9.6 GB of coefficients + pixels)")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames (replicated to --frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)

@@ -778,6 +778,7 @@ __global__ __launch_bounds__(HVC_ENCODE_LB) void k_encode(EncodeParams P) {
 __device__ __forceinline__ unsigned avg2u(unsigned a, unsigned b) { return (a + b + 1) >> 1; }          // :4-8
 __device__ __forceinline__ unsigned avg4u(unsigned a, unsigned b, unsigned c, unsigned d) { return (a + b + c + d + 2) >> 2; } // :10-16
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_upsample420(UpsampleParams P) {
     const int groups = (P.cw + 3) >> 2;
     const long long total = (long long)groups * P.ch;
@@ -792,14 +793,41 @@ __global__ __launch_bounds__(256) void k_upsample420(UpsampleParams P) {
     const uint8_t *s2 = src + (size_t)row2 * P.src_stride;
     const int c0 = g * 4;
     unsigned a[5], b[5];
+    uint8_t *d1 = dst + (size_t)(2 * row) * P.dst_stride + 2 * c0;
+    uint8_t *d2 = d1 + P.dst_stride;
+    if (VEC) {
+        // aligned fast path (cw % 4 == 0, strides and bases aligned; chosen on the host): one dword
+        // per source row, one 8-byte store per destination row, 256 B / 512 B contiguous per wave
+        const unsigned wa = *reinterpret_cast<const unsigned *>(s1 + c0);
+        const unsigned wb = *reinterpret_cast<const unsigned *>(s2 + c0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            a[i] = (wa >> (8 * i)) & 0xffu;
+            b[i] = (wb >> (8 * i)) & 0xffu;
+        }
+        const bool last = c0 + 4 >= P.cw; // last column replicates (:98-102)
+        a[4] = last ? a[3] : s1[c0 + 4];
+        b[4] = last ? b[3] : s2[c0 + 4];
+        unsigned o1[8], o2[8];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            o1[2 * i] = a[i];
+            o1[2 * i + 1] = avg2u(a[i], a[i + 1]);
+            o2[2 * i] = avg2u(a[i], b[i]);
+            o2[2 * i + 1] = avg4u(a[i], a[i + 1], b[i], b[i + 1]);
+        }
+        *reinterpret_cast<uint2 *>(d1) = make_uint2(o1[0] | (o1[1] << 8) | (o1[2] << 16) | (o1[3] << 24),
+                                                    o1[4] | (o1[5] << 8) | (o1[6] << 16) | (o1[7] << 24));
+        *reinterpret_cast<uint2 *>(d2) = make_uint2(o2[0] | (o2[1] << 8) | (o2[2] << 16) | (o2[3] << 24),
+                                                    o2[4] | (o2[5] << 8) | (o2[6] << 16) | (o2[7] << 24));
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 5; i++) {
         int c = min(c0 + i, P.cw - 1); // last column replicates (:98-102)
         a[i] = s1[c];
         b[i] = s2[c];
     }
-    uint8_t *d1 = dst + (size_t)(2 * row) * P.dst_stride + 2 * c0;
-    uint8_t *d2 = d1 + P.dst_stride;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         if (c0 + i >= P.cw) break;
@@ -856,7 +884,12 @@ hipError_t launch_upsample420(const UpsampleParams &P, hipStream_t s) {
     if (P.n_planes <= 0 || P.cw <= 0 || P.ch <= 0) return hipSuccess;
     long long total = (long long)((P.cw + 3) >> 2) * P.ch;
     dim3 grid((unsigned)((total + 255) / 256), (unsigned)P.n_planes, 1);
-    hipLaunchKernelGGL(k_upsample420, grid, dim3(256), 0, s, P);
+    const bool vec = (P.cw % 4 == 0) && (P.src_stride % 4 == 0) && (P.dst_stride % 8 == 0) && (P.src_ps % 4 == 0) &&
+                     (P.dst_ps % 8 == 0) && ((uintptr_t)P.src % 4 == 0) && ((uintptr_t)P.dst % 8 == 0);
+    if (vec)
+        hipLaunchKernelGGL(k_upsample420<true>, grid, dim3(256), 0, s, P);
+    else
+        hipLaunchKernelGGL(k_upsample420<false>, grid, dim3(256), 0, s, P);
     return hipGetLastError();
 }
 
