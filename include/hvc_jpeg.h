@@ -74,10 +74,13 @@ HVC_API const char *hvc_strerror(int code);
 HVC_API int hvc_last_hip_error(const hvc_ctx *ctx);
 HVC_API const char *hvc_version(void);
 
-/* Use an existing HIP stream (hipStream_t passed as void*; NULL = ctx's own
- * stream).  Lets a host runtime order this library's kernels with its own
- * copies; torch.cuda.current_stream().cuda_stream is such a handle. */
+/* Use an existing HIP stream (hipStream_t passed as void*) so that a host runtime can order this
+ * library's kernels with its own work; torch.cuda.current_stream().cuda_stream is such a handle.
+ * NULL is a stream too -- HIP's default (null) stream, which is what PyTorch's default stream is --
+ * NOT "back to the context's own stream": a fresh hvc_ctx runs on its own non-blocking stream, which
+ * does not synchronise with the null stream; hvc_reset_stream returns to it. */
 HVC_API int hvc_set_stream(hvc_ctx *ctx, void *hip_stream);
+HVC_API int hvc_reset_stream(hvc_ctx *ctx);
 HVC_API int hvc_synchronize(hvc_ctx *ctx);
 
 /* HIP-event timer on ctx's stream (for benchmarks): begin, enqueue work, end. */
@@ -132,6 +135,12 @@ HVC_API int hvc_decode_frames(hvc_ctx *ctx, const int16_t *coefs, size_t coef_fr
                               const uint16_t *qtabs, int n_qtabs, const hvc_component *comps,
                               int n_comp, int n_frames, uint8_t *pixels,
                               size_t pixel_frame_stride, int where);
+
+/* Diagnostic: which implementation the decode entry points use.  0 = default (k_decode_packed, the
+ * int16-pair kernel, with the int64 fix-up for blocks outside its proven range), 1 = the unpacked
+ * int32 kernel k_decode_fast, 2 = the int64 kernel for every block.  All three produce identical
+ * bytes; tests use this to cross-check three independent implementations at full batch sizes. */
+HVC_API int hvc_set_decode_kernel(hvc_ctx *ctx, int which);
 
 /* Number of blocks the last decode call on ctx routed through the wide
  * (64-bit) fix-up kernel (diagnostic; synchronises the stream). */

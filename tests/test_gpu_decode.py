@@ -151,7 +151,7 @@ def test_device_memory_path_torch(ctx):
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.dequant_idct_recon(d_coefs, q, bw, bh, n, d_pix)
     ctx.synchronize()
-    ctx.set_stream(0)
+    ctx.reset_stream()
     assert np.array_equal(d_pix.cpu().numpy(), want)
 
 

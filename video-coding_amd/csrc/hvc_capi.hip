@@ -28,6 +28,7 @@ struct hvc_ctx {
     hipEvent_t k0[HVC_PROF_RING] = {}, k1[HVC_PROF_RING] = {};
     unsigned long long k_calls = 0;
     bool profiling = false;
+    int decode_kernel = 0; // hvc_set_decode_kernel: 0 packed (default), 1 unpacked int32, 2 int64 for every block
     unsigned *d_fix_count = nullptr; // two counters, used alternately (see k_decode_wide)
     int fix_phase = 0;               // index of the counter the NEXT decode call appends to
     int fix_last = 0;                // index of the counter the last decode call used
@@ -220,7 +221,13 @@ int hvc_last_hip_error(const hvc_ctx *c) { return c ? c->last_hip : 0; }
 
 int hvc_set_stream(hvc_ctx *c, void *s) {
     if (!c) return HVC_E_INVALID_ARG;
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = (hipStream_t)s; // NULL is a stream too: HIP's default (null) stream
+    return HVC_OK;
+}
+
+int hvc_reset_stream(hvc_ctx *c) {
+    if (!c) return HVC_E_INVALID_ARG;
+    c->stream = c->own_stream;
     return HVC_OK;
 }
 
@@ -244,6 +251,12 @@ int hvc_timer_end(hvc_ctx *c, float *ms) {
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev1));
     HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return HVC_OK;
+}
+
+int hvc_set_decode_kernel(hvc_ctx *c, int which) {
+    if (!c || which < 0 || which > 2) return HVC_E_INVALID_ARG;
+    c->decode_kernel = which;
     return HVC_OK;
 }
 
@@ -378,6 +391,8 @@ int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const ui
     // (|coef * q| must stay below 2^23): such planes go straight to the wide kernel.
     bool wide_only = false;
     for (int i = 0; i < n_qtabs * 64; i++) wide_only |= qtabs[i] > 255;
+    wide_only |= c->decode_kernel == 2;
+    P.kernel_sel = c->decode_kernel == 1 ? 1 : 0;
     if (!wide_only) { // this call consumes counter fix_phase; its wide kernel clears the other one
         c->fix_last = c->fix_phase;
         c->fix_phase ^= 1;

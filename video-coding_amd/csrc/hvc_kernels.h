@@ -39,7 +39,8 @@ struct DecodeParams {
     uint8_t *pixels;
     size_t coef_fs;   // int16 elements between frames
     size_t pixel_fs;  // bytes between frames
-    int n_frames, n_comp, tiles_per_frame, pad;
+    int n_frames, n_comp, tiles_per_frame;
+    int kernel_sel;   // 0 = k_decode_packed (default), 1 = k_decode_fast (hvc_set_decode_kernel; host-side only)
     CompK comp[HVC_MAX_COMP];
     int qt[HVC_MAX_QTABS * 64];  // quantiser tables, zig-zag order (kernarg segment -> scalar loads)
     int ethr[HVC_MAX_QTABS];     // per table: largest coefficient energy k_decode_fast accepts

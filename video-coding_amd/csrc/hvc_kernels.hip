@@ -847,7 +847,7 @@ hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0, hi
     if (k0 && (e = hipEventRecord(k0, s)) != hipSuccess) return e;
     // HVC_DECODE_KERNEL=v2 selects the unpacked int32 kernel (A/B measurements only)
     static const bool use_v2 = [] { const char *v = getenv("HVC_DECODE_KERNEL"); return v && v[0] == 'v' && v[1] == '2'; }();
-    if (use_v2)
+    if (use_v2 || P.kernel_sel == 1)
         hipLaunchKernelGGL(k_decode_fast, grid, dim3(HVC_TILE), 0, s, P);
     else
         hipLaunchKernelGGL(k_decode_packed, grid, dim3(HVC_TILE), 0, s, P);

@@ -20,7 +20,7 @@ SYMBOLS = [
     "hvc_device_free", "hvc_memcpy_h2d", "hvc_memcpy_d2h",
     "hvc_jpeg_read_header", "hvc_jpeg_entropy_decode", "hvc_jpeg_get_yuv_frame", "hvc_jpeg_decode",
     "hvc_jpeg_decode_batch", "hvc_quant_table", "hvc_jpeg_encoder_layout", "hvc_jpeg_entropy_encode",
-    "hvc_jpeg_encode",
+    "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream",
 ]
 
 
@@ -240,7 +240,14 @@ class Context:
             pass
 
     def set_stream(self, handle):
+        """handle: a hipStream_t as int, e.g. torch.cuda.current_stream().cuda_stream; 0 = HIP's
+        default (null) stream -- which is what PyTorch's default stream is."""
         _chk(lib().hvc_set_stream(self._h, C.c_void_p(handle)))
+
+    def reset_stream(self):
+        """back to the context's own (non-blocking) stream"""
+        lib().hvc_reset_stream.argtypes = [C.c_void_p]
+        _chk(lib().hvc_reset_stream(self._h))
 
     def synchronize(self):
         _chk(lib().hvc_synchronize(self._h))
@@ -252,6 +259,11 @@ class Context:
         ms = C.c_float()
         _chk(lib().hvc_timer_end(self._h, C.byref(ms)))
         return ms.value
+
+    def set_decode_kernel(self, which):
+        """0 packed (default) | 1 unpacked int32 | 2 int64 for every block -- identical output"""
+        lib().hvc_set_decode_kernel.argtypes = [C.c_void_p, C.c_int]
+        _chk(lib().hvc_set_decode_kernel(self._h, which))
 
     def set_profiling(self, on=True):
         _chk(lib().hvc_set_profiling(self._h, 1 if on else 0))
