@@ -13,7 +13,7 @@
  * Parity pin: the oracle is checked against the reference's own golden
  * vectors (tests/golden/, see tests/test_oracle_golden.py):
  *   G1 test_chen_dct.ml:47-87, G2 test_decoder_accelerator.ml:209-376,
- *   G3 mini.jpg byte equality, G4 PSNR pins of jpeg/test/*.t,
+ *   G3 mini.jpg byte equality, G4 PSNR pins of the jpeg/test cram files,
  *   G5/G6 test_quant_tables.ml, G7 planar_444.ml:197-249,
  *   G8 test_encode_headers.ml:17-134.
  * The reference itself (OCaml) cannot be built in this image: no ocaml/dune.
@@ -1088,7 +1088,7 @@ ORC_API i64 orc_encode_yuv(const uint8_t *y, const uint8_t *u, const uint8_t *v,
     int max_h = 0, max_v = 0;
     for (int i = 0; i < nsc; i++) { if (sc[i].h > max_h) max_h = sc[i].h; if (sc[i].v > max_v) max_v = sc[i].v; }
     uint8_t *planes[3] = {0, 0, 0};
-    int pw[3], ph[3];
+    int pw[3] = {0, 0, 0}, ph[3] = {0, 0, 0};
     const uint8_t *src[3] = {y, u, v};
     int cw = chroma == 444 || chroma == 400 ? width : width / 2;     /* frame.ml:10-24 */
     int chh = chroma == 420 ? height / 2 : height;

@@ -56,7 +56,7 @@ constexpr int W1 = 2841, W2 = 2676, W3 = 2408, W5 = 1609, W6 = 1108, W7 = 565;
 //   |argument of a 181*y product|    <= GUARD_Y   (row and column pass)
 // imply that no int32 operation wraps and every v_mul_i32_i24 / v_mad_i32_i24
 // operand lies in [-2^23, 2^23).
-constexpr int GUARD_D = HVC_GUARD_D;
+[[maybe_unused]] constexpr int GUARD_D = HVC_GUARD_D;
 constexpr int GUARD_R = (1 << 18) - 1;
 constexpr int GUARD_Y = (1 << 23) - 1;
 
