@@ -130,9 +130,13 @@ int parse_header(const uint8_t *data, size_t n, Header &h) {
 // ---------------------------------------------------------------------------
 // Huffman decode tables (Tables.Specification.create_code_table, tables.ml:27-45; Tables.Lut.create :490-501)
 struct Lut {
+    static constexpr int FAST_BITS = 10;
     int max_bits = 0;
-    std::vector<uint16_t> e; // (length << 8) | data ; 0 = no code
+    std::vector<uint16_t> e; // (length << 8) | data ; 0 = no code; indexed by max_bits peeked bits (Tables.Lut)
+    uint16_t fast[1 << FAST_BITS]; // the same entries for codes of <= FAST_BITS bits, indexed by FAST_BITS bits:
+                                   // 2 KB, L1-resident; 0 = longer code (or none): look in e
     bool build(const HuffSpec &s) {
+        std::memset(fast, 0, sizeof fast);
         int maxb = 0;
         for (int i = 0; i < 16; i++)
             if (s.lengths[i]) maxb = i + 1;
@@ -147,26 +151,64 @@ struct Lut {
                 const unsigned count = 1u << (maxb - len);
                 if (first + count > e.size()) return false; // over-subscribed table
                 for (unsigned j = 0; j < count; j++) e[first + j] = (uint16_t)((len << 8) | s.values[k]);
+                if (len <= FAST_BITS) {
+                    const unsigned f0 = (code + (unsigned)i) << (FAST_BITS - len), fc = 1u << (FAST_BITS - len);
+                    for (unsigned j = 0; j < fc && f0 + j < (1u << FAST_BITS); j++)
+                        fast[f0 + j] = (uint16_t)((len << 8) | s.values[k]);
+                }
             }
             code = (code + (unsigned)s.lengths[len - 1]) << 1;
         }
         return true;
+    }
+
+    // AC tables only: code AND magnitude bits decoded by one lookup when length + size <= FAST_BITS
+    // (most coefficients of real streams).  bits = 0: not covered, take the two-step path.
+    struct Whole { uint8_t bits, run; int16_t value; };
+    static constexpr uint8_t EOB = 0xff;
+    Whole whole[1 << FAST_BITS];
+    void build_whole() {
+        for (unsigned w = 0; w < (1u << FAST_BITS); w++) {
+            Whole o{0, 0, 0};
+            const unsigned e = fast[w];
+            if (e) {
+                const int len = (int)(e >> 8), run = (int)((e >> 4) & 15), size = (int)(e & 15);
+                if (len + size <= FAST_BITS) {
+                    int mag = 0;
+                    if (size) {
+                        const unsigned code = (w >> (FAST_BITS - len - size)) & ((1u << size) - 1u);
+                        mag = (code & (1u << (size - 1))) ? (int)code : (int)code - (int)((1u << size) - 1); // mag'
+                    }
+                    o.bits = (uint8_t)(len + size);
+                    o.run = (mag == 0 && run == 0) ? EOB : (uint8_t)run; // decoder.ml:131-132
+                    o.value = (int16_t)mag;
+                }
+            }
+            whole[w] = o;
+        }
     }
 };
 
 // ---------------------------------------------------------------------------
 // bit reader over the extracted entropy-coded segment (stuffing already removed)
 struct BitReader {
-    const uint8_t *p;
+    const uint8_t *p; // the segment, followed by >= 8 readable zero bytes
     size_t n, pos = 0;
     uint64_t buf = 0; // MSB-aligned
     int cnt = 0;
+    // after refill() at least 57 bits are valid; past the end the stream reads as zero bits
+    // (bitstream_reader.ml:19-22)
     inline void refill() {
-        while (cnt <= 56) {
-            const uint64_t b = pos < n ? p[pos] : 0; // past the end: zero bits (bitstream_reader.ml:19-22)
-            pos++;
-            buf |= b << (56 - cnt);
-            cnt += 8;
+        if (pos + 8 <= n + 8) { // one unaligned big-endian 64-bit load (the padding makes it safe)
+            uint64_t w;
+            std::memcpy(&w, p + pos, 8);
+            w = __builtin_bswap64(w);
+            buf |= w >> cnt;
+            const int adv = (63 - cnt) >> 3;
+            pos += (size_t)adv;
+            cnt += adv * 8;
+        } else {
+            cnt = 64; // far past the end: zeros only
         }
     }
     inline unsigned peek(int k) const { return k ? (unsigned)(buf >> (64 - k)) : 0u; }
@@ -266,12 +308,13 @@ int hvc_jpeg_entropy_decode(const uint8_t *data, size_t n, const hvc_jpeg_info *
         }
         if (di < 0 || ai < 0) return HVC_E_BAD_JPEG;
         if (!dc[i].build(h.dht[di].spec) || !ac[i].build(h.dht[ai].spec)) return HVC_E_BAD_JPEG;
+        ac[i].build_whole();
     }
     // extract_entropy_coded_bits (decoder.ml:261-281): up to the first marker, 0xff00 -> 0xff
     std::vector<uint8_t> ecs;
     {
         size_t pos = h.ecs_pos;
-        ecs.reserve(n > pos ? n - pos : 0);
+        ecs.reserve((n > pos ? n - pos : 0) + 16);
         while (pos < n) {
             const uint8_t *ff = (const uint8_t *)std::memchr(data + pos, 0xff, n - pos);
             const size_t stop = ff ? (size_t)(ff - data) : n;
@@ -283,8 +326,10 @@ int hvc_jpeg_entropy_decode(const uint8_t *data, size_t n, const hvc_jpeg_info *
             pos = stop + 2;
         }
     }
+    const size_t ecs_len = ecs.size();
+    ecs.insert(ecs.end(), 16, 0); // zero padding: the reader loads 8 bytes at a time
     std::memset(coefs, 0, info->coef_count * sizeof(int16_t)); // clear_block for every block
-    BitReader br{ecs.data(), ecs.size()};
+    BitReader br{ecs.data(), ecs_len};
     int dc_pred[4] = {0, 0, 0, 0};
     const hvc_jpeg_component &c0 = info->comp[0];
     const int mbs_wide = c0.decoded_width / (8 * c0.hscale), mbs_high = c0.decoded_height / (8 * c0.vscale);
@@ -294,6 +339,8 @@ int hvc_jpeg_entropy_decode(const uint8_t *data, size_t n, const hvc_jpeg_info *
                 const hvc_jpeg_component &c = info->comp[i];
                 const hvc_component &L = info->layout[i];
                 const uint16_t *dct = dc[i].e.data(), *act = ac[i].e.data();
+                const uint16_t *dcf = dc[i].fast, *acf = ac[i].fast;
+                const Lut::Whole *acw = ac[i].whole;
                 const int dmax = dc[i].max_bits, amax = ac[i].max_bits;
                 for (int sy = 0; sy < c.vscale; sy++)
                     for (int sx = 0; sx < c.hscale; sx++) {
@@ -301,7 +348,8 @@ int hvc_jpeg_entropy_decode(const uint8_t *data, size_t n, const hvc_jpeg_info *
                         if (bx >= L.blocks_w || by >= L.blocks_h) return HVC_E_BAD_JPEG; // Plane.set out of bounds
                         int16_t *blk = coefs + L.coef_offset + ((size_t)by * L.blocks_w + bx) * 64;
                         br.refill();
-                        unsigned e = dct[br.peek(dmax)];
+                        unsigned e = dcf[br.peek(Lut::FAST_BITS)];
+                        if (!e) e = dct[br.peek(dmax)];
                         if (!e) return HVC_E_BAD_JPEG; // "Can't find dc code"
                         br.skip(e >> 8);
                         int cat = e & 0xff, diff = 0;
@@ -318,7 +366,18 @@ int hvc_jpeg_entropy_decode(const uint8_t *data, size_t n, const hvc_jpeg_info *
                         int k = 1;
                         while (k < 64) {
                             br.refill();
-                            e = act[br.peek(amax)];
+                            // symbol + magnitude in one lookup when both fit the look-ahead window
+                            const Lut::Whole wh = acw[br.peek(Lut::FAST_BITS)];
+                            if (wh.bits) {
+                                br.skip(wh.bits);
+                                if (wh.run == Lut::EOB) break;
+                                k += wh.run;
+                                if (k >= 64) return HVC_E_BAD_JPEG; // "coefficient index out of range"
+                                blk[k++] = wh.value;
+                                continue;
+                            }
+                            e = acf[br.peek(Lut::FAST_BITS)];
+                            if (!e) e = act[br.peek(amax)];
                             if (!e) return HVC_E_BAD_JPEG; // "Can't find ac code"
                             br.skip(e >> 8);
                             const int run = (e >> 4) & 15, size = e & 15;
@@ -418,31 +477,53 @@ void build_enc(EncTable &t, const uint8_t *dc_bits, const uint8_t *dc_vals, cons
 
 // Bitstream_writer (common/src/bitstream_writer.ml): MSB first, 0xff -> 0xff00 stuffing
 struct BitWriter {
-    std::vector<uint8_t> &out;
+    std::vector<uint8_t> &out; // grown in large steps; `pos` is the logical size while writing
+    size_t pos;
     uint64_t acc = 0;
     int nbits = 0;
-    explicit BitWriter(std::vector<uint8_t> &o) : out(o) {}
-    inline void put(unsigned value, int bits) {
-        if (!bits) return;
+    explicit BitWriter(std::vector<uint8_t> &o) : out(o), pos(o.size()) {}
+    // room for one block's worst case (64 x 26 bits, every byte stuffed) without further checks
+    inline void reserve_block() {
+        if (out.size() - pos < 512) out.resize(out.size() * 2 + 4096);
+    }
+    inline void put(unsigned value, int bits) { // bits <= 16
         acc = (acc << bits) | (value & ((1u << bits) - 1u));
         nbits += bits;
-        while (nbits >= 8) {
-            const uint8_t d = (uint8_t)(acc >> (nbits - 8));
-            out.push_back(d);
-            if (d == 0xff) out.push_back(0);
-            nbits -= 8;
+        if (nbits >= 32) {
+            const uint32_t w = (uint32_t)(acc >> (nbits - 32));
+            nbits -= 32;
+            uint8_t *o = out.data() + pos;
+            if ((((~w) - 0x01010101u) & w & 0x80808080u) == 0) { // no 0xff byte: four bytes at once
+                o[0] = (uint8_t)(w >> 24);
+                o[1] = (uint8_t)(w >> 16);
+                o[2] = (uint8_t)(w >> 8);
+                o[3] = (uint8_t)w;
+                pos += 4;
+            } else {
+                for (int sh = 24; sh >= 0; sh -= 8) {
+                    const uint8_t d = (uint8_t)(w >> sh);
+                    out[pos++] = d;
+                    if (d == 0xff) out[pos++] = 0;
+                }
+            }
         }
     }
-    void flush_with_1s() { // bitstream_writer.ml:45-49
-        while (nbits & 7) put(1, 1);
+    void finish_with_1s() { // Bitstream_writer.flush_with_1s (bitstream_writer.ml:45-49), then trim
+        while (nbits & 7) { acc = (acc << 1) | 1u; nbits++; }
+        reserve_block();
+        while (nbits >= 8) {
+            const uint8_t d = (uint8_t)(acc >> (nbits - 8));
+            out[pos++] = d;
+            if (d == 0xff) out[pos++] = 0;
+            nbits -= 8;
+        }
+        out.resize(pos);
     }
 };
 
 inline int bit_size(int v) { // encoder.ml:143
-    unsigned a = (unsigned)(v < 0 ? -v : v);
-    int n = 0;
-    while (a) { n++; a >>= 1; }
-    return n;
+    const unsigned a = (unsigned)(v < 0 ? -v : v);
+    return a ? 32 - __builtin_clz(a) : 0;
 }
 
 void put_marker(std::vector<uint8_t> &o, int code) { o.push_back(0xff); o.push_back((uint8_t)code); }
@@ -578,6 +659,7 @@ int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uin
                     for (int sx = 0; sx < c.hscale; sx++) {
                         const int bx = mx * c.hscale + sx, by = my * c.vscale + sy;
                         const int16_t *q = coefs + L.coef_offset + ((size_t)by * L.blocks_w + bx) * 64;
+                        bw.reserve_block();
                         // DC: difference to the predictor (encoder.ml:138-140), size + magnitude (:155-160)
                         const int diff = q[0] - dc_pred[i];
                         dc_pred[i] = q[0];
@@ -601,7 +683,7 @@ int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uin
                         if (run) bw.put(t.ac[0].bits, t.ac[0].len);
                     }
             }
-    bw.flush_with_1s();
+    bw.finish_with_1s();
     put_marker(o, 0xd9);
     *out_len = o.size();
     if (!out || o.size() > cap) return HVC_E_INVALID_ARG;
