@@ -126,3 +126,50 @@ def test_batch_rejects_mixed_geometry(ctx):
     pixels = np.zeros(3 * info.pixel_bytes, dtype=np.uint8)
     with pytest.raises(hvc.HvcError):
         ctx.jpeg_decode_batch(jpegs, pixels, info.pixel_bytes, threads=2, frames_per_chunk=2)
+
+
+def _widen_dqt(jpg: bytes) -> bytes:
+    """Rewrite every 8-bit DQT segment of a JPEG as a 16-bit one (Pq = 1) with the same values."""
+    out, i = bytearray(), 0
+    while i < len(jpg):
+        if jpg[i] == 0xFF and i + 1 < len(jpg) and jpg[i + 1] == 0xDB:
+            ln = (jpg[i + 2] << 8) | jpg[i + 3]
+            assert ln == 67 and (jpg[i + 4] >> 4) == 0
+            tq = jpg[i + 4] & 15
+            out += b"\xff\xdb" + (3 + 128).to_bytes(2, "big") + bytes([0x10 | tq])
+            for q in jpg[i + 5:i + 5 + 64]:
+                out += bytes([0, q])
+            i += 2 + ln
+        elif jpg[i] == 0xFF and i + 1 < len(jpg) and jpg[i + 1] == 0xDA:
+            out += jpg[i:]
+            break
+        else:
+            out.append(jpg[i])
+            i += 1
+    return bytes(out)
+
+
+def test_sixteen_bit_dqt_file(ctx):
+    """Markers.Dqt.decode reads element_precision = 8 lsl Pq (markers.ml:162-167): a file with 16-bit
+    tables decodes to the same planes."""
+    jpg16 = _widen_dqt(golden_bytes("mini.jpg"))
+    assert jpg16 != golden_bytes("mini.jpg")
+    info, pixels = ctx.jpeg_decode(jpg16)
+    d = orc.Decoder(jpg16)
+    d.decode()
+    d8 = orc.Decoder(golden_bytes("mini.jpg"))
+    d8.decode()
+    for i, plane in enumerate(info.planes(pixels)):
+        assert np.array_equal(plane, d.plane(i)) and np.array_equal(plane, d8.plane(i))
+
+
+def test_single_component_scan(ctx):
+    """Decoder.init / decode_seq handle any number of scan components (decoder.ml:304-345, 374-395):
+    a monochrome file (Encoder.encode_monochrome, encoder.ml:543-551) has one 1x1 component."""
+    y = synth_pixels(5, 40, 72)
+    jpg = orc.encode_yuv(y, y[:1, :1], y[:1, :1], 72, 40, 400, 80)
+    info, pixels = ctx.jpeg_decode(jpg)
+    assert info.n_comp == 1
+    d = orc.Decoder(jpg)
+    d.decode()
+    assert np.array_equal(info.planes(pixels)[0], d.plane(0))
