@@ -15,13 +15,19 @@ the path shards as independent frame batches: no data-path collective, weak
 scaling (per-GPU batch fixed).  The barrier / max-over-ranks reduction below is
 timing closure only.
 
+Inputs: seeded synthetic pixel frames (video-coding_amd/synth.py) pushed through
+this library's OWN forward path (k_encode, quality 75) on the GPU, outside the
+timed region -- so the coefficients are encoder-producible.
+
 The JSON line also carries
-  roofline      achieved algorithmic GB/s of the dominant kernel (k_decode_fast:
+  roofline      achieved algorithmic GB/s of the dominant kernel (k_decode_packed:
                 192 B per 8x8 block = 128 B int16 coefficients read + 64 B pixels
                 written) over its HIP-event-timed duration, against 8 TB/s HBM;
+                `traffic` = the HBM bytes of the committed rocprofv3 PMC passes;
   cpu_baseline  the CPU oracle (oracle/hvc_oracle.c, the restated model path,
                 scalar, 1 thread) timed on this host on a bounded sample of the
-                same workload.  It is the checker, timed as a baseline only.
+                same workload.  The oracle is the checker, timed as a baseline
+                only: this leg (and the optional --check) is its only use here.
 """
 import argparse
 import json
@@ -42,22 +48,21 @@ ALGO_BYTES_PER_BLOCK = 192  # 128 B read + 64 B written
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def make_distinct_frames(n_distinct, seed):
-    """Coefficient records of n_distinct synthetic frames (valid, encoder-producible):
-    synthetic pixels -> the CPU oracle's forward path at quality 75."""
-    from oracle import orc
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from helpers import synth_pixels
-    ql = orc.quant_scale(orc.quant_luma(), 75).astype(np.uint16)
-    qc = orc.quant_scale(orc.quant_chroma(), 75).astype(np.uint16)
-    frames = []
-    for f in range(n_distinct):
-        rec = []
-        for ci, (bw, bh, qt) in enumerate(PLANES):
-            pix = synth_pixels(seed + 16 * f + ci, bh * 8, bw * 8)
-            rec.append(orc.fdct_quant(pix, ql if qt == 0 else qc, bw, bh))
-        frames.append(np.concatenate(rec))
-    return np.stack(frames), np.stack([ql, qc])
+def make_distinct_frames(ctx, hvc, n_distinct, seed):
+    """Coefficient records of n_distinct synthetic frames via the library's own forward path
+    (hvc_encode_frames on the GPU, Quant_tables.scale 75).  Returns (device int16 tensor
+    [n_distinct, coef_count], qtabs uint16 [2, 64])."""
+    import torch
+    from video_coding_amd.synth import synth_frame_pixels
+    qtabs = np.stack([hvc.hvc.quant_table(0, 75), hvc.hvc.quant_table(1, 75)])
+    specs, cfs, pfs = hvc.hvc.frame_layout(PLANES)
+    pix = np.stack([synth_frame_pixels(seed + 16 * f, PLANES) for f in range(n_distinct)])
+    d_pix = torch.from_numpy(pix).cuda()
+    d_coefs = torch.zeros((n_distinct, cfs), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    ctx.encode_frames(d_pix, pfs, qtabs, hvc.hvc.components(specs), n_distinct, d_coefs, cfs)
+    ctx.synchronize()
+    return d_coefs, qtabs
 
 
 def cpu_baseline(frames, qtabs, min_seconds=10.0):
@@ -164,15 +169,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = dist_init(world, "nccl", torch.device("cuda", local_rank))
 
-    frames, qtabs = make_distinct_frames(args.distinct, seed=0x4A504547 + 1000 * rank)
+    ctx = hvc.Context(local_rank)  # raises without a gfx950 GPU: there is no CPU fallback
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_distinct, qtabs = make_distinct_frames(ctx, hvc, args.distinct, seed=0x4A504547 + 1000 * rank)
     specs, cfs, pfs = hvc.hvc.frame_layout(PLANES)
     reps = (args.frames + args.distinct - 1) // args.distinct
-    d_coefs = torch.from_numpy(frames).cuda().repeat(reps, 1)[:args.frames].contiguous()
+    d_coefs = d_distinct.repeat(reps, 1)[:args.frames].contiguous()
     d_pix = torch.zeros((args.frames, pfs), dtype=torch.uint8, device="cuda")
     comps = hvc.hvc.components(specs)
-
-    ctx = hvc.Context(local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
     ctx.set_profiling(True)
 
     def step():
@@ -181,9 +186,10 @@ def main():
     dt = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, world, dist)
     dt = max_over_ranks(dt, world, dist, "cuda")
 
-    # HIP events recorded around k_decode_fast inside the timed region (one pair per step)
+    # HIP events recorded around k_decode_packed inside the timed region (one pair per step)
     kernel_ms = ctx.kernel_ms_history(min(args.steps, 64))
     wide = ctx.last_wide_blocks()
+    frames_host = d_distinct.cpu().numpy() if (args.check or (rank == 0 and world == 1 and not args.no_cpu_baseline)) else None
     if args.check:
         from oracle import orc
         got = d_pix[:args.distinct].cpu().numpy()
@@ -191,7 +197,7 @@ def main():
             off = 0
             for (bw, bh, qt), s in zip(PLANES, specs):
                 n = bw * bh * 64
-                want = orc.dequant_idct_recon(frames[f][off:off + n], qtabs[qt], bw, bh)
+                want = orc.dequant_idct_recon(frames_host[f][off:off + n], qtabs[qt], bw, bh)
                 assert np.array_equal(got[f][s["plane_offset"]:s["plane_offset"] + n], want), (f, bw)
                 off += n
 
@@ -221,7 +227,7 @@ def main():
                                        "for blocks outside the proven range"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames, qtabs, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(frames_host, qtabs, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

@@ -6,9 +6,9 @@
   --config 4   4K 4:4:4 decode, one GPU's shard shape (388 800 blocks/frame), HBM-resident
   --config 5   encoder: forward 8x8 DCT + quantise, 4K 4:2:0, HBM-resident (hvc_encode_frames)
 
-Each prints one JSON line.  Inputs are synthetic; the oracle is used only to PREPARE inputs
-(JPEG byte strings / valid coefficient planes) outside every timed region and, with --check, as
-the checker.
+Each prints one JSON line.  Inputs are synthetic and are prepared with the library's own paths
+(hvc_jpeg_encode / hvc_encode_frames) outside every timed region; the oracle appears only with
+--check, as the checker.
 """
 import argparse
 import json
@@ -26,18 +26,17 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def config3(args):
     import torch
     import video_coding_amd as hvc
-    from helpers import synth_pixels
-    from oracle import orc
+    from video_coding_amd.synth import synth_pixels
     W, H = 1920, 1080
+    ctx = hvc.Context(0)
     jpegs = []
-    for f in range(args.distinct):
+    for f in range(args.distinct):  # the library's own encoder (hvc_jpeg_encode) makes the input files
         y = synth_pixels(10 + f, 1088, 1920)[:H]
         u = synth_pixels(20 + f, 544, 960)[:H // 2]
         v = synth_pixels(30 + f, 544, 960)[:H // 2]
-        jpegs.append(orc.encode_yuv(y, u, v, W, H, 420, 75))
+        jpegs.append(ctx.jpeg_encode(y, u, v, W, H, 420, 75))
     batch = [jpegs[i % len(jpegs)] for i in range(args.frames)]
     info = hvc.hvc.jpeg_read_header(batch[0])
-    ctx = hvc.Context(0)
     d_pix = torch.zeros(args.frames * info.pixel_bytes, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     ctx.jpeg_decode_batch(batch[:min(64, args.frames)], d_pix, info.pixel_bytes, threads=args.threads,
@@ -51,6 +50,7 @@ def config3(args):
             best = (dt, st)
     dt, st = best
     if args.check:
+        from oracle import orc
         got = d_pix[:info.pixel_bytes * len(jpegs)].cpu().numpy()
         for f, j in enumerate(jpegs):
             d = orc.Decoder(j)
@@ -76,24 +76,20 @@ def config3(args):
 def resident_decode(args, planes, W, H, tag):
     import torch
     import video_coding_amd as hvc
-    from helpers import synth_pixels
-    from oracle import orc
-    ql = orc.quant_scale(orc.quant_luma(), 75).astype(np.uint16)
-    qc = orc.quant_scale(orc.quant_chroma(), 75).astype(np.uint16)
-    recs = []
-    for f in range(args.distinct):
-        rec = [orc.fdct_quant(synth_pixels(40 + 8 * f + i, bh * 8, bw * 8), ql if qt == 0 else qc, bw, bh)
-               for i, (bw, bh, qt) in enumerate(planes)]
-        recs.append(np.concatenate(rec))
+    from video_coding_amd.synth import synth_frame_pixels
+    qtabs = np.stack([hvc.hvc.quant_table(0, 75), hvc.hvc.quant_table(1, 75)])
     specs, cfs, pfs = hvc.hvc.frame_layout(planes)
-    reps = (args.frames + args.distinct - 1) // args.distinct
-    d_coefs = torch.from_numpy(np.stack(recs)).cuda().repeat(reps, 1)[:args.frames].contiguous()
-    d_pix = torch.zeros((args.frames, pfs), dtype=torch.uint8, device="cuda")
+    comps = hvc.hvc.components(specs)
     ctx = hvc.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # valid coefficients from the library's own forward path
+    src = torch.from_numpy(np.stack([synth_frame_pixels(40 + 8 * f, planes) for f in range(args.distinct)])).cuda()
+    d_distinct = torch.zeros((args.distinct, cfs), dtype=torch.int16, device="cuda")
+    ctx.encode_frames(src, pfs, qtabs, comps, args.distinct, d_distinct, cfs)
+    reps = (args.frames + args.distinct - 1) // args.distinct
+    d_coefs = d_distinct.repeat(reps, 1)[:args.frames].contiguous()
+    d_pix = torch.zeros((args.frames, pfs), dtype=torch.uint8, device="cuda")
     ctx.set_profiling(True)
-    comps = hvc.hvc.components(specs)
-    qtabs = np.stack([ql, qc])
     for _ in range(args.warmup):
         ctx.decode_frames(d_coefs, cfs, qtabs, comps, args.frames, d_pix, pfs)
     torch.cuda.synchronize()
@@ -115,17 +111,12 @@ def resident_decode(args, planes, W, H, tag):
 def config5(args):
     import torch
     import video_coding_amd as hvc
-    from helpers import synth_pixels
-    from oracle import orc
+    from video_coding_amd.synth import synth_frame_pixels
     W, H = 3840, 2160
     planes = [(480, 270, 0), (240, 135, 1), (240, 135, 1)]
-    ql = orc.quant_scale(orc.quant_luma(), 75).astype(np.uint16)
-    qc = orc.quant_scale(orc.quant_chroma(), 75).astype(np.uint16)
+    ql, qc = hvc.hvc.quant_table(0, 75), hvc.hvc.quant_table(1, 75)
     specs, cfs, pfs = hvc.hvc.frame_layout(planes)
-    recs = []
-    for f in range(args.distinct):
-        recs.append(np.concatenate([synth_pixels(60 + 8 * f + i, bh * 8, bw * 8).reshape(-1)
-                                    for i, (bw, bh, _) in enumerate(planes)]))
+    recs = [synth_frame_pixels(60 + 8 * f, planes) for f in range(args.distinct)]
     reps = (args.frames + args.distinct - 1) // args.distinct
     d_pix = torch.from_numpy(np.stack(recs)).cuda().repeat(reps, 1)[:args.frames].contiguous()
     d_coefs = torch.zeros((args.frames, cfs), dtype=torch.int16, device="cuda")
@@ -144,6 +135,7 @@ def config5(args):
     dt = time.perf_counter() - t0
     k_ms = float(np.mean(ctx.kernel_ms_history(min(args.steps, 64))))
     if args.check:
+        from oracle import orc
         got = d_coefs[:args.distinct].cpu().numpy()
         for f in range(args.distinct):
             for s, (bw, bh, qt) in zip(specs, planes):
@@ -165,7 +157,6 @@ def config_k2(args):
     """K2: 4:2:0 -> 4:4:4 chroma upsample of 1080p chroma planes (960x540 -> 1920x1080), 2 planes/frame."""
     import torch
     import video_coding_amd as hvc
-    from oracle import orc
     cw, ch = 960, 540
     n = 2 * args.frames
     rng = np.random.Generator(np.random.PCG64(5))
@@ -183,6 +174,7 @@ def config_k2(args):
         ctx.upsample420(d_src, cw, ch, d_dst, n_planes=n)
     ms = ctx.timer_end() / args.steps
     if args.check:
+        from oracle import orc
         got = d_dst[:args.distinct].cpu().numpy()
         for p in range(args.distinct):
             assert np.array_equal(got[p], orc.supersample_hv2(src[p]))
@@ -200,7 +192,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=4)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--threads", type=int, default=os.cpu_count() or 8)
+    ap.add_argument("--threads", type=int, default=len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 16)
     ap.add_argument("--chunk", type=int, default=32)
     ap.add_argument("--check", action="store_true")
     args = ap.parse_args()
