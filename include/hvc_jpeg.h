@@ -136,6 +136,21 @@ HVC_API int hvc_decode_frames(hvc_ctx *ctx, const int16_t *coefs, size_t coef_fr
                               int n_comp, int n_frames, uint8_t *pixels,
                               size_t pixel_frame_stride, int where);
 
+/* The step after the path, fused into it: 4:2:0 coefficient records in,
+ * tight 4:4:4 frames out.  Per frame:
+ *     the block stage of hvc_decode_frames on the three component planes
+ *     Decoder.get_yuv_frame / crop        decoder.ml:403-420  (luma width x height, chroma /2)
+ *     Planar_444.convert_from_420         tools/src/planar_444.ml:82-103, 122-131 (supersample_hv2)
+ * Output record f = frames + f*frame_stride: planes Y, U, V, each width x height bytes, row-major,
+ * stride = width, back to back.  The quarter-resolution chroma planes never reach memory.
+ * comps: the 4:2:0 geometry of Decoder.init (blocks_w, blocks_h, qtab, coef_offset are used;
+ * plane_offset / stride are ignored); n_comp must be 3, width and height even
+ * (Yuv.assert_is_420, tools/src/yuv.ml:104-116) and inside the decoded planes. */
+HVC_API int hvc_decode_frames_yuv444(hvc_ctx *ctx, const int16_t *coefs, size_t coef_frame_stride,
+                                     const uint16_t *qtabs, int n_qtabs, const hvc_component *comps,
+                                     int n_comp, int n_frames, int width, int height, uint8_t *frames,
+                                     size_t frame_stride, int where);
+
 /* Diagnostic: which implementation the decode entry points use.  0 = default (k_decode_packed, the
  * int16-pair kernel, with the int64 fix-up for blocks outside its proven range), 1 = the unpacked
  * int32 kernel k_decode_fast, 2 = the int64 kernel for every block.  All three produce identical

@@ -253,3 +253,16 @@ def test_packed_energy_thresholds():
     # real-data headroom: a full-amplitude block has sum(pixel^2) <= 64 * 128^2, its row outputs
     # carry energy ~ 511x that (22.6^2): about half of the 32767^2 threshold.
     assert 511 * 64 * 128 * 128 < 32767 * 32767
+
+
+def test_avg4_by_lerp_identity():
+    """k_decode_444 computes Planar_444.avg4 (tools/src/planar_444.ml:10-16) on four samples per
+    instruction as v_lerp_u8(avg2(a, b), (c + d) >> 1, r) with r = ~(a ^ b) | (c ^ d) (bit 0):
+    ((a+b+1)>>1 + (c+d)>>1 + r) >> 1 == (a+b+c+d+2) >> 2 for every a, b, c, d in 0..255.
+    Both sides depend on (a, b) and (c, d) only through their sums, so all 511 x 511 sums cover it."""
+    import numpy as np
+    s1, s2 = np.meshgrid(np.arange(511), np.arange(511), indexing="ij")
+    hc = (s1 + 1) >> 1            # avg2(a, b), v_lerp_u8 with rounding bit 1
+    hf = s2 >> 1                  # v_lerp_u8 with rounding bit 0
+    r = (~s1 | s2) & 1            # parity(a ^ b) = parity(a + b)
+    assert np.array_equal((hc + hf + r) >> 1, (s1 + s2 + 2) >> 2)

@@ -153,6 +153,41 @@ def config5(args):
     ctx.close()
 
 
+def config_host(args):
+    """The HVC_MEM_HOST form of the boundary (what a caller holding OCaml Bigarrays gets): pageable
+    host coefficient records in, host pixel records out -- PCIe-inclusive, never the headline value."""
+    import video_coding_amd as hvc
+    from video_coding_amd.synth import synth_frame_pixels
+    planes = [(240, 136, 0), (120, 68, 1), (120, 68, 1)]
+    qtabs = np.stack([hvc.hvc.quant_table(0, 75), hvc.hvc.quant_table(1, 75)])
+    specs, cfs, pfs = hvc.hvc.frame_layout(planes)
+    comps = hvc.hvc.components(specs)
+    ctx = hvc.Context(0)
+    src = np.stack([synth_frame_pixels(70 + 8 * f, planes) for f in range(args.distinct)])
+    distinct = np.zeros((args.distinct, cfs), dtype=np.int16)
+    ctx.encode_frames(src, pfs, qtabs, comps, args.distinct, distinct, cfs)  # host in, host out
+    coefs = np.ascontiguousarray(np.tile(distinct, ((args.frames + args.distinct - 1) // args.distinct, 1))[:args.frames])
+    pixels = np.zeros((args.frames, pfs), dtype=np.uint8)
+    for _ in range(2):
+        ctx.decode_frames(coefs, cfs, qtabs, comps, args.frames, pixels, pfs)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.decode_frames(coefs, cfs, qtabs, comps, args.frames, pixels, pfs)
+    dt = (time.perf_counter() - t0) / args.steps
+    if args.check:
+        from oracle import orc
+        for (bw, bh, qt), sp in zip(planes, specs):
+            n = bw * bh * 64
+            want = orc.dequant_idct_recon(coefs[1][sp["coef_offset"]:sp["coef_offset"] + n], qtabs[qt], bw, bh)
+            assert np.array_equal(pixels[1][sp["plane_offset"]:sp["plane_offset"] + n], want)
+    moved = args.frames * (cfs * 2 + pfs)
+    print(json.dumps({"config": "host", "metric": "Mpixel/s decoded, host buffers in and out (PCIe-inclusive)",
+                      "value": round(args.frames * 1920 * 1080 / dt / 1e6, 1), "unit": "Mpixel/s", "frames": args.frames,
+                      "ms_per_call": round(dt * 1e3, 2), "bytes_over_pcie": moved,
+                      "pcie_GBps": round(moved / dt / 1e9, 1)}))
+    ctx.close()
+
+
 def config_k2(args):
     """K2: 4:2:0 -> 4:4:4 chroma upsample of 1080p chroma planes (960x540 -> 1920x1080), 2 planes/frame."""
     import torch
@@ -187,27 +222,36 @@ def config_k2(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", type=int, required=True, choices=[2, 3, 4, 5])
+    ap.add_argument("--config", type=int, required=True, choices=[2, 3, 4, 5, 6])
     ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--distinct", type=int, default=4)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--threads", type=int, default=len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 16)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--threads", type=int, default=min(16, os.cpu_count() or 16))
     ap.add_argument("--chunk", type=int, default=32)
     ap.add_argument("--check", action="store_true")
     args = ap.parse_args()
     if args.config == 2:  # K2 upsample (optional output stage)
         args.frames = args.frames or 256
+        args.steps = args.steps or 20
         config_k2(args)
+    elif args.config == 6:  # host-buffer boundary of config 2
+        args.frames = args.frames or 128
+        args.steps = args.steps or 5
+        config_host(args)
     elif args.config == 3:
         args.frames = args.frames or 256
-        args.steps = min(args.steps, 3)
+        args.steps = args.steps or 3
         config3(args)
     elif args.config == 4:
-        args.frames = args.frames or 32
+        # one GPU's shard of config 4 = 2048 frames, processed as 16 resident chunks of 128 frames
+        # (9.6 GB per launch), re-using the same device-resident synthetic chunk
+        args.frames = args.frames or 128
+        args.steps = args.steps or 16
         resident_decode(args, [(480, 270, 0), (480, 270, 1), (480, 270, 1)], 3840, 2160, 4)
     else:
-        args.frames = args.frames or 64
+        args.frames = args.frames or 256
+        args.steps = args.steps or 30
         config5(args)
 
 

@@ -325,6 +325,30 @@ int hvc_last_wide_blocks(hvc_ctx *c, uint64_t *count) {
     return HVC_OK;
 }
 
+// Kernel-side forms of the quantiser tables: plain ints, the energy thresholds of the two int32
+// kernels, and the packed kernel's per-row operand pairs.
+static void prepare_tables(const uint16_t *qtabs, int n_qtabs, int *qt, int *ethr, int *ethr_packed, unsigned *qpair) {
+    for (int i = 0; i < n_qtabs * 64; i++) qt[i] = (int)qtabs[i];
+    for (int t = 0; t < n_qtabs; t++) {
+        // every |coef * q| <= qmax * sqrt(E): the fast kernel accepts E up to (HVC_GUARD_D / qmax)^2
+        unsigned qmax = 1;
+        for (int i = 0; i < 64; i++) qmax = qtabs[t * 64 + i] > qmax ? qtabs[t * 64 + i] : qmax;
+        unsigned long long m = HVC_GUARD_D / qmax;
+        unsigned long long thr = m * m;
+        ethr[t] = thr > 0x7ffffffeull ? 0x7ffffffe : (int)thr;
+        m = HVC_GUARD_D_PACKED / qmax;
+        thr = m * m;
+        ethr_packed[t] = thr > 0x7ffffffeull ? 0x7ffffffe : (int)thr;
+        static const int PAIRS[4][2] = {{1, 7}, {5, 3}, {2, 6}, {0, 4}};
+        for (int r = 0; r < 8; r++)
+            for (int k = 0; k < 4; k++) {
+                unsigned lo = qtabs[t * 64 + hvc::HVC_ZF[8 * r + PAIRS[k][0]]];
+                unsigned hi = qtabs[t * 64 + hvc::HVC_ZF[8 * r + PAIRS[k][1]]];
+                qpair[t * 32 + r * 4 + k] = (lo & 0xffffu) | (hi << 16);
+            }
+    }
+}
+
 // ---------------------------------------------------------------------------
 int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const uint16_t *qtabs, int n_qtabs,
                       const hvc_component *comps, int n_comp, int n_frames, uint8_t *pixels, size_t pixel_fs,
@@ -364,25 +388,7 @@ int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const ui
     P.n_comp = L.n_comp;
     P.tiles_per_frame = L.tiles_per_frame;
     for (int i = 0; i < L.n_comp; i++) P.comp[i] = L.comp[i];
-    for (int i = 0; i < n_qtabs * 64; i++) P.qt[i] = (int)qtabs[i];
-    for (int t = 0; t < n_qtabs; t++) {
-        // every |coef * q| <= qmax * sqrt(E): the fast kernel accepts E up to (HVC_GUARD_D / qmax)^2
-        unsigned qmax = 1;
-        for (int i = 0; i < 64; i++) qmax = qtabs[t * 64 + i] > qmax ? qtabs[t * 64 + i] : qmax;
-        unsigned long long m = HVC_GUARD_D / qmax;
-        unsigned long long thr = m * m;
-        P.ethr[t] = thr > 0x7ffffffeull ? 0x7ffffffe : (int)thr;
-        m = HVC_GUARD_D_PACKED / qmax;
-        thr = m * m;
-        P.ethr_packed[t] = thr > 0x7ffffffeull ? 0x7ffffffe : (int)thr;
-        static const int PAIRS[4][2] = {{1, 7}, {5, 3}, {2, 6}, {0, 4}};
-        for (int r = 0; r < 8; r++)
-            for (int k = 0; k < 4; k++) {
-                unsigned lo = qtabs[t * 64 + hvc::HVC_ZF[8 * r + PAIRS[k][0]]];
-                unsigned hi = qtabs[t * 64 + hvc::HVC_ZF[8 * r + PAIRS[k][1]]];
-                P.qpair[t * 32 + r * 4 + k] = (lo & 0xffffu) | (hi << 16);
-            }
-    }
+    prepare_tables(qtabs, n_qtabs, P.qt, P.ethr, P.ethr_packed, P.qpair);
     P.fix_count = c->d_fix_count + c->fix_phase;
     P.fix_count_next = c->d_fix_count + (c->fix_phase ^ 1);
     P.fix_list = c->d_fix_list;
@@ -430,6 +436,107 @@ int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const ui
                                        (size_t)comps[i].blocks_w * 8, (size_t)comps[i].blocks_h * 8,
                                        hipMemcpyDeviceToHost, c->stream));
         }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HVC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// 4:2:0 coefficient records -> tight 4:4:4 frames (block stage + crop + chroma upsample fused)
+int hvc_decode_frames_yuv444(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const uint16_t *qtabs, int n_qtabs,
+                             const hvc_component *comps, int n_comp, int n_frames, int width, int height,
+                             uint8_t *frames, size_t frame_stride, int where) {
+    if (!c || !coefs || !frames || !comps || n_frames < 0) return HVC_E_INVALID_ARG;
+    if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
+    int r = check_qtabs(qtabs, n_qtabs);
+    if (r) return r;
+    // Yuv.assert_is_420 (tools/src/yuv.ml:104-116): wy = 2 wu, hy = 2 hu -- even luma size only
+    if (n_comp != 3 || width < 2 || height < 2 || (width & 1) || (height & 1)) return HVC_E_INVALID_ARG;
+    if (width > 65535 || height > 65535) return HVC_E_TOO_LARGE;
+    Layout L; // validates blocks_w / blocks_h / qtab / offsets exactly as hvc_decode_frames does
+    r = make_layout(comps, n_comp, n_qtabs, L);
+    if (r) return r;
+    const int aw[3] = {width, width / 2, width / 2}, ah[3] = {height, height / 2, height / 2};
+    for (int i = 0; i < 3; i++) // the crop must lie inside the decoded planes (decoder.ml:403-413)
+        if (comps[i].blocks_w * 8 < aw[i] || comps[i].blocks_h * 8 < ah[i]) return HVC_E_INVALID_ARG;
+    const size_t plane_bytes = (size_t)width * (size_t)height, out_span = 3 * plane_bytes;
+    if (n_frames == 0) return HVC_OK;
+    if (n_frames > 65535) return HVC_E_TOO_LARGE;
+    if (n_frames > 1 && (coef_fs < L.coef_span || frame_stride < out_span)) return HVC_E_INVALID_ARG;
+    if (coef_fs & 7) return HVC_E_ALIGNMENT;
+
+    hvc::Decode444Params P;
+    std::memset(&P, 0, sizeof P);
+    P.coef_fs = coef_fs;
+    P.out_fs = frame_stride;
+    P.n_frames = n_frames;
+    P.width = width;
+    P.height = height;
+    for (int i = 0; i < 3; i++) {
+        hvc::Plane444K &K = P.pl[i];
+        K.bw = comps[i].blocks_w;
+        K.cbw = (aw[i] + 7) / 8;
+        K.cbh = (ah[i] + 7) / 8;
+        K.aw = aw[i];
+        K.ah = ah[i];
+        K.qtab = comps[i].qtab;
+        K.coef_off = comps[i].coef_offset;
+        K.out_off = (size_t)i * plane_bytes;
+    }
+    // umulhi(b, ceil(2^32 / d)) == b / d needs b * d < 2^32
+    if ((unsigned long long)P.pl[0].cbw * P.pl[0].cbw * P.pl[0].cbh >= (1ull << 32)) return HVC_E_TOO_LARGE;
+    P.y_tiles = (P.pl[0].cbw * P.pl[0].cbh + HVC_TILE - 1) / HVC_TILE;
+    P.y_magic = (unsigned)(((1ull << 32) + P.pl[0].cbw - 1) / P.pl[0].cbw);
+    P.c_tiles_x = (P.pl[1].cbw + HVC_444_TILE_BW - 1) / HVC_444_TILE_BW;
+    P.c_tiles_y = (P.pl[1].cbh + HVC_444_TILE_BH - 1) / HVC_444_TILE_BH;
+    P.c_magic = (unsigned)(((1ull << 32) + P.c_tiles_x - 1) / P.c_tiles_x);
+    P.tiles_per_frame = P.y_tiles + 2 * P.c_tiles_x * P.c_tiles_y;
+    const unsigned long long ids = (unsigned long long)n_frames * P.tiles_per_frame * HVC_TILE;
+    if (ids >= (1ull << 32)) return HVC_E_TOO_LARGE;
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
+    if ((size_t)ids > c->fix_cap) {
+        void *p = c->d_fix_list;
+        size_t cap = c->fix_cap * sizeof(unsigned);
+        r = grow(c, &p, &cap, (size_t)ids * sizeof(unsigned));
+        c->d_fix_list = (unsigned *)p;
+        c->fix_cap = cap / sizeof(unsigned);
+        if (r) return r;
+    }
+    int ethr_unused[HVC_MAX_QTABS];
+    prepare_tables(qtabs, n_qtabs, P.qt, ethr_unused, P.ethr_packed, P.qpair);
+    bool wide_only = c->decode_kernel == 2;
+    for (int i = 0; i < n_qtabs * 64; i++) wide_only |= qtabs[i] > 255;
+    P.fix_list = c->d_fix_list;
+    if (!wide_only) {
+        P.fix_count = c->d_fix_count + c->fix_phase;
+        P.fix_count_next = c->d_fix_count + (c->fix_phase ^ 1);
+        c->fix_last = c->fix_phase;
+        c->fix_phase ^= 1;
+    }
+
+    if (where == HVC_MEM_DEVICE) {
+        if ((uintptr_t)coefs & 15) return HVC_E_ALIGNMENT;
+        P.coefs = coefs;
+        P.out = frames;
+        const bool prof = c->profiling && !wide_only;
+        const int slot = (int)(c->k_calls % HVC_PROF_RING);
+        HIPCHK(c, hvc::launch_decode_444(P, wide_only, c->stream, prof ? c->k0[slot] : nullptr,
+                                         prof ? c->k1[slot] : nullptr));
+        if (prof) c->k_calls++;
+        return HVC_OK;
+    }
+    const size_t cbytes = ((size_t)(n_frames - 1) * coef_fs + L.coef_span) * sizeof(int16_t);
+    const size_t obytes = (size_t)(n_frames - 1) * frame_stride + out_span;
+    r = grow(c, &c->d_in, &c->in_cap, cbytes);
+    if (r) return r;
+    r = grow(c, &c->d_out, &c->out_cap, obytes);
+    if (r) return r;
+    HIPCHK(c, hipMemcpyAsync(c->d_in, coefs, cbytes, hipMemcpyHostToDevice, c->stream));
+    P.coefs = (const int16_t *)c->d_in;
+    P.out = (uint8_t *)c->d_out;
+    HIPCHK(c, hvc::launch_decode_444(P, wide_only, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(frames, frame_stride, c->d_out, frame_stride, out_span, (size_t)n_frames,
+                               hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HVC_OK;
 }

@@ -69,7 +69,44 @@ struct UpsampleParams {
     size_t src_stride, dst_stride, src_ps, dst_ps;
 };
 
+// One plane of a 4:2:0 coefficient record decoded straight to a tight 4:4:4 frame
+// (Decoder.get_yuv_frame's crop, decoder.ml:403-420, and Planar_444.convert_from_420,
+// tools/src/planar_444.ml:82-131, folded into the block stage).
+struct Plane444K {
+    int bw;           // blocks per row of the coefficient plane (padded geometry, decoder.ml:304-345)
+    int cbw, cbh;     // block columns / rows that intersect the crop
+    int aw, ah;       // cropped plane size in samples (luma W x H, chroma W/2 x H/2)
+    int qtab;
+    size_t coef_off;  // int16 elements from the frame's coefficient record
+    size_t out_off;   // bytes from the frame's output record (plane p sits at p * W * H)
+};
+
+#define HVC_444_TILE_BW 64 /* chroma workgroup tile: 64 x 4 blocks (one block row per wave) */
+#define HVC_444_TILE_BH 4
+
+struct Decode444Params {
+    const int16_t *coefs;
+    uint8_t *out;
+    size_t coef_fs;   // int16 elements between frames
+    size_t out_fs;    // bytes between output frames
+    int n_frames, tiles_per_frame;
+    int width, height;     // luma crop = size of all three output planes
+    int y_tiles;           // luma: linear tiles of HVC_TILE blocks over cbw * cbh blocks
+    unsigned y_magic;      // ceil(2^32 / cbw)
+    int c_tiles_x, c_tiles_y; // chroma: tiles of 64 x 4 blocks over cbw x cbh, per plane
+    unsigned c_magic;      // ceil(2^32 / c_tiles_x)
+    int pad;
+    Plane444K pl[3];
+    int qt[HVC_MAX_QTABS * 64];
+    unsigned qpair[HVC_MAX_QTABS * 32];
+    int ethr_packed[HVC_MAX_QTABS];
+    unsigned *fix_count, *fix_count_next, *fix_list;
+};
+
 // k0/k1 (optional): events recorded right before / after the dominant kernel.
+// wide_only: every block through the int64 kernel (tables with entries > 255).
+hipError_t launch_decode_444(const Decode444Params &P, bool wide_only, hipStream_t s, hipEvent_t k0 = nullptr,
+                             hipEvent_t k1 = nullptr);
 hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr);
 hipError_t launch_decode_wide_only(const DecodeParams &P, hipStream_t s);
 hipError_t launch_encode(const EncodeParams &P, hipStream_t s, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr);

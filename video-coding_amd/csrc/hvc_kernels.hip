@@ -488,67 +488,68 @@ __device__ __forceinline__ void ashr14_sat_pack2(unsigned &dst, int a, int b) {
 // waves with bursty memory phases win.
 #define HVC_PACKED_LB HVC_TILE, 4
 #endif
+// One block per lane: 128 B of coefficients (SRC: const uint4 *) -> the block's 8 pixel rows as
+// byte-packed dword pairs OUT[8][2]; QP = the table's 32 packed quantiser pairs; G = PackedGuard.
+// A macro, not a function: spelled inline, hipcc 7.2 schedules the kernel for <= 4 waves/SIMD
+// (116 VGPRs, rows interleaved); through an (always-inlined) function it settles on 64 VGPRs /
+// 8 waves, measured 6 % slower on the same box (1.764 vs 1.660 ms per 1024-frame launch).
+#define HVC_DECODE_BLOCK_PACKED(SRC, QP, OUT, G)                                                        \
+    do {                                                                                                \
+        unsigned w[32];                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 8; j++) {                                                 \
+            const uint4 t = (SRC)[j];                                                                   \
+            w[4 * j + 0] = t.x;                                                                         \
+            w[4 * j + 1] = t.y;                                                                         \
+            w[4 * j + 2] = t.z;                                                                         \
+            w[4 * j + 3] = t.w;                                                                         \
+        }                                                                                               \
+        _Pragma("unroll") for (int d = 0; d < 32; d++) (G).energy = dot2_sat(w[d], w[d], (G).energy);   \
+        /* rows in the order that completes one column operand pair per two rows */                    \
+        unsigned cA[8], cB[8], cC[8], cZ[8];                                                            \
+        {                                                                                               \
+            int ra[8], rb[8];                                                                           \
+            idct_row_packed<1>(w, (QP) + 4 * 1, ra, (G));                                               \
+            idct_row_packed<7>(w, (QP) + 4 * 7, rb, (G));                                               \
+            _Pragma("unroll") for (int c = 0; c < 8; c++) cA[c] = pack_rows(ra[c], rb[c], (G)); /* (x4, x5) = (r1, r7) */ \
+            idct_row_packed<5>(w, (QP) + 4 * 5, ra, (G));                                               \
+            idct_row_packed<3>(w, (QP) + 4 * 3, rb, (G));                                               \
+            _Pragma("unroll") for (int c = 0; c < 8; c++) cB[c] = pack_rows(ra[c], rb[c], (G)); /* (x6, x7) = (r5, r3) */ \
+            idct_row_packed<2>(w, (QP) + 4 * 2, ra, (G));                                               \
+            idct_row_packed<6>(w, (QP) + 4 * 6, rb, (G));                                               \
+            _Pragma("unroll") for (int c = 0; c < 8; c++) cC[c] = pack_rows(ra[c], rb[c], (G)); /* (x3, x2) = (r2, r6) */ \
+            idct_row_packed<0>(w, (QP) + 4 * 0, ra, (G));                                               \
+            idct_row_packed<4>(w, (QP) + 4 * 4, rb, (G));                                               \
+            _Pragma("unroll") for (int c = 0; c < 8; c++) cZ[c] = pack_rows(ra[c], rb[c], (G)); /* (b0, b4) = (r0, r4) */ \
+        }                                                                                               \
+        /* columns two at a time: 16 results -> 8 row halves of the output dwords */                   \
+        _Pragma("unroll") for (int c = 0; c < 8; c += 2) {                                              \
+            int ca[8], cb[8];                                                                           \
+            idct_col_packed(cA[c], cB[c], cC[c], cZ[c], ca, (G));                                       \
+            idct_col_packed(cA[c + 1], cB[c + 1], cC[c + 1], cZ[c + 1], cb, (G));                       \
+            _Pragma("unroll") for (int j = 0; j < 8; j++) {                                             \
+                if ((c & 2) == 0)                                                                       \
+                    ashr14_sat_pack2<0>((OUT)[j][c >> 2], ca[j], cb[j]);                                \
+                else                                                                                    \
+                    ashr14_sat_pack2<1>((OUT)[j][c >> 2], ca[j], cb[j]);                                \
+            }                                                                                           \
+        }                                                                                               \
+    } while (0)
+
+__device__ __forceinline__ bool packed_guard_failed(const PackedGuard &g, int ethr) {
+    return (g.energy > ethr) | (g.renergy >= GUARD_RE) | (g.ymax > GUARD_Y) | (g.ymin < -GUARD_Y);
+}
+
 __global__ __launch_bounds__(HVC_PACKED_LB) void k_decode_packed(DecodeParams P) {
     BlockRef br;
     const int lane = threadIdx.x;
     const bool active = locate(P, blockIdx.y, blockIdx.x, lane, br);
-
     const uint4 *src = reinterpret_cast<const uint4 *>(P.coefs + br.coef_idx);
-    unsigned w[32];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const uint4 t = src[j];
-        w[4 * j + 0] = t.x;
-        w[4 * j + 1] = t.y;
-        w[4 * j + 2] = t.z;
-        w[4 * j + 3] = t.w;
-    }
-    PackedGuard g;
-#pragma unroll
-    for (int d = 0; d < 32; d++) g.energy = dot2_sat(w[d], w[d], g.energy);
-
     const unsigned *__restrict__ qp = P.qpair + br.qtab * 32; // wave-uniform, kernarg segment
-
-    // rows in the order that completes one column operand pair per two rows
-    unsigned cA[8], cB[8], cC[8], cZ[8];
-    {
-        int ra[8], rb[8];
-        idct_row_packed<1>(w, qp + 4 * 1, ra, g);
-        idct_row_packed<7>(w, qp + 4 * 7, rb, g);
-#pragma unroll
-        for (int c = 0; c < 8; c++) cA[c] = pack_rows(ra[c], rb[c], g); // (x4, x5) = (r1, r7)
-        idct_row_packed<5>(w, qp + 4 * 5, ra, g);
-        idct_row_packed<3>(w, qp + 4 * 3, rb, g);
-#pragma unroll
-        for (int c = 0; c < 8; c++) cB[c] = pack_rows(ra[c], rb[c], g); // (x6, x7) = (r5, r3)
-        idct_row_packed<2>(w, qp + 4 * 2, ra, g);
-        idct_row_packed<6>(w, qp + 4 * 6, rb, g);
-#pragma unroll
-        for (int c = 0; c < 8; c++) cC[c] = pack_rows(ra[c], rb[c], g); // (x3, x2) = (r2, r6)
-        idct_row_packed<0>(w, qp + 4 * 0, ra, g);
-        idct_row_packed<4>(w, qp + 4 * 4, rb, g);
-#pragma unroll
-        for (int c = 0; c < 8; c++) cZ[c] = pack_rows(ra[c], rb[c], g); // (b0, b4) = (r0, r4)
-    }
-
-    // columns two at a time: 16 results -> 8 row halves of the output dwords
+    PackedGuard g;
     unsigned out[8][2];
-#pragma unroll
-    for (int c = 0; c < 8; c += 2) {
-        int ca[8], cb[8];
-        idct_col_packed(cA[c], cB[c], cC[c], cZ[c], ca, g);
-        idct_col_packed(cA[c + 1], cB[c + 1], cC[c + 1], cZ[c + 1], cb, g);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if ((c & 2) == 0)
-                ashr14_sat_pack2<0>(out[j][c >> 2], ca[j], cb[j]);
-            else
-                ashr14_sat_pack2<1>(out[j][c >> 2], ca[j], cb[j]);
-        }
-    }
+    HVC_DECODE_BLOCK_PACKED(src, qp, out, g);
 
-    const bool bad = (g.energy > P.ethr_packed[br.qtab]) | (g.renergy >= GUARD_RE) | (g.ymax > GUARD_Y) |
-                     (g.ymin < -GUARD_Y);
+    const bool bad = packed_guard_failed(g, P.ethr_packed[br.qtab]);
     if (active && !bad) {
 #pragma unroll
         for (int j = 0; j < 8; j++)
@@ -597,6 +598,312 @@ __global__ __launch_bounds__(64) void k_decode_wide(DecodeParams P, const unsign
                 x = x < -128 ? -128 : (x > 127 ? 127 : x);
                 P.pixels[br.pix_idx + (size_t)j * br.stride + i2] = (uint8_t)(x + 128);
             }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1 + crop + K2 fused: 4:2:0 coefficient records -> tight 4:4:4 frames
+// (Decoder.decode -> get_yuv_frame, decoder.ml:403-420 -> Planar_444.convert_from_420,
+// tools/src/planar_444.ml:82-131).  The quarter-resolution chroma planes never reach HBM.
+//
+// Luma: the linear 256-block tiles of k_decode_packed over the block rows / columns that intersect
+// the crop, rows below the crop not stored.  Chroma: a workgroup owns 64 x 4 blocks (one block row
+// per wave).  supersample_hv2 needs, for every source sample a, its right / lower / lower-right
+// neighbours b, c, d: inside a block they are in the lane's own registers; across blocks each lane
+// publishes its block's first row and first column through LDS (16 B per lane, one barrier).
+//   avg2(a,b) = (a+b+1)>>1           = v_lerp_u8(a, b, 0x01010101) on four samples at once
+//   avg4(a,b,c,d) = (a+b+c+d+2)>>2   = v_lerp_u8(avg2(a,b), (c+d)>>1, r),
+//                                       r = ~(a^b) | (c^d)   (bit 0 of each byte is used)
+// (tests/test_guard_bounds.py::test_avg4_by_lerp_identity proves the identity over all sums.)
+// Two things are left to k_reinterp_444, which recomputes interpolated samples from the source
+// samples already sitting at the even output coordinates: the seams between workgroup tiles
+// (every 512th source column, every 32nd source row) and the surroundings of blocks that failed
+// the int32 guard (their source samples are written by k_decode_wide_444 first).
+struct Ref444 {
+    int p, bx, by;
+    bool active;
+};
+
+__device__ __forceinline__ Ref444 locate444(const Decode444Params &P, int tile, int lane) {
+    Ref444 r;
+    if (tile < P.y_tiles) {
+        const Plane444K &K = P.pl[0];
+        const int n = K.cbw * K.cbh;
+        int b = tile * HVC_TILE + lane;
+        r.active = b < n;
+        b = r.active ? b : n - 1;
+        const unsigned by = K.cbw == 1 ? (unsigned)b : __umulhi((unsigned)b, P.y_magic);
+        r.p = 0;
+        r.by = (int)by;
+        r.bx = b - (int)by * K.cbw;
+    } else {
+        int t = tile - P.y_tiles;
+        const int per = P.c_tiles_x * P.c_tiles_y;
+        r.p = 1;
+        if (t >= per) {
+            r.p = 2;
+            t -= per;
+        }
+        const unsigned ty = P.c_tiles_x == 1 ? (unsigned)t : __umulhi((unsigned)t, P.c_magic);
+        const unsigned tx = (unsigned)t - ty * (unsigned)P.c_tiles_x;
+        const Plane444K &K = P.pl[r.p];
+        const int bx = (int)tx * HVC_444_TILE_BW + (lane & 63), by = (int)ty * HVC_444_TILE_BH + (lane >> 6);
+        r.active = bx < K.cbw && by < K.cbh;
+        r.bx = min(bx, K.cbw - 1);
+        r.by = min(by, K.cbh - 1);
+    }
+    return r;
+}
+
+template <bool ALIGNED>
+__device__ __forceinline__ void store16(uint8_t *row, int x0, int w, unsigned d0, unsigned d1, unsigned d2,
+                                        unsigned d3) {
+    if (ALIGNED) {
+        typedef unsigned u4s __attribute__((ext_vector_type(4)));
+        const u4s t = {d0, d1, d2, d3};
+        __builtin_nontemporal_store(t, reinterpret_cast<u4s *>(row + x0));
+    } else {
+        const unsigned d[4] = {d0, d1, d2, d3};
+        for (int i = 0; i < 16; i++)
+            if (x0 + i < w) row[x0 + i] = (uint8_t)(d[i >> 2] >> (8 * (i & 3)));
+    }
+}
+
+// One source row of a chroma block: the samples a, the rounded-up and rounded-down averages with the
+// right neighbour, and a ^ b.
+struct RowQ {
+    unsigned a0, a1, hc0, hc1, hf0, hf1, x0, x1;
+};
+// NEXT = the dword holding the sample right of a's last one, in byte K; m0/m1 = bytes at or beyond
+// the plane's last column (there b = a: supersample_hv2's "w - 1" column, planar_444.ml:97-102)
+template <int K>
+__device__ __forceinline__ RowQ rowq(unsigned a0, unsigned a1, unsigned next, unsigned m0, unsigned m1) {
+    RowQ q;
+    q.a0 = a0;
+    q.a1 = a1;
+    unsigned b0 = __builtin_amdgcn_alignbyte(a1, a0, 1);
+    unsigned b1 = __builtin_amdgcn_perm(next, a1, ((unsigned)(4 + K) << 24) | 0x030201u);
+    b0 = (m0 & a0) | (~m0 & b0);
+    b1 = (m1 & a1) | (~m1 & b1);
+    q.hc0 = __builtin_amdgcn_lerp(a0, b0, 0x01010101u);
+    q.hc1 = __builtin_amdgcn_lerp(a1, b1, 0x01010101u);
+    q.hf0 = __builtin_amdgcn_lerp(a0, b0, 0u);
+    q.hf1 = __builtin_amdgcn_lerp(a1, b1, 0u);
+    q.x0 = a0 ^ b0;
+    q.x1 = a1 ^ b1;
+    return q;
+}
+
+// output rows 2y and 2y + 1 of a chroma block's source row `cur` (next = source row y + 1)
+template <bool ALIGNED>
+__device__ __forceinline__ void emit_rows444(uint8_t *row_even, size_t W, int x0, const RowQ &cur, const RowQ &nxt,
+                                             bool last_row) {
+    constexpr unsigned LO = 0x05010400u, HI = 0x07030602u; // interleave (a, h): a.b0 h.b0 a.b1 h.b1 / a.b2 ...
+    store16<ALIGNED>(row_even, x0, (int)W, __builtin_amdgcn_perm(cur.hc0, cur.a0, LO),
+                     __builtin_amdgcn_perm(cur.hc0, cur.a0, HI), __builtin_amdgcn_perm(cur.hc1, cur.a1, LO),
+                     __builtin_amdgcn_perm(cur.hc1, cur.a1, HI));
+    unsigned v0 = __builtin_amdgcn_lerp(cur.a0, nxt.a0, 0x01010101u);
+    unsigned v1 = __builtin_amdgcn_lerp(cur.a1, nxt.a1, 0x01010101u);
+    unsigned q0 = __builtin_amdgcn_lerp(cur.hc0, nxt.hf0, ~cur.x0 | nxt.x0);
+    unsigned q1 = __builtin_amdgcn_lerp(cur.hc1, nxt.hf1, ~cur.x1 | nxt.x1);
+    if (last_row) { // row2 = min (h - 1) (row + 1) = row (planar_444.ml:86): avg2 a a = a, avg4 a b a b = avg2 a b
+        v0 = cur.a0;
+        v1 = cur.a1;
+        q0 = cur.hc0;
+        q1 = cur.hc1;
+    }
+    store16<ALIGNED>(row_even + W, x0, (int)W, __builtin_amdgcn_perm(q0, v0, LO), __builtin_amdgcn_perm(q0, v0, HI),
+                     __builtin_amdgcn_perm(q1, v1, LO), __builtin_amdgcn_perm(q1, v1, HI));
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(HVC_PACKED_LB) void k_decode_444(Decode444Params P) {
+    __shared__ uint4 edge[HVC_TILE]; // per lane: first row (x, y) and first column (z, w) of its chroma block
+    const int lane = threadIdx.x;
+    const bool chroma = (int)blockIdx.x >= P.y_tiles; // workgroup-uniform
+    const Ref444 r = locate444(P, blockIdx.x, lane);
+    const Plane444K &K = P.pl[r.p];
+    const uint4 *src = reinterpret_cast<const uint4 *>(P.coefs + (size_t)blockIdx.y * P.coef_fs + K.coef_off +
+                                                       ((size_t)r.by * K.bw + r.bx) * 64);
+    const unsigned *__restrict__ qp = P.qpair + K.qtab * 32;
+    PackedGuard g;
+    unsigned out[8][2];
+    HVC_DECODE_BLOCK_PACKED(src, qp, out, g);
+    const bool bad = packed_guard_failed(g, P.ethr_packed[K.qtab]);
+
+    const size_t W = (size_t)P.width;
+    uint8_t *plane = P.out + (size_t)blockIdx.y * P.out_fs + K.out_off;
+    const int lasty = K.ah - 1 - r.by * 8; // last block row that is inside the crop (>= 0 for active lanes)
+    if (!chroma) {
+        if (r.active && !bad) {
+            uint8_t *p = plane + (size_t)r.by * 8 * W + (size_t)r.bx * 8;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (j <= lasty) {
+                    if (ALIGNED) {
+                        store_row8(p + (size_t)j * W, out[j][0], out[j][1]);
+                    } else {
+                        for (int i = 0; i < 8; i++)
+                            if (r.bx * 8 + i < K.aw) p[(size_t)j * W + i] = (uint8_t)(out[j][i >> 2] >> (8 * (i & 3)));
+                    }
+                }
+            }
+        }
+    } else {
+        // first column of the block, rows 0-3 and 4-7
+        constexpr unsigned B0 = 0x0c0c0400u, JOIN = 0x05040100u;
+        const unsigned c0 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(out[3][0], out[2][0], B0),
+                                                  __builtin_amdgcn_perm(out[1][0], out[0][0], B0), JOIN);
+        const unsigned c1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(out[7][0], out[6][0], B0),
+                                                  __builtin_amdgcn_perm(out[5][0], out[4][0], B0), JOIN);
+        edge[lane] = make_uint4(out[0][0], out[0][1], c0, c1);
+        __syncthreads();
+        // right / lower / lower-right neighbours; past the tile the values are placeholders (seam pass)
+        const uint4 rt = edge[min(lane + 1, HVC_TILE - 1)];
+        const uint4 dn = edge[min(lane + 64, HVC_TILE - 1)];
+        const unsigned dg = edge[min(lane + 65, HVC_TILE - 1)].x;
+        const int lastx = K.aw - 1 - r.bx * 8; // samples at or beyond it take b = a
+        const unsigned long long mm = lastx >= 8 ? 0ull : (~0ull << (8 * max(lastx, 0)));
+        const unsigned m0 = (unsigned)mm, m1 = (unsigned)(mm >> 32);
+        if (r.active && !bad) {
+            uint8_t *p = plane + (size_t)r.by * 16 * W;
+            const int x0 = r.bx * 16;
+            const RowQ q0 = rowq<0>(out[0][0], out[0][1], rt.z, m0, m1);
+            const RowQ q1 = rowq<1>(out[1][0], out[1][1], rt.z, m0, m1);
+            const RowQ q2 = rowq<2>(out[2][0], out[2][1], rt.z, m0, m1);
+            const RowQ q3 = rowq<3>(out[3][0], out[3][1], rt.z, m0, m1);
+            const RowQ q4 = rowq<0>(out[4][0], out[4][1], rt.w, m0, m1);
+            const RowQ q5 = rowq<1>(out[5][0], out[5][1], rt.w, m0, m1);
+            const RowQ q6 = rowq<2>(out[6][0], out[6][1], rt.w, m0, m1);
+            const RowQ q7 = rowq<3>(out[7][0], out[7][1], rt.w, m0, m1);
+            const RowQ q8 = rowq<0>(dn.x, dn.y, dg, m0, m1);
+            if (0 <= lasty) emit_rows444<ALIGNED>(p + 0 * W, W, x0, q0, q1, lasty == 0);
+            if (1 <= lasty) emit_rows444<ALIGNED>(p + 2 * W, W, x0, q1, q2, lasty == 1);
+            if (2 <= lasty) emit_rows444<ALIGNED>(p + 4 * W, W, x0, q2, q3, lasty == 2);
+            if (3 <= lasty) emit_rows444<ALIGNED>(p + 6 * W, W, x0, q3, q4, lasty == 3);
+            if (4 <= lasty) emit_rows444<ALIGNED>(p + 8 * W, W, x0, q4, q5, lasty == 4);
+            if (5 <= lasty) emit_rows444<ALIGNED>(p + 10 * W, W, x0, q5, q6, lasty == 5);
+            if (6 <= lasty) emit_rows444<ALIGNED>(p + 12 * W, W, x0, q6, q7, lasty == 6);
+            if (7 <= lasty) emit_rows444<ALIGNED>(p + 14 * W, W, x0, q7, q8, lasty == 7);
+        }
+    }
+    const bool flag = r.active && bad;
+    const unsigned long long m = __ballot(flag);
+    if (m) {
+        const int wl = lane & 63;
+        unsigned base = 0;
+        if (wl == 0) base = atomicAdd(P.fix_count, (unsigned)__popcll(m));
+        base = __shfl(base, 0);
+        if (flag) {
+            unsigned idx = base + (unsigned)__popcll(m & ((1ull << wl) - 1ull));
+            P.fix_list[idx] = ((unsigned)blockIdx.y * (unsigned)P.tiles_per_frame + blockIdx.x) * HVC_TILE + lane;
+        }
+    }
+}
+
+// int64 model arithmetic for listed blocks (list == nullptr: every block).  Luma blocks are written
+// as they are; a chroma block's 64 samples go to the EVEN output coordinates, where supersample_hv2
+// puts the source sample; k_reinterp_444 then rebuilds the interpolated ones around it.
+__global__ __launch_bounds__(64) void k_decode_wide_444(Decode444Params P, const unsigned *count, const unsigned *list,
+                                                        unsigned long long total) {
+    const unsigned long long n = list ? (unsigned long long)*count : total;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && P.fix_count_next) *P.fix_count_next = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 64 + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * 64) {
+        const unsigned long long id = list ? list[i] : i;
+        const int lane = (int)(id % HVC_TILE);
+        const unsigned long long t = id / HVC_TILE;
+        const int tile = (int)(t % (unsigned)P.tiles_per_frame);
+        const size_t frame = (size_t)(t / (unsigned)P.tiles_per_frame);
+        const Ref444 r = locate444(P, tile, lane);
+        if (!r.active) continue;
+        const Plane444K &K = P.pl[r.p];
+        const int *q = P.qt + K.qtab * 64;
+        int64_t v[64];
+        const int16_t *cf = P.coefs + frame * P.coef_fs + K.coef_off + ((size_t)r.by * K.bw + r.bx) * 64;
+        for (int k = 0; k < 64; k++) v[ZI[k]] = (int64_t)cf[k] * (int64_t)q[k];
+        for (int rr = 0; rr < 8; rr++) idct_1d_wide<false>(v + rr * 8, 1);
+        for (int c = 0; c < 8; c++) idct_1d_wide<true>(v + c, 8);
+        uint8_t *plane = P.out + frame * P.out_fs + K.out_off;
+        const int step = r.p == 0 ? 1 : 2;
+        for (int j = 0; j < 8; j++)
+            for (int i2 = 0; i2 < 8; i2++) {
+                const int x = r.bx * 8 + i2, y = r.by * 8 + j;
+                if (x >= K.aw || y >= K.ah) continue;
+                int64_t s = v[j * 8 + i2];
+                s = s < -128 ? -128 : (s > 127 ? 127 : s);
+                plane[(size_t)(y * step) * (size_t)P.width + (size_t)(x * step)] = (uint8_t)(s + 128);
+            }
+    }
+}
+
+// tools/src/planar_444.ml avg2 / avg4
+__device__ __forceinline__ unsigned avg2u(unsigned a, unsigned b) { return (a + b + 1) >> 1; }          // :4-8
+__device__ __forceinline__ unsigned avg4u(unsigned a, unsigned b, unsigned c, unsigned d) { return (a + b + c + d + 2) >> 2; } // :10-16
+
+// supersample_hv2 (planar_444.ml:82-103) of ONE source sample (c, r) of an output plane whose even
+// coordinates already hold the source samples: writes (2c+1, 2r), (2c, 2r+1), (2c+1, 2r+1).
+__device__ __forceinline__ void reinterp_sample(uint8_t *plane, size_t W, int aw, int ah, int c, int r) {
+    const int c2 = min(c + 1, aw - 1), r2 = min(r + 1, ah - 1);
+    const unsigned a = plane[(size_t)(2 * r) * W + 2 * c], b = plane[(size_t)(2 * r) * W + 2 * c2];
+    const unsigned cc = plane[(size_t)(2 * r2) * W + 2 * c], d = plane[(size_t)(2 * r2) * W + 2 * c2];
+    plane[(size_t)(2 * r) * W + 2 * c + 1] = (uint8_t)avg2u(a, b);
+    plane[(size_t)(2 * r + 1) * W + 2 * c] = (uint8_t)avg2u(a, cc);
+    plane[(size_t)(2 * r + 1) * W + 2 * c + 1] = (uint8_t)avg4u(a, b, cc, d);
+}
+
+// Pass 3 of the fused path.  all = 1: every source sample of both chroma planes (after a wide-only
+// decode).  Otherwise: the tile seams (source columns 512k + 511, source rows 32k + 31) and the 9 x 9
+// source samples around every listed chroma block (its own 8 x 8 plus the column / row before it,
+// whose interpolated samples read this block).
+__global__ __launch_bounds__(256) void k_reinterp_444(Decode444Params P, const unsigned *count, const unsigned *list,
+                                                      int all) {
+    const Plane444K &K1 = P.pl[1];
+    const int aw = K1.aw, ah = K1.ah;
+    const size_t W = (size_t)P.width;
+    const size_t frame = blockIdx.y;
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (all) {
+        const long long per = (long long)aw * ah;
+        if (tid < 2 * per) {
+            const int p = tid >= per ? 2 : 1;
+            const long long s = tid - (p - 1) * per;
+            reinterp_sample(P.out + frame * P.out_fs + P.pl[p].out_off, W, aw, ah, (int)(s % aw), (int)(s / aw));
+        }
+        return;
+    }
+    const int nvs = P.c_tiles_x - 1, nhs = P.c_tiles_y - 1;
+    const long long per = (long long)nvs * ah + (long long)nhs * aw;
+    if (tid < 2 * per) {
+        const int p = tid >= per ? 2 : 1;
+        long long s = tid - (p - 1) * per;
+        int c, r;
+        if (s < (long long)nhs * aw) { // horizontal seams first: consecutive threads, consecutive bytes
+            r = (int)(s / aw) * (8 * HVC_444_TILE_BH) + 8 * HVC_444_TILE_BH - 1;
+            c = (int)(s % aw);
+        } else {
+            s -= (long long)nhs * aw;
+            c = (int)(s / ah) * (8 * HVC_444_TILE_BW) + 8 * HVC_444_TILE_BW - 1;
+            r = (int)(s % ah);
+        }
+        if (c < aw && r < ah) reinterp_sample(P.out + frame * P.out_fs + P.pl[p].out_off, W, aw, ah, c, r);
+    }
+    // guard failures (rare: never for encoder-produced data)
+    const unsigned long long n = (unsigned long long)*count * 81ull;
+    const unsigned long long nthreads = (unsigned long long)gridDim.x * gridDim.y * 256ull;
+    for (unsigned long long i = (unsigned long long)blockIdx.y * gridDim.x * 256ull + (unsigned long long)tid; i < n;
+         i += nthreads) {
+        const unsigned long long id = list[i / 81];
+        const int k = (int)(i % 81);
+        const int lane = (int)(id % HVC_TILE);
+        const unsigned long long t = id / HVC_TILE;
+        const int tile = (int)(t % (unsigned)P.tiles_per_frame);
+        const size_t f = (size_t)(t / (unsigned)P.tiles_per_frame);
+        const Ref444 rr = locate444(P, tile, lane);
+        if (!rr.active || rr.p == 0) continue;
+        const int c = rr.bx * 8 - 1 + k % 9, r = rr.by * 8 - 1 + k / 9;
+        if (c < 0 || r < 0 || c >= aw || r >= ah) continue;
+        reinterp_sample(P.out + f * P.out_fs + P.pl[rr.p].out_off, W, aw, ah, c, r);
     }
 }
 
@@ -775,8 +1082,6 @@ __global__ __launch_bounds__(HVC_ENCODE_LB) void k_encode(EncodeParams P) {
 // K2: 4:2:0 -> 4:4:4 chroma upsample, tools/src/planar_444.ml:82-103
 // (supersample_hv2 for every row, :122-131).  One thread per 4 source pixels of
 // a source row: writes 8 + 8 destination bytes (rows 2r and 2r+1).
-__device__ __forceinline__ unsigned avg2u(unsigned a, unsigned b) { return (a + b + 1) >> 1; }          // :4-8
-__device__ __forceinline__ unsigned avg4u(unsigned a, unsigned b, unsigned c, unsigned d) { return (a + b + c + d + 2) >> 2; } // :10-16
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_upsample420(UpsampleParams P) {
@@ -865,6 +1170,37 @@ hipError_t launch_decode_wide_only(const DecodeParams &P, hipStream_t s) {
     unsigned long long total = (unsigned long long)P.n_frames * P.tiles_per_frame * HVC_TILE;
     hipLaunchKernelGGL(k_decode_wide, dim3(4096), dim3(64), 0, s, P, (const unsigned *)nullptr,
                        (const unsigned *)nullptr, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_444(const Decode444Params &P, bool wide_only, hipStream_t s, hipEvent_t k0, hipEvent_t k1) {
+    if (P.n_frames <= 0 || P.tiles_per_frame <= 0) return hipSuccess;
+    const dim3 grid((unsigned)P.tiles_per_frame, (unsigned)P.n_frames, 1);
+    const long long per_plane = (long long)P.pl[1].aw * P.pl[1].ah;
+    if (wide_only) {
+        const unsigned long long total = (unsigned long long)P.n_frames * P.tiles_per_frame * HVC_TILE;
+        if (k0) (void)hipEventRecord(k0, s);
+        hipLaunchKernelGGL(k_decode_wide_444, dim3(4096), dim3(64), 0, s, P, (const unsigned *)nullptr,
+                           (const unsigned *)nullptr, total);
+        if (k1) (void)hipEventRecord(k1, s);
+        hipLaunchKernelGGL(k_reinterp_444, dim3((unsigned)((2 * per_plane + 255) / 256), (unsigned)P.n_frames, 1),
+                           dim3(256), 0, s, P, (const unsigned *)P.fix_count, (const unsigned *)P.fix_list, 1);
+        return hipGetLastError();
+    }
+    const size_t W = (size_t)P.width;
+    const bool aligned = (W % 16 == 0) && (P.out_fs % 16 == 0) && ((uintptr_t)P.out % 16 == 0);
+    if (k0) (void)hipEventRecord(k0, s);
+    if (aligned)
+        hipLaunchKernelGGL(k_decode_444<true>, grid, dim3(HVC_TILE), 0, s, P);
+    else
+        hipLaunchKernelGGL(k_decode_444<false>, grid, dim3(HVC_TILE), 0, s, P);
+    if (k1) (void)hipEventRecord(k1, s);
+    hipLaunchKernelGGL(k_decode_wide_444, dim3(256), dim3(64), 0, s, P, (const unsigned *)P.fix_count,
+                       (const unsigned *)P.fix_list, 0ull);
+    const long long seams = 2 * ((long long)(P.c_tiles_x - 1) * P.pl[1].ah + (long long)(P.c_tiles_y - 1) * P.pl[1].aw);
+    const unsigned gx = (unsigned)((seams + 255) / 256);
+    hipLaunchKernelGGL(k_reinterp_444, dim3(gx ? gx : 1u, (unsigned)P.n_frames, 1), dim3(256), 0, s, P,
+                       (const unsigned *)P.fix_count, (const unsigned *)P.fix_list, 0);
     return hipGetLastError();
 }
 
