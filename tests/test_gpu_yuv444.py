@@ -78,8 +78,11 @@ def run(ctx, recs, planes, qtabs, width, height, device, frame_stride=None):
 @pytest.mark.parametrize("width,height", [
     (64, 48),      # one tile, block aligned
     (64, 40),      # chroma crop ends inside a block row (ah = 20)
-    (1056, 144),   # chroma 528 x 72: two tiles across (seam at source column 511), three down (rows 31, 63)
-    (2080, 80),    # chroma 1040 wide: three tiles across
+    (1056, 144),   # chroma 528 x 72: two tiles across (sharing block column 63), three down (seams at rows 31, 63)
+    (2080, 80),    # chroma 130 blocks wide: three tiles across
+    (1024, 32),    # chroma exactly 64 blocks wide: one tile, lane 63 owns the last column
+    (1040, 32),    # 65 blocks: the second tile holds two columns
+    (2032, 32),    # 127 blocks = 2 * 63 + 1: the last column is the second tile's overlap lane
     (48, 272),     # chroma 136 rows: five tiles down
     (1920, 1080),  # the headline geometry: 1088 decoded rows, crop at 1080 / 540
 ])

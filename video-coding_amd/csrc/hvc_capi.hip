@@ -486,7 +486,7 @@ int hvc_decode_frames_yuv444(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, c
     if ((unsigned long long)P.pl[0].cbw * P.pl[0].cbw * P.pl[0].cbh >= (1ull << 32)) return HVC_E_TOO_LARGE;
     P.y_tiles = (P.pl[0].cbw * P.pl[0].cbh + HVC_TILE - 1) / HVC_TILE;
     P.y_magic = (unsigned)(((1ull << 32) + P.pl[0].cbw - 1) / P.pl[0].cbw);
-    P.c_tiles_x = (P.pl[1].cbw + HVC_444_TILE_BW - 1) / HVC_444_TILE_BW;
+    P.c_tiles_x = P.pl[1].cbw <= HVC_444_TILE_BW ? 1 : (P.pl[1].cbw - 1 + HVC_444_TILE_STEP - 1) / HVC_444_TILE_STEP;
     P.c_tiles_y = (P.pl[1].cbh + HVC_444_TILE_BH - 1) / HVC_444_TILE_BH;
     P.c_magic = (unsigned)(((1ull << 32) + P.c_tiles_x - 1) / P.c_tiles_x);
     P.tiles_per_frame = P.y_tiles + 2 * P.c_tiles_x * P.c_tiles_y;

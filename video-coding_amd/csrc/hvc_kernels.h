@@ -83,6 +83,7 @@ struct Plane444K {
 
 #define HVC_444_TILE_BW 64 /* chroma workgroup tile: 64 x 4 blocks (one block row per wave) */
 #define HVC_444_TILE_BH 4
+#define HVC_444_TILE_STEP 63 /* consecutive tiles overlap by one block column */
 
 struct Decode444Params {
     const int16_t *coefs;
@@ -93,7 +94,7 @@ struct Decode444Params {
     int width, height;     // luma crop = size of all three output planes
     int y_tiles;           // luma: linear tiles of HVC_TILE blocks over cbw * cbh blocks
     unsigned y_magic;      // ceil(2^32 / cbw)
-    int c_tiles_x, c_tiles_y; // chroma: tiles of 64 x 4 blocks over cbw x cbh, per plane
+    int c_tiles_x, c_tiles_y; // chroma: tiles of 64 x 4 blocks (x step 63) over cbw x cbh, per plane
     unsigned c_magic;      // ceil(2^32 / c_tiles_x)
     int pad;
     Plane444K pl[3];

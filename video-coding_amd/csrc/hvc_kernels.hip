@@ -615,13 +615,16 @@ __global__ __launch_bounds__(64) void k_decode_wide(DecodeParams P, const unsign
 //   avg4(a,b,c,d) = (a+b+c+d+2)>>2   = v_lerp_u8(avg2(a,b), (c+d)>>1, r),
 //                                       r = ~(a^b) | (c^d)   (bit 0 of each byte is used)
 // (tests/test_guard_bounds.py::test_avg4_by_lerp_identity proves the identity over all sums.)
-// Two things are left to k_reinterp_444, which recomputes interpolated samples from the source
-// samples already sitting at the even output coordinates: the seams between workgroup tiles
-// (every 512th source column, every 32nd source row) and the surroundings of blocks that failed
-// the int32 guard (their source samples are written by k_decode_wide_444 first).
+// Across workgroups: horizontally, consecutive tiles overlap by one block column (lane 63's block is
+// decoded twice, 1.6 % more chroma work, so no tile ever needs a block it did not decode);
+// vertically, the output row below every 32nd source row is left to k_reinterp_444, which
+// recomputes interpolated samples from the source samples already sitting at the even output
+// coordinates (coalesced: two rows read, one written).  The same pass rebuilds the surroundings of
+// blocks that failed the int32 guard (their source samples are written by k_decode_wide_444 first).
 struct Ref444 {
     int p, bx, by;
-    bool active;
+    bool active; // the lane's block exists
+    bool store;  // ... and this lane owns its output (false for a chroma tile's overlap column)
 };
 
 __device__ __forceinline__ Ref444 locate444(const Decode444Params &P, int tile, int lane) {
@@ -636,6 +639,7 @@ __device__ __forceinline__ Ref444 locate444(const Decode444Params &P, int tile, 
         r.p = 0;
         r.by = (int)by;
         r.bx = b - (int)by * K.cbw;
+        r.store = r.active;
     } else {
         int t = tile - P.y_tiles;
         const int per = P.c_tiles_x * P.c_tiles_y;
@@ -647,8 +651,12 @@ __device__ __forceinline__ Ref444 locate444(const Decode444Params &P, int tile, 
         const unsigned ty = P.c_tiles_x == 1 ? (unsigned)t : __umulhi((unsigned)t, P.c_magic);
         const unsigned tx = (unsigned)t - ty * (unsigned)P.c_tiles_x;
         const Plane444K &K = P.pl[r.p];
-        const int bx = (int)tx * HVC_444_TILE_BW + (lane & 63), by = (int)ty * HVC_444_TILE_BH + (lane >> 6);
+        // consecutive tiles share one block column: lane 63 only feeds lane 62's right-neighbour
+        // samples, its own output belongs to lane 0 of the next tile (unless it is the last column)
+        const int lx = lane & 63;
+        const int bx = (int)tx * HVC_444_TILE_STEP + lx, by = (int)ty * HVC_444_TILE_BH + (lane >> 6);
         r.active = bx < K.cbw && by < K.cbh;
+        r.store = r.active && (lx < HVC_444_TILE_STEP || bx == K.cbw - 1);
         r.bx = min(bx, K.cbw - 1);
         r.by = min(by, K.cbh - 1);
     }
@@ -765,7 +773,7 @@ __global__ __launch_bounds__(HVC_PACKED_LB) void k_decode_444(Decode444Params P)
         const int lastx = K.aw - 1 - r.bx * 8; // samples at or beyond it take b = a
         const unsigned long long mm = lastx >= 8 ? 0ull : (~0ull << (8 * max(lastx, 0)));
         const unsigned m0 = (unsigned)mm, m1 = (unsigned)(mm >> 32);
-        if (r.active && !bad) {
+        if (r.store && !bad) {
             uint8_t *p = plane + (size_t)r.by * 16 * W;
             const int x0 = r.bx * 16;
             const RowQ q0 = rowq<0>(out[0][0], out[0][1], rt.z, m0, m1);
@@ -787,7 +795,7 @@ __global__ __launch_bounds__(HVC_PACKED_LB) void k_decode_444(Decode444Params P)
             if (7 <= lasty) emit_rows444<ALIGNED>(p + 14 * W, W, x0, q7, q8, lasty == 7);
         }
     }
-    const bool flag = r.active && bad;
+    const bool flag = r.store && bad;
     const unsigned long long m = __ballot(flag);
     if (m) {
         const int wl = lane & 63;
@@ -816,7 +824,7 @@ __global__ __launch_bounds__(64) void k_decode_wide_444(Decode444Params P, const
         const int tile = (int)(t % (unsigned)P.tiles_per_frame);
         const size_t frame = (size_t)(t / (unsigned)P.tiles_per_frame);
         const Ref444 r = locate444(P, tile, lane);
-        if (!r.active) continue;
+        if (!r.store) continue;
         const Plane444K &K = P.pl[r.p];
         const int *q = P.qt + K.qtab * 64;
         int64_t v[64];
@@ -852,10 +860,30 @@ __device__ __forceinline__ void reinterp_sample(uint8_t *plane, size_t W, int aw
     plane[(size_t)(2 * r + 1) * W + 2 * c + 1] = (uint8_t)avg4u(a, b, cc, d);
 }
 
+// Output row 2r + 1 of a horizontal seam (source row r, r + 1 < ah), 8 source samples = 16 output
+// bytes per thread with 16-byte accesses: only that row reads the tile below.
+__device__ __forceinline__ void reinterp_hseam16(uint8_t *plane, size_t W, int aw, int r, int t) {
+    const uint8_t *re = plane + (size_t)(2 * r) * W + 16 * (size_t)t;
+    const uint8_t *rn = re + 2 * W;
+    const uint4 A = *reinterpret_cast<const uint4 *>(re), C = *reinterpret_cast<const uint4 *>(rn);
+    const bool more = 8 * t + 8 < aw;
+    const unsigned a[4] = {A.x, A.y, A.z, A.w}, c[4] = {C.x, C.y, C.z, C.w};
+    const unsigned an = more ? re[16] : (A.w >> 16) & 0xffu, cn = more ? rn[16] : (C.w >> 16) & 0xffu;
+    unsigned o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { // dword k holds source samples 2k (byte 0) and 2k + 1 (byte 2)
+        const unsigned a0 = a[k] & 0xffu, a1 = (a[k] >> 16) & 0xffu, c0 = c[k] & 0xffu, c1 = (c[k] >> 16) & 0xffu;
+        const unsigned a2 = k < 3 ? a[k + 1] & 0xffu : an, c2 = k < 3 ? c[k + 1] & 0xffu : cn;
+        o[k] = avg2u(a0, c0) | (avg4u(a0, a1, c0, c1) << 8) | (avg2u(a1, c1) << 16) | (avg4u(a1, a2, c1, c2) << 24);
+    }
+    *reinterpret_cast<uint4 *>(plane + (size_t)(2 * r + 1) * W + 16 * (size_t)t) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 // Pass 3 of the fused path.  all = 1: every source sample of both chroma planes (after a wide-only
-// decode).  Otherwise: the tile seams (source columns 512k + 511, source rows 32k + 31) and the 9 x 9
+// decode).  Otherwise: the tile seams (source rows 32k + 31) and the 9 x 9
 // source samples around every listed chroma block (its own 8 x 8 plus the column / row before it,
-// whose interpolated samples read this block).
+// whose interpolated samples read this block).  VEC: rows are 16-byte aligned (width % 16 == 0).
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_reinterp_444(Decode444Params P, const unsigned *count, const unsigned *list,
                                                       int all) {
     const Plane444K &K1 = P.pl[1];
@@ -872,21 +900,20 @@ __global__ __launch_bounds__(256) void k_reinterp_444(Decode444Params P, const u
         }
         return;
     }
-    const int nvs = P.c_tiles_x - 1, nhs = P.c_tiles_y - 1;
-    const long long per = (long long)nvs * ah + (long long)nhs * aw;
+    const int nhs = P.c_tiles_y - 1;
+    const int hw = VEC ? aw / 8 : aw; // work items per horizontal seam
+    const long long per = (long long)nhs * hw;
     if (tid < 2 * per) {
         const int p = tid >= per ? 2 : 1;
-        long long s = tid - (p - 1) * per;
-        int c, r;
-        if (s < (long long)nhs * aw) { // horizontal seams first: consecutive threads, consecutive bytes
-            r = (int)(s / aw) * (8 * HVC_444_TILE_BH) + 8 * HVC_444_TILE_BH - 1;
-            c = (int)(s % aw);
-        } else {
-            s -= (long long)nhs * aw;
-            c = (int)(s / ah) * (8 * HVC_444_TILE_BW) + 8 * HVC_444_TILE_BW - 1;
-            r = (int)(s % ah);
+        const long long s = tid - (p - 1) * per;
+        uint8_t *plane = P.out + frame * P.out_fs + P.pl[p].out_off;
+        const int r = (int)(s / hw) * (8 * HVC_444_TILE_BH) + 8 * HVC_444_TILE_BH - 1;
+        if (r + 1 < ah) { // the crop's last row was finished by k_decode_444 itself
+            if (VEC)
+                reinterp_hseam16(plane, W, aw, r, (int)(s % hw));
+            else
+                reinterp_sample(plane, W, aw, ah, (int)(s % hw), r);
         }
-        if (c < aw && r < ah) reinterp_sample(P.out + frame * P.out_fs + P.pl[p].out_off, W, aw, ah, c, r);
     }
     // guard failures (rare: never for encoder-produced data)
     const unsigned long long n = (unsigned long long)*count * 81ull;
@@ -900,7 +927,7 @@ __global__ __launch_bounds__(256) void k_reinterp_444(Decode444Params P, const u
         const int tile = (int)(t % (unsigned)P.tiles_per_frame);
         const size_t f = (size_t)(t / (unsigned)P.tiles_per_frame);
         const Ref444 rr = locate444(P, tile, lane);
-        if (!rr.active || rr.p == 0) continue;
+        if (!rr.store || rr.p == 0) continue;
         const int c = rr.bx * 8 - 1 + k % 9, r = rr.by * 8 - 1 + k / 9;
         if (c < 0 || r < 0 || c >= aw || r >= ah) continue;
         reinterp_sample(P.out + f * P.out_fs + P.pl[rr.p].out_off, W, aw, ah, c, r);
@@ -1183,7 +1210,7 @@ hipError_t launch_decode_444(const Decode444Params &P, bool wide_only, hipStream
         hipLaunchKernelGGL(k_decode_wide_444, dim3(4096), dim3(64), 0, s, P, (const unsigned *)nullptr,
                            (const unsigned *)nullptr, total);
         if (k1) (void)hipEventRecord(k1, s);
-        hipLaunchKernelGGL(k_reinterp_444, dim3((unsigned)((2 * per_plane + 255) / 256), (unsigned)P.n_frames, 1),
+        hipLaunchKernelGGL(k_reinterp_444<false>, dim3((unsigned)((2 * per_plane + 255) / 256), (unsigned)P.n_frames, 1),
                            dim3(256), 0, s, P, (const unsigned *)P.fix_count, (const unsigned *)P.fix_list, 1);
         return hipGetLastError();
     }
@@ -1197,10 +1224,15 @@ hipError_t launch_decode_444(const Decode444Params &P, bool wide_only, hipStream
     if (k1) (void)hipEventRecord(k1, s);
     hipLaunchKernelGGL(k_decode_wide_444, dim3(256), dim3(64), 0, s, P, (const unsigned *)P.fix_count,
                        (const unsigned *)P.fix_list, 0ull);
-    const long long seams = 2 * ((long long)(P.c_tiles_x - 1) * P.pl[1].ah + (long long)(P.c_tiles_y - 1) * P.pl[1].aw);
-    const unsigned gx = (unsigned)((seams + 255) / 256);
-    hipLaunchKernelGGL(k_reinterp_444, dim3(gx ? gx : 1u, (unsigned)P.n_frames, 1), dim3(256), 0, s, P,
-                       (const unsigned *)P.fix_count, (const unsigned *)P.fix_list, 0);
+    const long long hw = aligned ? P.pl[1].aw / 8 : P.pl[1].aw;
+    const long long seams = 2 * (long long)(P.c_tiles_y - 1) * hw;
+    const dim3 rgrid((unsigned)((seams + 255) / 256) ? (unsigned)((seams + 255) / 256) : 1u, (unsigned)P.n_frames, 1);
+    if (aligned)
+        hipLaunchKernelGGL(k_reinterp_444<true>, rgrid, dim3(256), 0, s, P, (const unsigned *)P.fix_count,
+                           (const unsigned *)P.fix_list, 0);
+    else
+        hipLaunchKernelGGL(k_reinterp_444<false>, rgrid, dim3(256), 0, s, P, (const unsigned *)P.fix_count,
+                           (const unsigned *)P.fix_list, 0);
     return hipGetLastError();
 }
 
