@@ -700,6 +700,29 @@ int hvc_upsample420(hvc_ctx *c, const uint8_t *src, int cw, int ch, size_t src_s
 // single-frame conveniences (host memory)
 
 // Decoder.decode_a_frame minus the crop (decoder.ml:422-427)
+int hvc_jpeg_decode_yuv444(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_info *info, uint8_t *frame,
+                           size_t frame_cap) {
+    if (!c || !jpeg || !info || !frame) return HVC_E_INVALID_ARG;
+    int r = hvc_jpeg_read_header(jpeg, n, info);
+    if (r) return r;
+    // a 4:2:0 scan: Y 2x2, Cb / Cr 1x1 (Frame.infer_chroma_subsampling, common/src/frame.ml:42-61)
+    if (info->n_comp != 3 || info->comp[0].hscale != 2 || info->comp[0].vscale != 2 || info->comp[1].hscale != 1 ||
+        info->comp[1].vscale != 1 || info->comp[2].hscale != 1 || info->comp[2].vscale != 1)
+        return HVC_E_INVALID_ARG;
+    if (frame_cap < (size_t)3 * info->width * info->height) return HVC_E_INVALID_ARG;
+    std::vector<int16_t> coefs;
+    try {
+        coefs.resize(info->coef_count);
+    } catch (const std::bad_alloc &) {
+        return HVC_E_OUT_OF_MEMORY;
+    }
+    r = hvc_jpeg_entropy_decode(jpeg, n, info, coefs.data());
+    if (r) return r;
+    return hvc_decode_frames_yuv444(c, coefs.data(), info->coef_count, &info->qtabs[0][0], info->n_qtabs, info->layout,
+                                    info->n_comp, 1, info->width, info->height, frame,
+                                    (size_t)3 * info->width * info->height, HVC_MEM_HOST);
+}
+
 int hvc_jpeg_decode(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_info *info, uint8_t *pixels, size_t pixel_cap) {
     if (!c || !jpeg || !info || !pixels) return HVC_E_INVALID_ARG;
     int r = hvc_jpeg_read_header(jpeg, n, info);

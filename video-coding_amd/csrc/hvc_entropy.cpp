@@ -691,4 +691,24 @@ int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uin
     return HVC_OK;
 }
 
+// Ocompare.max_difference / total_difference / square_error (tools/src/ocompare.ml:6-47) of two
+// equally sized planes given as n bytes each; the float metrics (mean_difference, mean_square_error,
+// psnr, :30-59) are one division / log10 on top and stay with the caller.
+int hvc_compare_planes(const uint8_t *a, const uint8_t *b, size_t n, int *max_difference, uint64_t *total_difference,
+                       uint64_t *square_error) {
+    if ((!a || !b) && n) return HVC_E_INVALID_ARG;
+    int mx = 0;
+    uint64_t tot = 0, se = 0;
+    for (size_t i = 0; i < n; i++) {
+        const int d = a[i] > b[i] ? a[i] - b[i] : b[i] - a[i];
+        mx = d > mx ? d : mx;
+        tot += (uint64_t)d;
+        se += (uint64_t)(d * d);
+    }
+    if (max_difference) *max_difference = mx;
+    if (total_difference) *total_difference = tot;
+    if (square_error) *square_error = se;
+    return HVC_OK;
+}
+
 } // extern "C"

@@ -20,7 +20,7 @@ SYMBOLS = [
     "hvc_device_free", "hvc_memcpy_h2d", "hvc_memcpy_d2h",
     "hvc_jpeg_read_header", "hvc_jpeg_entropy_decode", "hvc_jpeg_get_yuv_frame", "hvc_jpeg_decode",
     "hvc_jpeg_decode_batch", "hvc_quant_table", "hvc_jpeg_encoder_layout", "hvc_jpeg_entropy_encode",
-    "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444",
+    "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444", "hvc_jpeg_decode_yuv444", "hvc_compare_planes",
 ]
 
 
@@ -123,9 +123,11 @@ def lib():
         L.hvc_jpeg_entropy_decode.argtypes = [vp, sz, ip, vp]
         L.hvc_jpeg_get_yuv_frame.argtypes = [ip, vp, vp, sz, C.POINTER(sz)]
         L.hvc_jpeg_decode.argtypes = [vp, vp, sz, ip, vp, sz]
+        L.hvc_jpeg_decode_yuv444.argtypes = [vp, vp, sz, ip, vp, sz]
         L.hvc_jpeg_decode_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), i, i, i, vp, sz, i,
                                             C.POINTER(BatchStats)]
         L.hvc_quant_table.argtypes = [i, i, vp]
+        L.hvc_compare_planes.argtypes = [vp, vp, sz, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.hvc_jpeg_encoder_layout.argtypes = [i, i, i, i, ip]
         L.hvc_jpeg_entropy_encode.argtypes = [ip, vp, vp, sz, C.POINTER(sz)]
         L.hvc_jpeg_encode.argtypes = [vp, vp, vp, vp, i, i, i, i, vp, sz, C.POINTER(sz)]
@@ -203,6 +205,17 @@ def quant_table(chroma_table, quality):
     out = np.empty(64, dtype=np.uint16)
     _chk(lib().hvc_quant_table(1 if chroma_table else 0, quality, out.ctypes.data))
     return out
+
+
+def compare_planes(a, b):
+    """Ocompare.{max_difference, total_difference, square_error} (tools/src/ocompare.ml:6-47)"""
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    if a.shape != b.shape:
+        raise ValueError("planes differ in size")  # the model asserts (ocompare.ml:9-10)
+    mx, tot, se = C.c_int(), C.c_uint64(), C.c_uint64()
+    _chk(lib().hvc_compare_planes(a.ctypes.data, b.ctypes.data, a.size, C.byref(mx), C.byref(tot), C.byref(se)))
+    return mx.value, tot.value, se.value
 
 
 def jpeg_encoder_layout(width, height, chroma, quality):
@@ -324,6 +337,14 @@ class Context:
         _chk(lib().hvc_jpeg_decode(self._h, data, len(data), C.byref(info), pixels.ctypes.data, pixels.size),
              "hvc_jpeg_decode")
         return info, pixels
+
+    def jpeg_decode_yuv444(self, data: bytes):
+        """decode_a_frame + Planar_444.of_420 for a 4:2:0 file: (info, uint8 [3][height][width])"""
+        info = jpeg_read_header(data)
+        frame = np.zeros(3 * info.width * info.height, dtype=np.uint8)
+        _chk(lib().hvc_jpeg_decode_yuv444(self._h, data, len(data), C.byref(info), frame.ctypes.data, frame.size),
+             "hvc_jpeg_decode_yuv444")
+        return info, frame.reshape(3, info.height, info.width)
 
     def jpeg_decode_batch(self, jpegs, pixels, pixel_frame_stride, threads=8, frames_per_chunk=32):
         """config 3 pipeline.  jpegs: list of bytes; pixels: numpy (host) or torch cuda tensor."""
