@@ -1,0 +1,22 @@
+#!/bin/bash
+# One GPU session that produces every number DESIGN.md quotes (run via gpurun from the repo root):
+#   gpurun_out/m_*.json  bench lines, gpurun_out/prof_<tag>/ rocprofv3 databases
+set -e
+TAG=${1:-r01}
+mkdir -p gpurun_out
+python bench.py --check > gpurun_out/m_bench.json 2> gpurun_out/m_bench.err
+echo "bench done"
+python tools/bench_configs.py --config 3 --frames 1024 --threads 16 > gpurun_out/m_c3.json 2> gpurun_out/m_c3.err
+echo "c3 done"
+python tools/bench_configs.py --config 4 > gpurun_out/m_c4.json 2> gpurun_out/m_c4.err
+python tools/bench_configs.py --config 5 > gpurun_out/m_c5.json 2> gpurun_out/m_c5.err
+python tools/bench_configs.py --config 6 > gpurun_out/m_c6.json 2> gpurun_out/m_c6.err
+python tools/bench_configs.py --config 7 --check > gpurun_out/m_c7.json 2> gpurun_out/m_c7.err
+python tools/bench_configs.py --config 2 > gpurun_out/m_k2.json 2> gpurun_out/m_k2.err
+echo "configs done"
+bash tools/gpu_profile.sh ${TAG}_decode
+echo "decode profile done"
+bash tools/gpu_profile_cmd.sh ${TAG}_444 tools/bench_configs.py --config 7 --steps 10
+echo "444 profile done"
+bash tools/gpu_profile_cmd.sh ${TAG}_encode tools/bench_configs.py --config 5 --steps 10
+echo "encode profile done"

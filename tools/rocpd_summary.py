@@ -14,7 +14,11 @@ def q(db, sql):
     return list(sqlite3.connect(db).execute(sql))
 
 
+WARMUP = 10
+
+
 def main(d):
+    d_ = d
     print("# rocprofv3 summary of %s" % d)
     tr = glob.glob(os.path.join(d, "trace", "*.db"))
     if tr:
@@ -22,8 +26,22 @@ def main(d):
         print("%-60s %8s %14s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
         for name, calls, total, avg, pct in q(tr[0], "select name,total_calls,total_duration,average,percentage from top_kernels"):
             print("%-60s %8d %14.0f %12.1f %7.2f" % (name[:60], calls, total * 1e3 if total < 1e6 else total, avg * 1e3 if avg < 1e5 else avg, pct))
+        # the dominant hvc kernel: average over all dispatches and over the timed ones only (the first
+        # `warmup` launches of a bench run are the untimed warm-ups, still off the sustained clock)
+        dom = q(tr[0], "select name from top_kernels where name like '%hvc::%' order by total_duration desc limit 1")
+        if dom:
+            ds = [r[0] for r in q(tr[0], "select duration from kernels where name = ? order by start".replace("?", "'%s'" % dom[0][0].replace("'", "''")))]
+            w = WARMUP if len(ds) > WARMUP else 0
+            print("\ndominant kernel %s: %d dispatches, avg %.1f ns; without the first %d (warm-up): avg %.1f ns"
+                  % (dom[0][0][:60], len(ds), sum(ds) / len(ds), w, sum(ds[w:]) / len(ds[w:])))
+        for log in ("trace_bench.log", "trace.log"):
+            lp = os.path.join(d_, log)
+            if os.path.exists(lp):
+                for line in open(lp):
+                    if line.startswith("{"):
+                        print("bench line of this very run (HIP events inside the profiled process):\n  " + line.strip())
         rows = q(tr[0], "select name, duration, vgpr_count, sgpr_count, grid_x, grid_y, workgroup_x from kernels "
-                        "where name like 'hvc::%' order by start")
+                        "where name like '%hvc::%' order by start")
         print("\nper-dispatch (hvc kernels): name duration_ns vgpr sgpr grid wg")
         for r in rows:
             print("  %-48s %9d vgpr=%d sgpr=%d grid=%dx%d wg=%d" % (r[0][:48], r[1], r[2], r[3], r[4], r[5], r[6]))
@@ -33,7 +51,7 @@ def main(d):
         if not dbs:
             continue
         for kn, cn, avg, n in q(dbs[0], "select kernel_name, counter_name, avg(value), count(*) from counters_collection "
-                                        "where kernel_name like 'hvc::%' group by kernel_name, counter_name"):
+                                        "where kernel_name like '%hvc::%' group by kernel_name, counter_name"):
             extra = ""
             if cn == "FETCH_SIZE":
                 extra = "  KB -> x1024 x2 (gfx950 16B/lane read correction) = %.1f MB" % (avg * 1024 * 2 / 1e6)
