@@ -235,6 +235,7 @@ typedef struct hvc_batch_stats {
     double wall_ms, entropy_ms_sum, h2d_ms_sum, kernel_ms_sum, d2h_ms_sum; /* sums over chunks */
     int chunks, threads, frames_per_chunk;
     uint64_t coef_bytes;
+    double host_prep_ms_sum; /* hvc_jpeg_encode_batch: plane padding into the pinned ring, summed over threads */
 } hvc_batch_stats;
 HVC_API int hvc_jpeg_decode_batch(hvc_ctx *ctx, const uint8_t *const *jpegs, const size_t *sizes, int n_frames,
                                   int threads, int frames_per_chunk, uint8_t *pixels, size_t pixel_frame_stride,
@@ -260,6 +261,17 @@ HVC_API int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *co
  * frame (Frame.create sizes); padding, GPU forward stage and host entropy coding inside. */
 HVC_API int hvc_jpeg_encode(hvc_ctx *ctx, const uint8_t *y, const uint8_t *u, const uint8_t *v, int width,
                             int height, int chroma, int quality, uint8_t *out, size_t cap, size_t *out_len);
+
+/* The same for a batch of equally sized frames (BASELINE config 5 end to end): frames[f] is one raw
+ * planar frame as `model encode frame` reads it (Frame.input, common/src/frame.ml:72-76: the tight Y, U,
+ * V planes back to back); jpegs[f] receives the file (capacity caps[f]; its length in sizes[f]), byte-
+ * identical to Encoder.encode_420/422/444.  Host threads pad planes into a pinned ring, hipMemcpyAsync on a
+ * copy stream, the forward block stage and the download of the coefficient records on the compute
+ * stream, host threads RLE + Huffman -- three chunks in flight. */
+HVC_API int hvc_jpeg_encode_batch(hvc_ctx *ctx, const uint8_t *const *frames, int n_frames, int width, int height,
+                                  int chroma, int quality, int threads, int frames_per_chunk,
+                                  uint8_t *const *jpegs, const size_t *caps, size_t *sizes,
+                                  hvc_batch_stats *stats);
 
 /* Device memory helpers so that a binding needs no HIP of its own. */
 HVC_API int hvc_device_alloc(hvc_ctx *ctx, size_t bytes, void **out);

@@ -196,3 +196,53 @@ def test_decode_to_444_rejects_other_samplings(ctx):
     yc, uc, vc = orc.split_yuv(golden_bytes("mini64x64.420"), 64, 64, 420)
     with pytest.raises(hvc.HvcError):  # odd size: Yuv.assert_is_420 fails in the model's tool chain
         ctx.jpeg_decode_yuv444(orc.encode_yuv(yc[:44, :51], uc[:22, :25], vc[:22, :25], 51, 44, 420, 75))
+
+
+@pytest.mark.parametrize("chroma,w,h,n,threads,chunk", [(420, 96, 64, 11, 4, 3), (422, 70, 50, 7, 2, 1), (444, 33, 17, 5, 8, 16),
+                                                        (420, 52, 44, 9, 3, 2), (420, 1920, 1080, 5, 8, 2)])
+def test_encode_batch_is_byte_identical_to_the_model(ctx, chroma, w, h, n, threads, chunk):
+    """hvc_jpeg_encode_batch (config 5 end to end): every file equals Encoder.encode_4xx of its frame."""
+    cw, ch = orc.chroma_dims(chroma, w, h)
+    r8 = lambda x: (x + 7) // 8 * 8
+    frames, want = [], []
+    for f in range(n):
+        y = synth_pixels(400 + f, r8(h), r8(w))[:h, :w]
+        u = synth_pixels(500 + f, r8(ch), r8(cw))[:ch, :cw]
+        v = synth_pixels(600 + f, r8(ch), r8(cw))[:ch, :cw]
+        frames.append(np.concatenate([y.reshape(-1), u.reshape(-1), v.reshape(-1)]))
+        want.append(orc.encode_yuv(y, u, v, w, h, chroma, 70))
+    for rep in range(2):  # second call reuses the pinned rings
+        got, st = ctx.jpeg_encode_batch(frames, w, h, chroma, 70, threads=threads, frames_per_chunk=chunk)
+        assert st.chunks == (n + min(chunk, n) - 1) // min(chunk, n)
+        for f in range(n):
+            assert got[f] == want[f], (rep, f)
+
+
+def test_encode_batch_then_decode_batch_round_trip(ctx):
+    import video_coding_amd as hvc
+    w, h, n = 128, 80, 13
+    frames = [np.concatenate([synth_pixels(700 + f, h, w).reshape(-1), synth_pixels(800 + f, h // 2, w // 2).reshape(-1),
+                              synth_pixels(900 + f, h // 2, w // 2).reshape(-1)]) for f in range(n)]
+    jpegs, _ = ctx.jpeg_encode_batch(frames, w, h, 420, 85, threads=4, frames_per_chunk=4)
+    info = hvc.hvc.jpeg_read_header(jpegs[0])
+    pixels = np.zeros(n * info.pixel_bytes, dtype=np.uint8)
+    ctx.jpeg_decode_batch(jpegs, pixels, info.pixel_bytes, threads=4, frames_per_chunk=5)
+    for f in range(n):
+        d = orc.Decoder(jpegs[f])
+        d.decode()
+        for i, plane in enumerate(info.planes(pixels[f * info.pixel_bytes:(f + 1) * info.pixel_bytes])):
+            assert np.array_equal(plane, d.plane(i))
+
+
+def test_encode_batch_reports_a_too_small_output_buffer(ctx):
+    import ctypes as C
+    import video_coding_amd as hvc
+    w, h = 64, 64
+    frame = np.frombuffer(golden_bytes("mini64x64.420"), dtype=np.uint8)
+    out = np.empty(100, dtype=np.uint8)  # mini.jpg is 1.2 kB
+    fp = (C.c_void_p * 1)(frame.ctypes.data)
+    op = (C.c_void_p * 1)(out.ctypes.data)
+    caps = (C.c_size_t * 1)(100)
+    sizes = (C.c_size_t * 1)()
+    rc = hvc.lib().hvc_jpeg_encode_batch(ctx._h, fp, 1, w, h, 420, 75, 2, 1, op, caps, sizes, None)
+    assert rc == -1 and sizes[0] == len(golden_bytes("mini.jpg"))

@@ -12,6 +12,7 @@
 #include <mutex>
 #include <new>
 #include <thread>
+#include <deque>
 #include <vector>
 
 #include "../../include/hvc_jpeg.h"
@@ -43,6 +44,10 @@ struct hvc_ctx {
     void *h_ring[RING] = {}, *d_ring[RING] = {}, *d_oring[RING] = {};
     size_t ring_bytes = 0, oring_bytes = 0;
     hipEvent_t ev_h2d[RING] = {}, ev_kern[RING] = {}, ev_t[4] = {};
+    // hvc_jpeg_encode_batch: pinned / device rings of padded pixel chunks (in) and coefficient chunks (out)
+    void *eh_in[RING] = {}, *ed_in[RING] = {}, *eh_out[RING] = {}, *ed_out[RING] = {};
+    size_t e_in_bytes = 0, e_out_bytes = 0;
+    hipEvent_t ev_up[RING] = {}, ev_down[RING] = {}, ev_et[RING][3] = {};
 };
 
 namespace {
@@ -209,6 +214,14 @@ void hvc_destroy(hvc_ctx *c) {
         if (c->d_oring[i]) (void)hipFree(c->d_oring[i]);
         if (c->ev_h2d[i]) (void)hipEventDestroy(c->ev_h2d[i]);
         if (c->ev_kern[i]) (void)hipEventDestroy(c->ev_kern[i]);
+        if (c->eh_in[i]) (void)hipHostFree(c->eh_in[i]);
+        if (c->eh_out[i]) (void)hipHostFree(c->eh_out[i]);
+        if (c->ed_in[i]) (void)hipFree(c->ed_in[i]);
+        if (c->ed_out[i]) (void)hipFree(c->ed_out[i]);
+        if (c->ev_up[i]) (void)hipEventDestroy(c->ev_up[i]);
+        if (c->ev_down[i]) (void)hipEventDestroy(c->ev_down[i]);
+        for (int k = 0; k < 3; k++)
+            if (c->ev_et[i][k]) (void)hipEventDestroy(c->ev_et[i][k]);
     }
     for (int i = 0; i < 4; i++)
         if (c->ev_t[i]) (void)hipEventDestroy(c->ev_t[i]);
@@ -951,6 +964,211 @@ int hvc_jpeg_decode_batch(hvc_ctx *c, const uint8_t *const *jpegs, const size_t 
         stats->threads = threads;
         stats->frames_per_chunk = C;
         stats->coef_bytes = (uint64_t)frame_coef_bytes * (uint64_t)n_frames;
+    }
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
+// BASELINE config 5 end to end: raw frames in, JPEG files out.
+//   host threads: Plane.blit_available into zero-padded planes (pinned ring)     encoder.ml:514-516
+//   copy stream:  hipMemcpyAsync H2D                  compute stream: k_encode, then D2H of the coefficient records
+//   host threads: write_headers + rle + write_bits + EOI per frame                encoder.ml:127-193, 371-418
+// The orchestrating thread runs a three-stage software pipeline over chunks (pad k | GPU k-1 | entropy k-2).
+int hvc_jpeg_encode_batch(hvc_ctx *c, const uint8_t *const *frames, int n_frames, int width, int height, int chroma,
+                          int quality, int threads, int frames_per_chunk, uint8_t *const *jpegs, const size_t *caps,
+                          size_t *sizes, hvc_batch_stats *stats) {
+    if (!c || !frames || !jpegs || !caps || !sizes || n_frames < 0) return HVC_E_INVALID_ARG;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    hvc_jpeg_info info;
+    int r = hvc_jpeg_encoder_layout(width, height, chroma, quality, &info);
+    if (r) return r;
+    if (n_frames == 0) return HVC_OK;
+    for (int f = 0; f < n_frames; f++)
+        if (!frames[f] || !jpegs[f]) return HVC_E_INVALID_ARG;
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    if (frames_per_chunk < 1) frames_per_chunk = 16;
+    if (frames_per_chunk > n_frames) frames_per_chunk = n_frames;
+    const int C = frames_per_chunk, NB = hvc_ctx::RING;
+    const int n_chunks = (n_frames + C - 1) / C;
+    const size_t pix_bytes = info.pixel_bytes, coef_bytes = info.coef_count * sizeof(int16_t);
+    const size_t in_bytes = pix_bytes * (size_t)C, out_bytes = coef_bytes * (size_t)C;
+
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
+    if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < NB; i++) {
+        if (!c->ev_up[i]) HIPCHK(c, hipEventCreate(&c->ev_up[i]));
+        if (!c->ev_down[i]) HIPCHK(c, hipEventCreate(&c->ev_down[i]));
+        for (int k = 0; k < 3; k++)
+            if (!c->ev_et[i][k]) HIPCHK(c, hipEventCreate(&c->ev_et[i][k]));
+    }
+    if (in_bytes > c->e_in_bytes || out_bytes > c->e_out_bytes) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+        for (int i = 0; i < NB; i++) {
+            if (c->eh_in[i]) (void)hipHostFree(c->eh_in[i]);
+            if (c->eh_out[i]) (void)hipHostFree(c->eh_out[i]);
+            if (c->ed_in[i]) (void)hipFree(c->ed_in[i]);
+            if (c->ed_out[i]) (void)hipFree(c->ed_out[i]);
+            c->eh_in[i] = c->eh_out[i] = c->ed_in[i] = c->ed_out[i] = nullptr;
+        }
+        c->e_in_bytes = c->e_out_bytes = 0;
+        for (int i = 0; i < NB; i++)
+            if (hipHostMalloc(&c->eh_in[i], in_bytes, hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc(&c->eh_out[i], out_bytes, hipHostMallocDefault) != hipSuccess ||
+                hipMalloc(&c->ed_in[i], in_bytes) != hipSuccess || hipMalloc(&c->ed_out[i], out_bytes) != hipSuccess)
+                return HVC_E_OUT_OF_MEMORY;
+        c->e_in_bytes = in_bytes;
+        c->e_out_bytes = out_bytes;
+    }
+
+    const int cw = chroma == 444 ? width : width / 2, ch = chroma == 420 ? height / 2 : height;
+    const int sw[3] = {width, cw, cw}, sh[3] = {height, ch, ch};
+    struct Task {
+        int kind, frame; // 0 = pad into the pinned pixel ring, 1 = entropy-code from the pinned coefficient ring
+    };
+    std::mutex mu;
+    std::condition_variable cv_task, cv_done;
+    std::deque<Task> queue;
+    bool stop = false;
+    std::atomic<int> error{0};
+    std::vector<int> pads_done((size_t)n_chunks, 0), ent_done((size_t)n_chunks, 0);
+    std::atomic<long long> pad_ns{0}, ent_ns{0};
+    auto worker = [&]() {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_task.wait(lk, [&] { return stop || !queue.empty(); });
+                if (queue.empty()) return;
+                t = queue.front();
+                queue.pop_front();
+            }
+            const int f = t.frame, k = f / C, slot = k % NB;
+            const auto t0 = std::chrono::steady_clock::now();
+            int e = HVC_OK;
+            if (error.load() == 0) {
+                if (t.kind == 0) {
+                    uint8_t *rec = (uint8_t *)c->eh_in[slot] + (size_t)(f - k * C) * pix_bytes;
+                    const uint8_t *src = frames[f];
+                    for (int i = 0; i < 3; i++) {
+                        const hvc_component &L = info.layout[i];
+                        const int pw = info.comp[i].decoded_width, ph = info.comp[i].decoded_height;
+                        const int bw = sw[i] < pw ? sw[i] : pw, bh = sh[i] < ph ? sh[i] : ph;
+                        uint8_t *dst = rec + L.plane_offset;
+                        for (int row = 0; row < ph; row++) {
+                            uint8_t *d = dst + (size_t)row * L.stride;
+                            if (row < bh) {
+                                std::memcpy(d, src + (size_t)row * sw[i], (size_t)bw);
+                                std::memset(d + bw, 0, (size_t)(pw - bw)); // Plane.create is zero-filled
+                            } else {
+                                std::memset(d, 0, (size_t)pw);
+                            }
+                        }
+                        src += (size_t)sw[i] * sh[i];
+                    }
+                } else {
+                    const int16_t *cf = (const int16_t *)c->eh_out[slot] + (size_t)(f - k * C) * info.coef_count;
+                    e = hvc_jpeg_entropy_encode(&info, cf, jpegs[f], caps[f], &sizes[f]);
+                }
+            }
+            const long long ns =
+                std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            (t.kind == 0 ? pad_ns : ent_ns) += ns;
+            std::lock_guard<std::mutex> lk(mu);
+            if (e) error.store(e);
+            (t.kind == 0 ? pads_done : ent_done)[(size_t)k]++;
+            cv_done.notify_all();
+        }
+    };
+    const auto wall0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++) pool.emplace_back(worker);
+    auto chunk_count = [&](int k) { return (k * C + C <= n_frames) ? C : n_frames - k * C; };
+    auto submit = [&](int kind, int k) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (int f = k * C; f < k * C + chunk_count(k); f++) queue.push_back(Task{kind, f});
+        cv_task.notify_all();
+    };
+    auto wait_for = [&](std::vector<int> &done, int k) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return done[(size_t)k] == chunk_count(k); });
+    };
+
+    int rc = HVC_OK;
+    double h2d_ms = 0, k_ms = 0, d2h_ms = 0;
+    hipStream_t compute = c->stream;
+    const bool prof_saved = c->profiling;
+    c->profiling = false;
+    for (int it = 0; it < n_chunks + 2 && rc == HVC_OK; it++) {
+        // stage 1: pad chunk `it` (its pinned slot was uploaded and synchronised two iterations ago)
+        if (it < n_chunks) submit(0, it);
+        // stage 2: GPU work of chunk it - 1
+        const int j = it - 1;
+        if (j >= 0 && j < n_chunks) {
+            const int slot = j % NB, cnt = chunk_count(j);
+            wait_for(pads_done, j);
+            if (j >= NB) wait_for(ent_done, j - NB); // the pinned coefficient slot is free again
+            hipError_t he = hipEventRecord(c->ev_et[slot][0], c->copy_stream);
+            if (he == hipSuccess)
+                he = hipMemcpyAsync(c->ed_in[slot], c->eh_in[slot], pix_bytes * (size_t)cnt, hipMemcpyHostToDevice,
+                                    c->copy_stream);
+            if (he == hipSuccess) he = hipEventRecord(c->ev_up[slot], c->copy_stream);
+            if (he == hipSuccess) he = hipStreamWaitEvent(compute, c->ev_up[slot], 0);
+            if (he == hipSuccess) he = hipEventRecord(c->ev_et[slot][1], compute);
+            if (he != hipSuccess) { rc = fail_hip(c, he); break; }
+            rc = hvc_encode_frames(c, (const uint8_t *)c->ed_in[slot], pix_bytes, &info.qtabs[0][0], info.n_qtabs,
+                                   info.layout, 3, cnt, (int16_t *)c->ed_out[slot], info.coef_count, HVC_MEM_DEVICE);
+            if (rc) break;
+            he = hipEventRecord(c->ev_et[slot][2], compute);
+            if (he == hipSuccess)
+                he = hipMemcpyAsync(c->eh_out[slot], c->ed_out[slot], coef_bytes * (size_t)cnt, hipMemcpyDeviceToHost,
+                                    compute);
+            if (he == hipSuccess) he = hipEventRecord(c->ev_down[slot], compute);
+            if (he != hipSuccess) { rc = fail_hip(c, he); break; }
+        }
+        // stage 3: entropy-code chunk it - 2 once its coefficients have landed
+        const int e = it - 2;
+        if (e >= 0 && e < n_chunks) {
+            const int slot = e % NB;
+            hipError_t he = hipEventSynchronize(c->ev_down[slot]);
+            if (he != hipSuccess) { rc = fail_hip(c, he); break; }
+            submit(1, e);
+            float ms = 0; // stage times of the chunk that just landed
+            if (hipEventElapsedTime(&ms, c->ev_et[slot][0], c->ev_up[slot]) == hipSuccess) h2d_ms += ms;
+            if (hipEventElapsedTime(&ms, c->ev_et[slot][1], c->ev_et[slot][2]) == hipSuccess) k_ms += ms;
+            if (hipEventElapsedTime(&ms, c->ev_et[slot][2], c->ev_down[slot]) == hipSuccess) d2h_ms += ms;
+        }
+        if (error.load()) rc = error.load();
+    }
+    c->profiling = prof_saved;
+    if (rc == HVC_OK)
+        for (int k = 0; k < n_chunks; k++) wait_for(ent_done, k);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (rc != HVC_OK) {
+            error.store(rc);
+            queue.clear();
+        }
+        stop = true;
+        cv_task.notify_all();
+    }
+    for (auto &t : pool) t.join();
+    (void)hipStreamSynchronize(compute);
+    (void)hipStreamSynchronize(c->copy_stream);
+    if (rc == HVC_OK && error.load()) rc = error.load();
+    if (stats) {
+        stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        stats->entropy_ms_sum = (double)ent_ns.load() * 1e-6;
+        stats->host_prep_ms_sum = (double)pad_ns.load() * 1e-6;
+        stats->h2d_ms_sum = h2d_ms;
+        stats->kernel_ms_sum = k_ms;
+        stats->d2h_ms_sum = d2h_ms;
+        stats->chunks = n_chunks;
+        stats->threads = threads;
+        stats->frames_per_chunk = C;
+        stats->coef_bytes = (uint64_t)coef_bytes * (uint64_t)n_frames;
     }
     return rc;
 }

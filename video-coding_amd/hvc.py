@@ -20,7 +20,7 @@ SYMBOLS = [
     "hvc_device_free", "hvc_memcpy_h2d", "hvc_memcpy_d2h",
     "hvc_jpeg_read_header", "hvc_jpeg_entropy_decode", "hvc_jpeg_get_yuv_frame", "hvc_jpeg_decode",
     "hvc_jpeg_decode_batch", "hvc_quant_table", "hvc_jpeg_encoder_layout", "hvc_jpeg_entropy_encode",
-    "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444", "hvc_jpeg_decode_yuv444", "hvc_compare_planes",
+    "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444", "hvc_jpeg_decode_yuv444", "hvc_compare_planes", "hvc_jpeg_encode_batch",
 ]
 
 
@@ -66,7 +66,7 @@ class BatchStats(C.Structure):
     """struct hvc_batch_stats"""
     _fields_ = [("wall_ms", C.c_double), ("entropy_ms_sum", C.c_double), ("h2d_ms_sum", C.c_double),
                 ("kernel_ms_sum", C.c_double), ("d2h_ms_sum", C.c_double), ("chunks", C.c_int), ("threads", C.c_int),
-                ("frames_per_chunk", C.c_int), ("coef_bytes", C.c_uint64)]
+                ("frames_per_chunk", C.c_int), ("coef_bytes", C.c_uint64), ("host_prep_ms_sum", C.c_double)]
 
 
 def build(force=False):
@@ -127,6 +127,8 @@ def lib():
         L.hvc_jpeg_decode_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), i, i, i, vp, sz, i,
                                             C.POINTER(BatchStats)]
         L.hvc_quant_table.argtypes = [i, i, vp]
+        L.hvc_jpeg_encode_batch.argtypes = [vp, C.POINTER(vp), i, i, i, i, i, i, i, C.POINTER(vp), C.POINTER(sz),
+                                            C.POINTER(sz), C.POINTER(BatchStats)]
         L.hvc_compare_planes.argtypes = [vp, vp, sz, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.hvc_jpeg_encoder_layout.argtypes = [i, i, i, i, ip]
         L.hvc_jpeg_entropy_encode.argtypes = [ip, vp, vp, sz, C.POINTER(sz)]
@@ -366,6 +368,29 @@ class Context:
         _chk(lib().hvc_jpeg_encode(self._h, y.ctypes.data, u.ctypes.data, v.ctypes.data, width, height, chroma, quality,
                                    out.ctypes.data, cap, C.byref(n)), "hvc_jpeg_encode")
         return out[:n.value].tobytes()
+
+    def jpeg_encode_batch(self, frames, width, height, chroma=420, quality=75, threads=8, frames_per_chunk=16):
+        """Encoder.encode_4xx over a batch of raw planar frames (bytes / uint8 arrays in Frame.input layout).
+        Returns (list of jpeg byte strings, BatchStats)."""
+        n = len(frames)
+        arrs = [np.frombuffer(f, dtype=np.uint8) if isinstance(f, (bytes, bytearray)) else
+                np.ascontiguousarray(f, dtype=np.uint8).reshape(-1) for f in frames]
+        cw = width if chroma == 444 else width // 2
+        ch = height // 2 if chroma == 420 else height
+        need = width * height + 2 * cw * ch
+        for a in arrs:
+            if a.size < need:
+                raise ValueError("frame shorter than %d bytes" % need)
+        cap = 4 * width * height + 65536
+        outs = [np.empty(cap, dtype=np.uint8) for _ in range(n)]
+        fp = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrs])
+        op = (C.c_void_p * max(n, 1))(*[o.ctypes.data for o in outs])
+        caps = (C.c_size_t * max(n, 1))(*([cap] * n))
+        sizes = (C.c_size_t * max(n, 1))()
+        st = BatchStats()
+        _chk(lib().hvc_jpeg_encode_batch(self._h, fp, n, width, height, chroma, quality, threads, frames_per_chunk, op,
+                                         caps, sizes, C.byref(st)), "hvc_jpeg_encode_batch")
+        return [outs[f][:sizes[f]].tobytes() for f in range(n)], st
 
     # -- encode -------------------------------------------------------------
     def fdct_quant(self, plane, qtab, blocks_w, blocks_h, n_planes, coefs, stride=None, plane_stride=0,
