@@ -49,3 +49,37 @@ def test_product_never_imports_the_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, fn), errors="ignore").read()
                 assert "oracle" not in txt.lower().replace("checked against the cpu oracle", ""), os.path.join(dp, fn)
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/hvc_jpeg.h compiles as C99 (-pedantic) and a C program taking the address of every
+    declared entry point links against libhvc_jpeg.so -- the boundary a cgo / ctypes / OCaml
+    `foreign` binding sees.  Host-only calls are executed (no GPU needed)."""
+    import subprocess
+    import video_coding_amd as hvc
+    so = hvc.build()
+    syms = declared_symbols()
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <string.h>\n#include "hvc_jpeg.h"\n'
+        "int main(void) {\n"
+        "    typedef void (*anyfn)(void);\n"
+        "    const anyfn fn[] = {%s};\n" % ", ".join("(anyfn)%s" % s for s in syms) +
+        "    uint16_t q[64];\n"
+        "    hvc_jpeg_info info;\n"
+        "    int mx = -1;\n"
+        "    uint64_t tot = 0, se = 0;\n"
+        "    const uint8_t a[4] = {1, 2, 3, 250}, b[4] = {3, 2, 0, 255};\n"
+        "    if (hvc_quant_table(0, 50, q) != HVC_OK || q[0] != 16) return 1;   /* Quant_tables.luma at q50 */\n"
+        "    if (hvc_jpeg_encoder_layout(1920, 1080, 420, 75, &info) != HVC_OK || info.n_comp != 3) return 2;\n"
+        "    if (info.layout[0].blocks_w != 240 || info.layout[0].blocks_h != 136) return 3;\n"
+        "    if (hvc_compare_planes(a, b, 4, &mx, &tot, &se) != HVC_OK || mx != 5 || tot != 10 || se != 38) return 4;\n"
+        "    if (strcmp(hvc_strerror(HVC_E_NO_DEVICE), \"no usable gfx950 device\")) return 5;\n"
+        '    printf("%d symbols\\n", (int)(sizeof fn / sizeof fn[0]));\n'
+        "    return 0;\n}\n")
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), so, "-Wl,-rpath," + os.path.dirname(so)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stderr)
+    assert out.stdout.strip() == "%d symbols" % len(syms)
