@@ -115,6 +115,31 @@ def test_upsample_sizes(ctx, cw, ch):
         assert np.array_equal(dst[p], orc.supersample_hv2(src[p])), p
 
 
+@pytest.mark.parametrize("cw,ch,sstride,dstride", [(8, 1, 8, 16), (16, 3, 24, 48), (120, 67, 128, 256), (960, 540, 960, 1920),
+                                                   (968, 5, 976, 1936 + 16), (4, 4, 8, 16), (12, 2, 16, 32)])
+def test_upsample_wide_variant_and_strides(ctx, cw, ch, sstride, dstride):
+    """cw % 8 == 0 with 8 / 16-byte aligned rows takes k_upsample420_x8 (packed v_lerp_u8 arithmetic);
+    padded strides and plane strides, device memory; cw % 8 != 0 stays on the 4-sample kernel."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(cw * 7 + ch))
+    n = 4
+    sps, dps = sstride * ch + 64, dstride * 2 * ch + 128
+    src = rng.integers(0, 256, size=(n * sps,), dtype=np.uint8)
+    d_src = torch.from_numpy(src).cuda()
+    d_dst = torch.full((n * dps,), 0x5A, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.upsample420(d_src, cw, ch, d_dst, n_planes=n, src_stride=sstride, dst_stride=dstride, src_plane_stride=sps,
+                    dst_plane_stride=dps)
+    ctx.synchronize()
+    got = d_dst.cpu().numpy()
+    for p in range(n):
+        plane = src[p * sps:p * sps + sstride * ch].reshape(ch, sstride)[:, :cw]
+        out = got[p * dps:p * dps + dstride * 2 * ch].reshape(2 * ch, dstride)
+        assert np.array_equal(out[:, :2 * cw], orc.supersample_hv2(np.ascontiguousarray(plane))), p
+        assert (out[:, 2 * cw:] == 0x5A).all()   # row padding untouched
+        assert (got[p * dps + dstride * 2 * ch:(p + 1) * dps] == 0x5A).all()
+
+
 def test_encoder_rejects_wide_tables(ctx):
     import video_coding_amd as hvc
     q = np.full(64, 256, dtype=np.uint16)

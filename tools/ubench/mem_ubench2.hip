@@ -54,6 +54,36 @@ __global__ __launch_bounds__(256) void k(const uint4 *__restrict__ in, unsigned 
     }
 }
 
+// S: K1's loads, but the pixel rows leave as 16-byte nt stores, 1 KiB contiguous per wave instruction
+// (what an LDS transpose across the workgroup's four waves would produce; data is arbitrary here so
+// no LDS is needed).  Plane width 256 blocks so that a tile is exactly one block row; A256 = shape A
+// on the same geometry.
+template <int MODE>
+__global__ __launch_bounds__(256) void ks(const uint4 *__restrict__ in, unsigned char *__restrict__ out) {
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    const size_t frame = blockIdx.y;
+    constexpr int TPF = 128; // tiles (block rows) per frame
+    const uint4 *src = in + ((frame * TPF + tile) * 256 + lane) * 8;
+    uint4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = src[j];
+    unsigned char *base = out + (frame * TPF + tile) * (size_t)(2048 * 8);
+    if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            u2v t = {v[j].x ^ v[j].z, v[j].y ^ v[j].w};
+            __builtin_nontemporal_store(t, reinterpret_cast<u2v *>(base + j * 2048 + lane * 8));
+        }
+    } else {
+        const int w = lane >> 6, l = lane & 63;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { // rows 2w, 2w + 1; two 1 KiB halves each
+            u4v t = {v[2 * k].x ^ v[2 * k + 1].x, v[2 * k].y ^ v[2 * k + 1].y, v[2 * k].z ^ v[2 * k + 1].z, v[2 * k].w ^ v[2 * k + 1].w};
+            __builtin_nontemporal_store(t, reinterpret_cast<u4v *>(base + (2 * w + (k >> 1)) * 2048 + (k & 1) * 1024 + l * 16));
+        }
+    }
+}
+
 template <bool NT>
 __global__ __launch_bounds__(256) void kcopy(const u4v *__restrict__ in, u4v *__restrict__ out, size_t n) {
     size_t i = (size_t)blockIdx.x * 256 * 4 + threadIdx.x;
@@ -98,6 +128,13 @@ int main(int argc, char **argv) {
         double x = timeit([&] { hipLaunchKernelGGL(k<1>, dim3((unsigned)TILES * frames), dim3(256), 0, 0, in, out, frames); }, reps);
         double r = timeit([&] { hipLaunchKernelGGL(k<2>, dim3(frames, TILES), dim3(256), 0, 0, in, out, frames); }, reps);
         double w = timeit([&] { hipLaunchKernelGGL(k<3>, dim3(TILES / 2, frames), dim3(256), 0, 0, in, out, frames); }, reps);
+        const int f256 = (int)(nblk / (128 * 256));
+        double a256 = timeit([&] { hipLaunchKernelGGL(ks<0>, dim3(128, f256), dim3(256), 0, 0, in, out); }, reps);
+        double s256 = timeit([&] { hipLaunchKernelGGL(ks<1>, dim3(128, f256), dim3(256), 0, 0, in, out); }, reps);
+        if (rep == 1) {
+            printf("%-58s %8.4f ms %8.1f GB/s\n", "A256 K1 shape, 256-block-wide planes", a256, (double)f256 * 128 * 256 * 192.0 / (a256 * 1e-3) / 1e9);
+            printf("%-58s %8.4f ms %8.1f GB/s\n", "S256 same loads, 16 B nt stores 1 KiB per wave instruction", s256, (double)f256 * 128 * 256 * 192.0 / (s256 * 1e-3) / 1e9);
+        }
         if (rep == 1) {
             printf("frames %d (%.1f GB of 2:1 traffic)\n", frames, nblk * 192.0 / 1e9);
             printf("%-58s %8.4f ms %8.1f GB/s\n", "P  float4 copy 1:1, plain stores", c0, nblk * 256.0 / (c0 * 1e-3) / 1e9);

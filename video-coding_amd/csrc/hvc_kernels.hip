@@ -1172,6 +1172,28 @@ __global__ __launch_bounds__(256) void k_upsample420(UpsampleParams P) {
 
 // ---------------------------------------------------------------------------
 // launchers (host)
+// K2, wide form (cw % 8 == 0, 8 / 16-byte aligned rows): one thread = 8 source samples of one source row ->
+// two 16-byte output rows, with the packed-byte arithmetic of k_decode_444's epilogue (rowq / emit_rows444:
+// v_lerp_u8 averages, v_perm interleave, non-temporal 16-byte stores, 1 KiB contiguous per wave instruction).
+__global__ __launch_bounds__(256) void k_upsample420_x8(UpsampleParams P) {
+    const int groups = P.cw >> 3;
+    const long long total = (long long)groups * P.ch;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int row = (int)(t / groups), g = (int)(t % groups);
+    const uint8_t *src = P.src + (size_t)blockIdx.y * P.src_ps;
+    uint8_t *dst = P.dst + (size_t)blockIdx.y * P.dst_ps;
+    const int row2 = min(P.ch - 1, row + 1); // :86
+    const uint8_t *s1 = src + (size_t)row * P.src_stride + 8 * g;
+    const uint8_t *s2 = src + (size_t)row2 * P.src_stride + 8 * g;
+    const uint2 a = *reinterpret_cast<const uint2 *>(s1), b = *reinterpret_cast<const uint2 *>(s2);
+    const bool last = g == groups - 1; // the w - 1 column replicates (:97-102): b = a there
+    const unsigned an = last ? 0u : s1[8], bn = last ? 0u : s2[8];
+    const unsigned m1 = last ? 0xff000000u : 0u;
+    const RowQ cur = rowq<0>(a.x, a.y, an, 0u, m1), nxt = rowq<0>(b.x, b.y, bn, 0u, m1);
+    emit_rows444<true>(dst + (size_t)(2 * row) * P.dst_stride, P.dst_stride, 16 * g, cur, nxt, false);
+}
+
 hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0, hipEvent_t k1) {
     if (P.n_frames <= 0 || P.tiles_per_frame <= 0) return hipSuccess;
     hipError_t e;
@@ -1254,7 +1276,13 @@ hipError_t launch_upsample420(const UpsampleParams &P, hipStream_t s) {
     dim3 grid((unsigned)((total + 255) / 256), (unsigned)P.n_planes, 1);
     const bool vec = (P.cw % 4 == 0) && (P.src_stride % 4 == 0) && (P.dst_stride % 8 == 0) && (P.src_ps % 4 == 0) &&
                      (P.dst_ps % 8 == 0) && ((uintptr_t)P.src % 4 == 0) && ((uintptr_t)P.dst % 8 == 0);
-    if (vec)
+    const bool x8 = (P.cw % 8 == 0) && (P.src_stride % 8 == 0) && (P.dst_stride % 16 == 0) && (P.src_ps % 8 == 0) &&
+                    (P.dst_ps % 16 == 0) && ((uintptr_t)P.src % 8 == 0) && ((uintptr_t)P.dst % 16 == 0);
+    if (x8) {
+        const long long n8 = (long long)(P.cw >> 3) * P.ch;
+        hipLaunchKernelGGL(k_upsample420_x8, dim3((unsigned)((n8 + 255) / 256), (unsigned)P.n_planes, 1), dim3(256), 0,
+                           s, P);
+    } else if (vec)
         hipLaunchKernelGGL(k_upsample420<true>, grid, dim3(256), 0, s, P);
     else
         hipLaunchKernelGGL(k_upsample420<false>, grid, dim3(256), 0, s, P);
