@@ -931,13 +931,12 @@ int hvc_jpeg_decode_batch(hvc_ctx *c, const uint8_t *const *jpegs, const size_t 
         }
         float ms = 0;
         if (hipEventElapsedTime(&ms, c->ev_t[0], c->ev_h2d[slot]) == hipSuccess) h2d_ms += ms;
-        // kernel / d2h times of this chunk are read once it has finished; keep the loop asynchronous by
-        // reading them only for the chunk that just left the ring (below) or at the end
-        if (k == n_chunks - 1 || true) {
-            if (hipEventSynchronize(c->ev_t[3]) == hipSuccess) {
-                if (hipEventElapsedTime(&ms, c->ev_t[1], c->ev_t[2]) == hipSuccess) k_ms += ms;
-                if (hipEventElapsedTime(&ms, c->ev_t[2], c->ev_t[3]) == hipSuccess) d2h_ms += ms;
-            }
+        // kernel / d2h times of this chunk: the events are shared by all chunks, so they are read (and the
+        // chunk waited for) before the next one records them; the worker threads -- the bound of this
+        // pipeline -- keep decoding into the other ring slots meanwhile
+        if (hipEventSynchronize(c->ev_t[3]) == hipSuccess) {
+            if (hipEventElapsedTime(&ms, c->ev_t[1], c->ev_t[2]) == hipSuccess) k_ms += ms;
+            if (hipEventElapsedTime(&ms, c->ev_t[2], c->ev_t[3]) == hipSuccess) d2h_ms += ms;
         }
     }
     if (rc != HVC_OK) {
