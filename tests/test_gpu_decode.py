@@ -132,6 +132,40 @@ def test_guard_boundary_sweep(ctx):
     assert 0 < ctx.last_wide_blocks() < n
 
 
+@pytest.mark.parametrize("quality", [None, 75, 1])
+def test_every_single_coefficient_value(ctx, quality):
+    """Exhaustive over one-coefficient blocks: every zig-zag position x every value a baseline JPEG
+    can code (-2048 .. 2047: the basis functions at every amplitude and sign), with a flat table
+    of ones, Quant_tables.scale 75 and the coarsest table (quality 1: entries up to 255, where the
+    largest values leave the int32 kernel's proven range and must take the int64 path)."""
+    vals = np.arange(-2048, 2048, dtype=np.int16)
+    coefs = np.zeros((64, vals.size, 64), dtype=np.int16)
+    for k in range(64):
+        coefs[k, :, k] = vals
+    q = np.ones(64, dtype=np.uint16) if quality is None else orc.quant_scale(orc.quant_luma(), quality).astype(np.uint16)
+    want = orc.dequant_idct_recon(coefs, q, vals.size, 64).reshape(64 * 8, vals.size * 8)
+    got = gpu_decode_plane(ctx, coefs, q)
+    assert np.array_equal(got, want)
+    if quality == 1:
+        assert ctx.last_wide_blocks() > 0
+
+
+def test_dc_plus_one_ac_extremes(ctx):
+    """DC at its extremes combined with every single AC position at +-1023 (the largest AC magnitude
+    baseline Huffman coding can express) and the q = 50 table."""
+    q = orc.quant_scale(orc.quant_luma(), 50).astype(np.uint16)
+    blocks = []
+    for dc in (-2048, -1, 0, 2047):
+        for k in range(1, 64):
+            for ac in (-1023, 1023):
+                b = np.zeros(64, dtype=np.int16)
+                b[0], b[k] = dc, ac
+                blocks.append(b)
+    coefs = np.stack(blocks).reshape(1, len(blocks), 64)
+    want = orc.dequant_idct_recon(coefs, q, len(blocks), 1).reshape(8, len(blocks) * 8)
+    assert np.array_equal(gpu_decode_plane(ctx, coefs, q), want)
+
+
 def test_sixteen_bit_quant_table_goes_wide(ctx):
     rng = np.random.Generator(np.random.PCG64(8))
     coefs = rng.integers(-50, 51, size=(2, 3, 64)).astype(np.int16)

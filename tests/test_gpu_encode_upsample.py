@@ -140,6 +140,26 @@ def test_upsample_wide_variant_and_strides(ctx, cw, ch, sstride, dstride):
         assert (got[p * dps + dstride * 2 * ch:(p + 1) * dps] == 0x5A).all()
 
 
+def test_encoder_every_constant_and_two_level_block(ctx):
+    """Forward path on structured extremes: all 256 flat blocks, and every pair of levels (0 / v, v / 255)
+    laid out as vertical, horizontal and checkerboard edges -- the inputs that drive each Chen rotation
+    to its largest outputs -- at qualities 100 (divisor 4) and 50."""
+    blocks = [np.full((8, 8), v, dtype=np.uint8) for v in range(256)]
+    yy, xx = np.mgrid[0:8, 0:8]
+    for v in range(0, 256, 5):
+        for lo, hi in ((0, v), (v, 255)):
+            for mask in (xx < 4, yy < 4, (xx + yy) % 2 == 0, xx % 2 == 0, yy == 0, (xx == 7) & (yy == 7)):
+                blocks.append(np.where(mask, lo, hi).astype(np.uint8))
+    n = len(blocks)
+    plane = np.concatenate(blocks, axis=1)  # 8 x 8n
+    for quality in (100, 50):
+        q = orc.quant_scale(orc.quant_luma(), quality).astype(np.uint16)
+        want = orc.fdct_quant(plane, q, n, 1)
+        got = np.zeros(n * 64, dtype=np.int16)
+        ctx.fdct_quant(np.ascontiguousarray(plane), q, n, 1, 1, got)
+        assert np.array_equal(got, want.reshape(-1)), quality
+
+
 def test_encoder_rejects_wide_tables(ctx):
     import video_coding_amd as hvc
     q = np.full(64, 256, dtype=np.uint16)
