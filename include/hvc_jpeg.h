@@ -152,9 +152,11 @@ HVC_API int hvc_decode_frames_yuv444(hvc_ctx *ctx, const int16_t *coefs, size_t 
                                      size_t frame_stride, int where);
 
 /* Diagnostic: which implementation the decode entry points use.  0 = default (k_decode_packed, the
- * int16-pair kernel, with the int64 fix-up for blocks outside its proven range), 1 = the unpacked
- * int32 kernel k_decode_fast, 2 = the int64 kernel for every block.  All three produce identical
- * bytes; tests use this to cross-check three independent implementations at full batch sizes. */
+ * int16-pair block-per-lane kernel, with the int64 fix-up for blocks outside its proven range), 1 = the
+ * unpacked int32 kernel k_decode_fast, 2 = the int64 kernel for every block, 3 = k_decode_q16, the
+ * mapping BASELINE.json's north star describes (one block per quarter wavefront, coefficients staged in
+ * LDS between the passes; 1.7x slower).  All four produce identical bytes; tests use
+ * this to cross-check independent implementations at full batch sizes. */
 HVC_API int hvc_set_decode_kernel(hvc_ctx *ctx, int which);
 
 /* Number of blocks the last decode call on ctx routed through the wide

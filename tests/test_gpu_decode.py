@@ -166,6 +166,28 @@ def test_dc_plus_one_ac_extremes(ctx):
     assert np.array_equal(gpu_decode_plane(ctx, coefs, q), want)
 
 
+@pytest.mark.parametrize("bw,bh", [(1, 1), (15, 1), (17, 3), (255, 3), (240, 136)])
+def test_quarter_wavefront_kernel(ctx, bw, bh):
+    """hvc_set_decode_kernel(3): the north star's mapping (one block per 16 lanes, LDS between the
+    passes) gives the same bytes -- valid data without the fix-up path, adversarial data through it."""
+    q = orc.quant_scale(orc.quant_chroma(), 60).astype(np.uint16)
+    coefs, _ = synth_coefs(bw * 31 + bh, bh, bw, q)
+    rng = np.random.Generator(np.random.PCG64(bw))
+    adv = rng.integers(-2047, 2048, size=coefs.shape).astype(np.int16)
+    ctx.set_decode_kernel(3)
+    try:
+        got = gpu_decode_plane(ctx, coefs, q)
+        wide = ctx.last_wide_blocks()
+        got_adv = gpu_decode_plane(ctx, adv, q)
+        wide_adv = ctx.last_wide_blocks()
+    finally:
+        ctx.set_decode_kernel(0)
+    assert np.array_equal(got, orc.dequant_idct_recon(coefs, q, bw, bh).reshape(bh * 8, bw * 8))
+    assert wide == 0
+    assert np.array_equal(got_adv, orc.dequant_idct_recon(adv, q, bw, bh).reshape(bh * 8, bw * 8))
+    assert wide_adv > 0
+
+
 def test_sixteen_bit_quant_table_goes_wide(ctx):
     rng = np.random.Generator(np.random.PCG64(8))
     coefs = rng.integers(-50, 51, size=(2, 3, 64)).astype(np.int16)

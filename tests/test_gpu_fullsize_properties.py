@@ -60,7 +60,7 @@ def gpu_decode_batch(ctx, d_coefs, cfs, qtabs, specs, n, pfs, which):
     ([(240, 136, 0), (120, 68, 1), (120, 68, 1)], 64, "1080p 4:2:0 x 64 (config 2)"),
     ([(480, 270, 0), (480, 270, 1), (480, 270, 1)], 4, "4K 4:4:4 x 4 (config 4 shard shape)"),
 ])
-def test_three_implementations_agree_at_full_size(ctx, planes, n_frames, tag):
+def test_four_implementations_agree_at_full_size(ctx, planes, n_frames, tag):
     import torch
     import video_coding_amd as hvc
     recs, qtabs, _ = make_records(planes, 4, seed=900)
@@ -71,8 +71,11 @@ def test_three_implementations_agree_at_full_size(ctx, planes, n_frames, tag):
     assert ctx.last_wide_blocks() == 0
     b = gpu_decode_batch(ctx, d_coefs, cfs, qtabs, specs, n_frames, pfs, 1)
     c = gpu_decode_batch(ctx, d_coefs, cfs, qtabs, specs, n_frames, pfs, 2)
+    d = gpu_decode_batch(ctx, d_coefs, cfs, qtabs, specs, n_frames, pfs, 3)  # quarter-wavefront + LDS kernel
+    assert ctx.last_wide_blocks() == 0
     assert torch.equal(a, b), tag
     assert torch.equal(a, c), tag
+    assert torch.equal(a, d), tag
     # frame order: a permuted batch gives the permuted output
     perm = torch.randperm(n_frames, generator=torch.Generator().manual_seed(1)).cuda()
     p = gpu_decode_batch(ctx, d_coefs[perm].contiguous(), cfs, qtabs, specs, n_frames, pfs, 0)

@@ -268,7 +268,7 @@ int hvc_timer_end(hvc_ctx *c, float *ms) {
 }
 
 int hvc_set_decode_kernel(hvc_ctx *c, int which) {
-    if (!c || which < 0 || which > 2) return HVC_E_INVALID_ARG;
+    if (!c || which < 0 || which > 3) return HVC_E_INVALID_ARG;
     c->decode_kernel = which;
     return HVC_OK;
 }
@@ -411,7 +411,7 @@ int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const ui
     bool wide_only = false;
     for (int i = 0; i < n_qtabs * 64; i++) wide_only |= qtabs[i] > 255;
     wide_only |= c->decode_kernel == 2;
-    P.kernel_sel = c->decode_kernel == 1 ? 1 : 0;
+    P.kernel_sel = (c->decode_kernel == 1 || c->decode_kernel == 3) ? c->decode_kernel : 0;
     if (!wide_only) { // this call consumes counter fix_phase; its wide kernel clears the other one
         c->fix_last = c->fix_phase;
         c->fix_phase ^= 1;

@@ -569,6 +569,198 @@ __global__ __launch_bounds__(HVC_PACKED_LB) void k_decode_packed(DecodeParams P)
     }
 }
 
+// ---------------------------------------------------------------------------
+// K1 q16: the mapping BASELINE.json's north star describes -- one 8x8 block per QUARTER WAVEFRONT
+// (16 lanes), coefficients staged in LDS between the passes, coalesced loads of the zig-zag
+// records -- kept as a selectable alternative (hvc_set_decode_kernel(ctx, 3)) so that the choice of
+// the block-per-lane kernel rests on a measurement, not an argument.  Same arithmetic and the same
+// guard as k_decode_packed (int16 operand pairs + v_dot2_i32_i16), so the same interval proof holds.
+//   load     lane l of a group reads zig-zag coefficients 4l .. 4l+3 (8 B; 128 B contiguous per block,
+//            16 adjacent blocks = 2 KiB per workgroup iteration), dequantises them (v_pk_mul_lo_u16)
+//            and scatters them (inverse zig-zag) into the block's LDS stage as int16
+//   row pass lane (r = l >> 1, h = l & 1): the even half owns (b0,b4) (b2,b6), the odd half
+//            (b1,b7) (b5,b3): both run the SAME instruction stream -- two rotations by v_dot2 with
+//            per-lane constant pairs, one butterfly; only the odd half keeps the 181 stage (select) --
+//            then swap their four values with the partner lane (DPP quad_perm) and form sums (even)
+//            or differences (odd): row outputs 0,3,1,2 / 7,4,6,5
+//   transpose through LDS, column pass the same way, >> 14 / clip / +128 by v_ashr_pk_u8_i32
+//   store    pixels collect in a 16 KiB LDS tile (256 blocks); after 16 iterations the workgroup
+//            writes it with K1's store shape (8 x 8 B per lane, non-temporal)
+constexpr int Q16_ITERS = HVC_TILE / 16;
+
+__device__ __forceinline__ int dot2vv(unsigned pair, unsigned k, int add) {
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(pair), "v"(k), "v"(add));
+    return d;
+}
+// value of the partner lane (l ^ 1)
+__device__ __forceinline__ int partner(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true); } // quad_perm:[1,0,3,2]
+
+struct Q16Lane {
+    unsigned k00, k01, k10, k11; // constant pairs of the two rotations
+    int a0, a1, sh0, sh1;        // addend / right shift of each rotation's outputs
+};
+
+// One half-butterfly + exchange.  P0 / P1: the lane's two operand pairs.  Returns the lane's four
+// outputs (even half: positions 0,3,1,2; odd half: 7,4,6,5), unshifted.
+__device__ __forceinline__ void q16_pass(unsigned P0, unsigned P1, const Q16Lane &K, bool odd, int negm, int (&o)[4],
+                                         int &ymax, int &ymin) {
+    const int p = dot2vv(P0, K.k00, K.a0) >> K.sh0, q = dot2vv(P0, K.k01, K.a0) >> K.sh0;
+    const int s = dot2vv(P1, K.k10, K.a1) >> K.sh1, t = dot2vv(P1, K.k11, K.a1) >> K.sh1;
+    const int u1 = p + s, u2 = p - s, u3 = q + t, u4 = q - t;
+    // odd half: x2 = (181 (x4 + x5) + 128) >> 8, x4 = (181 (x4 - x5) + 128) >> 8   (dct.ml:41-42, 83-84)
+    const int ys = odd ? u2 + u4 : 0, yd = odd ? u2 - u4 : 0;
+    ymax = max(max(ymax, ys), yd);
+    ymin = min(min(ymin, ys), yd);
+    const int w2 = mad24(181, ys, 128) >> 8, w4 = mad24(181, yd, 128) >> 8;
+    // even: (x7, x8, x3, x0)   odd: (x1, x6, x2, x4)   -> outputs (0|7, 3|4, 1|6, 2|5)
+    const int m0 = u1, m1 = odd ? u3 : u2, m2 = odd ? w2 : u3, m3 = odd ? w4 : u4;
+    // even lanes add the partner's values, odd lanes subtract their own from the partner's:
+    // theirs + (mine ^ negm) - negm with negm = odd ? -1 : 0
+    o[0] = partner(m0) + ((m0 ^ negm) - negm);
+    o[1] = partner(m1) + ((m1 ^ negm) - negm);
+    o[2] = partner(m2) + ((m2 ^ negm) - negm);
+    o[3] = partner(m3) + ((m3 ^ negm) - negm);
+}
+
+__global__ __launch_bounds__(HVC_TILE) void k_decode_q16(DecodeParams P) {
+    __shared__ short stage[16][64];          // per group: the block's 64 int16 operands of the next pass
+    __shared__ uint8_t tile[8][HVC_TILE][8]; // pixel rows of the workgroup's 256 blocks
+    __shared__ unsigned short qlds[64];      // the component's quantiser table (zig-zag order)
+    __shared__ uint8_t badflag[HVC_TILE];
+
+    const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
+    BlockRef br; // of block `lane` of the tile: used by the store phase
+    const bool active = locate(P, blockIdx.y, blockIdx.x, lane, br);
+    if (lane < 64) qlds[lane] = (unsigned short)P.qt[br.qtab * 64 + lane]; // kernarg -> LDS once per tile
+    __syncthreads();
+
+    const bool odd = l & 1;
+    const int negm = odd ? -1 : 0;
+    const int r = l >> 1; // row in the row pass, column in the column pass
+    Q16Lane KR, KC;
+    KR.k10 = odd ? pk(W5, W3) : pk(W2, W6);
+    KR.k11 = odd ? pk(W3, -W5) : pk(W6, -W2);
+    KR.k00 = odd ? pk(W1, W7) : pk(2048, 2048);
+    KR.k01 = odd ? pk(W7, -W1) : pk(2048, -2048);
+    KR.a0 = odd ? 0 : 128;
+    KR.a1 = 0;
+    KR.sh0 = KR.sh1 = 0;
+    KC.k10 = KR.k10;
+    KC.k11 = KR.k11;
+    KC.k00 = odd ? pk(W1, W7) : pk(256, 256);
+    KC.k01 = odd ? pk(W7, -W1) : pk(256, -256);
+    KC.a0 = odd ? 4 : 8192 + (128 << 14);
+    KC.a1 = 4;
+    KC.sh0 = odd ? 3 : 0;
+    KC.sh1 = 3;
+    const unsigned q01 = qlds[4 * l] | ((unsigned)qlds[4 * l + 1] << 16), q23 = qlds[4 * l + 2] | ((unsigned)qlds[4 * l + 3] << 16);
+
+    // operand slot of raster position (row, col) for the pass that runs along `row`:
+    // lane 2*row + (col & 1); even lanes hold [c0 c4 | c2 c6], odd lanes [c1 c7 | c5 c3]
+    auto slot = [](int row, int col) {
+        const int pos = (col & 1) ? ((col == 1) ? 0 : (col == 7) ? 1 : (col == 5) ? 2 : 3)
+                                  : ((col == 0) ? 0 : (col == 4) ? 1 : (col == 2) ? 2 : 3);
+        return (2 * row + (col & 1)) * 4 + pos;
+    };
+    int ld_slot[4]; // where this lane's four loaded coefficients (zig-zag 4l + i) go for the row pass
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int p = ZI[4 * l + i];
+        ld_slot[i] = slot(p >> 3, p & 7);
+    }
+    // this lane's four row outputs are columns (0,3,1,2) / (7,4,6,5) of row r: slots for the column pass
+    // (the column pass runs along the column, so the roles of row and column swap)
+    const int oc[4] = {odd ? 7 : 0, odd ? 4 : 3, odd ? 6 : 1, odd ? 5 : 2};
+    int tr_slot[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) tr_slot[i] = slot(oc[i], r);
+
+    const size_t plane_coefs = br.plane_coef_idx;
+    for (int it = 0; it < Q16_ITERS; it++) {
+        const int bi = it * 16 + g;                                  // block inside the tile
+        int b = br.tile_b0 + bi;
+        const bool exists = b < br.nblk;
+        b = exists ? b : br.nblk - 1;
+        const uint2 cz = reinterpret_cast<const uint2 *>(P.coefs + plane_coefs + (size_t)b * 64)[l];
+        int energy = dot2_sat(cz.y, cz.y, dot2_sat(cz.x, cz.x, 0));
+        const unsigned d01 = pk_mul_lo(cz.x, q01), d23 = pk_mul_lo(cz.y, q23);
+        short *st = stage[g];
+        st[ld_slot[0]] = (short)(d01 & 0xffffu);
+        st[ld_slot[1]] = (short)(d01 >> 16);
+        st[ld_slot[2]] = (short)(d23 & 0xffffu);
+        st[ld_slot[3]] = (short)(d23 >> 16);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint2 ops = reinterpret_cast<const uint2 *>(st)[l];
+        int ymax = 0, ymin = 0, o[4];
+        q16_pass(ops.x, ops.y, KR, odd, negm, o, ymax, ymin);
+        // row outputs >> 8, saturating int16 (the energy of the saturated values is the guard)
+        const unsigned r01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(o[0] >> 8, o[1] >> 8));
+        const unsigned r23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(o[2] >> 8, o[3] >> 8));
+        int renergy = dot2_sat(r23, r23, dot2_sat(r01, r01, 0));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier(); // every lane has read its operands before the stage is overwritten
+        st[tr_slot[0]] = (short)(r01 & 0xffffu);
+        st[tr_slot[1]] = (short)(r01 >> 16);
+        st[tr_slot[2]] = (short)(r23 & 0xffffu);
+        st[tr_slot[3]] = (short)(r23 >> 16);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        ops = reinterpret_cast<const uint2 *>(st)[l];
+        q16_pass(ops.x, ops.y, KC, odd, negm, o, ymax, ymin);
+        __builtin_amdgcn_wave_barrier();
+        // guard: the two energies are sums over the group's 16 lanes -- quad_perm, quad_perm,
+        // row_half_mirror, row_mirror butterflies (DPP; no LDS), saturating at 2^30 (> both thresholds,
+        // so a clipped sum still compares the right way; 2^30 + 2^30 fits an unsigned dword).
+        constexpr unsigned CAP = 1u << 30;
+        unsigned es = min((unsigned)energy, CAP), rs = min((unsigned)renergy, CAP);
+#define HVC_Q16_STEP(CTRL)                                                                       \
+        es = min(es + (unsigned)__builtin_amdgcn_mov_dpp((int)es, CTRL, 0xf, 0xf, true), CAP); \
+        rs = min(rs + (unsigned)__builtin_amdgcn_mov_dpp((int)rs, CTRL, 0xf, 0xf, true), CAP);
+        HVC_Q16_STEP(0xB1)  // lane ^ 1
+        HVC_Q16_STEP(0x4E)  // lane ^ 2
+        HVC_Q16_STEP(0x141) // the other quad of the 8
+        HVC_Q16_STEP(0x140) // the other half of the 16
+#undef HVC_Q16_STEP
+        const bool lbad = (es > (unsigned)P.ethr_packed[br.qtab]) | (rs >= (unsigned)GUARD_RE) | (ymax > GUARD_Y) |
+                          (ymin < -GUARD_Y);
+        const bool bad = ((__ballot(lbad) >> (lane & 48)) & 0xffffull) != 0; // any lane of the group
+        // column outputs: rows (0,3,1,2) / (7,4,6,5) of column r of the block
+        unsigned px01 = 0, px23 = 0;
+        ashr14_sat_pack2<0>(px01, o[0], o[1]);
+        ashr14_sat_pack2<0>(px23, o[2], o[3]);
+        tile[oc[0]][bi][r] = (uint8_t)(px01 & 0xffu);
+        tile[oc[1]][bi][r] = (uint8_t)((px01 >> 8) & 0xffu);
+        tile[oc[2]][bi][r] = (uint8_t)(px23 & 0xffu);
+        tile[oc[3]][bi][r] = (uint8_t)((px23 >> 8) & 0xffu);
+        if (l == 0) badflag[bi] = (uint8_t)(bad && exists);
+    }
+    __syncthreads();
+    const bool bad = badflag[lane] != 0;
+    if (active && !bad) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint2 px = *reinterpret_cast<const uint2 *>(&tile[j][lane][0]);
+            store_row8(P.pixels + br.pix_idx + (size_t)j * br.stride, px.x, px.y);
+        }
+    }
+    const bool flag = active && bad;
+    const unsigned long long m = __ballot(flag);
+    if (m) {
+        const int wl = lane & 63;
+        unsigned base = 0;
+        if (wl == 0) base = atomicAdd(P.fix_count, (unsigned)__popcll(m));
+        base = __shfl(base, 0);
+        if (flag) {
+            unsigned idx = base + (unsigned)__popcll(m & ((1ull << wl) - 1ull));
+            P.fix_list[idx] = ((unsigned)blockIdx.y * (unsigned)P.tiles_per_frame + blockIdx.x) * HVC_TILE + lane;
+        }
+    }
+}
+
 // K1 wide: int64, one flagged block per thread; also usable on its own for a
 // whole batch (list == nullptr: every block).
 __global__ __launch_bounds__(64) void k_decode_wide(DecodeParams P, const unsigned *count, const unsigned *list,
@@ -1199,9 +1391,16 @@ hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0, hi
     hipError_t e;
     dim3 grid((unsigned)P.tiles_per_frame, (unsigned)P.n_frames, 1);
     if (k0 && (e = hipEventRecord(k0, s)) != hipSuccess) return e;
-    // HVC_DECODE_KERNEL=v2 selects the unpacked int32 kernel (A/B measurements only)
-    static const bool use_v2 = [] { const char *v = getenv("HVC_DECODE_KERNEL"); return v && v[0] == 'v' && v[1] == '2'; }();
-    if (use_v2 || P.kernel_sel == 1)
+    // HVC_DECODE_KERNEL=v2 / q16 selects the unpacked int32 kernel / the quarter-wavefront kernel
+    // (A/B measurements only; hvc_set_decode_kernel is the API)
+    static const int env_sel = [] {
+        const char *v = getenv("HVC_DECODE_KERNEL");
+        return !v ? 0 : (v[0] == 'v' && v[1] == '2') ? 1 : (v[0] == 'q') ? 3 : 0;
+    }();
+    const int sel = P.kernel_sel ? P.kernel_sel : env_sel;
+    if (sel == 3)
+        hipLaunchKernelGGL(k_decode_q16, grid, dim3(HVC_TILE), 0, s, P);
+    else if (sel == 1)
         hipLaunchKernelGGL(k_decode_fast, grid, dim3(HVC_TILE), 0, s, P);
     else
         hipLaunchKernelGGL(k_decode_packed, grid, dim3(HVC_TILE), 0, s, P);
