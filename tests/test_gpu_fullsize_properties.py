@@ -138,3 +138,45 @@ def test_encode_decode_generations_4k_420(ctx):
     assert np.abs(e1).mean() < 4.0 and 10 * np.log10(255.0 ** 2 / (e1.astype(np.float64) ** 2).mean()) > 30.0
     assert (e2.astype(np.float64) ** 2).mean() < 0.5 * (e1.astype(np.float64) ** 2).mean()
     assert c1.shape == c2.shape
+
+
+def test_two_contexts_on_two_host_threads():
+    """An hvc_ctx is per host thread (include/hvc_jpeg.h): two threads, each with its own context and
+    stream, decode different batches at the same time (ctypes releases the GIL during the calls)."""
+    import threading
+    import video_coding_amd as hvc
+    planes = [(120, 68, 0), (60, 34, 1), (60, 34, 1)]
+    specs, cfs, pfs = hvc.hvc.frame_layout(planes)
+    results, errors = {}, []
+
+    def work(tid):
+        try:
+            recs, qtabs, _ = make_records(planes, 3, seed=1200 + tid)
+            c = hvc.Context(0)
+            try:
+                for rep in range(6):
+                    out = np.zeros((3, pfs), dtype=np.uint8)
+                    c.decode_frames(recs, cfs, qtabs, hvc.hvc.components(specs), 3, out, pfs)  # host buffers
+                    results[(tid, rep)] = (recs, qtabs, out)
+            finally:
+                c.close()
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 12
+    for (tid, rep), (recs, qtabs, out) in results.items():
+        if rep not in (0, 5):
+            continue
+        for f in range(3):
+            off = 0
+            for (bw, bh, qt), s in zip(planes, specs):
+                n = bw * bh * 64
+                want = orc.dequant_idct_recon(recs[f][off:off + n], qtabs[qt], bw, bh)
+                assert np.array_equal(out[f][s["plane_offset"]:s["plane_offset"] + n], want), (tid, rep, f)
+                off += n
