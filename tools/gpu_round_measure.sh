@@ -4,14 +4,14 @@
 set -e
 TAG=${1:-r01}
 mkdir -p gpurun_out
-python bench.py --check > gpurun_out/m_bench.json 2> gpurun_out/m_bench.err
+python bench.py > gpurun_out/m_bench.json 2> gpurun_out/m_bench.err
 echo "bench done"
 python tools/bench_configs.py --config 3 --frames 1024 --threads 16 > gpurun_out/m_c3.json 2> gpurun_out/m_c3.err
 echo "c3 done"
 python tools/bench_configs.py --config 4 > gpurun_out/m_c4.json 2> gpurun_out/m_c4.err
 python tools/bench_configs.py --config 5 > gpurun_out/m_c5.json 2> gpurun_out/m_c5.err
 python tools/bench_configs.py --config 6 > gpurun_out/m_c6.json 2> gpurun_out/m_c6.err
-python tools/bench_configs.py --config 7 --check > gpurun_out/m_c7.json 2> gpurun_out/m_c7.err
+python tools/bench_configs.py --config 7 > gpurun_out/m_c7.json 2> gpurun_out/m_c7.err
 python tools/bench_configs.py --config 2 > gpurun_out/m_k2.json 2> gpurun_out/m_k2.err
 echo "configs done"
 bash tools/gpu_profile.sh ${TAG}_decode
