@@ -186,8 +186,13 @@ def main():
     rank, world, local_rank = dist_env()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    # Rehearsal on a one-GPU box (never the measured configuration): HVC_BENCH_REHEARSAL=1 puts every
+    # rank on cuda:0 and closes the timing with gloo instead of RCCL (which refuses two ranks per GPU).
+    rehearsal = os.environ.get("HVC_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = dist_init(world, "nccl", torch.device("cuda", local_rank))
+    dist = dist_init(world, "gloo" if rehearsal else "nccl", torch.device("cuda", local_rank))
 
     ctx = hvc.Context(local_rank)  # raises without a gfx950 GPU: there is no CPU fallback
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -204,7 +209,7 @@ def main():
         ctx.decode_frames(d_coefs, cfs, qtabs, comps, args.frames, d_pix, pfs)
 
     dt = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, world, dist)
-    dt = max_over_ranks(dt, world, dist, "cuda")
+    dt = max_over_ranks(dt, world, dist, "cpu" if rehearsal else "cuda")
 
     # HIP events recorded around k_decode_packed inside the timed region (one pair per step)
     kernel_ms = ctx.kernel_ms_history(min(args.steps, 64))
@@ -223,7 +228,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32",
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: all ranks share cuda:0, gloo)" if rehearsal else ""),
             "config": {"workload": "1080p 4:2:0 baseline, synthetic valid coefficient blocks (Huffman bypassed), "
                                    "HBM-resident, %d frames/GPU/step" % args.frames,
                        "frames_per_gpu_per_step": args.frames, "blocks_per_frame": BLOCKS_PER_FRAME,
