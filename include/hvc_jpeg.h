@@ -242,6 +242,11 @@ typedef struct hvc_batch_stats {
 HVC_API int hvc_jpeg_decode_batch(hvc_ctx *ctx, const uint8_t *const *jpegs, const size_t *sizes, int n_frames,
                                   int threads, int frames_per_chunk, uint8_t *pixels, size_t pixel_frame_stride,
                                   int where, hvc_batch_stats *stats);
+/* The same pipeline ending in the fused kernel: 4:2:0 files in, tight 4:4:4 frames out (3 * width *
+ * height bytes each, frame_stride apart) -- hvc_jpeg_decode_yuv444 for a batch. */
+HVC_API int hvc_jpeg_decode_batch_yuv444(hvc_ctx *ctx, const uint8_t *const *jpegs, const size_t *sizes,
+                                         int n_frames, int threads, int frames_per_chunk, uint8_t *frames,
+                                         size_t frame_stride, int where, hvc_batch_stats *stats);
 
 /* Quant_tables.scale Quant_tables.luma/chroma quality (quant_tables.ml:139-147). */
 HVC_API int hvc_quant_table(int chroma_table, int quality, uint16_t *out64);

@@ -246,3 +246,34 @@ def test_encode_batch_reports_a_too_small_output_buffer(ctx):
     sizes = (C.c_size_t * 1)()
     rc = hvc.lib().hvc_jpeg_encode_batch(ctx._h, fp, 1, w, h, 420, 75, 2, 1, op, caps, sizes, None)
     assert rc == -1 and sizes[0] == len(golden_bytes("mini.jpg"))
+
+
+@pytest.mark.parametrize("device", [False, True])
+def test_batch_pipeline_to_444(ctx, device):
+    """hvc_jpeg_decode_batch_yuv444: every frame == decode_a_frame + Planar_444.of_420 of its file."""
+    import torch
+    jpegs = _make_jpegs(10, 112, 80, q=65)
+    w, h = 112, 80
+    fs = 3 * w * h
+    if device:
+        out = torch.zeros(len(jpegs) * fs, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+    else:
+        out = np.zeros(len(jpegs) * fs, dtype=np.uint8)
+    st = ctx.jpeg_decode_batch(jpegs, out, fs, threads=3, frames_per_chunk=4, yuv444=True)
+    assert st.chunks == 3
+    got = out.cpu().numpy() if device else out
+    for f, j in enumerate(jpegs):
+        d = orc.Decoder(j)
+        d.decode()
+        y, u, v = d.get_yuv_frame()
+        want = np.concatenate([y.reshape(-1), orc.supersample_hv2(u).reshape(-1), orc.supersample_hv2(v).reshape(-1)])
+        assert np.array_equal(got[f * fs:(f + 1) * fs], want), f
+
+
+def test_batch_to_444_rejects_444_files(ctx):
+    import video_coding_amd as hvc
+    y, u, v = orc.split_yuv(golden_bytes("mini64x64.444"), 64, 64, 444)
+    j = orc.encode_yuv(y, u, v, 64, 64, 444, 75)
+    with pytest.raises(hvc.HvcError):
+        ctx.jpeg_decode_batch([j, j], np.zeros(2 * 3 * 64 * 64, dtype=np.uint8), 3 * 64 * 64, yuv444=True)

@@ -787,8 +787,16 @@ int hvc_jpeg_encode(hvc_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_
 
 // ---------------------------------------------------------------------------
 // BASELINE config 3: host Huffman || hipMemcpyAsync (copy stream) || block-stage kernel (compute stream)
-int hvc_jpeg_decode_batch(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *sizes, int n_frames, int threads,
-                          int frames_per_chunk, uint8_t *pixels, size_t pixel_fs, int where, hvc_batch_stats *stats) {
+static bool is_420_scan(const hvc_jpeg_info &info) { // Y 2x2, Cb / Cr 1x1 (frame.ml:42-61)
+    return info.n_comp == 3 && info.comp[0].hscale == 2 && info.comp[0].vscale == 2 && info.comp[1].hscale == 1 &&
+           info.comp[1].vscale == 1 && info.comp[2].hscale == 1 && info.comp[2].vscale == 1;
+}
+
+// yuv444 = false: padded component planes per frame (hvc_jpeg_decode_batch);
+// yuv444 = true: tight 4:4:4 frames through the fused kernel (hvc_jpeg_decode_batch_yuv444)
+static int decode_batch_impl(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *sizes, int n_frames, int threads,
+                             int frames_per_chunk, uint8_t *pixels, size_t pixel_fs, int where, hvc_batch_stats *stats,
+                             bool yuv444) {
     if (!c || !jpegs || !sizes || !pixels || n_frames < 0) return HVC_E_INVALID_ARG;
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
     if (stats) std::memset(stats, 0, sizeof *stats);
@@ -796,7 +804,9 @@ int hvc_jpeg_decode_batch(hvc_ctx *c, const uint8_t *const *jpegs, const size_t 
     hvc_jpeg_info info0;
     int r = hvc_jpeg_read_header(jpegs[0], sizes[0], &info0);
     if (r) return r;
-    if (pixel_fs < info0.pixel_bytes || (pixel_fs & 7)) return HVC_E_INVALID_ARG;
+    if (yuv444 && (!is_420_scan(info0) || (info0.width & 1) || (info0.height & 1))) return HVC_E_INVALID_ARG;
+    const size_t out_bytes = yuv444 ? (size_t)3 * info0.width * info0.height : info0.pixel_bytes; // per frame
+    if (pixel_fs < out_bytes || (!yuv444 && (pixel_fs & 7))) return HVC_E_INVALID_ARG;
     if (threads < 1) threads = 1;
     if (threads > 256) threads = 256;
     if (frames_per_chunk < 1) frames_per_chunk = 32;
@@ -805,7 +815,7 @@ int hvc_jpeg_decode_batch(hvc_ctx *c, const uint8_t *const *jpegs, const size_t 
     const int n_chunks = (n_frames + C - 1) / C;
     const size_t frame_coef_bytes = info0.coef_count * sizeof(int16_t);
     const size_t ring_bytes = frame_coef_bytes * (size_t)C;
-    const size_t oring_bytes = where == HVC_MEM_HOST ? info0.pixel_bytes * (size_t)C : 0;
+    const size_t oring_bytes = where == HVC_MEM_HOST ? out_bytes * (size_t)C : 0;
 
     DeviceGuard g(c->device);
     if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
@@ -896,7 +906,7 @@ int hvc_jpeg_decode_batch(hvc_ctx *c, const uint8_t *const *jpegs, const size_t 
         if (error.load()) { rc = error.load(); break; }
         hipError_t he = hipSuccess;
         uint8_t *dst = where == HVC_MEM_DEVICE ? pixels + (size_t)first * pixel_fs : (uint8_t *)c->d_oring[slot];
-        const size_t dst_fs = where == HVC_MEM_DEVICE ? pixel_fs : info0.pixel_bytes;
+        const size_t dst_fs = where == HVC_MEM_DEVICE ? pixel_fs : out_bytes;
         // the device chunk (and output ring slot) is reused every NB chunks: its previous kernel must be done
         if (k >= NB) he = hipStreamWaitEvent(c->copy_stream, c->ev_kern[slot], 0);
         if (he == hipSuccess) he = hipEventRecord(c->ev_t[0], c->copy_stream);
@@ -909,14 +919,17 @@ int hvc_jpeg_decode_batch(hvc_ctx *c, const uint8_t *const *jpegs, const size_t 
         const bool prof_saved = c->profiling;
         c->profiling = false;
         he = hipEventRecord(c->ev_t[1], compute);
-        rc = hvc_decode_frames(c, (const int16_t *)c->d_ring[slot], info0.coef_count, &info0.qtabs[0][0], info0.n_qtabs,
-                               info0.layout, info0.n_comp, cnt, dst, dst_fs, HVC_MEM_DEVICE);
+        rc = yuv444 ? hvc_decode_frames_yuv444(c, (const int16_t *)c->d_ring[slot], info0.coef_count, &info0.qtabs[0][0],
+                                               info0.n_qtabs, info0.layout, info0.n_comp, cnt, info0.width, info0.height,
+                                               dst, dst_fs, HVC_MEM_DEVICE)
+                    : hvc_decode_frames(c, (const int16_t *)c->d_ring[slot], info0.coef_count, &info0.qtabs[0][0],
+                                        info0.n_qtabs, info0.layout, info0.n_comp, cnt, dst, dst_fs, HVC_MEM_DEVICE);
         c->profiling = prof_saved;
         if (rc) break;
         if (he == hipSuccess) he = hipEventRecord(c->ev_t[2], compute);
         if (he == hipSuccess && where == HVC_MEM_HOST) {
             for (int f = 0; f < cnt && he == hipSuccess; f++)
-                he = hipMemcpyAsync(pixels + (size_t)(first + f) * pixel_fs, dst + (size_t)f * dst_fs, info0.pixel_bytes,
+                he = hipMemcpyAsync(pixels + (size_t)(first + f) * pixel_fs, dst + (size_t)f * dst_fs, out_bytes,
                                     hipMemcpyDeviceToHost, compute);
         }
         if (he == hipSuccess) he = hipEventRecord(c->ev_kern[slot], compute);
@@ -965,6 +978,18 @@ int hvc_jpeg_decode_batch(hvc_ctx *c, const uint8_t *const *jpegs, const size_t 
         stats->coef_bytes = (uint64_t)frame_coef_bytes * (uint64_t)n_frames;
     }
     return rc;
+}
+
+int hvc_jpeg_decode_batch(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *sizes, int n_frames, int threads,
+                          int frames_per_chunk, uint8_t *pixels, size_t pixel_fs, int where, hvc_batch_stats *stats) {
+    return decode_batch_impl(c, jpegs, sizes, n_frames, threads, frames_per_chunk, pixels, pixel_fs, where, stats, false);
+}
+
+int hvc_jpeg_decode_batch_yuv444(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *sizes, int n_frames,
+                                 int threads, int frames_per_chunk, uint8_t *frames, size_t frame_stride, int where,
+                                 hvc_batch_stats *stats) {
+    return decode_batch_impl(c, jpegs, sizes, n_frames, threads, frames_per_chunk, frames, frame_stride, where, stats,
+                             true);
 }
 
 // ---------------------------------------------------------------------------
