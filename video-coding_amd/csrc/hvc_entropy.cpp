@@ -328,7 +328,8 @@ int hvc_jpeg_entropy_decode(const uint8_t *data, size_t n, const hvc_jpeg_info *
     }
     const size_t ecs_len = ecs.size();
     ecs.insert(ecs.end(), 16, 0); // zero padding: the reader loads 8 bytes at a time
-    std::memset(coefs, 0, info->coef_count * sizeof(int16_t)); // clear_block for every block
+    // clear_block (decoder.ml:109-116) happens per block below, right before the block is written: one
+    // pass over the record instead of a 6 MB memset that has left the cache by the time the block comes up
     BitReader br{ecs.data(), ecs_len};
     int dc_pred[4] = {0, 0, 0, 0};
     const hvc_jpeg_component &c0 = info->comp[0];
@@ -347,6 +348,7 @@ int hvc_jpeg_entropy_decode(const uint8_t *data, size_t n, const hvc_jpeg_info *
                         const int bx = mx * c.hscale + sx, by = my * c.vscale + sy;
                         if (bx >= L.blocks_w || by >= L.blocks_h) return HVC_E_BAD_JPEG; // Plane.set out of bounds
                         int16_t *blk = coefs + L.coef_offset + ((size_t)by * L.blocks_w + bx) * 64;
+                        std::memset(blk, 0, 64 * sizeof(int16_t));
                         br.refill();
                         unsigned e = dcf[br.peek(Lut::FAST_BITS)];
                         if (!e) e = dct[br.peek(dmax)];
