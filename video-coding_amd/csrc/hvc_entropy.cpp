@@ -16,6 +16,8 @@
 #include <new>
 #include <vector>
 
+#include <emmintrin.h>
+
 #include "../../include/hvc_jpeg.h"
 #include "hvc_kernels.h"
 
@@ -488,7 +490,7 @@ struct BitWriter {
     inline void reserve_block() {
         if (out.size() - pos < 512) out.resize(out.size() * 2 + 4096);
     }
-    inline void put(unsigned value, int bits) { // bits <= 16
+    inline void put(unsigned value, int bits) { // bits <= 27 (nbits < 32 on entry: the accumulator holds 64)
         acc = (acc << bits) | (value & ((1u << bits) - 1u));
         nbits += bits;
         if (nbits >= 32) {
@@ -522,6 +524,19 @@ struct BitWriter {
         out.resize(pos);
     }
 };
+
+// bit k set <=> q[k] != 0
+inline uint64_t nonzero_mask(const int16_t *q) {
+    const __m128i z = _mm_setzero_si128();
+    uint64_t m = 0;
+    for (int i = 0; i < 4; i++) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(q + 16 * i));
+        const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(q + 16 * i + 8));
+        const unsigned zero16 = (unsigned)_mm_movemask_epi8(_mm_packs_epi16(_mm_cmpeq_epi16(a, z), _mm_cmpeq_epi16(b, z)));
+        m |= (uint64_t)(~zero16 & 0xffffu) << (16 * i);
+    }
+    return m;
+}
 
 inline int bit_size(int v) { // encoder.ml:143
     const unsigned a = (unsigned)(v < 0 ? -v : v);
@@ -667,22 +682,27 @@ int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uin
                         dc_pred[i] = q[0];
                         int size = bit_size(diff);
                         if (size > 11) return HVC_E_RANGE; // no code in the default DC tables
-                        bw.put(t.dc[size].bits, t.dc[size].len);
-                        bw.put((unsigned)(diff >= 0 ? diff : diff - 1), size);
-                        // AC: runs of zeros, ZRL for runs >= 16, EOB when the tail is zero (:127-141, 162-187)
-                        int run = 0;
-                        for (int k = 1; k < 64; k++) {
-                            const int v = q[k];
-                            if (v == 0) { run++; continue; }
+                        // code and magnitude bits leave as one field (<= 16 + 11 bits)
+                        bw.put((t.dc[size].bits << size) | ((unsigned)(diff >= 0 ? diff : diff - 1) & ((1u << size) - 1u)),
+                               t.dc[size].len + size);
+                        // AC: runs of zeros, ZRL for runs >= 16, EOB when the tail is zero (:127-141, 162-187).
+                        // The non-zero positions come from one 64-bit mask (SSE2 compares), so the loop runs
+                        // once per coded coefficient with no data-dependent "is it zero" branch.
+                        uint64_t nz = nonzero_mask(q) & ~1ull;
+                        int prev = 0;
+                        while (nz) {
+                            const int k = __builtin_ctzll(nz);
+                            nz &= nz - 1;
+                            int run = k - prev - 1;
+                            prev = k;
                             while (run >= 16) { bw.put(t.ac[0xf0].bits, t.ac[0xf0].len); run -= 16; }
+                            const int v = q[k];
                             size = bit_size(v);
                             if (size > 10) return HVC_E_RANGE; // no code in the default AC tables
                             const EncCode e = t.ac[(run << 4) | size];
-                            bw.put(e.bits, e.len);
-                            bw.put((unsigned)(v >= 0 ? v : v - 1), size);
-                            run = 0;
+                            bw.put((e.bits << size) | ((unsigned)(v >= 0 ? v : v - 1) & ((1u << size) - 1u)), e.len + size);
                         }
-                        if (run) bw.put(t.ac[0].bits, t.ac[0].len);
+                        if (prev != 63) bw.put(t.ac[0].bits, t.ac[0].len);
                     }
             }
     bw.finish_with_1s();
