@@ -295,10 +295,10 @@ def main():
         args.steps = args.steps or 20
         config_k2(args)
     elif args.config == 8:  # config 5 with files out
-        args.frames = args.frames or 128
+        args.frames = args.frames or 256
         args.steps = args.steps or 3
         if args.chunk == 32:
-            args.chunk = 8
+            args.chunk = 16
         config5_files(args)
     elif args.config == 7:  # fused 4:4:4 output (next-3)
         args.frames = args.frames or 512

@@ -13,6 +13,8 @@ python tools/bench_configs.py --config 5 > gpurun_out/m_c5.json 2> gpurun_out/m_
 python tools/bench_configs.py --config 6 > gpurun_out/m_c6.json 2> gpurun_out/m_c6.err
 python tools/bench_configs.py --config 7 > gpurun_out/m_c7.json 2> gpurun_out/m_c7.err
 python tools/bench_configs.py --config 2 > gpurun_out/m_k2.json 2> gpurun_out/m_k2.err
+python tools/bench_configs.py --config 8 > gpurun_out/m_c5_files.json 2> gpurun_out/m_c5_files.err
+HVC_DECODE_KERNEL=q16 python bench.py --no-cpu-baseline > gpurun_out/m_bench_q16.json 2> gpurun_out/m_bench_q16.err
 echo "configs done"
 bash tools/gpu_profile.sh ${TAG}_decode
 echo "decode profile done"
