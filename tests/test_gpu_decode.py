@@ -226,3 +226,29 @@ def test_errors(ctx):
     with pytest.raises(hvc.HvcError) as e:
         ctx.dequant_idct_recon(c, q, 0, 1, 1, out)
     assert e.value.code == -1
+
+
+def test_empty_batches_are_no_ops(ctx):
+    """Zero planes / frames / files: every batch entry point returns HVC_OK and touches nothing."""
+    import video_coding_amd as hvc
+    q = np.ones(64, dtype=np.uint16)
+    c = np.zeros((1, 1, 64), dtype=np.int16)
+    out = np.full((8, 8), 0x77, dtype=np.uint8)
+    ctx.dequant_idct_recon(c, q, 1, 1, 0, out)
+    planes = [(2, 2, 0), (1, 1, 1), (1, 1, 1)]
+    specs, cfs, pfs = hvc.hvc.frame_layout(planes)
+    qt = np.ones((2, 64), dtype=np.uint16)
+    coefs = np.zeros(cfs, dtype=np.int16)
+    pix = np.full(pfs, 0x77, dtype=np.uint8)
+    ctx.decode_frames(coefs, cfs, qt, specs, 0, pix, pfs)
+    ctx.encode_frames(pix, pfs, qt, specs, 0, coefs, cfs)
+    f444 = np.full(3 * 16 * 16, 0x77, dtype=np.uint8)
+    ctx.decode_frames_yuv444(coefs, cfs, qt, specs, 0, 16, 16, f444)
+    up = np.full((4, 4), 0x77, dtype=np.uint8)
+    ctx.upsample420(np.zeros((2, 2), dtype=np.uint8), 2, 2, up, n_planes=0)
+    st = ctx.jpeg_decode_batch([], pix, pfs)
+    assert st.chunks == 0
+    jpegs, st = ctx.jpeg_encode_batch([], 16, 16)
+    assert jpegs == [] and st.chunks == 0
+    assert (out == 0x77).all() and (pix == 0x77).all() and (f444 == 0x77).all() and (up == 0x77).all()
+    assert not coefs.any()
