@@ -252,3 +252,28 @@ def test_empty_batches_are_no_ops(ctx):
     assert jpegs == [] and st.chunks == 0
     assert (out == 0x77).all() and (pix == 0x77).all() and (f444 == 0x77).all() and (up == 0x77).all()
     assert not coefs.any()
+
+
+def test_frame_count_limits(ctx):
+    """grid.y carries the frame index: 65 535 frames per call work (here one block each), 65 536 are refused
+    with HVC_E_TOO_LARGE (hvc_dequant_idct_recon splits larger plane batches itself)."""
+    import video_coding_amd as hvc
+    n = 65535
+    rng = np.random.Generator(np.random.PCG64(99))
+    q = orc.quant_scale(orc.quant_luma(), 90).astype(np.uint16)
+    coefs = rng.integers(-40, 41, size=(n, 64)).astype(np.int16)
+    specs, cfs, pfs = hvc.hvc.frame_layout([(1, 1, 0)])
+    pix = np.zeros((n, 64), dtype=np.uint8)
+    ctx.decode_frames(coefs, cfs, q, specs, n, pix, pfs)
+    want = orc.dequant_idct_recon(coefs.reshape(1, n, 64), q, n, 1).reshape(8, n, 8).transpose(1, 0, 2).reshape(n, 64)
+    assert np.array_equal(pix, want)
+    with pytest.raises(hvc.HvcError) as e:
+        ctx.decode_frames(np.zeros((n + 1, 64), dtype=np.int16), cfs, q, specs, n + 1, np.zeros((n + 1, 64), dtype=np.uint8), pfs)
+    assert e.value.code == -7
+    # the per-plane entry point accepts more planes than one launch holds
+    m = 70000
+    c2 = rng.integers(-40, 41, size=(m, 64)).astype(np.int16)
+    out = np.zeros((m, 64), dtype=np.uint8)
+    ctx.dequant_idct_recon(c2, q, 1, 1, m, out)
+    want2 = orc.dequant_idct_recon(c2.reshape(1, m, 64), q, m, 1).reshape(8, m, 8).transpose(1, 0, 2).reshape(m, 64)
+    assert np.array_equal(out, want2)
