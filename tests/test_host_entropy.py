@@ -211,3 +211,56 @@ def test_mutated_streams_never_crash_and_agree_with_the_model_when_accepted(hvc)
         assert ok, it
         agree += 1
     assert agree > 50 and rejected > 20
+
+
+@pytest.mark.parametrize("chroma,w,h", [(420, 32, 16), (422, 24, 8), (444, 16, 24)])
+def test_entropy_round_trip_on_constructed_coefficient_patterns(hvc, chroma, w, h):
+    """Coefficient records built to hit every branch of rle / write_bits (encoder.ml:127-193): runs of
+    15, 16, 17, 31, 32, 47, 48 and 62 zeros (ZRL chains), a last coefficient at index 63 (no EOB) and at 62 (EOB),
+    all-zero blocks, magnitudes 1 / 1023 / -1023, DC differences spanning +-2047, dense blocks.  The
+    back end's file decodes to the same record through the front end AND through the model restatement."""
+    info = hvc.jpeg_encoder_layout(w, h, chroma, 50)
+    nblk = info.coef_count // 64
+    rng = np.random.Generator(np.random.PCG64(chroma + w))
+    blocks = np.zeros((nblk, 64), dtype=np.int16)
+    gaps = [15, 16, 17, 31, 32, 47, 48, 62]
+    for b in range(nblk):
+        kind = b % 8
+        if kind == 0:
+            pass                                              # all zero: DC diff + EOB only
+        elif kind == 1:
+            blocks[b, 63] = rng.choice([-1023, -1, 1, 1023])  # 62 zeros then the last position: three ZRLs, no EOB
+        elif kind == 2:
+            g = gaps[(b // 8) % len(gaps)]
+            blocks[b, 1 + g] = rng.choice([-1023, 1023, 5])   # one run of g zeros after the DC
+        elif kind == 3:
+            blocks[b, 1:] = rng.integers(-1023, 1024, size=63)  # dense, extreme magnitudes
+        elif kind == 4:
+            blocks[b, 62] = 7                                 # last coefficient at 62: EOB follows
+            blocks[b, 1] = -3
+        elif kind == 5:
+            pos = rng.choice(np.arange(1, 64), size=5, replace=False)
+            blocks[b, pos] = rng.integers(-40, 41, size=5)
+        elif kind == 6:
+            blocks[b, 17] = 1
+            blocks[b, 34] = -1                                # exactly 16 zeros between two coefficients
+            blocks[b, 51] = 2
+        else:
+            blocks[b, 1:8] = rng.integers(-2, 3, size=7)
+    # DC values: consecutive differences must stay within the 11-bit categories the default tables code
+    for i in range(info.n_comp):
+        L = info.layout[i]
+        n = L.blocks_w * L.blocks_h
+        first = L.coef_offset // 64
+        blocks[first:first + n, 0] = np.resize(np.array([0, 1023, -1024, 1000, -1, 0, 0, 512, -1024, 1023], dtype=np.int16), n)
+    rec = blocks.reshape(-1)
+    jpg = hvc.jpeg_entropy_encode(info, rec)
+    dinfo, got = hvc.jpeg_entropy_decode(jpg)
+    comps, _ = coef_planes_from_jpeg(jpg)  # the model restatement's view of the same file
+    for i, (mine, c) in enumerate(zip(record_planes(dinfo, got), comps)):
+        assert np.array_equal(mine, c["coefs"]), i
+    # per block (raster order inside each plane is the same on both sides when the geometries agree)
+    if dinfo.coef_count == info.coef_count and all(
+            (dinfo.layout[i].blocks_w, dinfo.layout[i].blocks_h) == (info.layout[i].blocks_w, info.layout[i].blocks_h)
+            for i in range(3)):
+        assert np.array_equal(got, rec)
