@@ -88,8 +88,8 @@ HVC_API int hvc_timer_begin(hvc_ctx *ctx);
 HVC_API int hvc_timer_end(hvc_ctx *ctx, float *elapsed_ms);
 
 /* Per-kernel timing: when enabled, every decode/encode call brackets its
- * dominant kernel (K1 / K3 -- not the memset or the fix-up kernel) with HIP
- * events on ctx's stream (device-memory calls only); hvc_last_kernel_ms waits
+ * dominant kernel (K1 / K3 / the fused 4:4:4 kernel -- not the fix-up or seam
+ * kernels) with HIP events on ctx's stream (device-memory calls only); hvc_last_kernel_ms waits
  * for that kernel and returns its duration.  bench.py's roofline figure comes
  * from here. */
 HVC_API int hvc_set_profiling(hvc_ctx *ctx, int enabled);
