@@ -204,3 +204,14 @@ def test_argument_errors(ctx):
         ctx.decode_frames_yuv444(coefs, cfs, qt, specs, 1, 64, 66, out)
     with pytest.raises(hvc.HvcError):  # not three components
         ctx.decode_frames_yuv444(coefs, cfs, qt, specs[:2], 1, 64, 48, out)
+
+
+def test_single_frame_ignores_the_frame_stride(ctx):
+    import video_coding_amd as hvc
+    width, height = 48, 32
+    planes, qt = geometry420(width, height), tables()
+    rec = make_record(71, planes, qt)
+    specs, cfs, _ = hvc.hvc.frame_layout(planes)
+    out = np.zeros(3 * width * height, dtype=np.uint8)
+    ctx.decode_frames_yuv444(rec, cfs, qt, specs, 1, width, height, out, 16)  # host buffers, stride < frame
+    assert np.array_equal(out, expected444(rec, planes, qt, width, height))

@@ -548,8 +548,11 @@ int hvc_decode_frames_yuv444(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, c
     P.coefs = (const int16_t *)c->d_in;
     P.out = (uint8_t *)c->d_out;
     HIPCHK(c, hvc::launch_decode_444(P, wide_only, c->stream));
-    HIPCHK(c, hipMemcpy2DAsync(frames, frame_stride, c->d_out, frame_stride, out_span, (size_t)n_frames,
-                               hipMemcpyDeviceToHost, c->stream));
+    if (n_frames == 1) // frame_stride is irrelevant for a single frame (and may be smaller than the frame)
+        HIPCHK(c, hipMemcpyAsync(frames, c->d_out, out_span, hipMemcpyDeviceToHost, c->stream));
+    else
+        HIPCHK(c, hipMemcpy2DAsync(frames, frame_stride, c->d_out, frame_stride, out_span, (size_t)n_frames,
+                                   hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HVC_OK;
 }
