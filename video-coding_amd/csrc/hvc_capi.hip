@@ -29,7 +29,7 @@ struct hvc_ctx {
     hipEvent_t k0[HVC_PROF_RING] = {}, k1[HVC_PROF_RING] = {};
     unsigned long long k_calls = 0;
     bool profiling = false;
-    int decode_kernel = 0; // hvc_set_decode_kernel: 0 packed (default), 1 unpacked int32, 2 int64 for every block
+    int decode_kernel = 0; // hvc_set_decode_kernel: 0 packed (default), 1 unpacked int32, 2 int64 for every block, 3 q16
     unsigned *d_fix_count = nullptr; // two counters, used alternately (see k_decode_wide)
     int fix_phase = 0;               // index of the counter the NEXT decode call appends to
     int fix_last = 0;                // index of the counter the last decode call used
@@ -465,8 +465,14 @@ int hvc_decode_frames_yuv444(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, c
     // Yuv.assert_is_420 (tools/src/yuv.ml:104-116): wy = 2 wu, hy = 2 hu -- even luma size only
     if (n_comp != 3 || width < 2 || height < 2 || (width & 1) || (height & 1)) return HVC_E_INVALID_ARG;
     if (width > 65535 || height > 65535) return HVC_E_TOO_LARGE;
-    Layout L; // validates blocks_w / blocks_h / qtab / offsets exactly as hvc_decode_frames does
-    r = make_layout(comps, n_comp, n_qtabs, L);
+    Layout L; // validates blocks_w / blocks_h / qtab / coef_offset exactly as hvc_decode_frames does
+    hvc_component geo[3];
+    for (int i = 0; i < 3; i++) { // plane_offset / stride are not used by this entry point: anything goes
+        geo[i] = comps[i];
+        geo[i].plane_offset = 0;
+        geo[i].stride = comps[i].blocks_w > 0 ? (size_t)comps[i].blocks_w * 8 : 0;
+    }
+    r = make_layout(geo, n_comp, n_qtabs, L);
     if (r) return r;
     const int aw[3] = {width, width / 2, width / 2}, ah[3] = {height, height / 2, height / 2};
     for (int i = 0; i < 3; i++) // the crop must lie inside the decoded planes (decoder.ml:403-413)
