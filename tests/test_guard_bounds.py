@@ -266,3 +266,30 @@ def test_avg4_by_lerp_identity():
     hf = s2 >> 1                  # v_lerp_u8 with rounding bit 0
     r = (~s1 | s2) & 1            # parity(a ^ b) = parity(a + b)
     assert np.array_equal((hc + hf + r) >> 1, (s1 + s2 + 2) >> 2)
+
+
+def test_q16_exchange_step_is_covered_by_the_packed_proof():
+    """k_decode_q16 (one block per quarter wavefront) evaluates exactly the expressions of
+    idct_1d_packed, split over an even and an odd lane; the one operation it adds is the two's-complement
+    negation of the odd lane's four values before the cross-lane add (theirs + (-mine) = E - O).
+    Under the same guards those values are far from INT_MIN, so the negation is exact."""
+    gy = kernel_constants()["GUARD_Y"]
+
+    def odd_lane_values(A, B, col):
+        rnd, rs = (4, 3) if col else (0, 0)
+        n4, n5 = dot2(A, (W1, W7), rnd).asr(rs), dot2(A, (W7, -W1), rnd).asr(rs)
+        n6, n7 = dot2(B, (W5, W3), rnd).asr(rs), dot2(B, (W3, -W5), rnd).asr(rs)
+        x1, x6, x4, x5 = n4 + n6, n5 + n7, n4 - n6, n5 - n7
+        ys = (x4 + x5).clampto(-gy, gy)
+        yd = (x4 - x5).clampto(-gy, gy)
+        return [x1, x6, mad24(181, ys, 128).asr(8), mad24(181, yd, 128).asr(8)]
+
+    d, r = Iv(-32767, 32767), Iv(-32766, 32766)
+    for vals in (odd_lane_values((d, d), (d, d), False), odd_lane_values((r, r), (r, r), True)):
+        for v in vals:
+            assert v.lo > I32[0] and -v.hi >= I32[0] and -v.lo <= I32[1]
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-coding_amd", "csrc",
+                            "hvc_kernels.hip")).read()
+    # the kernel uses the packed kernel's thresholds, not its own
+    q16 = src[src.index("void k_decode_q16("):src.index("// K1 wide: int64")]
+    assert "P.ethr_packed[br.qtab]" in q16 and "GUARD_RE" in q16 and "GUARD_Y" in q16
