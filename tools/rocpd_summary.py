@@ -2,7 +2,9 @@
 """Summarise the rocprofv3 (rocpd sqlite) outputs of tools/gpu_profile.sh into a
 small text file for profiles/.
 
-    python tools/rocpd_summary.py gpurun_out/prof_<tag> > profiles/<name>.txt
+    python tools/rocpd_summary.py gpurun_out/prof_<tag> [untimed launches, default 10] > profiles/<name>.txt
+
+(bench.py issues 8 setup launches + W warm-up steps before the timed ones: pass 8 + W for its profiles.)
 """
 import glob
 import os
@@ -32,7 +34,7 @@ def main(d):
         if dom:
             ds = [r[0] for r in q(tr[0], "select duration from kernels where name = ? order by start".replace("?", "'%s'" % dom[0][0].replace("'", "''")))]
             w = WARMUP if len(ds) > WARMUP else 0
-            print("\ndominant kernel %s: %d dispatches, avg %.1f ns; without the first %d (warm-up): avg %.1f ns"
+            print("\ndominant kernel %s: %d dispatches, avg %.1f ns; without the first %d (setup / warm-up): avg %.1f ns"
                   % (dom[0][0][:60], len(ds), sum(ds) / len(ds), w, sum(ds[w:]) / len(ds[w:])))
         for log in ("trace_bench.log", "trace.log"):
             lp = os.path.join(d_, log)
@@ -61,6 +63,8 @@ def main(d):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2:
+        WARMUP = int(sys.argv[2])
     main(sys.argv[1])
 
 
