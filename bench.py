@@ -10,7 +10,9 @@ pixels per frame).
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 is launched by the driver with torch.distributed.run (one rank per GPU);
+Setup (untimed, before the W warm-up steps): input generation on the GPU and eight launches of the
+step itself (page touch + clock ramp).  N > 1 is launched by the driver with torch.distributed.run
+(one rank per GPU);
 the path shards as independent frame batches: no data-path collective, weak
 scaling (per-GPU batch fixed).  The barrier / max-over-ranks reduction below is
 timing closure only.
