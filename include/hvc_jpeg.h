@@ -260,6 +260,11 @@ HVC_API int hvc_compare_planes(const uint8_t *a, const uint8_t *b, size_t n, int
 /* Encoder.Parameters.c420/c422/c444 + Encoder.create geometry (encoder.ml:287-349, 437-472): chroma is
  * 420, 422 or 444.  Fills the padded plane layout (zero padding, plane.ml:11-17) and the tables. */
 HVC_API int hvc_jpeg_encoder_layout(int width, int height, int chroma, int quality, hvc_jpeg_info *info);
+/* HVC_OK when Encoder.encode_seq can walk this geometry; HVC_E_INVALID_ARG where the model raises
+ * "[Plane.get] out of bounds" (encoder.ml:476-505 with plane.ml:43-50): the MCU grid of the luma
+ * component reaches past a chroma plane for 4:2:0 / 4:2:2 frames of width (or height) 16k + 1.  The
+ * encode entry points below return the same error for such frames. */
+HVC_API int hvc_jpeg_encoder_check(const hvc_jpeg_info *info);
 /* Encoder.write_headers + rle + write_bits + EOI over a coefficient record (encoder.ml:127-193,
  * 371-418, 476-510): byte-identical to Model.Encoder's output. */
 HVC_API int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uint8_t *out, size_t cap,

@@ -1116,6 +1116,13 @@ ORC_API i64 orc_encode_yuv(const uint8_t *y, const uint8_t *u, const uint8_t *v,
                 for (int ys = 0; ys < sc[i].v; ys++)
                     for (int xs = 0; xs < sc[i].h; xs++) {
                         int x_blk = x_mb * sc[i].h + xs, y_blk = y_mb * sc[i].v + ys;
+                        if (x_blk * 8 + 8 > pw[i] || y_blk * 8 + 8 > ph[i]) {
+                            /* "[Plane.get] out of bounds" (plane.ml:43-50 via encoder.ml:85): the MCU grid of
+                             * component 0 reaches past this component's plane (e.g. 4:2:0 at width 16k + 1) */
+                            free(w.buffer);
+                            for (int k = 0; k < nsc; k++) free(planes[k]);
+                            return -13;
+                        }
                         const int *tab = sc[i].quant_table == 0 ? ql : qc;
                         for (int k = 0; k < 64; k++) qt[k] = tab[k];
                         /* encode_block :195-205 */

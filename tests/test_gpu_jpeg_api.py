@@ -277,3 +277,14 @@ def test_batch_to_444_rejects_444_files(ctx):
     j = orc.encode_yuv(y, u, v, 64, 64, 444, 75)
     with pytest.raises(hvc.HvcError):
         ctx.jpeg_decode_batch([j, j], np.zeros(2 * 3 * 64 * 64, dtype=np.uint8), 3 * 64 * 64, yuv444=True)
+
+
+def test_encode_refuses_frames_the_model_cannot_walk(ctx):
+    """4:2:0 at width 16k + 1: the model raises "[Plane.get] out of bounds"; the library returns an error
+    before touching the GPU (single frame and batch)."""
+    import video_coding_amd as hvc
+    y, u, v = np.zeros((9, 17), np.uint8), np.zeros((4, 8), np.uint8), np.zeros((4, 8), np.uint8)
+    with pytest.raises(hvc.HvcError):
+        ctx.jpeg_encode(y, u, v, 17, 9, 420, 75)
+    with pytest.raises(hvc.HvcError):
+        ctx.jpeg_encode_batch([np.zeros(17 * 9 + 2 * 8 * 4, np.uint8)], 17, 9, 420, 75)

@@ -769,6 +769,7 @@ int hvc_jpeg_encode(hvc_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_
     hvc_jpeg_info info;
     int r = hvc_jpeg_encoder_layout(width, height, chroma, quality, &info);
     if (r) return r;
+    if ((r = hvc_jpeg_encoder_check(&info))) return r; // the model raises for this geometry
     std::vector<uint8_t> planes;
     std::vector<int16_t> coefs;
     try {
@@ -1015,6 +1016,7 @@ int hvc_jpeg_encode_batch(hvc_ctx *c, const uint8_t *const *frames, int n_frames
     hvc_jpeg_info info;
     int r = hvc_jpeg_encoder_layout(width, height, chroma, quality, &info);
     if (r) return r;
+    if ((r = hvc_jpeg_encoder_check(&info))) return r; // the model raises for this geometry
     if (n_frames == 0) return HVC_OK;
     for (int f = 0; f < n_frames; f++)
         if (!frames[f] || !jpegs[f]) return HVC_E_INVALID_ARG;

@@ -616,6 +616,21 @@ int hvc_jpeg_encoder_layout(int width, int height, int chroma, int quality, hvc_
 
 // Encoder.write_headers (encoder.ml:371-418) + encode_seq's rle / write_bits (:127-193, 476-505) +
 // complete_and_write_eoi (:507-510) over one frame's quantised coefficient record (zig-zag, DC absolute).
+// encode_seq (encoder.ml:476-505) walks the MCU grid of component 0 and reads h x v blocks of every
+// component per MCU; where that grid reaches past a component's plane the model raises
+// "[Plane.get] out of bounds" (plane.ml:43-50): 4:2:0 / 4:2:2 at width 16k + 1 (or height 16k + 1).
+int hvc_jpeg_encoder_check(const hvc_jpeg_info *info) {
+    if (!info || info->n_comp != 3) return HVC_E_INVALID_ARG;
+    const hvc_jpeg_component &c0 = info->comp[0];
+    if (c0.hscale < 1 || c0.vscale < 1) return HVC_E_INVALID_ARG;
+    const int mbs_wide = c0.decoded_width / (8 * c0.hscale), mbs_high = c0.decoded_height / (8 * c0.vscale);
+    for (int i = 0; i < 3; i++)
+        if (mbs_wide * info->comp[i].hscale > info->layout[i].blocks_w ||
+            mbs_high * info->comp[i].vscale > info->layout[i].blocks_h)
+            return HVC_E_INVALID_ARG;
+    return HVC_OK;
+}
+
 int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uint8_t *out, size_t cap, size_t *out_len) {
     if (!info || !coefs || !out_len || info->n_comp != 3) return HVC_E_INVALID_ARG;
     std::vector<uint8_t> o;
@@ -659,6 +674,7 @@ int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uin
     o.push_back(63);
     o.push_back(0);
 
+    if (hvc_jpeg_encoder_check(info)) return HVC_E_INVALID_ARG;
     EncTable et[2];
     build_enc(et[0], K_DC_LUMA_BITS, K_DC_VALS, K_AC_LUMA_BITS, K_AC_LUMA_VALS);
     build_enc(et[1], K_DC_CHROMA_BITS, K_DC_VALS, K_AC_CHROMA_BITS, K_AC_CHROMA_VALS);
