@@ -260,6 +260,20 @@ HVC_API int hvc_compare_planes(const uint8_t *a, const uint8_t *b, size_t n, int
 /* Encoder.Parameters.c420/c422/c444 + Encoder.create geometry (encoder.ml:287-349, 437-472): chroma is
  * 420, 422 or 444.  Fills the padded plane layout (zero padding, plane.ml:11-17) and the tables. */
 HVC_API int hvc_jpeg_encoder_layout(int width, int height, int chroma, int quality, hvc_jpeg_info *info);
+/* The encoder's back end ON THE GPU (csrc/hvc_huff.hip): Encoder.rle + write_bits + Bitstream_writer
+ * with byte stuffing and flush_with_1s (encoder.ml:127-193, 507-510; bitstream_writer.ml) for n_frames
+ * coefficient records, as data-parallel passes -- every block's bit string depends only on its own
+ * coefficients and on the DC of the block before it in scan order.  Frame f's entropy-coded segment
+ * (what stands between the SOS header and EOI) is out[offsets[f] .. offsets[f+1]); offsets has
+ * n_frames + 1 entries.  coefs, out and offsets live where `where` says; the call returns when the
+ * result is complete (it has to read the status back).  HVC_E_RANGE: a value without a code in the
+ * default tables (as hvc_jpeg_entropy_encode); HVC_E_INVALID_ARG: out_cap too small.
+ * hvc_jpeg_header gives the bytes in front of the segment (SOI .. SOS); 0xFF 0xD9 (EOI) closes the file. */
+HVC_API int hvc_huffman_encode_frames(hvc_ctx *ctx, const hvc_jpeg_info *info, const int16_t *coefs,
+                                      size_t coef_frame_stride, int n_frames, uint8_t *out, size_t out_cap,
+                                      uint64_t *offsets, int where);
+HVC_API int hvc_jpeg_header(const hvc_jpeg_info *info, uint8_t *out, size_t cap, size_t *len);
+
 /* HVC_OK when Encoder.encode_seq can walk this geometry; HVC_E_INVALID_ARG where the model raises
  * "[Plane.get] out of bounds" (encoder.ml:476-505 with plane.ml:43-50): the MCU grid of the luma
  * component reaches past a chroma plane for 4:2:0 / 4:2:2 frames of width (or height) 16k + 1.  The

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/hvc_jpeg.h"
+#include "hvc_huff.h"
 #include "hvc_kernels.h"
 
 #define HVC_PROF_RING 64
@@ -48,6 +49,10 @@ struct hvc_ctx {
     void *eh_in[RING] = {}, *ed_in[RING] = {}, *eh_out[RING] = {}, *ed_out[RING] = {};
     size_t e_in_bytes = 0, e_out_bytes = 0;
     hipEvent_t ev_up[RING] = {}, ev_down[RING] = {}, ev_et[RING][3] = {};
+    // GPU Huffman coder (hvc_huffman_encode_frames): tables + scratch, grown on demand
+    unsigned *hd_tables = nullptr;
+    void *hd_lens = nullptr, *hd_meta = nullptr, *hd_bitbuf = nullptr, *hd_ff = nullptr, *hd_out = nullptr;
+    size_t hd_lens_cap = 0, hd_meta_cap = 0, hd_bitbuf_cap = 0, hd_ff_cap = 0, hd_out_cap = 0;
 };
 
 namespace {
@@ -225,6 +230,12 @@ void hvc_destroy(hvc_ctx *c) {
     }
     for (int i = 0; i < 4; i++)
         if (c->ev_t[i]) (void)hipEventDestroy(c->ev_t[i]);
+    if (c->hd_tables) (void)hipFree(c->hd_tables);
+    if (c->hd_lens) (void)hipFree(c->hd_lens);
+    if (c->hd_meta) (void)hipFree(c->hd_meta);
+    if (c->hd_bitbuf) (void)hipFree(c->hd_bitbuf);
+    if (c->hd_ff) (void)hipFree(c->hd_ff);
+    if (c->hd_out) (void)hipFree(c->hd_out);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -1000,6 +1011,126 @@ int hvc_jpeg_decode_batch_yuv444(hvc_ctx *c, const uint8_t *const *jpegs, const 
                                  hvc_batch_stats *stats) {
     return decode_batch_impl(c, jpegs, sizes, n_frames, threads, frames_per_chunk, frames, frame_stride, where, stats,
                              true);
+}
+
+// ---------------------------------------------------------------------------
+// Encoder back end on the GPU: RLE + Huffman + byte stuffing of coefficient records (hvc_huff.hip)
+
+// Geometry + scratch of one call.  `out` / `offsets` are device pointers (the caller's, or NULL = scratch
+// inside ctx, see huffman_scratch_out).
+static int huffman_prepare(hvc_ctx *c, const hvc_jpeg_info *info, const int16_t *d_coefs, size_t coef_fs, int n_frames,
+                           uint8_t *d_out, size_t out_cap, unsigned long long *d_offsets, hvc::HuffParams &P) {
+    int r = hvc_jpeg_encoder_check(info);
+    if (r) return r;
+    std::memset(&P, 0, sizeof P);
+    const hvc_jpeg_component &c0 = info->comp[0];
+    P.mbs_wide = c0.decoded_width / (8 * c0.hscale);
+    P.mbs_high = c0.decoded_height / (8 * c0.vscale);
+    int tile = 0, base = 0;
+    for (int i = 0; i < 3; i++) {
+        hvc::HuffComp &K = P.comp[i];
+        K.bw = info->layout[i].blocks_w;
+        K.bh = info->layout[i].blocks_h;
+        K.nblk = K.bw * K.bh;
+        K.tile0 = tile;
+        K.h = info->comp[i].hscale;
+        K.v = info->comp[i].vscale;
+        K.mcu_base = base;
+        K.table = info->comp[i].dc_table ? 1 : 0;
+        K.coef_off = info->layout[i].coef_offset;
+        tile += (K.nblk + 255) / 256;
+        base += K.h * K.v;
+    }
+    P.tiles_per_frame = tile;
+    P.blocks_per_mcu = base;
+    const unsigned long long bpf = (unsigned long long)P.mbs_wide * P.mbs_high * base;
+    if (bpf == 0 || bpf * 64ull * 27ull >= (1ull << 32)) return HVC_E_TOO_LARGE; // 32-bit bit offsets per frame
+    P.blocks_per_frame = (unsigned)bpf;
+    P.n_frames = n_frames;
+    P.coefs = d_coefs;
+    P.coef_fs = coef_fs;
+    // worst case per block: 64 fields of 27 bits (216 bytes); the segment buffer is sized for it
+    const size_t words = ((size_t)bpf * 216 + 3) / 4 + 2;
+    P.bitbuf_words = (words + 15) / 16 * 16;
+    P.ff_stride = P.bitbuf_words / 16;
+    if (!c->hd_tables) {
+        uint32_t t[2][16 + 256];
+        hvc::default_enc_tables(t);
+        HIPCHK(c, hipMalloc((void **)&c->hd_tables, sizeof t));
+        HIPCHK(c, hipMemcpy(c->hd_tables, t, sizeof t, hipMemcpyHostToDevice));
+    }
+    P.tables = c->hd_tables;
+    const size_t nf = (size_t)n_frames;
+    if ((r = grow(c, &c->hd_lens, &c->hd_lens_cap, nf * bpf * sizeof(unsigned)))) return r;
+    if ((r = grow(c, &c->hd_meta, &c->hd_meta_cap, (4 * nf + 2 * (nf + 1) + 4) * sizeof(unsigned) + 64))) return r;
+    if ((r = grow(c, &c->hd_bitbuf, &c->hd_bitbuf_cap, nf * P.bitbuf_words * sizeof(unsigned)))) return r;
+    if ((r = grow(c, &c->hd_ff, &c->hd_ff_cap, nf * P.ff_stride * sizeof(unsigned)))) return r;
+    P.lens = (unsigned *)c->hd_lens;
+    unsigned *m = (unsigned *)c->hd_meta;
+    P.status = m;
+    P.frame_bits = m + 4;
+    P.frame_bytes = P.frame_bits + nf;
+    P.frame_pieces = P.frame_bytes + nf;
+    P.frame_ff = P.frame_pieces + nf;
+    unsigned long long *scratch_off = (unsigned long long *)(((uintptr_t)(P.frame_ff + nf) + 7) & ~(uintptr_t)7);
+    P.bitbuf = (unsigned *)c->hd_bitbuf;
+    P.ff = (unsigned *)c->hd_ff;
+    P.out_offsets = d_offsets ? d_offsets : scratch_off;
+    P.out = d_out;
+    P.out_cap = out_cap;
+    return HVC_OK;
+}
+
+int hvc_jpeg_header(const hvc_jpeg_info *info, uint8_t *out, size_t cap, size_t *len) {
+    if (!info || !len || info->n_comp != 3) return HVC_E_INVALID_ARG;
+    std::vector<uint8_t> o;
+    hvc::jpeg_header_bytes(info, o);
+    *len = o.size();
+    if (!out || cap < o.size()) return HVC_E_INVALID_ARG;
+    std::memcpy(out, o.data(), o.size());
+    return HVC_OK;
+}
+
+int hvc_huffman_encode_frames(hvc_ctx *c, const hvc_jpeg_info *info, const int16_t *coefs, size_t coef_fs, int n_frames,
+                              uint8_t *out, size_t out_cap, uint64_t *offsets, int where) {
+    if (!c || !info || !coefs || !out || !offsets || n_frames < 0 || info->n_comp != 3) return HVC_E_INVALID_ARG;
+    if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
+    if (n_frames == 0) {
+        if (where == HVC_MEM_HOST) offsets[0] = 0;
+        return HVC_OK;
+    }
+    if (n_frames > 65535) return HVC_E_TOO_LARGE;
+    if (n_frames > 1 && coef_fs < info->coef_count) return HVC_E_INVALID_ARG;
+    if (coef_fs & 7) return HVC_E_ALIGNMENT;
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
+    hvc::HuffParams P;
+    int r;
+    unsigned status = 0;
+    if (where == HVC_MEM_DEVICE) {
+        if (((uintptr_t)coefs & 15) || ((uintptr_t)offsets & 7)) return HVC_E_ALIGNMENT;
+        if ((r = huffman_prepare(c, info, coefs, coef_fs, n_frames, out, out_cap, (unsigned long long *)offsets, P))) return r;
+        HIPCHK(c, hvc::launch_huffman_encode(P, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&status, P.status, sizeof status, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    } else {
+        const size_t cbytes = ((size_t)(n_frames - 1) * coef_fs + info->coef_count) * sizeof(int16_t);
+        if ((r = grow(c, &c->d_in, &c->in_cap, cbytes))) return r;
+        if ((r = grow(c, &c->hd_out, &c->hd_out_cap, out_cap))) return r;
+        if ((r = huffman_prepare(c, info, (const int16_t *)c->d_in, coef_fs, n_frames, (uint8_t *)c->hd_out, out_cap, nullptr, P)))
+            return r;
+        HIPCHK(c, hipMemcpyAsync(c->d_in, coefs, cbytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hvc::launch_huffman_encode(P, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&status, P.status, sizeof status, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(offsets, P.out_offsets, (size_t)(n_frames + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                 c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!(status & 7u) && offsets[n_frames] <= out_cap)
+            HIPCHK(c, hipMemcpy(out, c->hd_out, (size_t)offsets[n_frames], hipMemcpyDeviceToHost));
+    }
+    if (status & 1u) return HVC_E_RANGE;       // a value the default tables have no code for
+    if (status & 6u) return HVC_E_INVALID_ARG; // out_cap too small
+    return HVC_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -631,10 +631,11 @@ int hvc_jpeg_encoder_check(const hvc_jpeg_info *info) {
     return HVC_OK;
 }
 
-int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uint8_t *out, size_t cap, size_t *out_len) {
-    if (!info || !coefs || !out_len || info->n_comp != 3) return HVC_E_INVALID_ARG;
-    std::vector<uint8_t> o;
-    o.reserve(info->coef_count / 4 + 1024);
+} // extern "C"
+
+namespace hvc {
+// Encoder.write_headers (encoder.ml:371-418) for `info`: SOI .. SOS, appended to o
+void jpeg_header_bytes(const hvc_jpeg_info *info, std::vector<uint8_t> &o) {
     put_marker(o, 0xd8);
     { // write_app0 "Hardcaml JPEG."
         static const char tag[] = "Hardcaml JPEG.";
@@ -674,6 +675,28 @@ int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uin
     o.push_back(63);
     o.push_back(0);
 
+}
+
+// the default Huffman tables as the GPU coder wants them: per table set t (0 luma, 1 chroma)
+// out[t][size] for DC (12 entries) and out[t][16 + ((run << 4) | size)] for AC, each (code << 5) | length
+void default_enc_tables(uint32_t (*out)[16 + 256]) {
+    EncTable et[2];
+    build_enc(et[0], K_DC_LUMA_BITS, K_DC_VALS, K_AC_LUMA_BITS, K_AC_LUMA_VALS);
+    build_enc(et[1], K_DC_CHROMA_BITS, K_DC_VALS, K_AC_CHROMA_BITS, K_AC_CHROMA_VALS);
+    for (int t = 0; t < 2; t++) {
+        for (int i = 0; i < 16; i++) out[t][i] = ((uint32_t)et[t].dc[i].bits << 5) | et[t].dc[i].len;
+        for (int i = 0; i < 256; i++) out[t][16 + i] = ((uint32_t)et[t].ac[i].bits << 5) | et[t].ac[i].len;
+    }
+}
+} // namespace hvc
+
+extern "C" {
+
+int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uint8_t *out, size_t cap, size_t *out_len) {
+    if (!info || !coefs || !out_len || info->n_comp != 3) return HVC_E_INVALID_ARG;
+    std::vector<uint8_t> o;
+    o.reserve(info->coef_count / 4 + 1024);
+    hvc::jpeg_header_bytes(info, o);
     if (hvc_jpeg_encoder_check(info)) return HVC_E_INVALID_ARG;
     EncTable et[2];
     build_enc(et[0], K_DC_LUMA_BITS, K_DC_VALS, K_AC_LUMA_BITS, K_AC_LUMA_VALS);

@@ -20,7 +20,7 @@ SYMBOLS = [
     "hvc_device_free", "hvc_memcpy_h2d", "hvc_memcpy_d2h",
     "hvc_jpeg_read_header", "hvc_jpeg_entropy_decode", "hvc_jpeg_get_yuv_frame", "hvc_jpeg_decode",
     "hvc_jpeg_decode_batch", "hvc_quant_table", "hvc_jpeg_encoder_layout", "hvc_jpeg_entropy_encode",
-    "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444", "hvc_jpeg_decode_yuv444", "hvc_compare_planes", "hvc_jpeg_encode_batch", "hvc_jpeg_decode_batch_yuv444", "hvc_jpeg_encoder_check",
+    "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444", "hvc_jpeg_decode_yuv444", "hvc_compare_planes", "hvc_jpeg_encode_batch", "hvc_jpeg_decode_batch_yuv444", "hvc_jpeg_encoder_check", "hvc_huffman_encode_frames", "hvc_jpeg_header",
 ]
 
 
@@ -127,6 +127,8 @@ def lib():
         L.hvc_jpeg_decode_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), i, i, i, vp, sz, i,
                                             C.POINTER(BatchStats)]
         L.hvc_quant_table.argtypes = [i, i, vp]
+        L.hvc_huffman_encode_frames.argtypes = [vp, ip, vp, sz, i, vp, sz, vp, i]
+        L.hvc_jpeg_header.argtypes = [ip, vp, sz, C.POINTER(sz)]
         L.hvc_jpeg_decode_batch_yuv444.argtypes = L.hvc_jpeg_decode_batch.argtypes
         L.hvc_jpeg_encode_batch.argtypes = [vp, C.POINTER(vp), i, i, i, i, i, i, i, C.POINTER(vp), C.POINTER(sz),
                                             C.POINTER(sz), C.POINTER(BatchStats)]
@@ -219,6 +221,14 @@ def compare_planes(a, b):
     mx, tot, se = C.c_int(), C.c_uint64(), C.c_uint64()
     _chk(lib().hvc_compare_planes(a.ctypes.data, b.ctypes.data, a.size, C.byref(mx), C.byref(tot), C.byref(se)))
     return mx.value, tot.value, se.value
+
+
+def jpeg_header(info):
+    """SOI .. SOS of the file Encoder.write_headers produces for this geometry / quality"""
+    n = C.c_size_t()
+    buf = np.empty(2048, dtype=np.uint8)
+    _chk(lib().hvc_jpeg_header(C.byref(info), buf.ctypes.data, buf.size, C.byref(n)), "hvc_jpeg_header")
+    return buf[:n.value].tobytes()
 
 
 def jpeg_encoder_layout(width, height, chroma, quality):
@@ -371,6 +381,28 @@ class Context:
         _chk(lib().hvc_jpeg_encode(self._h, y.ctypes.data, u.ctypes.data, v.ctypes.data, width, height, chroma, quality,
                                    out.ctypes.data, cap, C.byref(n)), "hvc_jpeg_encode")
         return out[:n.value].tobytes()
+
+    def huffman_encode_frames(self, info, coefs, coef_frame_stride, n_frames, out_cap=None):
+        """Encoder back end on the GPU: (list of per-frame entropy-coded segments as bytes).  coefs: host
+        int16 array or device tensor holding n_frames records."""
+        ca, where = _addr(coefs)
+        cap = out_cap or (n_frames * (info.coef_count // 64) * 243 + 4096)
+        if where == 1:
+            import torch
+            out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+            offs = torch.zeros(n_frames + 1, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            _chk(lib().hvc_huffman_encode_frames(self._h, C.byref(info), ca, coef_frame_stride, n_frames, out.data_ptr(),
+                                                 cap, offs.data_ptr(), 1), "hvc_huffman_encode_frames")
+            o = offs.cpu().numpy()
+            data = out[:int(o[-1])].cpu().numpy()
+        else:
+            out = np.empty(cap, dtype=np.uint8)
+            offs = np.zeros(n_frames + 1, dtype=np.uint64)
+            _chk(lib().hvc_huffman_encode_frames(self._h, C.byref(info), ca, coef_frame_stride, n_frames, out.ctypes.data,
+                                                 cap, offs.ctypes.data, 0), "hvc_huffman_encode_frames")
+            o, data = offs, out
+        return [data[int(o[f]):int(o[f + 1])].tobytes() for f in range(n_frames)]
 
     def jpeg_encode_batch(self, frames, width, height, chroma=420, quality=75, threads=8, frames_per_chunk=16):
         """Encoder.encode_4xx over a batch of raw planar frames (bytes / uint8 arrays in Frame.input layout).
