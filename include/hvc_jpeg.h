@@ -298,6 +298,15 @@ HVC_API int hvc_jpeg_encode_batch(hvc_ctx *ctx, const uint8_t *const *frames, in
                                   int chroma, int quality, int threads, int frames_per_chunk,
                                   uint8_t *const *jpegs, const size_t *caps, size_t *sizes,
                                   hvc_batch_stats *stats);
+/* The same with the Huffman coder on the GPU as well (hvc_huffman_encode_frames): the coefficient records
+ * never leave the device, only the packed entropy-coded segments come back (about 1/6 of the bytes), and
+ * the host threads just pad planes and assemble header + segment + EOI.  Same files, byte for byte.
+ * HVC_E_TOO_LARGE if a chunk's segments exceed twice the size of its raw frames (use the host-coder
+ * variant for such content); stats->coef_bytes then counts the segment bytes downloaded. */
+HVC_API int hvc_jpeg_encode_batch_gpu(hvc_ctx *ctx, const uint8_t *const *frames, int n_frames, int width,
+                                      int height, int chroma, int quality, int threads, int frames_per_chunk,
+                                      uint8_t *const *jpegs, const size_t *caps, size_t *sizes,
+                                      hvc_batch_stats *stats);
 
 /* Device memory helpers so that a binding needs no HIP of its own. */
 HVC_API int hvc_device_alloc(hvc_ctx *ctx, size_t bytes, void **out);

@@ -200,7 +200,8 @@ def test_decode_to_444_rejects_other_samplings(ctx):
 
 @pytest.mark.parametrize("chroma,w,h,n,threads,chunk", [(420, 96, 64, 11, 4, 3), (422, 70, 50, 7, 2, 1), (444, 33, 17, 5, 8, 16),
                                                         (420, 52, 44, 9, 3, 2), (420, 1920, 1080, 5, 8, 2)])
-def test_encode_batch_is_byte_identical_to_the_model(ctx, chroma, w, h, n, threads, chunk):
+@pytest.mark.parametrize("gpu_entropy", [False, True])
+def test_encode_batch_is_byte_identical_to_the_model(ctx, chroma, w, h, n, threads, chunk, gpu_entropy):
     """hvc_jpeg_encode_batch (config 5 end to end): every file equals Encoder.encode_4xx of its frame."""
     cw, ch = orc.chroma_dims(chroma, w, h)
     r8 = lambda x: (x + 7) // 8 * 8
@@ -212,7 +213,8 @@ def test_encode_batch_is_byte_identical_to_the_model(ctx, chroma, w, h, n, threa
         frames.append(np.concatenate([y.reshape(-1), u.reshape(-1), v.reshape(-1)]))
         want.append(orc.encode_yuv(y, u, v, w, h, chroma, 70))
     for rep in range(2):  # second call reuses the pinned rings
-        got, st = ctx.jpeg_encode_batch(frames, w, h, chroma, 70, threads=threads, frames_per_chunk=chunk)
+        got, st = ctx.jpeg_encode_batch(frames, w, h, chroma, 70, threads=threads, frames_per_chunk=chunk,
+                                        gpu_entropy=gpu_entropy)
         assert st.chunks == (n + min(chunk, n) - 1) // min(chunk, n)
         for f in range(n):
             assert got[f] == want[f], (rep, f)

@@ -231,18 +231,22 @@ def config5_files(args):
         v = synth_pixels(130 + f, H // 2, W // 2)
         distinct.append(np.concatenate([y.reshape(-1), u.reshape(-1), v.reshape(-1)]))
     frames = [distinct[i % len(distinct)] for i in range(args.frames)]
+    gpu = bool(getattr(args, "gpu_entropy", False))
     ctx.jpeg_encode_batch(frames[:min(2 * args.chunk, args.frames)], W, H, 420, 75, threads=args.threads,
-                          frames_per_chunk=args.chunk)  # warm-up: allocates the pinned rings
+                          frames_per_chunk=args.chunk, gpu_entropy=gpu)  # warm-up: allocates the pinned rings
     best = None
     for _ in range(args.steps):
         t0 = time.perf_counter()
-        jpegs, st = ctx.jpeg_encode_batch(frames, W, H, 420, 75, threads=args.threads, frames_per_chunk=args.chunk)
+        jpegs, st = ctx.jpeg_encode_batch(frames, W, H, 420, 75, threads=args.threads, frames_per_chunk=args.chunk,
+                                          gpu_entropy=gpu)
         dt = time.perf_counter() - t0
         if best is None or dt < best[0]:
             best = (dt, st, jpegs)
     dt, st, jpegs = best
     print(json.dumps({
-        "config": "5-files", "metric": "Mpixel/s encoded to JPEG files, host pad + H2D + GPU fDCT/quantise + D2H + host Huffman overlapped",
+        "config": "5-files" + ("-gpu-entropy" if gpu else ""),
+        "metric": "Mpixel/s encoded to JPEG files, host pad + H2D + GPU fDCT/quantise + " +
+                  ("GPU Huffman + D2H of segments + host assembly" if gpu else "D2H + host Huffman") + " overlapped",
         "value": round(args.frames * W * H / dt / 1e6, 1), "unit": "Mpixel/s", "frames": args.frames,
         "host_threads": args.threads, "frames_per_chunk": st.frames_per_chunk, "chunks": st.chunks,
         "wall_ms": round(dt * 1e3, 2), "jpeg_MB": round(sum(len(j) for j in jpegs) / 1e6, 1),
@@ -250,6 +254,45 @@ def config5_files(args):
         "entropy_Mpixel_s_per_thread": round(args.frames * W * H / (st.entropy_ms_sum * 1e-3) / 1e6, 1),
         "h2d_ms_sum": round(st.h2d_ms_sum, 2), "kernel_ms_sum": round(st.kernel_ms_sum, 2),
         "d2h_ms_sum": round(st.d2h_ms_sum, 2), "d2h_GBps": round(st.coef_bytes / (st.d2h_ms_sum * 1e-3) / 1e9, 1)}))
+    ctx.close()
+
+
+def config_huffman(args):
+    """Encoder back end on the GPU: 4K 4:2:0 coefficient records (device resident, from k_encode) ->
+    entropy-coded segments (hvc_huffman_encode_frames: length pass, scan, emit pass, stuffing passes)."""
+    import torch
+    import video_coding_amd as hvc
+    from video_coding_amd.synth import synth_frame_pixels
+    W, H = 3840, 2160
+    info = hvc.hvc.jpeg_encoder_layout(W, H, 420, 75)
+    planes = [(info.layout[i].blocks_w, info.layout[i].blocks_h, info.layout[i].qtab) for i in range(3)]
+    specs, cfs, pfs = hvc.hvc.frame_layout(planes)
+    qtabs = info.qtab_array()[:2]
+    ctx = hvc.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    src = torch.from_numpy(np.stack([synth_frame_pixels(140 + 8 * f, planes) for f in range(args.distinct)])).cuda()
+    d_distinct = torch.zeros((args.distinct, cfs), dtype=torch.int16, device="cuda")
+    ctx.encode_frames(src, pfs, qtabs, hvc.hvc.components(specs), args.distinct, d_distinct, cfs)
+    n = args.frames
+    d_coefs = d_distinct.repeat((n + args.distinct - 1) // args.distinct, 1)[:n].contiguous()
+    cap = n * 6 * 1024 * 1024
+    out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    offs = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    import ctypes as C
+    call = lambda: hvc.hvc._chk(hvc.lib().hvc_huffman_encode_frames(ctx._h, C.byref(info), d_coefs.data_ptr(), cfs, n,
+                                                                    out.data_ptr(), cap, offs.data_ptr(), 1))
+    for _ in range(args.warmup):
+        call()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        call()
+    dt = (time.perf_counter() - t0) / args.steps
+    seg_bytes = int(offs[-1].item())
+    print(json.dumps({"config": "huffman", "metric": "Mpixel/s entropy-coded on the GPU (4K 4:2:0, q75)", "frames": n,
+                      "value": round(n * W * H / dt / 1e6, 1), "unit": "Mpixel/s", "ms_per_call": round(dt * 1e3, 3),
+                      "segment_MB": round(seg_bytes / 1e6, 1), "bits_per_pixel": round(seg_bytes * 8 / (n * W * H), 2),
+                      "coef_GBps": round(n * cfs * 2 / dt / 1e9, 1)}))
     ctx.close()
 
 
@@ -282,18 +325,23 @@ def config_k2(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", type=int, required=True, choices=[2, 3, 4, 5, 6, 7, 8])
+    ap.add_argument("--config", type=int, required=True, choices=[2, 3, 4, 5, 6, 7, 8, 9])
     ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--distinct", type=int, default=4)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--threads", type=int, default=min(16, os.cpu_count() or 16))
     ap.add_argument("--chunk", type=int, default=32)
+    ap.add_argument("--gpu-entropy", action="store_true", help="config 8: Huffman coding on the GPU as well")
     args = ap.parse_args()
     if args.config == 2:  # K2 upsample (optional output stage)
         args.frames = args.frames or 256
         args.steps = args.steps or 20
         config_k2(args)
+    elif args.config == 9:  # GPU Huffman coder alone
+        args.frames = args.frames or 32
+        args.steps = args.steps or 10
+        config_huffman(args)
     elif args.config == 8:  # config 5 with files out
         args.frames = args.frames or 256
         args.steps = args.steps or 3

@@ -41,14 +41,16 @@ struct hvc_ctx {
     int last_hip = 0;
     // hvc_jpeg_decode_batch: copy stream + ring of pinned host / device coefficient chunks
     static constexpr int RING = 3;
-    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream = nullptr, down_stream = nullptr;
     void *h_ring[RING] = {}, *d_ring[RING] = {}, *d_oring[RING] = {};
     size_t ring_bytes = 0, oring_bytes = 0;
     hipEvent_t ev_h2d[RING] = {}, ev_kern[RING] = {}, ev_t[4] = {};
     // hvc_jpeg_encode_batch: pinned / device rings of padded pixel chunks (in) and coefficient chunks (out)
     void *eh_in[RING] = {}, *ed_in[RING] = {}, *eh_out[RING] = {}, *ed_out[RING] = {};
     size_t e_in_bytes = 0, e_out_bytes = 0;
-    hipEvent_t ev_up[RING] = {}, ev_down[RING] = {}, ev_et[RING][3] = {};
+    hipEvent_t ev_up[RING] = {}, ev_down[RING] = {}, ev_et[RING][3] = {}, ev_gpu[RING] = {};
+    void *ed_seg[RING] = {}, *ed_off[RING] = {}, *eh_off[RING] = {}; // hvc_jpeg_encode_batch_gpu: packed segments + offsets
+    size_t e_seg_bytes = 0, e_off_bytes = 0;
     // GPU Huffman coder (hvc_huffman_encode_frames): tables + scratch, grown on demand
     unsigned *hd_tables = nullptr;
     void *hd_lens = nullptr, *hd_meta = nullptr, *hd_bitbuf = nullptr, *hd_ff = nullptr, *hd_out = nullptr;
@@ -227,6 +229,10 @@ void hvc_destroy(hvc_ctx *c) {
         if (c->ev_down[i]) (void)hipEventDestroy(c->ev_down[i]);
         for (int k = 0; k < 3; k++)
             if (c->ev_et[i][k]) (void)hipEventDestroy(c->ev_et[i][k]);
+        if (c->ev_gpu[i]) (void)hipEventDestroy(c->ev_gpu[i]);
+        if (c->ed_seg[i]) (void)hipFree(c->ed_seg[i]);
+        if (c->ed_off[i]) (void)hipFree(c->ed_off[i]);
+        if (c->eh_off[i]) (void)hipHostFree(c->eh_off[i]);
     }
     for (int i = 0; i < 4; i++)
         if (c->ev_t[i]) (void)hipEventDestroy(c->ev_t[i]);
@@ -237,6 +243,7 @@ void hvc_destroy(hvc_ctx *c) {
     if (c->hd_ff) (void)hipFree(c->hd_ff);
     if (c->hd_out) (void)hipFree(c->hd_out);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1139,9 +1146,12 @@ int hvc_huffman_encode_frames(hvc_ctx *c, const hvc_jpeg_info *info, const int16
 //   copy stream:  hipMemcpyAsync H2D                  compute stream: k_encode, then D2H of the coefficient records
 //   host threads: write_headers + rle + write_bits + EOI per frame                encoder.ml:127-193, 371-418
 // The orchestrating thread runs a three-stage software pipeline over chunks (pad k | GPU k-1 | entropy k-2).
-int hvc_jpeg_encode_batch(hvc_ctx *c, const uint8_t *const *frames, int n_frames, int width, int height, int chroma,
-                          int quality, int threads, int frames_per_chunk, uint8_t *const *jpegs, const size_t *caps,
-                          size_t *sizes, hvc_batch_stats *stats) {
+// gpu_entropy = false: coefficient records come back to the host and host threads entropy-code them;
+// gpu_entropy = true: the Huffman coder runs on the GPU too (hvc_huff.hip), only the packed segments come back
+// and host threads just assemble header + segment + EOI.
+static int encode_batch_impl(hvc_ctx *c, const uint8_t *const *frames, int n_frames, int width, int height, int chroma,
+                             int quality, int threads, int frames_per_chunk, uint8_t *const *jpegs, const size_t *caps,
+                             size_t *sizes, hvc_batch_stats *stats, bool gpu_entropy) {
     if (!c || !frames || !jpegs || !caps || !sizes || n_frames < 0) return HVC_E_INVALID_ARG;
     if (stats) std::memset(stats, 0, sizeof *stats);
     hvc_jpeg_info info;
@@ -1163,11 +1173,36 @@ int hvc_jpeg_encode_batch(hvc_ctx *c, const uint8_t *const *frames, int n_frames
     DeviceGuard g(c->device);
     if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
     if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->down_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
     for (int i = 0; i < NB; i++) {
         if (!c->ev_up[i]) HIPCHK(c, hipEventCreate(&c->ev_up[i]));
         if (!c->ev_down[i]) HIPCHK(c, hipEventCreate(&c->ev_down[i]));
         for (int k = 0; k < 3; k++)
             if (!c->ev_et[i][k]) HIPCHK(c, hipEventCreate(&c->ev_et[i][k]));
+        if (!c->ev_gpu[i]) HIPCHK(c, hipEventCreate(&c->ev_gpu[i]));
+    }
+    std::vector<uint8_t> header;
+    if (gpu_entropy) {
+        hvc::jpeg_header_bytes(&info, header);
+        // per slot: packed segments on the device (capacity = the coefficient chunk: 2 bytes per sample, twice the raw
+        // frames), and (C + 1) offsets + one status word, on the device and pinned
+        const size_t off_bytes = ((size_t)C + 2) * sizeof(unsigned long long);
+        if (out_bytes > c->e_seg_bytes || off_bytes > c->e_off_bytes) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            for (int i = 0; i < NB; i++) {
+                if (c->ed_seg[i]) (void)hipFree(c->ed_seg[i]);
+                if (c->ed_off[i]) (void)hipFree(c->ed_off[i]);
+                if (c->eh_off[i]) (void)hipHostFree(c->eh_off[i]);
+                c->ed_seg[i] = c->ed_off[i] = c->eh_off[i] = nullptr;
+            }
+            c->e_seg_bytes = c->e_off_bytes = 0;
+            for (int i = 0; i < NB; i++)
+                if (hipMalloc(&c->ed_seg[i], out_bytes) != hipSuccess || hipMalloc(&c->ed_off[i], off_bytes) != hipSuccess ||
+                    hipHostMalloc(&c->eh_off[i], off_bytes, hipHostMallocDefault) != hipSuccess)
+                    return HVC_E_OUT_OF_MEMORY;
+            c->e_seg_bytes = out_bytes;
+            c->e_off_bytes = off_bytes;
+        }
     }
     if (in_bytes > c->e_in_bytes || out_bytes > c->e_out_bytes) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1234,9 +1269,22 @@ int hvc_jpeg_encode_batch(hvc_ctx *c, const uint8_t *const *frames, int n_frames
                         }
                         src += (size_t)sw[i] * sh[i];
                     }
-                } else {
+                } else if (!gpu_entropy) {
                     const int16_t *cf = (const int16_t *)c->eh_out[slot] + (size_t)(f - k * C) * info.coef_count;
                     e = hvc_jpeg_entropy_encode(&info, cf, jpegs[f], caps[f], &sizes[f]);
+                } else { // header + the frame's segment + EOI (complete_and_write_eoi, encoder.ml:507-510)
+                    const unsigned long long *off = (const unsigned long long *)c->eh_off[slot];
+                    const int fi = f - k * C;
+                    const size_t seg = (size_t)(off[fi + 1] - off[fi]);
+                    sizes[f] = header.size() + seg + 2;
+                    if (sizes[f] > caps[f]) {
+                        e = HVC_E_INVALID_ARG;
+                    } else {
+                        std::memcpy(jpegs[f], header.data(), header.size());
+                        std::memcpy(jpegs[f] + header.size(), (const uint8_t *)c->eh_out[slot] + off[fi], seg);
+                        jpegs[f][header.size() + seg] = 0xff;
+                        jpegs[f][header.size() + seg + 1] = 0xd9;
+                    }
                 }
             }
             const long long ns =
@@ -1264,10 +1312,11 @@ int hvc_jpeg_encode_batch(hvc_ctx *c, const uint8_t *const *frames, int n_frames
 
     int rc = HVC_OK;
     double h2d_ms = 0, k_ms = 0, d2h_ms = 0;
+    unsigned long long seg_bytes = 0;
     hipStream_t compute = c->stream;
     const bool prof_saved = c->profiling;
     c->profiling = false;
-    for (int it = 0; it < n_chunks + 2 && rc == HVC_OK; it++) {
+    for (int it = 0; it < n_chunks + 3 && rc == HVC_OK; it++) {
         // stage 1: pad chunk `it` (its pinned slot was uploaded and synchronised two iterations ago)
         if (it < n_chunks) submit(0, it);
         // stage 2: GPU work of chunk it - 1
@@ -1275,7 +1324,9 @@ int hvc_jpeg_encode_batch(hvc_ctx *c, const uint8_t *const *frames, int n_frames
         if (j >= 0 && j < n_chunks) {
             const int slot = j % NB, cnt = chunk_count(j);
             wait_for(pads_done, j);
-            if (j >= NB) wait_for(ent_done, j - NB); // the pinned coefficient slot is free again
+            // the slot's pinned buffers (coefficients, or offsets + segments) are free again once chunk j - NB
+            // has been entropy-coded / assembled
+            if (j >= NB) wait_for(ent_done, j - NB);
             hipError_t he = hipEventRecord(c->ev_et[slot][0], c->copy_stream);
             if (he == hipSuccess)
                 he = hipMemcpyAsync(c->ed_in[slot], c->eh_in[slot], pix_bytes * (size_t)cnt, hipMemcpyHostToDevice,
@@ -1287,24 +1338,73 @@ int hvc_jpeg_encode_batch(hvc_ctx *c, const uint8_t *const *frames, int n_frames
             rc = hvc_encode_frames(c, (const uint8_t *)c->ed_in[slot], pix_bytes, &info.qtabs[0][0], info.n_qtabs,
                                    info.layout, 3, cnt, (int16_t *)c->ed_out[slot], info.coef_count, HVC_MEM_DEVICE);
             if (rc) break;
-            he = hipEventRecord(c->ev_et[slot][2], compute);
-            if (he == hipSuccess)
-                he = hipMemcpyAsync(c->eh_out[slot], c->ed_out[slot], coef_bytes * (size_t)cnt, hipMemcpyDeviceToHost,
-                                    compute);
-            if (he == hipSuccess) he = hipEventRecord(c->ev_down[slot], compute);
+            if (!gpu_entropy) {
+                he = hipEventRecord(c->ev_et[slot][2], compute);
+                if (he == hipSuccess)
+                    he = hipMemcpyAsync(c->eh_out[slot], c->ed_out[slot], coef_bytes * (size_t)cnt, hipMemcpyDeviceToHost,
+                                        compute);
+                if (he == hipSuccess) he = hipEventRecord(c->ev_down[slot], compute);
+            } else {
+                hvc::HuffParams HP;
+                rc = huffman_prepare(c, &info, (const int16_t *)c->ed_out[slot], info.coef_count, cnt,
+                                     (uint8_t *)c->ed_seg[slot], out_bytes, (unsigned long long *)c->ed_off[slot], HP);
+                if (rc) break;
+                he = hvc::launch_huffman_encode(HP, compute);
+                if (he == hipSuccess) he = hipEventRecord(c->ev_et[slot][2], compute);
+                // offsets, then the status word behind them (slot C + 1 of the pinned array)
+                if (he == hipSuccess)
+                    he = hipMemcpyAsync(c->eh_off[slot], c->ed_off[slot], ((size_t)cnt + 1) * sizeof(unsigned long long),
+                                        hipMemcpyDeviceToHost, compute);
+                if (he == hipSuccess)
+                    he = hipMemcpyAsync((unsigned long long *)c->eh_off[slot] + C + 1, HP.status, sizeof(unsigned),
+                                        hipMemcpyDeviceToHost, compute);
+                if (he == hipSuccess) he = hipEventRecord(c->ev_gpu[slot], compute);
+            }
             if (he != hipSuccess) { rc = fail_hip(c, he); break; }
         }
-        // stage 3: entropy-code chunk it - 2 once its coefficients have landed
+        // stage 3:
+        //   host coder: wait for chunk it - 2's coefficients, hand them to the entropy threads
+        //   GPU coder:  wait for chunk it - 2's offsets, then download exactly its packed segments -- on a
+        //               stream of its own, so that the copy is not queued behind the next chunk's kernels
         const int e = it - 2;
         if (e >= 0 && e < n_chunks) {
             const int slot = e % NB;
+            float ms = 0;
+            if (!gpu_entropy) {
+                hipError_t he = hipEventSynchronize(c->ev_down[slot]);
+                if (he != hipSuccess) { rc = fail_hip(c, he); break; }
+                submit(1, e);
+                if (hipEventElapsedTime(&ms, c->ev_et[slot][0], c->ev_up[slot]) == hipSuccess) h2d_ms += ms;
+                if (hipEventElapsedTime(&ms, c->ev_et[slot][2], c->ev_down[slot]) == hipSuccess) d2h_ms += ms;
+            } else {
+                hipError_t he = hipEventSynchronize(c->ev_gpu[slot]);
+                if (he != hipSuccess) { rc = fail_hip(c, he); break; }
+                if (hipEventElapsedTime(&ms, c->ev_et[slot][0], c->ev_up[slot]) == hipSuccess) h2d_ms += ms;
+                const unsigned long long *off = (const unsigned long long *)c->eh_off[slot];
+                const int cnt = chunk_count(e);
+                const unsigned status = (unsigned)off[C + 1];
+                if (status & 1u) { rc = HVC_E_RANGE; break; }              // a value without a code
+                if ((status & 6u) || off[cnt] > out_bytes) { rc = HVC_E_TOO_LARGE; break; } // > 2x the raw frames
+                if (e >= NB) wait_for(ent_done, e - NB); // the pinned segment slot has been assembled
+                he = hipEventRecord(c->ev_et[slot][0], c->down_stream);
+                if (he == hipSuccess && off[cnt])
+                    he = hipMemcpyAsync(c->eh_out[slot], c->ed_seg[slot], (size_t)off[cnt], hipMemcpyDeviceToHost,
+                                        c->down_stream);
+                if (he == hipSuccess) he = hipEventRecord(c->ev_down[slot], c->down_stream);
+                if (he != hipSuccess) { rc = fail_hip(c, he); break; }
+                seg_bytes += off[cnt];
+            }
+            if (hipEventElapsedTime(&ms, c->ev_et[slot][1], c->ev_et[slot][2]) == hipSuccess) k_ms += ms;
+        }
+        // stage 4 (GPU coder): assemble the files of chunk it - 3 once its segments have landed
+        const int a = it - 3;
+        if (gpu_entropy && a >= 0 && a < n_chunks) {
+            const int slot = a % NB;
             hipError_t he = hipEventSynchronize(c->ev_down[slot]);
             if (he != hipSuccess) { rc = fail_hip(c, he); break; }
-            submit(1, e);
-            float ms = 0; // stage times of the chunk that just landed
-            if (hipEventElapsedTime(&ms, c->ev_et[slot][0], c->ev_up[slot]) == hipSuccess) h2d_ms += ms;
-            if (hipEventElapsedTime(&ms, c->ev_et[slot][1], c->ev_et[slot][2]) == hipSuccess) k_ms += ms;
-            if (hipEventElapsedTime(&ms, c->ev_et[slot][2], c->ev_down[slot]) == hipSuccess) d2h_ms += ms;
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, c->ev_et[slot][0], c->ev_down[slot]) == hipSuccess) d2h_ms += ms;
+            submit(1, a);
         }
         if (error.load()) rc = error.load();
     }
@@ -1323,6 +1423,7 @@ int hvc_jpeg_encode_batch(hvc_ctx *c, const uint8_t *const *frames, int n_frames
     for (auto &t : pool) t.join();
     (void)hipStreamSynchronize(compute);
     (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipStreamSynchronize(c->down_stream);
     if (rc == HVC_OK && error.load()) rc = error.load();
     if (stats) {
         stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
@@ -1334,9 +1435,23 @@ int hvc_jpeg_encode_batch(hvc_ctx *c, const uint8_t *const *frames, int n_frames
         stats->chunks = n_chunks;
         stats->threads = threads;
         stats->frames_per_chunk = C;
-        stats->coef_bytes = (uint64_t)coef_bytes * (uint64_t)n_frames;
+        stats->coef_bytes = gpu_entropy ? (uint64_t)seg_bytes : (uint64_t)coef_bytes * (uint64_t)n_frames; // bytes downloaded
     }
     return rc;
+}
+
+int hvc_jpeg_encode_batch(hvc_ctx *c, const uint8_t *const *frames, int n_frames, int width, int height, int chroma,
+                          int quality, int threads, int frames_per_chunk, uint8_t *const *jpegs, const size_t *caps,
+                          size_t *sizes, hvc_batch_stats *stats) {
+    return encode_batch_impl(c, frames, n_frames, width, height, chroma, quality, threads, frames_per_chunk, jpegs, caps,
+                             sizes, stats, false);
+}
+
+int hvc_jpeg_encode_batch_gpu(hvc_ctx *c, const uint8_t *const *frames, int n_frames, int width, int height, int chroma,
+                              int quality, int threads, int frames_per_chunk, uint8_t *const *jpegs, const size_t *caps,
+                              size_t *sizes, hvc_batch_stats *stats) {
+    return encode_batch_impl(c, frames, n_frames, width, height, chroma, quality, threads, frames_per_chunk, jpegs, caps,
+                             sizes, stats, true);
 }
 
 } // extern "C"

@@ -20,7 +20,7 @@ SYMBOLS = [
     "hvc_device_free", "hvc_memcpy_h2d", "hvc_memcpy_d2h",
     "hvc_jpeg_read_header", "hvc_jpeg_entropy_decode", "hvc_jpeg_get_yuv_frame", "hvc_jpeg_decode",
     "hvc_jpeg_decode_batch", "hvc_quant_table", "hvc_jpeg_encoder_layout", "hvc_jpeg_entropy_encode",
-    "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444", "hvc_jpeg_decode_yuv444", "hvc_compare_planes", "hvc_jpeg_encode_batch", "hvc_jpeg_decode_batch_yuv444", "hvc_jpeg_encoder_check", "hvc_huffman_encode_frames", "hvc_jpeg_header",
+    "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444", "hvc_jpeg_decode_yuv444", "hvc_compare_planes", "hvc_jpeg_encode_batch", "hvc_jpeg_decode_batch_yuv444", "hvc_jpeg_encoder_check", "hvc_huffman_encode_frames", "hvc_jpeg_header", "hvc_jpeg_encode_batch_gpu",
 ]
 
 
@@ -132,6 +132,7 @@ def lib():
         L.hvc_jpeg_decode_batch_yuv444.argtypes = L.hvc_jpeg_decode_batch.argtypes
         L.hvc_jpeg_encode_batch.argtypes = [vp, C.POINTER(vp), i, i, i, i, i, i, i, C.POINTER(vp), C.POINTER(sz),
                                             C.POINTER(sz), C.POINTER(BatchStats)]
+        L.hvc_jpeg_encode_batch_gpu.argtypes = L.hvc_jpeg_encode_batch.argtypes
         L.hvc_compare_planes.argtypes = [vp, vp, sz, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.hvc_jpeg_encoder_layout.argtypes = [i, i, i, i, ip]
         L.hvc_jpeg_entropy_encode.argtypes = [ip, vp, vp, sz, C.POINTER(sz)]
@@ -404,9 +405,10 @@ class Context:
             o, data = offs, out
         return [data[int(o[f]):int(o[f + 1])].tobytes() for f in range(n_frames)]
 
-    def jpeg_encode_batch(self, frames, width, height, chroma=420, quality=75, threads=8, frames_per_chunk=16):
+    def jpeg_encode_batch(self, frames, width, height, chroma=420, quality=75, threads=8, frames_per_chunk=16,
+                          gpu_entropy=False):
         """Encoder.encode_4xx over a batch of raw planar frames (bytes / uint8 arrays in Frame.input layout).
-        Returns (list of jpeg byte strings, BatchStats)."""
+        Returns (list of jpeg byte strings, BatchStats).  gpu_entropy: Huffman coding on the GPU as well."""
         n = len(frames)
         arrs = [np.frombuffer(f, dtype=np.uint8) if isinstance(f, (bytes, bytearray)) else
                 np.ascontiguousarray(f, dtype=np.uint8).reshape(-1) for f in frames]
@@ -423,8 +425,9 @@ class Context:
         caps = (C.c_size_t * max(n, 1))(*([cap] * n))
         sizes = (C.c_size_t * max(n, 1))()
         st = BatchStats()
-        _chk(lib().hvc_jpeg_encode_batch(self._h, fp, n, width, height, chroma, quality, threads, frames_per_chunk, op,
-                                         caps, sizes, C.byref(st)), "hvc_jpeg_encode_batch")
+        fn = lib().hvc_jpeg_encode_batch_gpu if gpu_entropy else lib().hvc_jpeg_encode_batch
+        _chk(fn(self._h, fp, n, width, height, chroma, quality, threads, frames_per_chunk, op, caps, sizes, C.byref(st)),
+             "hvc_jpeg_encode_batch_gpu" if gpu_entropy else "hvc_jpeg_encode_batch")
         return [outs[f][:sizes[f]].tobytes() for f in range(n)], st
 
     # -- encode -------------------------------------------------------------
