@@ -284,7 +284,8 @@ HVC_API int hvc_jpeg_encoder_check(const hvc_jpeg_info *info);
 HVC_API int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uint8_t *out, size_t cap,
                                     size_t *out_len);
 /* Encoder.encode_420/422/444 ~frame ~quality (encoder.ml:512-541): y/u/v are the tight planes of the
- * frame (Frame.create sizes); padding, GPU forward stage and host entropy coding inside. */
+ * frame (Frame.create sizes); padding on the host, forward block stage AND Huffman coder on the GPU
+ * (only the entropy-coded segment is downloaded), header + segment + EOI assembled into out. */
 HVC_API int hvc_jpeg_encode(hvc_ctx *ctx, const uint8_t *y, const uint8_t *u, const uint8_t *v, int width,
                             int height, int chroma, int quality, uint8_t *out, size_t cap, size_t *out_len);
 

@@ -781,6 +781,9 @@ int hvc_jpeg_decode(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_info *in
 }
 
 // Encoder.encode_420/422/444 (encoder.ml:512-541)
+static int huffman_prepare(hvc_ctx *c, const hvc_jpeg_info *info, const int16_t *d_coefs, size_t coef_fs, int n_frames,
+                           uint8_t *d_out, size_t out_cap, unsigned long long *d_offsets, hvc::HuffParams &P);
+
 int hvc_jpeg_encode(hvc_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v, int width, int height, int chroma,
                     int quality, uint8_t *out, size_t cap, size_t *out_len) {
     if (!c || !y || !u || !v || !out_len) return HVC_E_INVALID_ARG;
@@ -788,11 +791,9 @@ int hvc_jpeg_encode(hvc_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_
     int r = hvc_jpeg_encoder_layout(width, height, chroma, quality, &info);
     if (r) return r;
     if ((r = hvc_jpeg_encoder_check(&info))) return r; // the model raises for this geometry
-    std::vector<uint8_t> planes;
-    std::vector<int16_t> coefs;
+    std::vector<uint8_t> planes, header;
     try {
         planes.assign(info.pixel_bytes, 0); // Plane.create is zero-filled (plane.ml:11-17)
-        coefs.resize(info.coef_count);
     } catch (const std::bad_alloc &) {
         return HVC_E_OUT_OF_MEMORY;
     }
@@ -807,10 +808,40 @@ int hvc_jpeg_encode(hvc_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_
             std::memcpy(planes.data() + info.layout[i].plane_offset + (size_t)row * info.layout[i].stride,
                         src[i] + (size_t)row * sw[i], (size_t)bw);
     }
-    r = hvc_encode_frames(c, planes.data(), info.pixel_bytes, &info.qtabs[0][0], info.n_qtabs, info.layout, 3, 1,
-                          coefs.data(), info.coef_count, HVC_MEM_HOST);
+    // forward block stage and Huffman coder both on the device; only the entropy-coded segment comes back
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
+    const size_t coef_bytes = info.coef_count * sizeof(int16_t);
+    const size_t seg_cap = (info.coef_count / 64) * 243 + 64; // worst case incl. stuffing
+    if ((r = grow(c, &c->d_in, &c->in_cap, info.pixel_bytes))) return r;
+    if ((r = grow(c, &c->d_out, &c->out_cap, coef_bytes))) return r;
+    if ((r = grow(c, &c->hd_out, &c->hd_out_cap, seg_cap))) return r;
+    HIPCHK(c, hipMemcpyAsync(c->d_in, planes.data(), info.pixel_bytes, hipMemcpyHostToDevice, c->stream));
+    const bool prof_saved = c->profiling;
+    c->profiling = false;
+    r = hvc_encode_frames(c, (const uint8_t *)c->d_in, info.pixel_bytes, &info.qtabs[0][0], info.n_qtabs, info.layout, 3, 1,
+                          (int16_t *)c->d_out, info.coef_count, HVC_MEM_DEVICE);
+    c->profiling = prof_saved;
     if (r) return r;
-    return hvc_jpeg_entropy_encode(&info, coefs.data(), out, cap, out_len);
+    hvc::HuffParams P;
+    if ((r = huffman_prepare(c, &info, (const int16_t *)c->d_out, info.coef_count, 1, (uint8_t *)c->hd_out, seg_cap, nullptr, P)))
+        return r;
+    HIPCHK(c, hvc::launch_huffman_encode(P, c->stream));
+    unsigned status = 0;
+    unsigned long long off[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(&status, P.status, sizeof status, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(off, P.out_offsets, sizeof off, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (status & 1u) return HVC_E_RANGE;
+    if ((status & 6u) || off[1] > seg_cap) return HVC_E_TOO_LARGE;
+    hvc::jpeg_header_bytes(&info, header);
+    *out_len = header.size() + (size_t)off[1] + 2;
+    if (!out || *out_len > cap) return HVC_E_INVALID_ARG;
+    std::memcpy(out, header.data(), header.size());
+    HIPCHK(c, hipMemcpy(out + header.size(), c->hd_out, (size_t)off[1], hipMemcpyDeviceToHost));
+    out[header.size() + off[1]] = 0xff; // complete_and_write_eoi (encoder.ml:507-510)
+    out[header.size() + off[1] + 1] = 0xd9;
+    return HVC_OK;
 }
 
 // ---------------------------------------------------------------------------
