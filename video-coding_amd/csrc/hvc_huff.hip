@@ -310,6 +310,25 @@ __global__ __launch_bounds__(256) void k_stuff_write(HuffParams P) {
     const uint8_t *src = reinterpret_cast<const uint8_t *>(P.bitbuf + (size_t)frame * P.bitbuf_words) + (size_t)piece * 64;
     uint8_t *dst = P.out + P.out_offsets[frame] + (size_t)piece * 64 + P.ff[(size_t)frame * P.ff_stride + piece];
     const unsigned n = min(64u, bytes - piece * 64u);
+    const unsigned nff = (piece + 1 < P.frame_pieces[frame] ? P.ff[(size_t)frame * P.ff_stride + piece + 1]
+                                                            : P.frame_ff[frame]) -
+                         P.ff[(size_t)frame * P.ff_stride + piece];
+    if (nff == 0 && n == 64) {
+        // four out of five pieces hold no 0xFF: a straight copy, dwords at whatever alignment the
+        // earlier stuffing bytes left (global memory takes unaligned dwords)
+        typedef unsigned unaligned_u32 __attribute__((aligned(1)));
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        unaligned_u32 *d = reinterpret_cast<unaligned_u32 *>(dst);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint4 t = s4[j];
+            d[4 * j + 0] = t.x;
+            d[4 * j + 1] = t.y;
+            d[4 * j + 2] = t.z;
+            d[4 * j + 3] = t.w;
+        }
+        return;
+    }
     for (unsigned i = 0; i < n; i++) {
         const uint8_t v = src[i];
         *dst++ = v;
