@@ -260,6 +260,19 @@ HVC_API int hvc_compare_planes(const uint8_t *a, const uint8_t *b, size_t n, int
 /* Encoder.Parameters.c420/c422/c444 + Encoder.create geometry (encoder.ml:287-349, 437-472): chroma is
  * 420, 422 or 444.  Fills the padded plane layout (zero padding, plane.ml:11-17) and the tables. */
 HVC_API int hvc_jpeg_encoder_layout(int width, int height, int chroma, int quality, hvc_jpeg_info *info);
+/* Huffman DEcoding on the GPU (csrc/hvc_hdec.hip): the entropy-coded segments of n_frames files (one
+ * geometry, one set of Huffman tables, as in hvc_jpeg_decode_batch) -> coefficient records exactly as
+ * hvc_jpeg_entropy_decode writes them.  The segment is cut into 1024-bit subsequences, one lane each;
+ * lanes start from guessed states, adopt their predecessor's exit state round after round until nothing
+ * changes (Huffman streams re-synchronise), then decode once more writing coefficients; a prefix sum
+ * resolves the DC predictor (decoder.ml:143).  Whatever the model raises on, a DC outside int16, tables
+ * that are no prefix code, or a stream that ends early makes the call fall back to the host decoder, so the
+ * result (and every error code) is the host decoder's.  *used_gpu (optional) tells which one ran.
+ * info receives the header of jpegs[0].  The call returns when the records are complete. */
+HVC_API int hvc_jpeg_entropy_decode_gpu(hvc_ctx *ctx, const uint8_t *const *jpegs, const size_t *sizes, int n_frames,
+                                        int16_t *coefs, size_t coef_frame_stride, int where, hvc_jpeg_info *info,
+                                        int *used_gpu);
+
 /* The encoder's back end ON THE GPU (csrc/hvc_huff.hip): Encoder.rle + write_bits + Bitstream_writer
  * with byte stuffing and flush_with_1s (encoder.ml:127-193, 507-510; bitstream_writer.ml) for n_frames
  * coefficient records, as data-parallel passes -- every block's bit string depends only on its own

@@ -1,0 +1,109 @@
+"""hvc_jpeg_entropy_decode_gpu: the Huffman reader as a self-synchronising parallel decoder on the GPU.
+Its coefficient records must equal the host front end's (itself equal to the model restatement) on every
+file; whatever it cannot or must not handle goes to the host decoder, with the same records / errors."""
+import numpy as np
+import pytest
+
+from conftest import golden_bytes
+from helpers import synth_pixels
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import video_coding_amd as hvc
+    c = hvc.Context(0)
+    yield c
+    c.close()
+
+
+def make_jpeg(seed, w, h, chroma, q):
+    cw, ch = orc.chroma_dims(chroma, w, h)
+    r8 = lambda x: (x + 7) // 8 * 8
+    y = synth_pixels(seed, r8(h), r8(w))[:h, :w]
+    u = synth_pixels(seed + 1, r8(ch), r8(cw))[:ch, :cw]
+    v = synth_pixels(seed + 2, r8(ch), r8(cw))[:ch, :cw]
+    return orc.encode_yuv(y, u, v, w, h, chroma, q)
+
+
+@pytest.mark.parametrize("fn", ["mini.jpg", "Mouse480.jpg"])
+@pytest.mark.parametrize("device", [False, True])
+def test_reference_files(ctx, fn, device):
+    import video_coding_amd as hvc
+    data = golden_bytes(fn)
+    info, got, used = ctx.jpeg_entropy_decode_gpu([data], device=device)
+    _, want = hvc.hvc.jpeg_entropy_decode(data)
+    assert used == 1
+    assert np.array_equal(got[0], want)
+
+
+@pytest.mark.parametrize("w,h,chroma,q", [(64, 64, 420, 75), (52, 44, 420, 95), (130, 70, 422, 40), (33, 17, 444, 80),
+                                          (16, 8, 420, 50), (480, 320, 420, 20), (1920, 1080, 420, 75), (200, 120, 444, 100),
+                                          (96, 64, 422, 1), (2048, 16, 420, 90), (16, 1024, 444, 60)])
+def test_batches_equal_the_host_decoder(ctx, w, h, chroma, q):
+    import video_coding_amd as hvc
+    jpegs = [make_jpeg(500 + 7 * f, w, h, chroma, q) for f in range(4)]
+    info, got, used = ctx.jpeg_entropy_decode_gpu(jpegs, device=True)
+    assert used == 1
+    for f, j in enumerate(jpegs):
+        _, want = hvc.hvc.jpeg_entropy_decode(j)
+        assert np.array_equal(got[f], want), f
+
+
+def test_smooth_content_with_long_zero_runs_and_tiny_blocks(ctx):
+    """flat frames: blocks of a few bits each (hundreds of blocks per subsequence) and EOB-only blocks"""
+    import video_coding_amd as hvc
+    w, h = 640, 480
+    y = np.full((h, w), 77, np.uint8)
+    y[100:200, 50:400] = 200
+    u = np.full((h // 2, w // 2), 128, np.uint8)
+    v = np.full((h // 2, w // 2), 90, np.uint8)
+    j = orc.encode_yuv(y, u, v, w, h, 420, 85)
+    info, got, used = ctx.jpeg_entropy_decode_gpu([j, j], device=True)
+    _, want = hvc.hvc.jpeg_entropy_decode(j)
+    assert used == 1 and np.array_equal(got[0], want) and np.array_equal(got[1], want)
+
+
+def test_streams_the_model_treats_specially_fall_back_to_the_host_decoder(ctx):
+    import video_coding_amd as hvc
+    data = golden_bytes("mini.jpg")
+    info = hvc.hvc.jpeg_read_header(data)
+    # truncated entropy segment (EOI kept): the model reads zero bits past the end
+    cut = data[:info.ecs_offset + 40] + b"\\xff\\xd9"
+    try:
+        _, want = hvc.hvc.jpeg_entropy_decode(cut)
+    except hvc.HvcError as e:
+        with pytest.raises(hvc.HvcError) as e2:
+            ctx.jpeg_entropy_decode_gpu([cut])
+        assert e2.value.code == e.code
+    else:
+        _, got, used = ctx.jpeg_entropy_decode_gpu([cut])
+        assert np.array_equal(got[0], want)
+    # random mutations: same records or same error code as the host decoder
+    rng = np.random.Generator(np.random.PCG64(77))
+    agree = 0
+    for it in range(120):
+        b = bytearray(golden_bytes("mini.jpg" if it % 2 else "Mouse480.jpg"))
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(0, len(b)))
+            b[pos] = int(rng.integers(0, 256))
+        b = bytes(b)
+        try:
+            hinfo = hvc.hvc.jpeg_read_header(b)
+            if hinfo.coef_count > 1 << 22:
+                continue
+            _, want = hvc.hvc.jpeg_entropy_decode(b, hinfo)
+            err = None
+        except hvc.HvcError as e:
+            want, err = None, e.code
+        if err is None:
+            _, got, used = ctx.jpeg_entropy_decode_gpu([b])
+            assert np.array_equal(got[0], want), it
+            agree += 1
+        else:
+            with pytest.raises(hvc.HvcError) as e2:
+                ctx.jpeg_entropy_decode_gpu([b])
+            assert e2.value.code == err, it
+    assert agree > 40

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/hvc_jpeg.h"
+#include "hvc_hdec.h"
 #include "hvc_huff.h"
 #include "hvc_kernels.h"
 
@@ -51,6 +52,9 @@ struct hvc_ctx {
     hipEvent_t ev_up[RING] = {}, ev_down[RING] = {}, ev_et[RING][3] = {}, ev_gpu[RING] = {};
     void *ed_seg[RING] = {}, *ed_off[RING] = {}, *eh_off[RING] = {}; // hvc_jpeg_encode_batch_gpu: packed segments + offsets
     size_t e_seg_bytes = 0, e_off_bytes = 0;
+    // GPU Huffman decoder (hvc_jpeg_entropy_decode_gpu): device scratch, grown on demand
+    void *gd_ecs = nullptr, *gd_meta = nullptr, *gd_state = nullptr, *gd_tables = nullptr, *gd_coefs = nullptr;
+    size_t gd_ecs_cap = 0, gd_meta_cap = 0, gd_state_cap = 0, gd_tables_cap = 0, gd_coefs_cap = 0;
     // GPU Huffman coder (hvc_huffman_encode_frames): tables + scratch, grown on demand
     unsigned *hd_tables = nullptr;
     void *hd_lens = nullptr, *hd_meta = nullptr, *hd_bitbuf = nullptr, *hd_ff = nullptr, *hd_out = nullptr;
@@ -236,6 +240,11 @@ void hvc_destroy(hvc_ctx *c) {
     }
     for (int i = 0; i < 4; i++)
         if (c->ev_t[i]) (void)hipEventDestroy(c->ev_t[i]);
+    if (c->gd_ecs) (void)hipFree(c->gd_ecs);
+    if (c->gd_meta) (void)hipFree(c->gd_meta);
+    if (c->gd_state) (void)hipFree(c->gd_state);
+    if (c->gd_tables) (void)hipFree(c->gd_tables);
+    if (c->gd_coefs) (void)hipFree(c->gd_coefs);
     if (c->hd_tables) (void)hipFree(c->hd_tables);
     if (c->hd_lens) (void)hipFree(c->hd_lens);
     if (c->hd_meta) (void)hipFree(c->hd_meta);
@@ -1049,6 +1058,178 @@ int hvc_jpeg_decode_batch_yuv444(hvc_ctx *c, const uint8_t *const *jpegs, const 
                                  hvc_batch_stats *stats) {
     return decode_batch_impl(c, jpegs, sizes, n_frames, threads, frames_per_chunk, frames, frame_stride, where, stats,
                              true);
+}
+
+// ---------------------------------------------------------------------------
+// Huffman decoding on the GPU (hvc_hdec.hip).  Returns HVC_OK with *used_gpu = 1 when the coefficient
+// records at d_coefs are complete; HVC_OK with *used_gpu = 0 when the stream needs the host decoder
+// (nothing usable was written); or the error the host decoder would report while parsing headers.
+static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *sizes, int n_frames,
+                              const hvc_jpeg_info &info0, int16_t *d_coefs, size_t coef_fs, int *used_gpu) {
+    *used_gpu = 0;
+    hvc::HdTables tables0, t;
+    std::vector<std::vector<uint8_t>> ecs((size_t)n_frames);
+    for (int f = 0; f < n_frames; f++) {
+        hvc_jpeg_info fi;
+        int r = hvc_jpeg_read_header(jpegs[f], sizes[f], &fi);
+        if (r) return r;
+        if (fi.n_comp != info0.n_comp || fi.coef_count != info0.coef_count || std::memcmp(fi.layout, info0.layout, sizeof fi.layout) ||
+            std::memcmp(fi.comp, info0.comp, sizeof fi.comp))
+            return HVC_E_INVALID_ARG; // a batch shares one geometry
+        bool ok = false;
+        r = hvc::prepare_gpu_decode(jpegs[f], sizes[f], &fi, f == 0 ? tables0 : t, ecs[(size_t)f], ok);
+        if (r) return r;
+        if (!ok) return HVC_OK;
+        if (f > 0 && std::memcmp(&t, &tables0, sizeof t)) return HVC_OK; // different Huffman tables: host path
+    }
+    hvc::HdParams P;
+    std::memset(&P, 0, sizeof P);
+    P.n_frames = n_frames;
+    P.n_comp = info0.n_comp;
+    const hvc_jpeg_component &c0 = info0.comp[0];
+    P.mbs_wide = c0.decoded_width / (8 * c0.hscale);
+    P.mbs_high = c0.decoded_height / (8 * c0.vscale);
+    int base = 0;
+    for (int i = 0; i < info0.n_comp; i++) {
+        P.comp[i].h = info0.comp[i].hscale;
+        P.comp[i].v = info0.comp[i].vscale;
+        P.comp[i].bw = info0.layout[i].blocks_w;
+        P.comp[i].mcu_base = base;
+        P.comp[i].coef_off = info0.layout[i].coef_offset;
+        // the decoder raises when the MCU grid leaves a plane ("Plane.set out of bounds"): host path decides
+        if (P.mbs_wide * P.comp[i].h > info0.layout[i].blocks_w || P.mbs_high * P.comp[i].v > info0.layout[i].blocks_h)
+            return HVC_OK;
+        for (int k = 0; k < P.comp[i].h * P.comp[i].v; k++) P.b2comp[base + k] = (unsigned char)i;
+        base += P.comp[i].h * P.comp[i].v;
+    }
+    P.blocks_per_mcu = base;
+    const unsigned long long bpf = (unsigned long long)P.mbs_wide * P.mbs_high * base;
+    if (bpf == 0 || bpf >= (1ull << 31)) return HVC_OK;
+    P.blocks_per_frame = (unsigned)bpf;
+    // layout of the segment buffer and the per-subsequence arrays
+    const unsigned SB = HVC_HD_SUBSEQ_BITS / 8;
+    std::vector<unsigned> ecs_off((size_t)n_frames), sub_off((size_t)n_frames + 1);
+    size_t bytes = 0, subs = 0;
+    for (int f = 0; f < n_frames; f++) {
+        const size_t nsub = (ecs[(size_t)f].size() + SB - 1) / SB + 1; // one extra: the reader sees zeros past the end
+        ecs_off[(size_t)f] = (unsigned)bytes;
+        sub_off[(size_t)f] = (unsigned)subs;
+        bytes += nsub * SB + 16;
+        subs += nsub;
+        if (bytes >= (1ull << 31) || subs >= (1ull << 31)) return HVC_OK;
+    }
+    sub_off[(size_t)n_frames] = (unsigned)subs;
+    P.total_sub = (unsigned)subs;
+    std::vector<uint8_t> h_ecs(bytes, 0);
+    std::vector<unsigned> frame_of(subs);
+    for (int f = 0; f < n_frames; f++) {
+        std::memcpy(h_ecs.data() + ecs_off[(size_t)f], ecs[(size_t)f].data(), ecs[(size_t)f].size());
+        for (unsigned k = sub_off[(size_t)f]; k < sub_off[(size_t)f + 1]; k++) frame_of[k] = (unsigned)f;
+    }
+    int r;
+    const size_t meta_words = (size_t)n_frames + ((size_t)n_frames + 1) + subs + (size_t)n_frames + 2;
+    if ((r = grow(c, &c->gd_ecs, &c->gd_ecs_cap, bytes))) return r;
+    if ((r = grow(c, &c->gd_meta, &c->gd_meta_cap, meta_words * sizeof(unsigned) + 64))) return r;
+    if ((r = grow(c, &c->gd_state, &c->gd_state_cap, subs * (3 * sizeof(unsigned long long) + sizeof(unsigned)) + 64))) return r;
+    if ((r = grow(c, &c->gd_tables, &c->gd_tables_cap, sizeof(hvc::HdTables)))) return r;
+    unsigned *m = (unsigned *)c->gd_meta;
+    unsigned *d_ecs_off = m, *d_sub_off = m + n_frames, *d_frame_of = d_sub_off + n_frames + 1;
+    unsigned *d_frame_blocks = d_frame_of + subs, *d_flags = d_frame_blocks + n_frames;
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->gd_ecs, h_ecs.data(), bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_ecs_off, ecs_off.data(), (size_t)n_frames * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_sub_off, sub_off.data(), ((size_t)n_frames + 1) * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_frame_of, frame_of.data(), subs * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->gd_tables, &tables0, sizeof tables0, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemsetAsync(d_flags, 0, 2 * sizeof(unsigned), st));
+    P.ecs = (const uint8_t *)c->gd_ecs;
+    P.ecs_off = d_ecs_off;
+    P.sub_off = d_sub_off;
+    P.frame_of = d_frame_of;
+    P.tables = (const hvc::HdTables *)c->gd_tables;
+    P.coefs = d_coefs;
+    P.coef_fs = coef_fs;
+    unsigned long long *sp = (unsigned long long *)c->gd_state;
+    P.start_used = sp;
+    P.exit_a = sp + subs;
+    P.exit_b = sp + 2 * subs;
+    P.nblk = (unsigned *)(sp + 3 * subs);
+    P.frame_blocks = d_frame_blocks;
+    P.changed = d_flags;
+    P.status = d_flags + 1;
+    // clear_block for every block: only non-zero coefficients are stored
+    for (int f = 0; f < n_frames; f++)
+        HIPCHK(c, hipMemsetAsync(d_coefs + (size_t)f * coef_fs, 0, info0.coef_count * sizeof(int16_t), st));
+    // synchronisation rounds: until a round changes no start state
+    int round = 0;
+    const int max_rounds = 48;
+    for (;; round++) {
+        if (round > 0) HIPCHK(c, hipMemsetAsync(P.changed, 0, sizeof(unsigned), st));
+        HIPCHK(c, hvc::launch_hd_round(P, round, st));
+        if (round >= 1) {
+            unsigned changed = 0;
+            HIPCHK(c, hipMemcpyAsync(&changed, P.changed, sizeof changed, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            if (!changed) break;
+            if (round >= max_rounds) return HVC_OK; // does not settle: let the host decoder handle it
+        }
+    }
+    HIPCHK(c, hvc::launch_hd_finish(P, round, st));
+    unsigned status = 0;
+    HIPCHK(c, hipMemcpyAsync(&status, P.status, sizeof status, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (status) return HVC_OK; // the model raises / range / truncated stream: the host decoder reproduces it exactly
+    *used_gpu = 1;
+    return HVC_OK;
+}
+
+int hvc_jpeg_entropy_decode_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *sizes, int n_frames, int16_t *coefs,
+                                size_t coef_fs, int where, hvc_jpeg_info *info, int *used_gpu) {
+    if (!c || !jpegs || !sizes || !coefs || !info || n_frames < 1) return HVC_E_INVALID_ARG;
+    if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
+    int r = hvc_jpeg_read_header(jpegs[0], sizes[0], info);
+    if (r) return r;
+    if ((n_frames > 1 && coef_fs < info->coef_count) || (coef_fs & 7)) return HVC_E_INVALID_ARG;
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
+    int16_t *d = coefs;
+    const size_t total = ((size_t)(n_frames - 1) * coef_fs + info->coef_count) * sizeof(int16_t);
+    if (where == HVC_MEM_HOST) {
+        if ((r = grow(c, &c->gd_coefs, &c->gd_coefs_cap, total))) return r;
+        d = (int16_t *)c->gd_coefs;
+    } else if ((uintptr_t)coefs & 15) {
+        return HVC_E_ALIGNMENT;
+    }
+    int gpu = 0;
+    r = gpu_entropy_decode(c, jpegs, sizes, n_frames, *info, d, coef_fs, &gpu);
+    if (r) return r;
+    if (used_gpu) *used_gpu = gpu;
+    if (gpu) {
+        if (where == HVC_MEM_HOST) {
+            for (int f = 0; f < n_frames; f++)
+                HIPCHK(c, hipMemcpyAsync(coefs + (size_t)f * coef_fs, d + (size_t)f * coef_fs, info->coef_count * sizeof(int16_t),
+                                         hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        return HVC_OK;
+    }
+    // host decoder (exact model behaviour for everything unusual)
+    std::vector<int16_t> tmp;
+    for (int f = 0; f < n_frames; f++) {
+        hvc_jpeg_info fi;
+        if ((r = hvc_jpeg_read_header(jpegs[f], sizes[f], &fi))) return r;
+        if (fi.coef_count != info->coef_count || std::memcmp(fi.layout, info->layout, sizeof fi.layout)) return HVC_E_INVALID_ARG;
+        if (where == HVC_MEM_HOST) {
+            if ((r = hvc_jpeg_entropy_decode(jpegs[f], sizes[f], &fi, coefs + (size_t)f * coef_fs))) return r;
+        } else {
+            tmp.resize(info->coef_count);
+            if ((r = hvc_jpeg_entropy_decode(jpegs[f], sizes[f], &fi, tmp.data()))) return r;
+            HIPCHK(c, hipMemcpyAsync(coefs + (size_t)f * coef_fs, tmp.data(), info->coef_count * sizeof(int16_t),
+                                     hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+    }
+    return HVC_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -19,6 +19,7 @@
 #include <emmintrin.h>
 
 #include "../../include/hvc_jpeg.h"
+#include "hvc_hdec.h"
 #include "hvc_kernels.h"
 
 namespace {
@@ -687,6 +688,74 @@ void default_enc_tables(uint32_t (*out)[16 + 256]) {
         for (int i = 0; i < 16; i++) out[t][i] = ((uint32_t)et[t].dc[i].bits << 5) | et[t].dc[i].len;
         for (int i = 0; i < 256; i++) out[t][16 + i] = ((uint32_t)et[t].ac[i].bits << 5) | et[t].ac[i].len;
     }
+}
+
+// ECS extraction shared by the host decoder and the GPU decoder: extract_entropy_coded_bits
+// (decoder.ml:261-281): up to the first marker, 0xff00 -> 0xff
+static void extract_ecs(const uint8_t *data, size_t n, size_t pos, std::vector<uint8_t> &ecs) {
+    ecs.clear();
+    ecs.reserve((n > pos ? n - pos : 0) + 16);
+    while (pos < n) {
+        const uint8_t *ff = (const uint8_t *)std::memchr(data + pos, 0xff, n - pos);
+        const size_t stop = ff ? (size_t)(ff - data) : n;
+        ecs.insert(ecs.end(), data + pos, data + stop);
+        if (!ff) break;
+        const int next = stop + 1 < n ? data[stop + 1] : 0;
+        if (next != 0x00) break;
+        ecs.push_back(0xff);
+        pos = stop + 2;
+    }
+}
+
+int prepare_gpu_decode(const uint8_t *jpeg, size_t n, const ::hvc_jpeg_info *info, HdTables &t, std::vector<uint8_t> &ecs,
+                       bool &gpu_ok) {
+    gpu_ok = false;
+    Header h;
+    int r = parse_header(jpeg, n, h);
+    if (r) return r;
+    std::memset(&t, 0, sizeof t);
+    auto fill = [&](const HuffSpec &s, HdTable &o) -> bool {
+        int maxb = 0;
+        for (int i = 0; i < 16; i++)
+            if (s.lengths[i]) maxb = i + 1;
+        o.max_bits = maxb;
+        unsigned code = 0;
+        int k = 0;
+        unsigned long long kraft = 0; // in units of 2^-16
+        for (int len = 1; len <= 16; len++) {
+            o.first[len] = code;
+            o.count[len] = (uint16_t)s.lengths[len - 1];
+            o.voff[len] = (uint16_t)k;
+            for (int i = 0; i < s.lengths[len - 1]; i++, k++) {
+                o.vals[k] = (uint8_t)s.values[k];
+                if (len <= 10) {
+                    const unsigned f0 = (code + (unsigned)i) << (10 - len), fc = 1u << (10 - len);
+                    for (unsigned j = 0; j < fc && f0 + j < 1024u; j++) o.fast[f0 + j] = (uint16_t)((len << 8) | s.values[k]);
+                }
+            }
+            kraft += (unsigned long long)s.lengths[len - 1] << (16 - len);
+            code = (code + (unsigned)s.lengths[len - 1]) << 1;
+        }
+        return kraft <= (1ull << 16); // a prefix code (possibly incomplete): the canonical search equals the model's LUT
+    };
+    bool ok = true;
+    for (int i = 0; i < info->n_comp; i++) {
+        int di = -1, ai = -1; // find_huffman_table (decoder.ml:238-259): newest match
+        for (int k = (int)h.dht.size() - 1; k >= 0; k--) {
+            if (di < 0 && h.dht[k].tclass == 0 && h.dht[k].id == info->comp[i].dc_table) di = k;
+            if (ai < 0 && h.dht[k].tclass == 1 && h.dht[k].id == info->comp[i].ac_table) ai = k;
+        }
+        if (di < 0 || ai < 0) return HVC_E_BAD_JPEG;
+        Lut probe; // the host decoder's own validity check
+        if (!probe.build(h.dht[di].spec) || !probe.build(h.dht[ai].spec)) return HVC_E_BAD_JPEG;
+        ok &= fill(h.dht[di].spec, t.dc[i]);
+        ok &= fill(h.dht[ai].spec, t.ac[i]);
+    }
+    extract_ecs(jpeg, n, h.ecs_pos, ecs);
+    int per_mcu = 0;
+    for (int i = 0; i < info->n_comp; i++) per_mcu += info->comp[i].hscale * info->comp[i].vscale;
+    gpu_ok = ok && per_mcu <= HVC_HD_MAX_MCU_BLOCKS && ecs.size() < (1u << 28);
+    return HVC_OK;
 }
 } // namespace hvc
 

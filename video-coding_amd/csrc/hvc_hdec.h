@@ -1,0 +1,71 @@
+// hvc_hdec.h -- parameter blocks of the GPU Huffman DEcoder (internal).
+#ifndef HVC_HDEC_H
+#define HVC_HDEC_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <vector>
+
+struct hvc_jpeg_info;
+
+namespace hvc {
+
+// One Huffman table as the GPU decoder reads it (built on the host from the DHT segment the model's
+// find_huffman_table picks, decoder.ml:238-259; canonical code assignment of tables.ml:27-45).
+struct HdTable {
+    uint16_t fast[1024];  // (length << 8) | value for codes of <= 10 bits, indexed by the next 10 bits; 0 = longer / none
+    uint32_t first[17];   // first code of each length (as a `length`-bit number)
+    uint16_t count[17];   // codes of each length
+    uint16_t voff[17];    // index into vals of the first code of each length
+    uint8_t vals[256];
+    int32_t max_bits;
+};
+struct HdTables {
+    HdTable dc[4], ac[4]; // per scan component
+};
+
+#define HVC_HD_SUBSEQ_BITS 1024 /* bits per lane in the synchronisation rounds */
+#define HVC_HD_MAX_MCU_BLOCKS 16
+
+struct HdComp {
+    int h, v, bw;      // sampling factors, plane width in blocks
+    int mcu_base;      // first block of the component inside an MCU
+    size_t coef_off;   // int16 elements from the frame's coefficient record
+};
+
+struct HdParams {
+    const uint8_t *ecs;        // the frames' unstuffed entropy-coded segments, each followed by zero padding
+    const unsigned *ecs_off;   // [n_frames] byte offset of frame f's segment inside ecs (multiple of 4)
+    const unsigned *sub_off;   // [n_frames + 1] first subsequence of every frame
+    const unsigned *frame_of;  // [total_sub] frame of every subsequence
+    const HdTables *tables;    // device
+    int n_frames;
+    unsigned total_sub;
+    int n_comp, blocks_per_mcu, mbs_wide, mbs_high;
+    unsigned blocks_per_frame;
+    HdComp comp[4];
+    unsigned char b2comp[HVC_HD_MAX_MCU_BLOCKS];
+    int16_t *coefs;
+    size_t coef_fs;
+    // per subsequence: state = bit position | k << 32 | block-in-MCU << 40
+    unsigned long long *start_used, *exit_a, *exit_b;
+    unsigned *nblk;            // blocks completed inside the subsequence, then (scan) index of its first block
+    unsigned *frame_blocks;    // [n_frames] blocks found in the whole segment
+    unsigned *changed;         // [1]
+    unsigned *status;          // [1] bit 0: invalid code / index out of range / DC category > 16 inside the coded blocks,
+                               //     bit 1: DC outside int16, bit 2: fewer blocks than the frame needs (truncated stream)
+};
+
+hipError_t launch_hd_round(const HdParams &P, int round, hipStream_t s);
+hipError_t launch_hd_finish(const HdParams &P, int rounds_done, hipStream_t s); // count scan, write pass, DC pass
+
+// hvc_entropy.cpp: header parse + table preparation + unstuffing for one file
+// returns HVC_OK, or an hvc_status the host decoder would also return at this stage;
+// gpu_ok = false when the stream needs the host decoder (tables that are no prefix code, > 16 blocks per MCU)
+int prepare_gpu_decode(const uint8_t *jpeg, size_t n, const ::hvc_jpeg_info *info, HdTables &t, std::vector<uint8_t> &ecs,
+                       bool &gpu_ok);
+
+} // namespace hvc
+#endif

@@ -20,7 +20,7 @@ SYMBOLS = [
     "hvc_device_free", "hvc_memcpy_h2d", "hvc_memcpy_d2h",
     "hvc_jpeg_read_header", "hvc_jpeg_entropy_decode", "hvc_jpeg_get_yuv_frame", "hvc_jpeg_decode",
     "hvc_jpeg_decode_batch", "hvc_quant_table", "hvc_jpeg_encoder_layout", "hvc_jpeg_entropy_encode",
-    "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444", "hvc_jpeg_decode_yuv444", "hvc_compare_planes", "hvc_jpeg_encode_batch", "hvc_jpeg_decode_batch_yuv444", "hvc_jpeg_encoder_check", "hvc_huffman_encode_frames", "hvc_jpeg_header", "hvc_jpeg_encode_batch_gpu",
+    "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444", "hvc_jpeg_decode_yuv444", "hvc_compare_planes", "hvc_jpeg_encode_batch", "hvc_jpeg_decode_batch_yuv444", "hvc_jpeg_encoder_check", "hvc_huffman_encode_frames", "hvc_jpeg_header", "hvc_jpeg_encode_batch_gpu", "hvc_jpeg_entropy_decode_gpu",
 ]
 
 
@@ -127,6 +127,7 @@ def lib():
         L.hvc_jpeg_decode_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), i, i, i, vp, sz, i,
                                             C.POINTER(BatchStats)]
         L.hvc_quant_table.argtypes = [i, i, vp]
+        L.hvc_jpeg_entropy_decode_gpu.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), i, vp, sz, i, ip, C.POINTER(i)]
         L.hvc_huffman_encode_frames.argtypes = [vp, ip, vp, sz, i, vp, sz, vp, i]
         L.hvc_jpeg_header.argtypes = [ip, vp, sz, C.POINTER(sz)]
         L.hvc_jpeg_decode_batch_yuv444.argtypes = L.hvc_jpeg_decode_batch.argtypes
@@ -382,6 +383,25 @@ class Context:
         _chk(lib().hvc_jpeg_encode(self._h, y.ctypes.data, u.ctypes.data, v.ctypes.data, width, height, chroma, quality,
                                    out.ctypes.data, cap, C.byref(n)), "hvc_jpeg_encode")
         return out[:n.value].tobytes()
+
+    def jpeg_entropy_decode_gpu(self, jpegs, device=False):
+        """Huffman decoding of a batch of files on the GPU: (info, coefficient records [n][coef_count], used_gpu)"""
+        n = len(jpegs)
+        info = jpeg_read_header(jpegs[0])
+        ptrs = (C.c_void_p * n)(*[C.cast(C.c_char_p(j), C.c_void_p) for j in jpegs])
+        sizes = (C.c_size_t * n)(*[len(j) for j in jpegs])
+        used = C.c_int(-1)
+        if device:
+            import torch
+            out = torch.empty((n, info.coef_count), dtype=torch.int16, device="cuda")
+            torch.cuda.synchronize()
+            _chk(lib().hvc_jpeg_entropy_decode_gpu(self._h, ptrs, sizes, n, out.data_ptr(), info.coef_count, 1,
+                                                   C.byref(info), C.byref(used)), "hvc_jpeg_entropy_decode_gpu")
+            return info, out.cpu().numpy(), used.value
+        out = np.empty((n, info.coef_count), dtype=np.int16)
+        _chk(lib().hvc_jpeg_entropy_decode_gpu(self._h, ptrs, sizes, n, out.ctypes.data, info.coef_count, 0, C.byref(info),
+                                               C.byref(used)), "hvc_jpeg_entropy_decode_gpu")
+        return info, out, used.value
 
     def huffman_encode_frames(self, info, coefs, coef_frame_stride, n_frames, out_cap=None):
         """Encoder back end on the GPU: (list of per-frame entropy-coded segments as bytes).  coefs: host
