@@ -1114,7 +1114,7 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
         const size_t nsub = (ecs[(size_t)f].size() + SB - 1) / SB + 1; // one extra: the reader sees zeros past the end
         ecs_off[(size_t)f] = (unsigned)bytes;
         sub_off[(size_t)f] = (unsigned)subs;
-        bytes += nsub * SB + 16;
+        bytes += nsub * SB + 16; // SB = 128: every frame starts on a 16-byte boundary, 16 zero bytes of overshoot
         subs += nsub;
         if (bytes >= (1ull << 31) || subs >= (1ull << 31)) return HVC_OK;
     }

@@ -715,30 +715,35 @@ int prepare_gpu_decode(const uint8_t *jpeg, size_t n, const ::hvc_jpeg_info *inf
     if (r) return r;
     std::memset(&t, 0, sizeof t);
     auto fill = [&](const HuffSpec &s, HdTable &o) -> bool {
-        int maxb = 0;
-        for (int i = 0; i < 16; i++)
-            if (s.lengths[i]) maxb = i + 1;
-        o.max_bits = maxb;
         unsigned code = 0;
-        int k = 0;
+        int k = 0, nsub = 0;
         unsigned long long kraft = 0; // in units of 2^-16
         for (int len = 1; len <= 16; len++) {
-            o.first[len] = code;
-            o.count[len] = (uint16_t)s.lengths[len - 1];
-            o.voff[len] = (uint16_t)k;
             for (int i = 0; i < s.lengths[len - 1]; i++, k++) {
-                o.vals[k] = (uint8_t)s.values[k];
+                const unsigned cw = code + (unsigned)i; // canonical code of this symbol, `len` bits
+                const uint16_t entry = (uint16_t)((len << 8) | s.values[k]);
                 if (len <= 10) {
-                    const unsigned f0 = (code + (unsigned)i) << (10 - len), fc = 1u << (10 - len);
-                    for (unsigned j = 0; j < fc && f0 + j < 1024u; j++) o.fast[f0 + j] = (uint16_t)((len << 8) | s.values[k]);
+                    const unsigned f0 = cw << (10 - len), fc = 1u << (10 - len);
+                    for (unsigned j = 0; j < fc && f0 + j < 1024u; j++) o.fast[f0 + j] = entry;
+                } else {
+                    const unsigned prefix = cw >> (len - 10);
+                    if (prefix >= 1024u) return false;
+                    if (!(o.fast[prefix] & 0x8000u)) {
+                        if (o.fast[prefix] != 0 || nsub == HVC_HD_SUBTABLES) return false; // no prefix code / pool exhausted
+                        o.fast[prefix] = (uint16_t)(0x8000u | (unsigned)nsub++);
+                    }
+                    const unsigned sub = o.fast[prefix] & 0x7fffu;
+                    const unsigned rest = cw & ((1u << (len - 10)) - 1u); // the len - 10 bits after the prefix
+                    const unsigned f0 = rest << (16 - len), fc = 1u << (16 - len);
+                    for (unsigned j = 0; j < fc; j++) o.sub[sub * 64 + f0 + j] = entry;
                 }
             }
             kraft += (unsigned long long)s.lengths[len - 1] << (16 - len);
             code = (code + (unsigned)s.lengths[len - 1]) << 1;
         }
-        return kraft <= (1ull << 16); // a prefix code (possibly incomplete): the canonical search equals the model's LUT
+        return kraft <= (1ull << 16); // a prefix code (possibly incomplete): the two-level table equals the model's LUT
     };
-    bool ok = true;
+    bool ok = info->n_comp <= 3;
     for (int i = 0; i < info->n_comp; i++) {
         int di = -1, ai = -1; // find_huffman_table (decoder.ml:238-259): newest match
         for (int k = (int)h.dht.size() - 1; k >= 0; k--) {
@@ -748,13 +753,15 @@ int prepare_gpu_decode(const uint8_t *jpeg, size_t n, const ::hvc_jpeg_info *inf
         if (di < 0 || ai < 0) return HVC_E_BAD_JPEG;
         Lut probe; // the host decoder's own validity check
         if (!probe.build(h.dht[di].spec) || !probe.build(h.dht[ai].spec)) return HVC_E_BAD_JPEG;
-        ok &= fill(h.dht[di].spec, t.dc[i]);
-        ok &= fill(h.dht[ai].spec, t.ac[i]);
+        if (i < 3) {
+            ok = ok && fill(h.dht[di].spec, t.dc[i]);
+            ok = ok && fill(h.dht[ai].spec, t.ac[i]);
+        }
     }
     extract_ecs(jpeg, n, h.ecs_pos, ecs);
     int per_mcu = 0;
     for (int i = 0; i < info->n_comp; i++) per_mcu += info->comp[i].hscale * info->comp[i].vscale;
-    gpu_ok = ok && per_mcu <= HVC_HD_MAX_MCU_BLOCKS && ecs.size() < (1u << 28);
+    gpu_ok = ok && info->n_comp <= 3 && per_mcu <= HVC_HD_MAX_MCU_BLOCKS && ecs.size() < (1u << 28);
     return HVC_OK;
 }
 } // namespace hvc

@@ -12,18 +12,18 @@ struct hvc_jpeg_info;
 
 namespace hvc {
 
+#define HVC_HD_SUBTABLES 8 /* 10-bit prefixes that continue into longer codes, per table */
+
 // One Huffman table as the GPU decoder reads it (built on the host from the DHT segment the model's
 // find_huffman_table picks, decoder.ml:238-259; canonical code assignment of tables.ml:27-45).
 struct HdTable {
-    uint16_t fast[1024];  // (length << 8) | value for codes of <= 10 bits, indexed by the next 10 bits; 0 = longer / none
-    uint32_t first[17];   // first code of each length (as a `length`-bit number)
-    uint16_t count[17];   // codes of each length
-    uint16_t voff[17];    // index into vals of the first code of each length
-    uint8_t vals[256];
-    int32_t max_bits;
+    // (length << 8) | value for codes of <= 10 bits, indexed by the next 10 bits; 0 = no code;
+    // 0x8000 | n = the code is longer: entry sub[n * 64 + next 6 bits] has it (two-level table)
+    uint16_t fast[1024];
+    uint16_t sub[HVC_HD_SUBTABLES * 64];
 };
 struct HdTables {
-    HdTable dc[4], ac[4]; // per scan component
+    HdTable dc[3], ac[3]; // per scan component (the GPU path takes at most three)
 };
 
 #define HVC_HD_SUBSEQ_BITS 1024 /* bits per lane in the synchronisation rounds */

@@ -31,101 +31,132 @@ __device__ __forceinline__ unsigned long long pack_state(unsigned p, int k, int 
     return (unsigned long long)p | ((unsigned long long)(unsigned)k << 32) | ((unsigned long long)(unsigned)b << 40);
 }
 
-// 64 bits of the stream starting at bit position p (MSB first), from a zero-padded byte buffer
-__device__ __forceinline__ unsigned long long window(const uint8_t *ecs, unsigned p) {
-    typedef unsigned unaligned_u32 __attribute__((aligned(1)));
-    const uint8_t *q = ecs + (p >> 3);
-    const unsigned a = __builtin_bswap32(*reinterpret_cast<const unaligned_u32 *>(q));
-    const unsigned b = __builtin_bswap32(*reinterpret_cast<const unaligned_u32 *>(q + 4));
-    const unsigned c = __builtin_bswap32(*reinterpret_cast<const unaligned_u32 *>(q + 8));
-    const unsigned long long hi = ((unsigned long long)a << 32) | b;
-    const int sh = (int)(p & 7u);
-    return sh ? (hi << sh) | ((unsigned long long)c >> (32 - sh)) : hi;
+// Every lane stages the bytes its subsequence can touch -- its 128 bytes plus 16 of overshoot -- in LDS
+// (36 dwords, row stride 37 against bank conflicts): the symbol loop then never waits for global memory.
+constexpr int SLOT = 37;
+__device__ __forceinline__ void stage_bits(const uint8_t *ecs, unsigned j, unsigned *slot) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(ecs + (size_t)j * (S / 8)); // frames start on 16-byte boundaries
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+        const uint4 t = src[q];
+        slot[4 * q + 0] = __builtin_bswap32(t.x);
+        slot[4 * q + 1] = __builtin_bswap32(t.y);
+        slot[4 * q + 2] = __builtin_bswap32(t.z);
+        slot[4 * q + 3] = __builtin_bswap32(t.w);
+    }
 }
-
 // (length << 8) | value, 0 = no code.  w = the next 64 bits.
 __device__ __forceinline__ unsigned lookup(const HdTable &t, unsigned long long w) {
     unsigned e = t.fast[(unsigned)(w >> 54)];
-    if (e) return e;
-    for (int len = 11; len <= t.max_bits; len++) {
-        const unsigned code = (unsigned)(w >> (64 - len));
-        const unsigned d = code - t.first[len];
-        if (code >= t.first[len] && d < t.count[len]) return ((unsigned)len << 8) | t.vals[t.voff[len] + d];
-    }
-    return 0;
+    if (e & 0x8000u) e = t.sub[(e & 0x7fffu) * 64u + ((unsigned)(w >> 48) & 63u)];
+    return e;
 }
 
 __device__ __forceinline__ int extend(int cat, unsigned code) { // decoder.ml:73-79 mag'
     return (code & (1u << (cat - 1))) ? (int)code : (int)code - (int)((1u << cat) - 1);
 }
 
+// The lane-varying part of the geometry, copied to LDS once per workgroup: indexing the kernel
+// argument block with a per-lane index makes every access a load from the kernarg segment (host memory:
+// ~1.5 us each -- it was 90 % of the first version's time).
+struct HdGeo {
+    int h[4], v[4], bw[4], mcu_base[4];
+    unsigned coef_off[4];
+    unsigned char b2comp[HVC_HD_MAX_MCU_BLOCKS];
+};
+__device__ __forceinline__ void load_geo(const HdParams &P, HdGeo &G) {
+    if (threadIdx.x < 4) {
+        const int i = threadIdx.x;
+        G.h[i] = P.comp[i].h;
+        G.v[i] = P.comp[i].v;
+        G.bw[i] = P.comp[i].bw;
+        G.mcu_base[i] = P.comp[i].mcu_base;
+        G.coef_off[i] = (unsigned)P.comp[i].coef_off;
+    }
+    if (threadIdx.x < HVC_HD_MAX_MCU_BLOCKS) G.b2comp[threadIdx.x] = P.b2comp[threadIdx.x];
+}
+
 // WRITE = false: walk only.  WRITE = true: store coefficients of blocks [0, blocks_per_frame).
 // Decodes symbols while p < limit.  Returns the exit state through p, k, b and the number of blocks
 // completed in nb.  err: bit 0 set when the walk hits something the model raises on.
 template <bool WRITE>
-__device__ __forceinline__ void walk(const HdParams &P, const HdTables &T, const uint8_t *ecs, unsigned limit, unsigned &p,
-                                     int &k, int &b, unsigned &nb, unsigned first_block, int16_t *rec, unsigned &err) {
+__device__ __forceinline__ void walk(const HdParams &P, const HdGeo &G, const HdTables &T, const unsigned *slot, unsigned base, unsigned limit,
+                                     unsigned &p, int &k, int &b, unsigned &nb, unsigned first_block, int16_t *rec,
+                                     unsigned &err) {
     const int B = P.blocks_per_mcu;
     unsigned bi = first_block;
     int16_t *blk = nullptr;
     auto block_ptr = [&](unsigned index, int bb) -> int16_t * {
         const unsigned mcu = index / (unsigned)B;
-        const int comp = P.b2comp[bb];
-        const HdComp &C = P.comp[comp];
-        const int r = bb - C.mcu_base, sy = r / C.h, sx = r - sy * C.h;
+        const int comp = G.b2comp[bb];
+        const int ch = G.h[comp], cv = G.v[comp];
+        const int r = bb - G.mcu_base[comp], sy = r / ch, sx = r - sy * ch;
         const unsigned my = mcu / (unsigned)P.mbs_wide, mx = mcu - my * (unsigned)P.mbs_wide;
-        return rec + C.coef_off + ((size_t)(my * C.v + sy) * C.bw + (size_t)(mx * C.h + sx)) * 64;
+        return rec + G.coef_off[comp] + ((size_t)(my * cv + sy) * G.bw[comp] + (size_t)(mx * ch + sx)) * 64;
     };
-    if (WRITE && bi < P.blocks_per_frame) blk = block_ptr(bi, b);
+    bool live = WRITE && bi < P.blocks_per_frame; // this block's coefficients are stored (and its errors count)
+    if (live) blk = block_ptr(bi, b);
+    // The serial chain per symbol is what bounds the whole decoder, so it is kept short: a 64-bit
+    // MSB-aligned window in registers (refilled a dword at a time from the lane's LDS slot, the next
+    // dword already loaded), one table load, and no per-symbol geometry look-ups (component and
+    // table pointers change only at block ends).
+    unsigned off = p - base;               // bits consumed from the slot so far
+    unsigned wi = (off >> 5) + 2;          // next dword of the slot to append
+    unsigned long long buf = (((unsigned long long)slot[off >> 5] << 32) | slot[(off >> 5) + 1]) << (off & 31u);
+    int avail = 64 - (int)(off & 31u);
+    unsigned nextw = slot[wi];
+    int comp = G.b2comp[b];
+    const HdTable *dct = &T.dc[comp], *act = &T.ac[comp];
     while (p < limit) {
-        const unsigned long long w = window(ecs, p);
-        const int comp = P.b2comp[b];
+        if (avail <= 32) { // append the pre-loaded dword; fetch the one after (wi stays inside the 36-dword slot)
+            buf |= (unsigned long long)nextw << (32 - avail);
+            avail += 32;
+            wi++;
+            nextw = slot[min(wi, 35u)];
+        }
+        const HdTable &t = k ? *act : *dct;
+        const unsigned e = lookup(t, buf);
+        if (!e) { // "Can't find dc / ac code": a real error in the true parse, noise in a speculative one
+            if (live) err |= 1u;
+            buf <<= 1;
+            avail -= 1;
+            p += 1;
+            continue;
+        }
+        const int len = (int)(e >> 8), val = (int)(e & 0xffu);
+        const bool is_dc = k == 0;
+        const int size = is_dc ? val : (val & 15), run = is_dc ? 0 : (val >> 4);
+        if (is_dc && size > 16) { // DC category above 16
+            if (live) err |= 1u;
+            buf <<= len;
+            avail -= len;
+            p += (unsigned)len;
+            continue;
+        }
+        int mag = 0;
+        if (size) mag = extend(size, (unsigned)((buf << len) >> (64 - size)));
+        const int used = len + size; // <= 32
+        buf <<= used;
+        avail -= used;
+        p += (unsigned)used;
         bool end_block = false;
-        if (k == 0) {
-            const unsigned e = lookup(T.dc[comp], w);
-            if (!e) { // "Can't find dc code": a real error in the true parse, noise in a speculative one
-                if (WRITE && bi < P.blocks_per_frame) err |= 1u;
-                p += 1;
-                continue;
-            }
-            const int len = (int)(e >> 8), cat = (int)(e & 0xffu);
-            if (cat > 16) {
-                if (WRITE && bi < P.blocks_per_frame) err |= 1u;
-                p += (unsigned)len;
-                continue;
-            }
-            int diff = 0;
-            if (cat) diff = extend(cat, (unsigned)((w << len) >> (64 - cat)));
-            p += (unsigned)(len + cat);
-            if (WRITE && bi < P.blocks_per_frame) {
-                // the difference; k_hd_dc turns it into the value.  A category above 15 cannot be an int16: flagged there
-                blk[0] = (int16_t)diff;
-                if (diff < -32768 || diff > 32767) err |= 2u;
+        if (is_dc) {
+            if (live) { // the difference; k_hd_dc turns it into the value
+                blk[0] = (int16_t)mag;
+                if (mag < -32768 || mag > 32767) err |= 2u;
             }
             k = 1;
+        } else if (mag == 0 && run == 0) { // EOB (or any zero-size code with run 0), decoder.ml:131-132
+            end_block = true;
         } else {
-            const unsigned e = lookup(T.ac[comp], w);
-            if (!e) { // "Can't find ac code"
-                if (WRITE && bi < P.blocks_per_frame) err |= 1u;
-                p += 1;
-                continue;
-            }
-            const int len = (int)(e >> 8), run = (int)((e >> 4) & 15u), size = (int)(e & 15u);
-            int mag = 0;
-            if (size) mag = extend(size, (unsigned)((w << len) >> (64 - size)));
-            p += (unsigned)(len + size);
-            if (mag == 0 && run == 0) { // EOB (or any zero-size code with run 0), decoder.ml:131-132
+            k += run;
+            if (k >= 64) { // "coefficient index out of range"
+                if (live) err |= 1u;
                 end_block = true;
             } else {
-                k += run;
-                if (k >= 64) { // "coefficient index out of range"
-                    if (WRITE && bi < P.blocks_per_frame) err |= 1u;
-                    end_block = true;
-                } else {
-                    if (WRITE && bi < P.blocks_per_frame && mag) blk[k] = (int16_t)mag;
-                    k++;
-                    if (k == 64) end_block = true;
-                }
+                if (live && mag) blk[k] = (int16_t)mag;
+                k++;
+                end_block = k == 64;
             }
         }
         if (end_block) {
@@ -133,44 +164,80 @@ __device__ __forceinline__ void walk(const HdParams &P, const HdTables &T, const
             b = b + 1 == B ? 0 : b + 1;
             nb++;
             bi++;
-            if (WRITE && bi < P.blocks_per_frame) blk = block_ptr(bi, b);
+            comp = G.b2comp[b];
+            dct = &T.dc[comp];
+            act = &T.ac[comp];
+            live = WRITE && bi < P.blocks_per_frame;
+            if (live) blk = block_ptr(bi, b);
         }
     }
 }
 
 } // namespace
 
-// One synchronisation round (see the header comment).  Even rounds write exit_a, odd rounds exit_b.
+// One synchronisation launch (see the header comment).  Even launches write exit_a, odd ones exit_b.
+// Inside the launch the 256 subsequences of a workgroup run up to INNER rounds among themselves through
+// LDS (exit of lane t - 1 -> start of lane t), so a launch settles whole workgroups and the launches only
+// have to carry states across workgroup boundaries.
+constexpr int INNER = 24;
 __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
     __shared__ HdTables T;
+    __shared__ HdGeo G;
+    __shared__ unsigned bits[256 * SLOT];
+    __shared__ unsigned long long exits[256];
+    load_geo(P, G);
     {
         const unsigned *src = reinterpret_cast<const unsigned *>(P.tables);
         unsigned *dst = reinterpret_cast<unsigned *>(&T);
         for (unsigned i = threadIdx.x; i < sizeof(HdTables) / 4; i += 256) dst[i] = src[i];
     }
+    const int tid = threadIdx.x;
+    const unsigned i = blockIdx.x * 256u + (unsigned)tid;
+    const bool valid = i < P.total_sub;
+    const unsigned f = valid ? P.frame_of[i] : 0u, j = valid ? i - P.sub_off[f] : 0u;
+    unsigned *slot = bits + tid * SLOT;
+    if (valid) stage_bits(P.ecs + P.ecs_off[f], j, slot);
     __syncthreads();
-    const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= P.total_sub) return;
-    const unsigned f = P.frame_of[i], j = i - P.sub_off[f];
     const unsigned long long *prev = (round & 1) ? P.exit_a : P.exit_b;
     unsigned long long *cur = (round & 1) ? P.exit_b : P.exit_a;
-    unsigned long long st;
-    if (round == 0 || j == 0)
-        st = pack_state(j * (unsigned)S, 0, 0);
-    else
-        st = prev[i - 1];
-    if (round > 0 && st == P.start_used[i]) {
-        cur[i] = prev[i];
-        return;
+    const unsigned base = j * (unsigned)S;
+    unsigned long long st = pack_state(base, 0, 0), used = 0, ex = 0;
+    bool have = false; // a decode with start `used` exists (from an earlier launch or an inner round)
+    unsigned nb = 0;
+    if (valid && round > 0) {
+        used = P.start_used[i];
+        ex = prev[i];
+        nb = P.nblk[i];
+        have = true;
+        if (j > 0) st = prev[i - 1];
     }
-    unsigned p = (unsigned)st;
-    int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
-    unsigned nb = 0, err = 0;
-    walk<false>(P, T, P.ecs + P.ecs_off[f], (j + 1) * (unsigned)S, p, k, b, nb, 0, nullptr, err);
-    cur[i] = pack_state(p, k, b);
-    P.start_used[i] = st;
-    P.nblk[i] = nb;
-    if (round > 0) *P.changed = 1u; // benign race: every writer stores the same value
+    bool changed = false;
+    for (int inner = 0; inner < INNER; inner++) {
+        if (valid && (!have || st != used)) {
+            unsigned p = (unsigned)st, err = 0;
+            int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
+            nb = 0;
+            walk<false>(P, G, T, slot, base, base + (unsigned)S, p, k, b, nb, 0, nullptr, err);
+            ex = pack_state(p, k, b);
+            used = st;
+            have = true;
+            changed = true;
+        }
+        exits[tid] = ex;
+        __syncthreads();
+        bool again = false;
+        if (valid && j > 0 && tid > 0) { // the predecessor sits in this workgroup (and in this frame, since j > 0)
+            st = exits[tid - 1];
+            again = st != used;
+        }
+        if (!__syncthreads_or(again)) break;
+    }
+    if (valid) {
+        cur[i] = ex;
+        P.start_used[i] = used;
+        P.nblk[i] = nb;
+        if (changed && round > 0) *P.changed = 1u; // benign race: every writer stores the same value
+    }
 }
 
 // Exclusive scan of nblk inside every frame (one workgroup per frame); total -> frame_blocks.
@@ -210,23 +277,29 @@ __global__ __launch_bounds__(1024) void k_hd_scan(HdParams P) {
 // The write pass: every lane decodes its subsequence from its (now true) start and stores coefficients.
 __global__ __launch_bounds__(256) void k_hd_write(HdParams P, int final_round) {
     __shared__ HdTables T;
+    __shared__ HdGeo G;
+    __shared__ unsigned bits[256 * SLOT];
+    load_geo(P, G);
     {
         const unsigned *src = reinterpret_cast<const unsigned *>(P.tables);
         unsigned *dst = reinterpret_cast<unsigned *>(&T);
         for (unsigned i = threadIdx.x; i < sizeof(HdTables) / 4; i += 256) dst[i] = src[i];
     }
-    __syncthreads();
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= P.total_sub) return;
-    const unsigned f = P.frame_of[i], j = i - P.sub_off[f];
+    const bool valid = i < P.total_sub;
+    const unsigned f = valid ? P.frame_of[i] : 0u, j = valid ? i - P.sub_off[f] : 0u;
+    unsigned *slot = bits + threadIdx.x * SLOT;
+    if (valid) stage_bits(P.ecs + P.ecs_off[f], j, slot);
+    __syncthreads();
+    if (!valid) return;
     const unsigned first_block = P.nblk[i];
     if (first_block >= P.blocks_per_frame) return; // past the last coded block: the model never reads this far
     const unsigned long long st = P.start_used[i];
     unsigned p = (unsigned)st;
     int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
     unsigned nb = 0, err = 0;
-    walk<true>(P, T, P.ecs + P.ecs_off[f], (j + 1) * (unsigned)S, p, k, b, nb, first_block,
-               P.coefs + (size_t)f * P.coef_fs, err);
+    const unsigned base = j * (unsigned)S;
+    walk<true>(P, G, T, slot, base, base + (unsigned)S, p, k, b, nb, first_block, P.coefs + (size_t)f * P.coef_fs, err);
     if (err) atomicOr(P.status, err);
     (void)final_round;
 }
