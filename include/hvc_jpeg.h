@@ -260,6 +260,15 @@ HVC_API int hvc_compare_planes(const uint8_t *a, const uint8_t *b, size_t n, int
 /* Encoder.Parameters.c420/c422/c444 + Encoder.create geometry (encoder.ml:287-349, 437-472): chroma is
  * 420, 422 or 444.  Fills the padded plane layout (zero padding, plane.ml:11-17) and the tables. */
 HVC_API int hvc_jpeg_encoder_layout(int width, int height, int chroma, int quality, hvc_jpeg_info *info);
+/* hvc_jpeg_decode_batch (or _yuv444 when yuv444 != 0) with the Huffman reader on the GPU as well
+ * (hvc_jpeg_entropy_decode_gpu below): host threads only parse headers and unstuff the entropy-coded
+ * segments into a pinned ring, ~1 MB per 1080p frame crosses PCIe instead of 6 MB of coefficients, and
+ * the coefficient records are produced where the block stage reads them.  If any file needs the host
+ * decoder (see below) the whole call is redone by the host-decoder pipeline: same output, same errors. */
+HVC_API int hvc_jpeg_decode_batch_gpu(hvc_ctx *ctx, const uint8_t *const *jpegs, const size_t *sizes, int n_frames,
+                                      int threads, int frames_per_chunk, uint8_t *pixels,
+                                      size_t pixel_frame_stride, int where, int yuv444, hvc_batch_stats *stats);
+
 /* Huffman DEcoding on the GPU (csrc/hvc_hdec.hip): the entropy-coded segments of n_frames files (one
  * geometry, one set of Huffman tables, as in hvc_jpeg_decode_batch) -> coefficient records exactly as
  * hvc_jpeg_entropy_decode writes them.  The segment is cut into 1024-bit subsequences, one lane each;

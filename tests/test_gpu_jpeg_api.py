@@ -85,14 +85,15 @@ def _make_jpegs(n, w, h, q=75):
     return out
 
 
+@pytest.mark.parametrize("gpu_entropy", [False, True])
 @pytest.mark.parametrize("threads,chunk", [(1, 1), (4, 3), (8, 32)])
-def test_batch_pipeline_host_output(ctx, threads, chunk):
+def test_batch_pipeline_host_output(ctx, threads, chunk, gpu_entropy):
     import video_coding_amd as hvc
     jpegs = _make_jpegs(11, 96, 64)
     info = hvc.hvc.jpeg_read_header(jpegs[0])
     stride = info.pixel_bytes
     pixels = np.zeros(len(jpegs) * stride, dtype=np.uint8)
-    st = ctx.jpeg_decode_batch(jpegs, pixels, stride, threads=threads, frames_per_chunk=chunk)
+    st = ctx.jpeg_decode_batch(jpegs, pixels, stride, threads=threads, frames_per_chunk=chunk, gpu_entropy=gpu_entropy)
     assert st.chunks == (len(jpegs) + min(chunk, len(jpegs)) - 1) // min(chunk, len(jpegs))
     for f, j in enumerate(jpegs):
         d = orc.Decoder(j)
@@ -290,3 +291,49 @@ def test_encode_refuses_frames_the_model_cannot_walk(ctx):
         ctx.jpeg_encode(y, u, v, 17, 9, 420, 75)
     with pytest.raises(hvc.HvcError):
         ctx.jpeg_encode_batch([np.zeros(17 * 9 + 2 * 8 * 4, np.uint8)], 17, 9, 420, 75)
+
+
+@pytest.mark.parametrize("yuv444", [False, True])
+def test_batch_pipeline_with_the_huffman_reader_on_the_gpu(ctx, yuv444):
+    """hvc_jpeg_decode_batch_gpu, device output, several chunks, ring reuse; 1080p-sized frames so that a
+    frame spans many workgroups of subsequences; every frame against the oracle."""
+    import torch
+    jpegs = _make_jpegs(7, 640, 352, q=80)
+    w, h = 640, 352
+    import video_coding_amd as hvc
+    info = hvc.hvc.jpeg_read_header(jpegs[0])
+    fs = 3 * w * h if yuv444 else info.pixel_bytes
+    for rep in range(2):
+        out = torch.zeros(len(jpegs) * fs, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        st = ctx.jpeg_decode_batch(jpegs, out, fs, threads=3, frames_per_chunk=2, yuv444=yuv444, gpu_entropy=True)
+        assert st.entropy_ms_sum == 0  # the GPU pipeline ran (the host-decoder pipeline reports its entropy time)
+        got = out.cpu().numpy()
+        for f, j in enumerate(jpegs):
+            d = orc.Decoder(j)
+            d.decode()
+            if yuv444:
+                y, u, v = d.get_yuv_frame()
+                want = np.concatenate([y.reshape(-1), orc.supersample_hv2(u).reshape(-1), orc.supersample_hv2(v).reshape(-1)])
+                assert np.array_equal(got[f * fs:(f + 1) * fs], want), (rep, f)
+            else:
+                for i, plane in enumerate(info.planes(got[f * fs:(f + 1) * fs])):
+                    assert np.array_equal(plane, d.plane(i)), (rep, f, i)
+
+
+def test_gpu_batch_falls_back_to_the_host_pipeline_for_special_streams(ctx):
+    """a truncated file inside the batch: the model reads zero bits past the end; the GPU decoder reports
+    'stream ends early' and the call is redone by the host-decoder pipeline -- same planes as the oracle"""
+    import video_coding_amd as hvc
+    jpegs = _make_jpegs(5, 96, 64)
+    info = hvc.hvc.jpeg_read_header(jpegs[2])
+    jpegs[2] = jpegs[2][:info.ecs_offset + 300] + b"\xff\xd9"
+    stride = info.pixel_bytes
+    pixels = np.zeros(len(jpegs) * stride, dtype=np.uint8)
+    st = ctx.jpeg_decode_batch(jpegs, pixels, stride, threads=2, frames_per_chunk=2, gpu_entropy=True)
+    assert st.entropy_ms_sum > 0  # the host-decoder pipeline produced the result
+    for f, j in enumerate(jpegs):
+        d = orc.Decoder(j)
+        d.decode()
+        for i, plane in enumerate(info.planes(pixels[f * stride:(f + 1) * stride])):
+            assert np.array_equal(plane, d.plane(i)), (f, i)

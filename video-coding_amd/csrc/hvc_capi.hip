@@ -52,6 +52,9 @@ struct hvc_ctx {
     hipEvent_t ev_up[RING] = {}, ev_down[RING] = {}, ev_et[RING][3] = {}, ev_gpu[RING] = {};
     void *ed_seg[RING] = {}, *ed_off[RING] = {}, *eh_off[RING] = {}; // hvc_jpeg_encode_batch_gpu: packed segments + offsets
     size_t e_seg_bytes = 0, e_off_bytes = 0;
+    // hvc_jpeg_decode_batch_gpu: pinned / device rings of unstuffed segments and their index arrays
+    void *gp_h_ecs[RING] = {}, *gp_d_ecs[RING] = {}, *gp_h_meta[RING] = {}, *gp_d_meta[RING] = {};
+    size_t gp_ecs_bytes = 0, gp_meta_bytes = 0;
     // GPU Huffman decoder (hvc_jpeg_entropy_decode_gpu): device scratch, grown on demand
     void *gd_ecs = nullptr, *gd_meta = nullptr, *gd_state = nullptr, *gd_tables = nullptr, *gd_coefs = nullptr;
     size_t gd_ecs_cap = 0, gd_meta_cap = 0, gd_state_cap = 0, gd_tables_cap = 0, gd_coefs_cap = 0;
@@ -234,6 +237,10 @@ void hvc_destroy(hvc_ctx *c) {
         for (int k = 0; k < 3; k++)
             if (c->ev_et[i][k]) (void)hipEventDestroy(c->ev_et[i][k]);
         if (c->ev_gpu[i]) (void)hipEventDestroy(c->ev_gpu[i]);
+        if (c->gp_h_ecs[i]) (void)hipHostFree(c->gp_h_ecs[i]);
+        if (c->gp_d_ecs[i]) (void)hipFree(c->gp_d_ecs[i]);
+        if (c->gp_h_meta[i]) (void)hipHostFree(c->gp_h_meta[i]);
+        if (c->gp_d_meta[i]) (void)hipFree(c->gp_d_meta[i]);
         if (c->ed_seg[i]) (void)hipFree(c->ed_seg[i]);
         if (c->ed_off[i]) (void)hipFree(c->ed_off[i]);
         if (c->eh_off[i]) (void)hipHostFree(c->eh_off[i]);
@@ -1060,6 +1067,49 @@ int hvc_jpeg_decode_batch_yuv444(hvc_ctx *c, const uint8_t *const *jpegs, const 
                              true);
 }
 
+// Geometry part of the GPU Huffman decoder's parameter block; false = this frame layout needs the host decoder.
+static bool gd_geometry(const hvc_jpeg_info &info0, hvc::HdParams &P) {
+    std::memset(&P, 0, sizeof P);
+    if (info0.n_comp < 1 || info0.n_comp > 3) return false;
+    P.n_comp = info0.n_comp;
+    const hvc_jpeg_component &c0 = info0.comp[0];
+    if (c0.hscale < 1 || c0.vscale < 1) return false;
+    P.mbs_wide = c0.decoded_width / (8 * c0.hscale);
+    P.mbs_high = c0.decoded_height / (8 * c0.vscale);
+    int base = 0;
+    for (int i = 0; i < info0.n_comp; i++) {
+        P.comp[i].h = info0.comp[i].hscale;
+        P.comp[i].v = info0.comp[i].vscale;
+        P.comp[i].bw = info0.layout[i].blocks_w;
+        P.comp[i].mcu_base = base;
+        P.comp[i].coef_off = info0.layout[i].coef_offset;
+        if (P.comp[i].h < 1 || P.comp[i].v < 1) return false;
+        // the decoder raises when the MCU grid leaves a plane ("Plane.set out of bounds"): host path decides
+        if (P.mbs_wide * P.comp[i].h > info0.layout[i].blocks_w || P.mbs_high * P.comp[i].v > info0.layout[i].blocks_h)
+            return false;
+        if (base + P.comp[i].h * P.comp[i].v > HVC_HD_MAX_MCU_BLOCKS) return false;
+        for (int k = 0; k < P.comp[i].h * P.comp[i].v; k++) P.b2comp[base + k] = (unsigned char)i;
+        base += P.comp[i].h * P.comp[i].v;
+    }
+    P.blocks_per_mcu = base;
+    const unsigned long long bpf = (unsigned long long)P.mbs_wide * P.mbs_high * base;
+    if (bpf == 0 || bpf >= (1ull << 31) || info0.coef_count >= (1ull << 32)) return false;
+    P.blocks_per_frame = (unsigned)bpf;
+    return true;
+}
+
+// Enqueue the whole decode on `st`: flags cleared, `rounds` synchronisation launches, finish passes.
+// P.changed afterwards holds the last launch's flag (0 = settled), P.status the error bits.
+static hipError_t gd_enqueue(const hvc::HdParams &P, int rounds, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(P.changed, 0, 2 * sizeof(unsigned), st); // changed + status are adjacent
+    for (int r = 0; r < rounds && e == hipSuccess; r++) {
+        if (r > 0) e = hipMemsetAsync(P.changed, 0, sizeof(unsigned), st);
+        if (e == hipSuccess) e = hvc::launch_hd_round(P, r, st);
+    }
+    if (e == hipSuccess) e = hvc::launch_hd_finish(P, rounds, st);
+    return e;
+}
+
 // ---------------------------------------------------------------------------
 // Huffman decoding on the GPU (hvc_hdec.hip).  Returns HVC_OK with *used_gpu = 1 when the coefficient
 // records at d_coefs are complete; HVC_OK with *used_gpu = 0 when the stream needs the host decoder
@@ -1083,29 +1133,8 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
         if (f > 0 && std::memcmp(&t, &tables0, sizeof t)) return HVC_OK; // different Huffman tables: host path
     }
     hvc::HdParams P;
-    std::memset(&P, 0, sizeof P);
+    if (!gd_geometry(info0, P)) return HVC_OK;
     P.n_frames = n_frames;
-    P.n_comp = info0.n_comp;
-    const hvc_jpeg_component &c0 = info0.comp[0];
-    P.mbs_wide = c0.decoded_width / (8 * c0.hscale);
-    P.mbs_high = c0.decoded_height / (8 * c0.vscale);
-    int base = 0;
-    for (int i = 0; i < info0.n_comp; i++) {
-        P.comp[i].h = info0.comp[i].hscale;
-        P.comp[i].v = info0.comp[i].vscale;
-        P.comp[i].bw = info0.layout[i].blocks_w;
-        P.comp[i].mcu_base = base;
-        P.comp[i].coef_off = info0.layout[i].coef_offset;
-        // the decoder raises when the MCU grid leaves a plane ("Plane.set out of bounds"): host path decides
-        if (P.mbs_wide * P.comp[i].h > info0.layout[i].blocks_w || P.mbs_high * P.comp[i].v > info0.layout[i].blocks_h)
-            return HVC_OK;
-        for (int k = 0; k < P.comp[i].h * P.comp[i].v; k++) P.b2comp[base + k] = (unsigned char)i;
-        base += P.comp[i].h * P.comp[i].v;
-    }
-    P.blocks_per_mcu = base;
-    const unsigned long long bpf = (unsigned long long)P.mbs_wide * P.mbs_high * base;
-    if (bpf == 0 || bpf >= (1ull << 31)) return HVC_OK;
-    P.blocks_per_frame = (unsigned)bpf;
     // layout of the segment buffer and the per-subsequence arrays
     const unsigned SB = HVC_HD_SUBSEQ_BITS / 8;
     std::vector<unsigned> ecs_off((size_t)n_frames), sub_off((size_t)n_frames + 1);
@@ -1230,6 +1259,299 @@ int hvc_jpeg_entropy_decode_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const s
         }
     }
     return HVC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// BASELINE config 3 with the Huffman reader on the GPU as well: host threads only parse headers and
+// unstuff the entropy-coded segments into a pinned ring; hipMemcpyAsync (copy stream) brings ~1 MB per
+// frame to the device, where the self-synchronising decoder (hvc_hdec.hip) writes the coefficient
+// records that the block stage reads.  Anything the GPU decoder hands back (unusual tables, streams the
+// model treats specially, a chunk that does not settle in four launches) restarts the call on the
+// host-decoder pipeline, so results and error codes are always the host decoder's.
+static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *sizes, int n_frames, int threads,
+                            int frames_per_chunk, uint8_t *pixels, size_t pixel_fs, int where, hvc_batch_stats *stats,
+                            bool yuv444) {
+    if (!c || !jpegs || !sizes || !pixels || n_frames < 0) return HVC_E_INVALID_ARG;
+    if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (n_frames == 0) return HVC_OK;
+    auto host_pipeline = [&]() {
+        return decode_batch_impl(c, jpegs, sizes, n_frames, threads, frames_per_chunk, pixels, pixel_fs, where, stats, yuv444);
+    };
+    hvc_jpeg_info info0;
+    int r = hvc_jpeg_read_header(jpegs[0], sizes[0], &info0);
+    if (r) return r;
+    if (yuv444 && (!is_420_scan(info0) || (info0.width & 1) || (info0.height & 1))) return HVC_E_INVALID_ARG;
+    const size_t out_bytes = yuv444 ? (size_t)3 * info0.width * info0.height : info0.pixel_bytes; // per frame
+    if (pixel_fs < out_bytes || (!yuv444 && (pixel_fs & 7))) return HVC_E_INVALID_ARG;
+    hvc::HdParams G;
+    hvc::HdTables tables0;
+    {
+        std::vector<uint8_t> tmp;
+        bool ok = false;
+        r = hvc::prepare_gpu_decode(jpegs[0], sizes[0], &info0, tables0, tmp, ok);
+        if (r) return r;
+        if (!ok || !gd_geometry(info0, G)) return host_pipeline();
+    }
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    if (frames_per_chunk < 1) frames_per_chunk = 32;
+    if (frames_per_chunk > n_frames) frames_per_chunk = n_frames;
+    const int C = frames_per_chunk, NB = hvc_ctx::RING;
+    const int n_chunks = (n_frames + C - 1) / C;
+    size_t max_file = 0;
+    for (int f = 0; f < n_frames; f++) {
+        if (!jpegs[f]) return HVC_E_INVALID_ARG;
+        max_file = sizes[f] > max_file ? sizes[f] : max_file;
+    }
+    const unsigned SB = HVC_HD_SUBSEQ_BITS / 8;
+    const size_t nsub_max = (max_file + SB - 1) / SB + 1;  // an entropy-coded segment is shorter than its file
+    const size_t R = nsub_max * SB + 16;                   // bytes per frame in the segment ring (16-byte multiple)
+    if ((size_t)C * nsub_max >= (1ull << 31) || (size_t)C * R >= (1ull << 31)) return host_pipeline();
+    const size_t ecs_bytes = (size_t)C * R;
+    const size_t meta_words = (size_t)C + ((size_t)C + 1) + (size_t)C * nsub_max + (size_t)C + 2;
+    const size_t meta_bytes = meta_words * sizeof(unsigned);
+    const size_t coef_chunk = info0.coef_count * sizeof(int16_t) * (size_t)C;
+    const size_t oring_bytes = where == HVC_MEM_HOST ? out_bytes * (size_t)C : 0;
+
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
+    if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < NB; i++) {
+        if (!c->ev_h2d[i]) HIPCHK(c, hipEventCreate(&c->ev_h2d[i]));
+        if (!c->ev_kern[i]) HIPCHK(c, hipEventCreate(&c->ev_kern[i]));
+    }
+    for (int i = 0; i < 4; i++)
+        if (!c->ev_t[i]) HIPCHK(c, hipEventCreate(&c->ev_t[i]));
+    if (ecs_bytes > c->gp_ecs_bytes || meta_bytes > c->gp_meta_bytes) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+        for (int i = 0; i < NB; i++) {
+            if (c->gp_h_ecs[i]) (void)hipHostFree(c->gp_h_ecs[i]);
+            if (c->gp_d_ecs[i]) (void)hipFree(c->gp_d_ecs[i]);
+            if (c->gp_h_meta[i]) (void)hipHostFree(c->gp_h_meta[i]);
+            if (c->gp_d_meta[i]) (void)hipFree(c->gp_d_meta[i]);
+            c->gp_h_ecs[i] = c->gp_d_ecs[i] = c->gp_h_meta[i] = c->gp_d_meta[i] = nullptr;
+        }
+        c->gp_ecs_bytes = c->gp_meta_bytes = 0;
+        for (int i = 0; i < NB; i++)
+            if (hipHostMalloc(&c->gp_h_ecs[i], ecs_bytes, hipHostMallocDefault) != hipSuccess ||
+                hipMalloc(&c->gp_d_ecs[i], ecs_bytes) != hipSuccess ||
+                hipHostMalloc(&c->gp_h_meta[i], meta_bytes, hipHostMallocDefault) != hipSuccess ||
+                hipMalloc(&c->gp_d_meta[i], meta_bytes) != hipSuccess)
+                return HVC_E_OUT_OF_MEMORY;
+        c->gp_ecs_bytes = ecs_bytes;
+        c->gp_meta_bytes = meta_bytes;
+    }
+    if (coef_chunk > c->ring_bytes) { // the device coefficient ring of the host-decoder pipeline is reused
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+        for (int i = 0; i < NB; i++) {
+            if (c->h_ring[i]) (void)hipHostFree(c->h_ring[i]);
+            if (c->d_ring[i]) (void)hipFree(c->d_ring[i]);
+            c->h_ring[i] = c->d_ring[i] = nullptr;
+        }
+        c->ring_bytes = 0;
+        for (int i = 0; i < NB; i++)
+            if (hipHostMalloc(&c->h_ring[i], coef_chunk, hipHostMallocDefault) != hipSuccess ||
+                hipMalloc(&c->d_ring[i], coef_chunk) != hipSuccess)
+                return HVC_E_OUT_OF_MEMORY;
+        c->ring_bytes = coef_chunk;
+    }
+    if (oring_bytes > c->oring_bytes) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < NB; i++) {
+            if (c->d_oring[i]) (void)hipFree(c->d_oring[i]);
+            c->d_oring[i] = nullptr;
+        }
+        c->oring_bytes = 0;
+        for (int i = 0; i < NB; i++)
+            if (hipMalloc(&c->d_oring[i], oring_bytes) != hipSuccess) return HVC_E_OUT_OF_MEMORY;
+        c->oring_bytes = oring_bytes;
+    }
+    if ((r = grow(c, &c->gd_state, &c->gd_state_cap,
+                  (size_t)C * nsub_max * (3 * sizeof(unsigned long long) + sizeof(unsigned)) + 64)))
+        return r;
+    if ((r = grow(c, &c->gd_tables, &c->gd_tables_cap, sizeof(hvc::HdTables)))) return r;
+    HIPCHK(c, hipMemcpyAsync(c->gd_tables, &tables0, sizeof tables0, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // tables0 lives on this stack frame
+
+    // workers: header parse, table check, unstuffing into the pinned segment ring
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<int> next_frame{0};
+    std::atomic<int> error{0};
+    std::atomic<int> need_host{0};
+    std::vector<int> done_in_chunk((size_t)n_chunks, 0);
+    std::vector<unsigned> ecs_size((size_t)n_frames, 0);
+    int released_upto = NB - 1;
+    std::atomic<long long> prep_ns{0};
+    auto worker = [&]() {
+        std::vector<uint8_t> ecs;
+        hvc::HdTables t;
+        for (;;) {
+            const int f = next_frame.fetch_add(1);
+            if (f >= n_frames || error.load() || need_host.load()) return;
+            const int k = f / C, slot = k % NB;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return k <= released_upto || error.load() || need_host.load(); });
+            }
+            if (error.load() || need_host.load()) return;
+            const auto t0 = std::chrono::steady_clock::now();
+            hvc_jpeg_info fi;
+            int e = hvc_jpeg_read_header(jpegs[f], sizes[f], &fi);
+            if (!e && (fi.n_comp != info0.n_comp || fi.n_qtabs != info0.n_qtabs || fi.coef_count != info0.coef_count ||
+                       std::memcmp(fi.layout, info0.layout, sizeof fi.layout) || std::memcmp(fi.comp, info0.comp, sizeof fi.comp) ||
+                       std::memcmp(fi.qtabs, info0.qtabs, sizeof fi.qtabs)))
+                e = HVC_E_INVALID_ARG; // a batch shares one geometry and one set of tables
+            bool ok = false;
+            if (!e) e = hvc::prepare_gpu_decode(jpegs[f], sizes[f], &fi, t, ecs, ok);
+            if (!e && (!ok || std::memcmp(&t, &tables0, sizeof t) || ecs.size() > (nsub_max - 1) * SB)) need_host.store(1);
+            if (!e && !need_host.load()) {
+                uint8_t *dst = (uint8_t *)c->gp_h_ecs[slot] + (size_t)(f - k * C) * R;
+                std::memcpy(dst, ecs.data(), ecs.size());
+                const size_t used = ((ecs.size() + SB - 1) / SB + 1) * SB + 16; // this frame's subsequences + overshoot
+                std::memset(dst + ecs.size(), 0, used - ecs.size());
+                ecs_size[(size_t)f] = (unsigned)ecs.size();
+            }
+            prep_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            std::lock_guard<std::mutex> lk(mu);
+            if (e) error.store(e);
+            done_in_chunk[(size_t)k]++;
+            cv.notify_all();
+        }
+    };
+    const auto wall0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++) pool.emplace_back(worker);
+
+    int rc = HVC_OK;
+    bool fallback = false;
+    double h2d_ms = 0, k_ms = 0;
+    uint64_t ecs_total = 0;
+    hipStream_t compute = c->stream;
+    const bool prof_saved = c->profiling;
+    c->profiling = false;
+    for (int it = 0; it < n_chunks + NB && rc == HVC_OK && !fallback; it++) {
+        // verdict on chunk it - NB's slot before it is overwritten (and on the last chunks at the end)
+        const int v = it - NB;
+        if (v >= 0) {
+            const int slot = v % NB;
+            hipError_t he = hipEventSynchronize(c->ev_kern[slot]);
+            if (he != hipSuccess) { rc = fail_hip(c, he); break; }
+            const unsigned *flags = (const unsigned *)c->gp_h_meta[slot] + (meta_words - 2);
+            if (flags[0] || flags[1]) { fallback = true; break; } // not settled / the model raises / truncated
+        }
+        if (it >= n_chunks) continue;
+        const int k = it, slot = k % NB, first = k * C, cnt = (first + C <= n_frames) ? C : n_frames - first;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return done_in_chunk[(size_t)k] == cnt || error.load() || need_host.load(); });
+        }
+        if (error.load()) { rc = error.load(); break; }
+        if (need_host.load()) { fallback = true; break; }
+        // the chunk's index arrays
+        unsigned *hm = (unsigned *)c->gp_h_meta[slot];
+        unsigned *h_ecs_off = hm, *h_sub_off = hm + C, *h_frame_of = h_sub_off + C + 1;
+        unsigned subs = 0;
+        for (int f = 0; f < cnt; f++) {
+            const unsigned nsub = (ecs_size[(size_t)(first + f)] + SB - 1) / SB + 1;
+            h_ecs_off[f] = (unsigned)((size_t)f * R);
+            h_sub_off[f] = subs;
+            for (unsigned q = 0; q < nsub; q++) h_frame_of[subs + q] = (unsigned)f;
+            subs += nsub;
+            ecs_total += ecs_size[(size_t)(first + f)];
+        }
+        h_sub_off[cnt] = subs;
+        unsigned *dm = (unsigned *)c->gp_d_meta[slot];
+        hvc::HdParams P = G;
+        P.n_frames = cnt;
+        P.total_sub = subs;
+        P.ecs = (const uint8_t *)c->gp_d_ecs[slot];
+        P.ecs_off = dm;
+        P.sub_off = dm + C;
+        P.frame_of = dm + C + C + 1;
+        P.frame_blocks = dm + (meta_words - 2 - C);
+        P.changed = dm + (meta_words - 2);
+        P.status = dm + (meta_words - 1);
+        P.tables = (const hvc::HdTables *)c->gd_tables;
+        P.coefs = (int16_t *)c->d_ring[slot];
+        P.coef_fs = info0.coef_count;
+        unsigned long long *sp = (unsigned long long *)c->gd_state;
+        P.start_used = sp;
+        P.exit_a = sp + (size_t)C * nsub_max;
+        P.exit_b = sp + 2 * (size_t)C * nsub_max;
+        P.nblk = (unsigned *)(sp + 3 * (size_t)C * nsub_max);
+        hipError_t he = hipEventRecord(c->ev_t[0], c->copy_stream);
+        if (he == hipSuccess)
+            he = hipMemcpyAsync(c->gp_d_ecs[slot], c->gp_h_ecs[slot], (size_t)cnt * R, hipMemcpyHostToDevice, c->copy_stream);
+        if (he == hipSuccess)
+            he = hipMemcpyAsync(dm, hm, ((size_t)2 * C + 1 + subs) * sizeof(unsigned), hipMemcpyHostToDevice, c->copy_stream);
+        if (he == hipSuccess) he = hipEventRecord(c->ev_h2d[slot], c->copy_stream);
+        if (he == hipSuccess) he = hipStreamWaitEvent(compute, c->ev_h2d[slot], 0);
+        if (he == hipSuccess) he = hipEventRecord(c->ev_t[1], compute);
+        if (he == hipSuccess) he = hipMemsetAsync(P.coefs, 0, info0.coef_count * sizeof(int16_t) * (size_t)cnt, compute);
+        if (he == hipSuccess) he = gd_enqueue(P, 4, compute);
+        if (he == hipSuccess) // changed + status -> the pinned copy of the index arrays
+            he = hipMemcpyAsync(hm + (meta_words - 2), P.changed, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, compute);
+        if (he != hipSuccess) { rc = fail_hip(c, he); break; }
+        uint8_t *dst = where == HVC_MEM_DEVICE ? pixels + (size_t)first * pixel_fs : (uint8_t *)c->d_oring[slot];
+        const size_t dst_fs = where == HVC_MEM_DEVICE ? pixel_fs : out_bytes;
+        rc = yuv444 ? hvc_decode_frames_yuv444(c, P.coefs, info0.coef_count, &info0.qtabs[0][0], info0.n_qtabs, info0.layout,
+                                               info0.n_comp, cnt, info0.width, info0.height, dst, dst_fs, HVC_MEM_DEVICE)
+                    : hvc_decode_frames(c, P.coefs, info0.coef_count, &info0.qtabs[0][0], info0.n_qtabs, info0.layout,
+                                        info0.n_comp, cnt, dst, dst_fs, HVC_MEM_DEVICE);
+        if (rc) break;
+        he = hipEventRecord(c->ev_t[2], compute);
+        if (he == hipSuccess && where == HVC_MEM_HOST)
+            for (int f = 0; f < cnt && he == hipSuccess; f++)
+                he = hipMemcpyAsync(pixels + (size_t)(first + f) * pixel_fs, dst + (size_t)f * dst_fs, out_bytes,
+                                    hipMemcpyDeviceToHost, compute);
+        if (he == hipSuccess) he = hipEventRecord(c->ev_kern[slot], compute);
+        // hand the pinned segment slot to chunk k + NB once this chunk's upload is through
+        if (he == hipSuccess) he = hipEventSynchronize(c->ev_h2d[slot]);
+        if (he != hipSuccess) { rc = fail_hip(c, he); break; }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            released_upto = k + NB;
+            cv.notify_all();
+        }
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev_t[0], c->ev_h2d[slot]) == hipSuccess) h2d_ms += ms;
+        if (hipEventSynchronize(c->ev_t[2]) == hipSuccess && hipEventElapsedTime(&ms, c->ev_t[1], c->ev_t[2]) == hipSuccess)
+            k_ms += ms;
+    }
+    c->profiling = prof_saved;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (rc != HVC_OK) error.store(rc);
+        if (fallback) need_host.store(1);
+        cv.notify_all();
+    }
+    for (auto &t : pool) t.join();
+    (void)hipStreamSynchronize(compute);
+    (void)hipStreamSynchronize(c->copy_stream);
+    if (rc == HVC_OK && error.load()) rc = error.load();
+    if (rc == HVC_OK && (fallback || need_host.load())) return host_pipeline();
+    if (stats) {
+        stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        stats->entropy_ms_sum = 0; // no host entropy decoding
+        stats->host_prep_ms_sum = (double)prep_ns.load() * 1e-6;
+        stats->h2d_ms_sum = h2d_ms;
+        stats->kernel_ms_sum = k_ms;
+        stats->chunks = n_chunks;
+        stats->threads = threads;
+        stats->frames_per_chunk = C;
+        stats->coef_bytes = ecs_total; // bytes uploaded: the unstuffed segments
+    }
+    return rc;
+}
+
+int hvc_jpeg_decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *sizes, int n_frames, int threads,
+                              int frames_per_chunk, uint8_t *pixels, size_t pixel_fs, int where, int yuv444,
+                              hvc_batch_stats *stats) {
+    return decode_batch_gpu(c, jpegs, sizes, n_frames, threads, frames_per_chunk, pixels, pixel_fs, where, stats, yuv444 != 0);
 }
 
 // ---------------------------------------------------------------------------

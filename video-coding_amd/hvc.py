@@ -20,7 +20,7 @@ SYMBOLS = [
     "hvc_device_free", "hvc_memcpy_h2d", "hvc_memcpy_d2h",
     "hvc_jpeg_read_header", "hvc_jpeg_entropy_decode", "hvc_jpeg_get_yuv_frame", "hvc_jpeg_decode",
     "hvc_jpeg_decode_batch", "hvc_quant_table", "hvc_jpeg_encoder_layout", "hvc_jpeg_entropy_encode",
-    "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444", "hvc_jpeg_decode_yuv444", "hvc_compare_planes", "hvc_jpeg_encode_batch", "hvc_jpeg_decode_batch_yuv444", "hvc_jpeg_encoder_check", "hvc_huffman_encode_frames", "hvc_jpeg_header", "hvc_jpeg_encode_batch_gpu", "hvc_jpeg_entropy_decode_gpu",
+    "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444", "hvc_jpeg_decode_yuv444", "hvc_compare_planes", "hvc_jpeg_encode_batch", "hvc_jpeg_decode_batch_yuv444", "hvc_jpeg_encoder_check", "hvc_huffman_encode_frames", "hvc_jpeg_header", "hvc_jpeg_encode_batch_gpu", "hvc_jpeg_entropy_decode_gpu", "hvc_jpeg_decode_batch_gpu",
 ]
 
 
@@ -127,6 +127,7 @@ def lib():
         L.hvc_jpeg_decode_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), i, i, i, vp, sz, i,
                                             C.POINTER(BatchStats)]
         L.hvc_quant_table.argtypes = [i, i, vp]
+        L.hvc_jpeg_decode_batch_gpu.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), i, i, i, vp, sz, i, i, C.POINTER(BatchStats)]
         L.hvc_jpeg_entropy_decode_gpu.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), i, vp, sz, i, ip, C.POINTER(i)]
         L.hvc_huffman_encode_frames.argtypes = [vp, ip, vp, sz, i, vp, sz, vp, i]
         L.hvc_jpeg_header.argtypes = [ip, vp, sz, C.POINTER(sz)]
@@ -361,14 +362,20 @@ class Context:
              "hvc_jpeg_decode_yuv444")
         return info, frame.reshape(3, info.height, info.width)
 
-    def jpeg_decode_batch(self, jpegs, pixels, pixel_frame_stride, threads=8, frames_per_chunk=32, yuv444=False):
+    def jpeg_decode_batch(self, jpegs, pixels, pixel_frame_stride, threads=8, frames_per_chunk=32, yuv444=False,
+                          gpu_entropy=False):
         """config 3 pipeline.  jpegs: list of bytes; pixels: numpy (host) or torch cuda tensor.
-        yuv444: 4:2:0 files straight to tight 4:4:4 frames (3 * width * height bytes each)."""
+        yuv444: 4:2:0 files straight to tight 4:4:4 frames (3 * width * height bytes each).
+        gpu_entropy: the Huffman reader on the GPU as well (hvc_jpeg_decode_batch_gpu)."""
         n = len(jpegs)
         ptrs = (C.c_void_p * n)(*[C.cast(C.c_char_p(j), C.c_void_p) for j in jpegs])
         sizes = (C.c_size_t * n)(*[len(j) for j in jpegs])
         pa, where = _addr(pixels)
         st = BatchStats()
+        if gpu_entropy:
+            _chk(lib().hvc_jpeg_decode_batch_gpu(self._h, ptrs, sizes, n, threads, frames_per_chunk, pa, pixel_frame_stride,
+                                                 where, 1 if yuv444 else 0, C.byref(st)), "hvc_jpeg_decode_batch_gpu")
+            return st
         fn = lib().hvc_jpeg_decode_batch_yuv444 if yuv444 else lib().hvc_jpeg_decode_batch
         _chk(fn(self._h, ptrs, sizes, n, threads, frames_per_chunk, pa, pixel_frame_stride, where, C.byref(st)),
              "hvc_jpeg_decode_batch_yuv444" if yuv444 else "hvc_jpeg_decode_batch")
