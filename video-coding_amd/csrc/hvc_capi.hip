@@ -755,6 +755,20 @@ int hvc_upsample420(hvc_ctx *c, const uint8_t *src, int cw, int ch, size_t src_s
 // ---------------------------------------------------------------------------
 // single-frame conveniences (host memory)
 
+static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *sizes, int n_frames,
+                              const hvc_jpeg_info &info0, int16_t *d_coefs, size_t coef_fs, int *used_gpu);
+
+// One file: Huffman reader on the GPU (hvc_hdec.hip) into device scratch; *used = 0 when the stream needs the
+// host decoder (nothing usable on the device then).
+static int single_frame_coefs_on_device(hvc_ctx *c, const uint8_t *jpeg, size_t n, const hvc_jpeg_info *info, int *used) {
+    *used = 0;
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
+    int r = grow(c, &c->gd_coefs, &c->gd_coefs_cap, info->coef_count * sizeof(int16_t));
+    if (r) return r;
+    return gpu_entropy_decode(c, &jpeg, &n, 1, *info, (int16_t *)c->gd_coefs, info->coef_count, used);
+}
+
 // Decoder.decode_a_frame minus the crop (decoder.ml:422-427)
 int hvc_jpeg_decode_yuv444(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_info *info, uint8_t *frame,
                            size_t frame_cap) {
@@ -766,6 +780,20 @@ int hvc_jpeg_decode_yuv444(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_i
         info->comp[1].vscale != 1 || info->comp[2].hscale != 1 || info->comp[2].vscale != 1)
         return HVC_E_INVALID_ARG;
     if (frame_cap < (size_t)3 * info->width * info->height) return HVC_E_INVALID_ARG;
+    int on_gpu = 0;
+    if ((r = single_frame_coefs_on_device(c, jpeg, n, info, &on_gpu))) return r;
+    if (on_gpu) { // coefficient record already on the device: fused block stage there, one download
+        DeviceGuard g(c->device);
+        const size_t fb = (size_t)3 * info->width * info->height;
+        if ((r = grow(c, &c->d_out, &c->out_cap, fb))) return r;
+        r = hvc_decode_frames_yuv444(c, (const int16_t *)c->gd_coefs, info->coef_count, &info->qtabs[0][0], info->n_qtabs,
+                                     info->layout, info->n_comp, 1, info->width, info->height, (uint8_t *)c->d_out, fb,
+                                     HVC_MEM_DEVICE);
+        if (r) return r;
+        HIPCHK(c, hipMemcpyAsync(frame, c->d_out, fb, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return HVC_OK;
+    }
     std::vector<int16_t> coefs;
     try {
         coefs.resize(info->coef_count);
@@ -784,6 +812,18 @@ int hvc_jpeg_decode(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_info *in
     int r = hvc_jpeg_read_header(jpeg, n, info);
     if (r) return r;
     if (pixel_cap < info->pixel_bytes) return HVC_E_INVALID_ARG;
+    int on_gpu = 0;
+    if ((r = single_frame_coefs_on_device(c, jpeg, n, info, &on_gpu))) return r;
+    if (on_gpu) { // coefficient record already on the device: block stage there, one download
+        DeviceGuard g(c->device);
+        if ((r = grow(c, &c->d_out, &c->out_cap, info->pixel_bytes))) return r;
+        r = hvc_decode_frames(c, (const int16_t *)c->gd_coefs, info->coef_count, &info->qtabs[0][0], info->n_qtabs, info->layout,
+                              info->n_comp, 1, (uint8_t *)c->d_out, info->pixel_bytes, HVC_MEM_DEVICE);
+        if (r) return r;
+        HIPCHK(c, hipMemcpyAsync(pixels, c->d_out, info->pixel_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return HVC_OK;
+    }
     std::vector<int16_t> coefs;
     try {
         coefs.resize(info->coef_count);
