@@ -31,20 +31,12 @@ __device__ __forceinline__ unsigned long long pack_state(unsigned p, int k, int 
     return (unsigned long long)p | ((unsigned long long)(unsigned)k << 32) | ((unsigned long long)(unsigned)b << 40);
 }
 
-// Every lane stages the bytes its subsequence can touch -- its 128 bytes plus 16 of overshoot -- in LDS
-// (36 dwords, row stride 37 against bank conflicts): the symbol loop then never waits for global memory.
-constexpr int SLOT = 37;
-__device__ __forceinline__ void stage_bits(const uint8_t *ecs, unsigned j, unsigned *slot) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(ecs + (size_t)j * (S / 8)); // frames start on 16-byte boundaries
-#pragma unroll
-    for (int q = 0; q < 9; q++) {
-        const uint4 t = src[q];
-        slot[4 * q + 0] = __builtin_bswap32(t.x);
-        slot[4 * q + 1] = __builtin_bswap32(t.y);
-        slot[4 * q + 2] = __builtin_bswap32(t.z);
-        slot[4 * q + 3] = __builtin_bswap32(t.w);
-    }
-}
+// A lane's bits come straight from global memory, one (byte-swapped) dword per 32 bits consumed, requested
+// two refills ahead -- a dozen symbols -- so their latency is covered.  (A first version staged each lane's
+// 144 bytes in LDS: 38 KB per workgroup, which held the kernel at 2 waves per SIMD; without it LDS holds only
+// the tables and the CU runs four times as many waves of this latency-bound loop.)
+__device__ __forceinline__ unsigned be32(const unsigned *g, unsigned i) { return __builtin_bswap32(g[i]); }
+
 // (length << 8) | value, 0 = no code.  w = the next 64 bits.
 __device__ __forceinline__ unsigned lookup(const HdTable &t, unsigned long long w) {
     unsigned e = t.fast[(unsigned)(w >> 54)];
@@ -100,19 +92,20 @@ __device__ __forceinline__ void walk(const HdParams &P, const HdGeo &G, const Hd
     // MSB-aligned window in registers (refilled a dword at a time from the lane's LDS slot, the next
     // dword already loaded), one table load, and no per-symbol geometry look-ups (component and
     // table pointers change only at block ends).
-    unsigned off = p - base;               // bits consumed from the slot so far
-    unsigned wi = (off >> 5) + 2;          // next dword of the slot to append
-    unsigned long long buf = (((unsigned long long)slot[off >> 5] << 32) | slot[(off >> 5) + 1]) << (off & 31u);
+    unsigned off = p - base;               // bits consumed from the subsequence so far
+    unsigned wi = (off >> 5) + 2;          // next dword to append (the subsequence's bytes + 16 of overshoot = 36 dwords)
+    unsigned long long buf = (((unsigned long long)be32(slot, off >> 5) << 32) | be32(slot, (off >> 5) + 1)) << (off & 31u);
     int avail = 64 - (int)(off & 31u);
-    unsigned nextw = slot[wi];
+    unsigned n0 = be32(slot, wi), n1 = be32(slot, min(wi + 1, 35u));
     int comp = G.b2comp[b];
     const HdTable *dct = &T.dc[comp], *act = &T.ac[comp];
     while (p < limit) {
-        if (avail <= 32) { // append the pre-loaded dword; fetch the one after (wi stays inside the 36-dword slot)
-            buf |= (unsigned long long)nextw << (32 - avail);
+        if (avail <= 32) { // append a pre-loaded dword; request the one after next (indices stay inside the 36 dwords)
+            buf |= (unsigned long long)n0 << (32 - avail);
             avail += 32;
             wi++;
-            nextw = slot[min(wi, 35u)];
+            n0 = n1;
+            n1 = be32(slot, min(wi + 1, 35u));
         }
         const HdTable &t = k ? *act : *dct;
         const unsigned e = lookup(t, buf);
@@ -183,7 +176,6 @@ constexpr int INNER = 24;
 __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
     __shared__ HdTables T;
     __shared__ HdGeo G;
-    __shared__ unsigned bits[256 * SLOT];
     __shared__ unsigned long long exits[256];
     load_geo(P, G);
     {
@@ -195,8 +187,7 @@ __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
     const unsigned i = blockIdx.x * 256u + (unsigned)tid;
     const bool valid = i < P.total_sub;
     const unsigned f = valid ? P.frame_of[i] : 0u, j = valid ? i - P.sub_off[f] : 0u;
-    unsigned *slot = bits + tid * SLOT;
-    if (valid) stage_bits(P.ecs + P.ecs_off[f], j, slot);
+    const unsigned *slot = reinterpret_cast<const unsigned *>(P.ecs + P.ecs_off[f] + (size_t)j * (S / 8));
     __syncthreads();
     const unsigned long long *prev = (round & 1) ? P.exit_a : P.exit_b;
     unsigned long long *cur = (round & 1) ? P.exit_b : P.exit_a;
@@ -278,7 +269,6 @@ __global__ __launch_bounds__(1024) void k_hd_scan(HdParams P) {
 __global__ __launch_bounds__(256) void k_hd_write(HdParams P, int final_round) {
     __shared__ HdTables T;
     __shared__ HdGeo G;
-    __shared__ unsigned bits[256 * SLOT];
     load_geo(P, G);
     {
         const unsigned *src = reinterpret_cast<const unsigned *>(P.tables);
@@ -288,8 +278,7 @@ __global__ __launch_bounds__(256) void k_hd_write(HdParams P, int final_round) {
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
     const bool valid = i < P.total_sub;
     const unsigned f = valid ? P.frame_of[i] : 0u, j = valid ? i - P.sub_off[f] : 0u;
-    unsigned *slot = bits + threadIdx.x * SLOT;
-    if (valid) stage_bits(P.ecs + P.ecs_off[f], j, slot);
+    const unsigned *slot = reinterpret_cast<const unsigned *>(P.ecs + P.ecs_off[f] + (size_t)j * (S / 8));
     __syncthreads();
     if (!valid) return;
     const unsigned first_block = P.nblk[i];
