@@ -54,7 +54,7 @@ __device__ __forceinline__ int extend(int cat, unsigned code) { // decoder.ml:73
 struct HdGeo {
     int h[4], v[4], bw[4], mcu_base[4];
     unsigned coef_off[4];
-    unsigned char b2comp[HVC_HD_MAX_MCU_BLOCKS];
+    unsigned char b2comp[HVC_HD_MAX_MCU_BLOCKS], b2sx[HVC_HD_MAX_MCU_BLOCKS], b2sy[HVC_HD_MAX_MCU_BLOCKS];
 };
 __device__ __forceinline__ void load_geo(const HdParams &P, HdGeo &G) {
     if (threadIdx.x < 4) {
@@ -65,7 +65,13 @@ __device__ __forceinline__ void load_geo(const HdParams &P, HdGeo &G) {
         G.mcu_base[i] = P.comp[i].mcu_base;
         G.coef_off[i] = (unsigned)P.comp[i].coef_off;
     }
-    if (threadIdx.x < HVC_HD_MAX_MCU_BLOCKS) G.b2comp[threadIdx.x] = P.b2comp[threadIdx.x];
+    if (threadIdx.x < HVC_HD_MAX_MCU_BLOCKS) {
+        const int bb = threadIdx.x, comp = P.b2comp[bb];
+        const int r = bb - P.comp[comp].mcu_base, hh = P.comp[comp].h > 0 ? P.comp[comp].h : 1;
+        G.b2comp[bb] = (unsigned char)comp;
+        G.b2sy[bb] = (unsigned char)(r >= 0 ? r / hh : 0);
+        G.b2sx[bb] = (unsigned char)(r >= 0 ? r % hh : 0);
+    }
 }
 
 // WRITE = false: walk only.  WRITE = true: store coefficients of blocks [0, blocks_per_frame).
@@ -78,16 +84,20 @@ __device__ __forceinline__ void walk(const HdParams &P, const HdGeo &G, const Hd
     const int B = P.blocks_per_mcu;
     unsigned bi = first_block;
     int16_t *blk = nullptr;
-    auto block_ptr = [&](unsigned index, int bb) -> int16_t * {
-        const unsigned mcu = index / (unsigned)B;
+    // position of the current block: MCU coordinates advance by counting, no divisions inside the loop
+    unsigned mx = 0, my = 0;
+    if (WRITE) {
+        const unsigned mcu = first_block / (unsigned)B;
+        my = mcu / (unsigned)P.mbs_wide;
+        mx = mcu - my * (unsigned)P.mbs_wide;
+    }
+    auto block_ptr = [&](int bb) -> int16_t * {
         const int comp = G.b2comp[bb];
-        const int ch = G.h[comp], cv = G.v[comp];
-        const int r = bb - G.mcu_base[comp], sy = r / ch, sx = r - sy * ch;
-        const unsigned my = mcu / (unsigned)P.mbs_wide, mx = mcu - my * (unsigned)P.mbs_wide;
-        return rec + G.coef_off[comp] + ((size_t)(my * cv + sy) * G.bw[comp] + (size_t)(mx * ch + sx)) * 64;
+        return rec + G.coef_off[comp] +
+               ((size_t)(my * (unsigned)G.v[comp] + G.b2sy[bb]) * (unsigned)G.bw[comp] + (size_t)(mx * (unsigned)G.h[comp] + G.b2sx[bb])) * 64;
     };
     bool live = WRITE && bi < P.blocks_per_frame; // this block's coefficients are stored (and its errors count)
-    if (live) blk = block_ptr(bi, b);
+    if (live) blk = block_ptr(b);
     // The serial chain per symbol is what bounds the whole decoder, so it is kept short: a 64-bit
     // MSB-aligned window in registers (refilled a dword at a time from the lane's LDS slot, the next
     // dword already loaded), one table load, and no per-symbol geometry look-ups (component and
@@ -160,8 +170,15 @@ __device__ __forceinline__ void walk(const HdParams &P, const HdGeo &G, const Hd
             comp = G.b2comp[b];
             dct = &T.dc[comp];
             act = &T.ac[comp];
+            if (WRITE && b == 0) { // next MCU
+                mx++;
+                if (mx == (unsigned)P.mbs_wide) {
+                    mx = 0;
+                    my++;
+                }
+            }
             live = WRITE && bi < P.blocks_per_frame;
-            if (live) blk = block_ptr(bi, b);
+            if (live) blk = block_ptr(b);
         }
     }
 }
