@@ -1338,7 +1338,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     }
     if (threads < 1) threads = 1;
     if (threads > 256) threads = 256;
-    if (frames_per_chunk < 1) frames_per_chunk = 32;
+    if (frames_per_chunk < 1) frames_per_chunk = 128; // the reader's launches want many subsequences at once
     if (frames_per_chunk > n_frames) frames_per_chunk = n_frames;
     const int C = frames_per_chunk, NB = hvc_ctx::RING;
     const int n_chunks = (n_frames + C - 1) / C;
@@ -1366,6 +1366,9 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     }
     for (int i = 0; i < 4; i++)
         if (!c->ev_t[i]) HIPCHK(c, hipEventCreate(&c->ev_t[i]));
+    for (int i = 0; i < NB; i++)
+        for (int k = 0; k < 3; k++)
+            if (!c->ev_et[i][k]) HIPCHK(c, hipEventCreate(&c->ev_et[i][k])); // per-slot stage timers
     if (ecs_bytes > c->gp_ecs_bytes || meta_bytes > c->gp_meta_bytes) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipStreamSynchronize(c->copy_stream));
@@ -1485,6 +1488,9 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
             if (he != hipSuccess) { rc = fail_hip(c, he); break; }
             const unsigned *flags = (const unsigned *)c->gp_h_meta[slot] + (meta_words - 2);
             if (flags[0] || flags[1]) { fallback = true; break; } // not settled / the model raises / truncated
+            float ms = 0; // stage times of the chunk that just finished (read late so that nothing waits for them)
+            if (hipEventElapsedTime(&ms, c->ev_et[slot][0], c->ev_h2d[slot]) == hipSuccess) h2d_ms += ms;
+            if (hipEventElapsedTime(&ms, c->ev_et[slot][1], c->ev_et[slot][2]) == hipSuccess) k_ms += ms;
         }
         if (it >= n_chunks) continue;
         const int k = it, slot = k % NB, first = k * C, cnt = (first + C <= n_frames) ? C : n_frames - first;
@@ -1526,14 +1532,14 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         P.exit_a = sp + (size_t)C * nsub_max;
         P.exit_b = sp + 2 * (size_t)C * nsub_max;
         P.nblk = (unsigned *)(sp + 3 * (size_t)C * nsub_max);
-        hipError_t he = hipEventRecord(c->ev_t[0], c->copy_stream);
+        hipError_t he = hipEventRecord(c->ev_et[slot][0], c->copy_stream);
         if (he == hipSuccess)
             he = hipMemcpyAsync(c->gp_d_ecs[slot], c->gp_h_ecs[slot], (size_t)cnt * R, hipMemcpyHostToDevice, c->copy_stream);
         if (he == hipSuccess)
             he = hipMemcpyAsync(dm, hm, ((size_t)2 * C + 1 + subs) * sizeof(unsigned), hipMemcpyHostToDevice, c->copy_stream);
         if (he == hipSuccess) he = hipEventRecord(c->ev_h2d[slot], c->copy_stream);
         if (he == hipSuccess) he = hipStreamWaitEvent(compute, c->ev_h2d[slot], 0);
-        if (he == hipSuccess) he = hipEventRecord(c->ev_t[1], compute);
+        if (he == hipSuccess) he = hipEventRecord(c->ev_et[slot][1], compute);
         if (he == hipSuccess) he = hipMemsetAsync(P.coefs, 0, info0.coef_count * sizeof(int16_t) * (size_t)cnt, compute);
         if (he == hipSuccess) he = gd_enqueue(P, 4, compute);
         if (he == hipSuccess) // changed + status -> the pinned copy of the index arrays
@@ -1546,7 +1552,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
                     : hvc_decode_frames(c, P.coefs, info0.coef_count, &info0.qtabs[0][0], info0.n_qtabs, info0.layout,
                                         info0.n_comp, cnt, dst, dst_fs, HVC_MEM_DEVICE);
         if (rc) break;
-        he = hipEventRecord(c->ev_t[2], compute);
+        he = hipEventRecord(c->ev_et[slot][2], compute);
         if (he == hipSuccess && where == HVC_MEM_HOST)
             for (int f = 0; f < cnt && he == hipSuccess; f++)
                 he = hipMemcpyAsync(pixels + (size_t)(first + f) * pixel_fs, dst + (size_t)f * dst_fs, out_bytes,
@@ -1560,10 +1566,6 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
             released_upto = k + NB;
             cv.notify_all();
         }
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, c->ev_t[0], c->ev_h2d[slot]) == hipSuccess) h2d_ms += ms;
-        if (hipEventSynchronize(c->ev_t[2]) == hipSuccess && hipEventElapsedTime(&ms, c->ev_t[1], c->ev_t[2]) == hipSuccess)
-            k_ms += ms;
     }
     c->profiling = prof_saved;
     {
