@@ -136,8 +136,10 @@ __device__ __forceinline__ void walk(const HdParams &P, const HdGeo &G, const Hd
             p += (unsigned)len;
             continue;
         }
-        int mag = 0;
-        if (size) mag = extend(size, (unsigned)((buf << len) >> (64 - size)));
+        // the value itself matters only when it is stored; the walk needs "is it zero", and a coded magnitude of
+        // size > 0 never is (decoder.ml:73-79)
+        int mag = size;
+        if (WRITE && size) mag = extend(size, (unsigned)((buf << len) >> (64 - size)));
         const int used = len + size; // <= 32
         buf <<= used;
         avail -= used;
