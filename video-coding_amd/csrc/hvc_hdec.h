@@ -26,7 +26,9 @@ struct HdTables {
     HdTable dc[3], ac[3]; // per scan component (the GPU path takes at most three)
 };
 
-#define HVC_HD_SUBSEQ_BITS 1024 /* bits per lane in the synchronisation rounds */
+#ifndef HVC_HD_SUBSEQ_BITS
+#define HVC_HD_SUBSEQ_BITS 1024 /* bits per lane in the synchronisation rounds (a multiple of 128) */
+#endif
 #define HVC_HD_MAX_MCU_BLOCKS 16
 
 struct HdComp {

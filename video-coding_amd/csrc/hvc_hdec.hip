@@ -103,19 +103,19 @@ __device__ __forceinline__ void walk(const HdParams &P, const HdGeo &G, const Hd
     // dword already loaded), one table load, and no per-symbol geometry look-ups (component and
     // table pointers change only at block ends).
     unsigned off = p - base;               // bits consumed from the subsequence so far
-    unsigned wi = (off >> 5) + 2;          // next dword to append (the subsequence's bytes + 16 of overshoot = 36 dwords)
+    unsigned wi = (off >> 5) + 2;          // next dword to append (the subsequence's bytes + 16 of overshoot)
     unsigned long long buf = (((unsigned long long)be32(slot, off >> 5) << 32) | be32(slot, (off >> 5) + 1)) << (off & 31u);
     int avail = 64 - (int)(off & 31u);
-    unsigned n0 = be32(slot, wi), n1 = be32(slot, min(wi + 1, 35u));
+    unsigned n0 = be32(slot, wi), n1 = be32(slot, min(wi + 1, (unsigned)(S / 32 + 3)));
     int comp = G.b2comp[b];
     const HdTable *dct = &T.dc[comp], *act = &T.ac[comp];
     while (p < limit) {
-        if (avail <= 32) { // append a pre-loaded dword; request the one after next (indices stay inside the 36 dwords)
+        if (avail <= 32) { // append a pre-loaded dword; request the one after next (indices stay inside the subsequence + overshoot)
             buf |= (unsigned long long)n0 << (32 - avail);
             avail += 32;
             wi++;
             n0 = n1;
-            n1 = be32(slot, min(wi + 1, 35u));
+            n1 = be32(slot, min(wi + 1, (unsigned)(S / 32 + 3)));
         }
         const HdTable &t = k ? *act : *dct;
         const unsigned e = lookup(t, buf);
