@@ -1229,9 +1229,7 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
     P.frame_blocks = d_frame_blocks;
     P.changed = d_flags;
     P.status = d_flags + 1;
-    // clear_block for every block: only non-zero coefficients are stored
-    for (int f = 0; f < n_frames; f++)
-        HIPCHK(c, hipMemsetAsync(d_coefs + (size_t)f * coef_fs, 0, info0.coef_count * sizeof(int16_t), st));
+    // (no clearing of the records: the write pass stores every index of every coded block exactly once)
     // synchronisation rounds: until a round changes no start state
     int round = 0;
     const int max_rounds = 48;
@@ -1540,7 +1538,6 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         if (he == hipSuccess) he = hipEventRecord(c->ev_h2d[slot], c->copy_stream);
         if (he == hipSuccess) he = hipStreamWaitEvent(compute, c->ev_h2d[slot], 0);
         if (he == hipSuccess) he = hipEventRecord(c->ev_et[slot][1], compute);
-        if (he == hipSuccess) he = hipMemsetAsync(P.coefs, 0, info0.coef_count * sizeof(int16_t) * (size_t)cnt, compute);
         if (he == hipSuccess) he = gd_enqueue(P, 4, compute);
         if (he == hipSuccess) // changed + status -> the pinned copy of the index arrays
             he = hipMemcpyAsync(hm + (meta_words - 2), P.changed, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, compute);

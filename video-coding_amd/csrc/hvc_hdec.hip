@@ -80,10 +80,17 @@ __device__ __forceinline__ void load_geo(const HdParams &P, HdGeo &G) {
 template <bool WRITE>
 __device__ __forceinline__ void walk(const HdParams &P, const HdGeo &G, const HdTables &T, const unsigned *slot, unsigned base, unsigned limit,
                                      unsigned &p, int &k, int &b, unsigned &nb, unsigned first_block, int16_t *rec,
-                                     unsigned &err) {
+                                     unsigned &err, int16_t *lb = nullptr) {
+    // WRITE: lb = this lane's 64-coefficient LDS buffer (zeroed).  Coefficients are assembled there and
+    // leave as whole 128-byte blocks (eight 16-byte stores); storing them one by one -- 2 bytes at random
+    // places of a record that is not in any cache -- made the write pass cost as much as all the
+    // synchronisation rounds together.  A block that straddles two subsequences is written by both
+    // lanes, each its own index range [lo, hi): the lane that decoded the DC owns [0, k at its exit), the
+    // next lane the rest; nothing is cleared beforehand, every index of every coded block is written once.
     const int B = P.blocks_per_mcu;
     unsigned bi = first_block;
     int16_t *blk = nullptr;
+    int lo = k; // first index of the current block this lane is responsible for
     // position of the current block: MCU coordinates advance by counting, no divisions inside the loop
     unsigned mx = 0, my = 0;
     if (WRITE) {
@@ -147,7 +154,7 @@ __device__ __forceinline__ void walk(const HdParams &P, const HdGeo &G, const Hd
         bool end_block = false;
         if (is_dc) {
             if (live) { // the difference; k_hd_dc turns it into the value
-                blk[0] = (int16_t)mag;
+                lb[0] = (int16_t)mag;
                 if (mag < -32768 || mag > 32767) err |= 2u;
             }
             k = 1;
@@ -159,12 +166,28 @@ __device__ __forceinline__ void walk(const HdParams &P, const HdGeo &G, const Hd
                 if (live) err |= 1u;
                 end_block = true;
             } else {
-                if (live && mag) blk[k] = (int16_t)mag;
+                if (live && mag) lb[k] = (int16_t)mag;
                 k++;
                 end_block = k == 64;
             }
         }
         if (end_block) {
+            if (live) { // the block is complete: flush [lo, 64) and clear the buffer
+                if (lo == 0) {
+                    const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        reinterpret_cast<uint4 *>(blk)[q] = reinterpret_cast<const uint4 *>(lb)[q];
+                        reinterpret_cast<uint4 *>(lb)[q] = z;
+                    }
+                } else {
+                    for (int q = lo; q < 64; q++) {
+                        blk[q] = lb[q];
+                        lb[q] = 0;
+                    }
+                }
+            }
+            lo = 0;
             k = 0;
             b = b + 1 == B ? 0 : b + 1;
             nb++;
@@ -183,6 +206,8 @@ __device__ __forceinline__ void walk(const HdParams &P, const HdGeo &G, const Hd
             if (live) blk = block_ptr(b);
         }
     }
+    if (live) // the block in progress at the exit: this lane owns [lo, k); the next lane starts at index k
+        for (int q = lo; q < k; q++) blk[q] = lb[q];
 }
 
 } // namespace
@@ -288,11 +313,14 @@ __global__ __launch_bounds__(1024) void k_hd_scan(HdParams P) {
 __global__ __launch_bounds__(256) void k_hd_write(HdParams P, int final_round) {
     __shared__ HdTables T;
     __shared__ HdGeo G;
+    __shared__ uint4 lbuf[256 * 8]; // 64 int16 per lane
     load_geo(P, G);
     {
         const unsigned *src = reinterpret_cast<const unsigned *>(P.tables);
         unsigned *dst = reinterpret_cast<unsigned *>(&T);
         for (unsigned i = threadIdx.x; i < sizeof(HdTables) / 4; i += 256) dst[i] = src[i];
+#pragma unroll
+        for (int q = 0; q < 8; q++) lbuf[threadIdx.x * 8 + q] = make_uint4(0, 0, 0, 0);
     }
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
     const bool valid = i < P.total_sub;
@@ -307,7 +335,8 @@ __global__ __launch_bounds__(256) void k_hd_write(HdParams P, int final_round) {
     int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
     unsigned nb = 0, err = 0;
     const unsigned base = j * (unsigned)S;
-    walk<true>(P, G, T, slot, base, base + (unsigned)S, p, k, b, nb, first_block, P.coefs + (size_t)f * P.coef_fs, err);
+    walk<true>(P, G, T, slot, base, base + (unsigned)S, p, k, b, nb, first_block, P.coefs + (size_t)f * P.coef_fs, err,
+               reinterpret_cast<int16_t *>(lbuf + threadIdx.x * 8));
     if (err) atomicOr(P.status, err);
     (void)final_round;
 }
