@@ -1141,6 +1141,39 @@ static bool gd_geometry(const hvc_jpeg_info &info0, hvc::HdParams &P) {
     return true;
 }
 
+// The per-subsequence arrays of the GPU Huffman decoder inside one allocation of HVC_HD_STATE_BYTES(n).
+static void gd_carve_state(hvc::HdParams &P, void *mem, size_t n) {
+    unsigned long long *sp = (unsigned long long *)mem;
+    P.start_used = sp;
+    P.exit_a = sp + n;
+    P.exit_b = sp + 2 * n;
+    P.exit_c = sp + 3 * n;
+    unsigned *up = (unsigned *)(sp + 4 * n);
+    P.nblk = up;
+    P.list0 = up + n;
+    P.list1 = up + 2 * n;
+    P.list_n = up + 3 * n;
+}
+
+// Huffman tables of a batch -> device: the value tables and, when the components use at most two table
+// sets, the synchronisation tables (HdSpec) behind them.  Fills P.tables / P.spec / P.slotmask.
+static int gd_upload_tables(hvc_ctx *c, const hvc::HdTables &t, hvc::HdParams &P, hipStream_t st) {
+    int r;
+    if ((r = grow(c, &c->gd_tables, &c->gd_tables_cap, sizeof(hvc::HdTables) + sizeof(hvc::HdSpec)))) return r;
+    hvc::HdSpec spec;
+    unsigned char slot[4];
+    const bool have_spec = hvc::make_spec(t, P.n_comp, spec, slot);
+    HIPCHK(c, hipMemcpyAsync(c->gd_tables, &t, sizeof t, hipMemcpyHostToDevice, st));
+    if (have_spec)
+        HIPCHK(c, hipMemcpyAsync((char *)c->gd_tables + sizeof t, &spec, sizeof spec, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st)); // both sources live on a stack frame
+    P.tables = (const hvc::HdTables *)c->gd_tables;
+    P.spec = have_spec ? (const hvc::HdSpec *)((char *)c->gd_tables + sizeof t) : nullptr;
+    P.slotmask = 0;
+    for (int b = 0; b < P.blocks_per_mcu; b++) P.slotmask |= (unsigned)slot[P.b2comp[b]] << b;
+    return HVC_OK;
+}
+
 // Enqueue the whole decode on `st`: flags cleared, `rounds` synchronisation launches, finish passes.
 // P.changed afterwards holds the last launch's flag (0 = settled), P.status the error bits.
 static hipError_t gd_enqueue(const hvc::HdParams &P, int rounds, hipStream_t st) {
@@ -1202,8 +1235,7 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
     const size_t meta_words = (size_t)n_frames + ((size_t)n_frames + 1) + subs + (size_t)n_frames + 2;
     if ((r = grow(c, &c->gd_ecs, &c->gd_ecs_cap, bytes))) return r;
     if ((r = grow(c, &c->gd_meta, &c->gd_meta_cap, meta_words * sizeof(unsigned) + 64))) return r;
-    if ((r = grow(c, &c->gd_state, &c->gd_state_cap, subs * (3 * sizeof(unsigned long long) + sizeof(unsigned)) + 64))) return r;
-    if ((r = grow(c, &c->gd_tables, &c->gd_tables_cap, sizeof(hvc::HdTables)))) return r;
+    if ((r = grow(c, &c->gd_state, &c->gd_state_cap, HVC_HD_STATE_BYTES(subs)))) return r;
     unsigned *m = (unsigned *)c->gd_meta;
     unsigned *d_ecs_off = m, *d_sub_off = m + n_frames, *d_frame_of = d_sub_off + n_frames + 1;
     unsigned *d_frame_blocks = d_frame_of + subs, *d_flags = d_frame_blocks + n_frames;
@@ -1212,20 +1244,15 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
     HIPCHK(c, hipMemcpyAsync(d_ecs_off, ecs_off.data(), (size_t)n_frames * sizeof(unsigned), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(d_sub_off, sub_off.data(), ((size_t)n_frames + 1) * sizeof(unsigned), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(d_frame_of, frame_of.data(), subs * sizeof(unsigned), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->gd_tables, &tables0, sizeof tables0, hipMemcpyHostToDevice, st));
+    if ((r = gd_upload_tables(c, tables0, P, st))) return r;
     HIPCHK(c, hipMemsetAsync(d_flags, 0, 2 * sizeof(unsigned), st));
     P.ecs = (const uint8_t *)c->gd_ecs;
     P.ecs_off = d_ecs_off;
     P.sub_off = d_sub_off;
     P.frame_of = d_frame_of;
-    P.tables = (const hvc::HdTables *)c->gd_tables;
     P.coefs = d_coefs;
     P.coef_fs = coef_fs;
-    unsigned long long *sp = (unsigned long long *)c->gd_state;
-    P.start_used = sp;
-    P.exit_a = sp + subs;
-    P.exit_b = sp + 2 * subs;
-    P.nblk = (unsigned *)(sp + 3 * subs);
+    gd_carve_state(P, c->gd_state, subs);
     P.frame_blocks = d_frame_blocks;
     P.changed = d_flags;
     P.status = d_flags + 1;
@@ -1244,7 +1271,7 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
             if (round >= max_rounds) return HVC_OK; // does not settle: let the host decoder handle it
         }
     }
-    HIPCHK(c, hvc::launch_hd_finish(P, round, st));
+    HIPCHK(c, hvc::launch_hd_finish(P, round + 1, st)); // launches 0..round have run
     unsigned status = 0;
     HIPCHK(c, hipMemcpyAsync(&status, P.status, sizeof status, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -1413,12 +1440,8 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
             if (hipMalloc(&c->d_oring[i], oring_bytes) != hipSuccess) return HVC_E_OUT_OF_MEMORY;
         c->oring_bytes = oring_bytes;
     }
-    if ((r = grow(c, &c->gd_state, &c->gd_state_cap,
-                  (size_t)C * nsub_max * (3 * sizeof(unsigned long long) + sizeof(unsigned)) + 64)))
-        return r;
-    if ((r = grow(c, &c->gd_tables, &c->gd_tables_cap, sizeof(hvc::HdTables)))) return r;
-    HIPCHK(c, hipMemcpyAsync(c->gd_tables, &tables0, sizeof tables0, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream)); // tables0 lives on this stack frame
+    if ((r = grow(c, &c->gd_state, &c->gd_state_cap, HVC_HD_STATE_BYTES((size_t)C * nsub_max)))) return r;
+    if ((r = gd_upload_tables(c, tables0, G, c->stream))) return r;
 
     // workers: header parse, table check, unstuffing into the pinned segment ring
     std::mutex mu;
@@ -1522,14 +1545,9 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         P.frame_blocks = dm + (meta_words - 2 - C);
         P.changed = dm + (meta_words - 2);
         P.status = dm + (meta_words - 1);
-        P.tables = (const hvc::HdTables *)c->gd_tables;
         P.coefs = (int16_t *)c->d_ring[slot];
         P.coef_fs = info0.coef_count;
-        unsigned long long *sp = (unsigned long long *)c->gd_state;
-        P.start_used = sp;
-        P.exit_a = sp + (size_t)C * nsub_max;
-        P.exit_b = sp + 2 * (size_t)C * nsub_max;
-        P.nblk = (unsigned *)(sp + 3 * (size_t)C * nsub_max);
+        gd_carve_state(P, c->gd_state, (size_t)C * nsub_max);
         hipError_t he = hipEventRecord(c->ev_et[slot][0], c->copy_stream);
         if (he == hipSuccess)
             he = hipMemcpyAsync(c->gp_d_ecs[slot], c->gp_h_ecs[slot], (size_t)cnt * R, hipMemcpyHostToDevice, c->copy_stream);

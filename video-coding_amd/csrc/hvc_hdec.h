@@ -26,10 +26,24 @@ struct HdTables {
     HdTable dc[3], ac[3]; // per scan component (the GPU path takes at most three)
 };
 
+// The same tables as the synchronisation walk wants them: it needs no values, only how far a symbol moves the
+// bit position and the zig-zag index.  Entry: bits 0-5 bits consumed (code + magnitude; 1 for "no code": the
+// walk steps one bit), bits 6-10 index advance (run + 1; 1 for a DC symbol; 0 where the index stays), bit 11
+// end of block (EOB); 0x8000 | n in the first level = continue in sub-table n, as in HdTable.
+// Components that share their tables share a slot; frames with three different table sets keep to k_hd_round.
+struct HdSpec {
+    uint16_t t[2][2][1024 + HVC_HD_SUBTABLES * 64]; // [slot][0 = DC, 1 = AC]
+};
+// slot of every component, or false when the frame uses more than two different (DC, AC) table pairs
+bool make_spec(const HdTables &t, int n_comp, HdSpec &out, unsigned char slot_of_comp[4]);
+
 #ifndef HVC_HD_SUBSEQ_BITS
 #define HVC_HD_SUBSEQ_BITS 1024 /* bits per lane in the synchronisation rounds (a multiple of 128) */
 #endif
 #define HVC_HD_MAX_MCU_BLOCKS 16
+#define HVC_HD_LIST_N 16 /* >= rounds of k_hd_sync + 2 */
+// device bytes of the per-subsequence state for n subsequences (hvc_capi.hip carves HdParams' arrays out of it)
+#define HVC_HD_STATE_BYTES(n) ((size_t)(n) * (4 * sizeof(unsigned long long) + 3 * sizeof(unsigned)) + HVC_HD_LIST_N * sizeof(unsigned) + 64)
 
 struct HdComp {
     int h, v, bw;      // sampling factors, plane width in blocks
@@ -43,6 +57,8 @@ struct HdParams {
     const unsigned *sub_off;   // [n_frames + 1] first subsequence of every frame
     const unsigned *frame_of;  // [total_sub] frame of every subsequence
     const HdTables *tables;    // device
+    const HdSpec *spec;        // device, or null: synchronise with k_hd_round only
+    unsigned slotmask;         // bit b = table slot (HdSpec) of block b of an MCU
     int n_frames;
     unsigned total_sub;
     int n_comp, blocks_per_mcu, mbs_wide, mbs_high;
@@ -53,6 +69,9 @@ struct HdParams {
     size_t coef_fs;
     // per subsequence: state = bit position | k << 32 | block-in-MCU << 40
     unsigned long long *start_used, *exit_a, *exit_b;
+    // k_hd_sync only: second per-round exit buffer (exit_b is the first), the two work lists, list lengths per round
+    unsigned long long *exit_c;
+    unsigned *list0, *list1, *list_n; // [total_sub], [total_sub], [HVC_HD_LIST_N]
     unsigned *nblk;            // blocks completed inside the subsequence, then (scan) index of its first block
     unsigned *frame_blocks;    // [n_frames] blocks found in the whole segment
     unsigned *changed;         // [1]

@@ -21,6 +21,8 @@
 // bit here: the caller then runs the host decoder, which reproduces the model's behaviour exactly.
 #include "hvc_hdec.h"
 
+#include <cstring>
+
 namespace hvc {
 
 namespace {
@@ -275,6 +277,129 @@ __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// The synchronisation rounds in their fast form.  k_hd_round spends its time in three places: its walk
+// carries everything the write pass needs (90 instructions per symbol, in a loop where every branch is taken
+// by some lane of the wavefront); it reads the bits dword by dword from global memory and has to wait for
+// each of them (any lane's refill stalls the wavefront); and from the third round on only the few
+// subsequences at the front of a not yet synchronised stretch have work, one lane here and there in wavefronts
+// that take as long as ever -- eight rounds cost eight passes where three passes' worth of lanes are busy.
+// k_hd_sync answers the three of them:
+//   * the walk reads HdSpec entries -- bits to skip, index advance, end of block -- and nothing else;
+//   * every lane's subsequence is staged in LDS (rows of 37 dwords, an odd stride: no bank conflicts), bytes
+//     already swapped, and read through a 64-bit window of two registers that v_alignbit_b32 looks into:
+//     no 64-bit shifts, no global loads inside the loop;
+//   * the rounds are level-synchronous with WORK LISTS: round 0 walks every subsequence from the guessed
+//     state, round 1 from the exit of its predecessor, and from then on round r + 1 walks exactly the
+//     subsequences whose predecessor's exit CHANGED in round r (the lane that sees its exit change appends
+//     its successor), packed densely into wavefronts.  Exits of round r go to exit buffer r & 1, which round
+//     r + 1 only reads, so a round never sees a half-updated neighbour; the canonical copy (exit_a), the
+//     start state and the block count belong to the subsequence's own lane.  ~3.2 passes per subsequence
+//     instead of 8 on the reference frames.
+// The rounds are enqueued back to back (SYNC_ROUNDS of them, the later ones over empty lists most of the
+// time).  What they leave -- start_used / exit_a / nblk -- is what k_hd_round leaves; k_hd_round(1..) then
+// verifies every hand-over and keeps going where a stream needs more rounds (smooth content with its periodic
+// bit patterns can take hundreds), and the write pass compares the exit of its own walk with the recorded one.
+constexpr int SYNC_ROUNDS = 12;
+constexpr int SROW = S / 32 + 5; // the subsequence, 16 bytes of overshoot, one pad dword
+static_assert((SROW & 1) == 1, "odd row stride");
+constexpr int SPEC_T = 1024 + HVC_HD_SUBTABLES * 64;
+
+__device__ __forceinline__ void spec_walk(const unsigned *row, const uint16_t *sp, unsigned slotmask, int B, unsigned base,
+                                          unsigned &p, int &k, int &b, unsigned &nb) {
+    const unsigned limit = base + (unsigned)S;
+    const unsigned off = p - base;      // < 32 + S
+    unsigned ni = off >> 5;             // next dword of the row
+    int s = (32 - (int)(off & 31u)) & 31; // bits of `hi` not yet consumed, 0..31; the window is {hi, lo} >> s
+    unsigned hi = 0;
+    if (s) hi = row[min(ni++, (unsigned)(SROW - 2))];
+    unsigned lo = row[min(ni++, (unsigned)(SROW - 2))];
+    unsigned nx = row[min(ni, (unsigned)(SROW - 2))];
+    const uint16_t *bt = sp + ((slotmask >> b) & 1u) * (2 * SPEC_T);
+    while (p < limit) {
+        const unsigned w = __builtin_amdgcn_alignbit(hi, lo, (unsigned)s); // the next 32 bits
+        const uint16_t *t = bt + (k ? SPEC_T : 0);
+        unsigned e = t[w >> 22];
+        if (e & 0x8000u) e = t[1024u + (e & 0x7fffu) * 64u + ((w >> 16) & 63u)];
+        const int used = (int)(e & 63u);
+        k += (int)((e >> 6) & 31u);
+        p += (unsigned)used;
+        s -= used;
+        if (s < 0) { // `hi` is used up (used <= 32: one step is enough)
+            hi = lo;
+            lo = nx;
+            s += 32;
+            ni++;
+            nx = row[min(ni, (unsigned)(SROW - 2))];
+        }
+        if ((e & 0x800u) || k >= 64) { // EOB, index 63 written, or past it (the model raises: the true parse never gets here)
+            k = 0;
+            b = b + 1 == B ? 0 : b + 1;
+            nb++;
+            bt = sp + ((slotmask >> b) & 1u) * (2 * SPEC_T);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hd_sync(HdParams P, int round) {
+    __shared__ uint16_t sp[2 * 2 * SPEC_T];
+    __shared__ unsigned rows[4][64 * SROW];
+    {
+        const unsigned *src = reinterpret_cast<const unsigned *>(P.spec);
+        unsigned *dst = reinterpret_cast<unsigned *>(sp);
+        for (unsigned i = threadIdx.x; i < sizeof(HdSpec) / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads(); // the tables; from here on the four wavefronts have nothing to do with one another
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned *row = rows[wave] + lane * SROW;
+    const unsigned *list = (round & 1) ? P.list1 : P.list0; // rounds 0 and 1: every subsequence, no list
+    unsigned *next = (round & 1) ? P.list0 : P.list1;
+    const unsigned count = round < 2 ? P.total_sub : P.list_n[round];
+    const unsigned long long *pe = (round & 1) ? P.exit_b : P.exit_c; // exits of round - 1
+    unsigned long long *ce = (round & 1) ? P.exit_c : P.exit_b;       // exits of this round
+    for (unsigned t0 = (blockIdx.x * 4u + (unsigned)wave) * 64u; t0 < count; t0 += gridDim.x * 256u) {
+        const unsigned t = t0 + (unsigned)lane;
+        const bool valid = t < count;
+        const unsigned i = !valid ? 0u : round < 2 ? t : list[t];
+        const unsigned f = P.frame_of[i], j = i - P.sub_off[f];
+        const unsigned base = j * (unsigned)S;
+        unsigned long long st = pack_state(base, 0, 0); // the guess; the truth for j == 0
+        if (round > 0 && j > 0) st = pe[i - 1];
+        const bool go = valid && (round == 0 || st != P.start_used[i]);
+        bool push = false;
+        if (go) {
+            // this lane's bytes: 128 + 16 of overshoot (the segment buffer has them, hvc_capi.hip)
+            const uint4 *src = reinterpret_cast<const uint4 *>(P.ecs + P.ecs_off[f] + (size_t)j * (S / 8));
+#pragma unroll
+            for (int q = 0; q < S / 128 + 1; q++) {
+                const uint4 v = src[q];
+                row[4 * q + 0] = __builtin_bswap32(v.x);
+                row[4 * q + 1] = __builtin_bswap32(v.y);
+                row[4 * q + 2] = __builtin_bswap32(v.z);
+                row[4 * q + 3] = __builtin_bswap32(v.w);
+            }
+            unsigned p = (unsigned)st, nb = 0;
+            int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
+            spec_walk(row, sp, P.slotmask, P.blocks_per_mcu, base, p, k, b, nb);
+            const unsigned long long ex = pack_state(p, k, b);
+            const bool differs = round == 0 || ex != P.exit_a[i];
+            P.exit_a[i] = ex;
+            ce[i] = ex;
+            P.start_used[i] = st;
+            P.nblk[i] = nb;
+            // the successor (same frame) has to start again; after round 0 everybody does, no list needed
+            push = round > 0 && differs && i + 1 < P.sub_off[f + 1];
+        }
+        const unsigned long long m = __ballot(push);
+        if (m) { // one atomic per wavefront
+            unsigned at = 0;
+            if (lane == 0) at = atomicAdd(&P.list_n[round + 1], (unsigned)__popcll(m));
+            at = __shfl(at, 0);
+            if (push) next[at + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = i + 1;
+        }
+    }
+}
+
 // Exclusive scan of nblk inside every frame (one workgroup per frame); total -> frame_blocks.
 __global__ __launch_bounds__(1024) void k_hd_scan(HdParams P) {
     __shared__ unsigned wsum[16];
@@ -337,8 +462,10 @@ __global__ __launch_bounds__(256) void k_hd_write(HdParams P, int final_round) {
     const unsigned base = j * (unsigned)S;
     walk<true>(P, G, T, slot, base, base + (unsigned)S, p, k, b, nb, first_block, P.coefs + (size_t)f * P.coef_fs, err,
                reinterpret_cast<int16_t *>(lbuf + threadIdx.x * 8));
+    // the exit the synchronisation launches recorded for this subsequence must be the one this walk arrives at
+    const unsigned long long *fin = (final_round & 1) ? P.exit_a : P.exit_b; // launch final_round - 1 wrote it
+    if (pack_state(p, k, b) != fin[i]) err |= 8u;
     if (err) atomicOr(P.status, err);
-    (void)final_round;
 }
 
 // DC differences -> DC values (decoder.ml:143): inclusive prefix sum over the component's blocks in scan
@@ -388,8 +515,54 @@ __global__ __launch_bounds__(1024) void k_hd_dc(HdParams P) {
     if (bad) atomicOr(P.status, 2u);
 }
 
+bool make_spec(const HdTables &t, int n_comp, HdSpec &out, unsigned char slot_of_comp[4]) {
+    if (n_comp < 1 || n_comp > 3) return false;
+    int rep[2] = {0, -1}; // the component whose tables a slot holds
+    for (int c = 0; c < 4; c++) slot_of_comp[c] = 0;
+    for (int c = 1; c < n_comp; c++) {
+        auto same = [&](int a) { return !std::memcmp(&t.dc[c], &t.dc[a], sizeof(HdTable)) && !std::memcmp(&t.ac[c], &t.ac[a], sizeof(HdTable)); };
+        if (same(rep[0])) continue;
+        if (rep[1] < 0) rep[1] = c;
+        if (!same(rep[1])) return false;
+        slot_of_comp[c] = 1;
+    }
+    std::memset(&out, 0, sizeof out);
+    auto conv = [](uint16_t e, bool dc) -> uint16_t {
+        if (e & 0x8000u) return e;             // continues in a sub-table
+        if (!e) return 1;                      // no code: one bit further, same state
+        const unsigned len = e >> 8, val = e & 0xffu;
+        if (dc) return (uint16_t)(val > 16 ? len : (len + val) | (1u << 6)); // category > 16: the index stays 0
+        const unsigned size = val & 15u, run = val >> 4;
+        if (!size && !run) return (uint16_t)(len | 0x800u);
+        return (uint16_t)((len + size) | ((run + 1u) << 6));
+    };
+    for (int sl = 0; sl < 2; sl++) {
+        if (rep[sl] < 0) continue;
+        const HdTable *src[2] = {&t.dc[rep[sl]], &t.ac[rep[sl]]};
+        for (int cls = 0; cls < 2; cls++) {
+            for (int q = 0; q < 1024; q++) out.t[sl][cls][q] = conv(src[cls]->fast[q], cls == 0);
+            for (int q = 0; q < HVC_HD_SUBTABLES * 64; q++) {
+                const uint16_t e = src[cls]->sub[q];
+                out.t[sl][cls][1024 + q] = (e & 0x8000u) ? (uint16_t)1 : conv(e, cls == 0);
+            }
+        }
+    }
+    return true;
+}
+
 hipError_t launch_hd_round(const HdParams &P, int round, hipStream_t s) {
     if (P.total_sub == 0) return hipSuccess;
+    if (round == 0 && P.spec) { // all the fast rounds; launches 1.. of k_hd_round verify and, if need be, continue
+        hipError_t e = hipMemsetAsync(P.list_n, 0, (SYNC_ROUNDS + 2) * sizeof(unsigned), s);
+        if (e != hipSuccess) return e;
+        const unsigned all = (P.total_sub + 255u) / 256u;
+        for (int r = 0; r < SYNC_ROUNDS; r++) {
+            // the lists shrink by about half a round; a grid-stride loop takes whatever is there
+            const unsigned grid = r < 2 ? all : min(all, r < 4 ? 4096u : 768u);
+            hipLaunchKernelGGL(k_hd_sync, dim3(grid), dim3(256), 0, s, P, r);
+        }
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_hd_round, dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, round);
     return hipGetLastError();
 }
