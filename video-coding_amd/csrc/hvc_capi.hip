@@ -43,6 +43,8 @@ struct hvc_ctx {
     // hvc_jpeg_decode_batch: copy stream + ring of pinned host / device coefficient chunks
     static constexpr int RING = 3;
     hipStream_t copy_stream = nullptr, down_stream = nullptr;
+    hipStream_t rd_stream[2] = {}; // hvc_jpeg_decode_batch_gpu: the Huffman reader of even / odd chunks
+    hipEvent_t ev_rd[3] = {};      // ... its "records complete" per ring slot (RING entries)
     void *h_ring[RING] = {}, *d_ring[RING] = {}, *d_oring[RING] = {};
     size_t ring_bytes = 0, oring_bytes = 0;
     hipEvent_t ev_h2d[RING] = {}, ev_kern[RING] = {}, ev_t[4] = {};
@@ -258,6 +260,10 @@ void hvc_destroy(hvc_ctx *c) {
     if (c->hd_bitbuf) (void)hipFree(c->hd_bitbuf);
     if (c->hd_ff) (void)hipFree(c->hd_ff);
     if (c->hd_out) (void)hipFree(c->hd_out);
+    for (int i = 0; i < 2; i++)
+        if (c->rd_stream[i]) (void)hipStreamDestroy(c->rd_stream[i]);
+    for (int i = 0; i < 3; i++)
+        if (c->ev_rd[i]) (void)hipEventDestroy(c->ev_rd[i]);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1162,7 +1168,8 @@ static int gd_upload_tables(hvc_ctx *c, const hvc::HdTables &t, hvc::HdParams &P
     if ((r = grow(c, &c->gd_tables, &c->gd_tables_cap, sizeof(hvc::HdTables) + sizeof(hvc::HdSpec)))) return r;
     hvc::HdSpec spec;
     unsigned char slot[4];
-    const bool have_spec = hvc::make_spec(t, P.n_comp, spec, slot);
+    static const bool classic = std::getenv("HVC_HD_CLASSIC") != nullptr; // tests: force k_hd_round / k_hd_write
+    const bool have_spec = hvc::make_spec(t, P.n_comp, spec, slot, P.slot_rep) && !classic;
     HIPCHK(c, hipMemcpyAsync(c->gd_tables, &t, sizeof t, hipMemcpyHostToDevice, st));
     if (have_spec)
         HIPCHK(c, hipMemcpyAsync((char *)c->gd_tables + sizeof t, &spec, sizeof spec, hipMemcpyHostToDevice, st));
@@ -1440,7 +1447,23 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
             if (hipMalloc(&c->d_oring[i], oring_bytes) != hipSuccess) return HVC_E_OUT_OF_MEMORY;
         c->oring_bytes = oring_bytes;
     }
-    if ((r = grow(c, &c->gd_state, &c->gd_state_cap, HVC_HD_STATE_BYTES((size_t)C * nsub_max)))) return r;
+    // The reader of chunk k runs on rd_stream[k & 1] with its own per-subsequence state, the block stage of all
+    // chunks on c->stream: the last synchronisation rounds of a chunk (a handful of wavefronts chasing the few
+    // stretches that are slow to synchronise, each round a full kernel's latency) overlap with the next chunk's
+    // first ones, which fill the GPU.
+    static_assert(hvc_ctx::RING <= 3, "ev_rd");
+    if (!c->rd_stream[0]) {
+        // two streams of the same priority can end up on one hardware queue (they did: no overlap at all);
+        // streams of different priorities never share one
+        int least = 0, greatest = 0;
+        HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(c, hipStreamCreateWithPriority(&c->rd_stream[0], hipStreamNonBlocking, least));
+        HIPCHK(c, hipStreamCreateWithPriority(&c->rd_stream[1], hipStreamNonBlocking, greatest));
+    }
+    for (int i = 0; i < NB; i++)
+        if (!c->ev_rd[i]) HIPCHK(c, hipEventCreate(&c->ev_rd[i]));
+    const size_t state_bytes = (HVC_HD_STATE_BYTES((size_t)C * nsub_max) + 255) & ~(size_t)255;
+    if ((r = grow(c, &c->gd_state, &c->gd_state_cap, 2 * state_bytes))) return r;
     if ((r = gd_upload_tables(c, tables0, G, c->stream))) return r;
 
     // workers: header parse, table check, unstuffing into the pinned segment ring
@@ -1547,18 +1570,22 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         P.status = dm + (meta_words - 1);
         P.coefs = (int16_t *)c->d_ring[slot];
         P.coef_fs = info0.coef_count;
-        gd_carve_state(P, c->gd_state, (size_t)C * nsub_max);
+        gd_carve_state(P, (char *)c->gd_state + (size_t)(k & 1) * state_bytes, (size_t)C * nsub_max);
+        hipStream_t rs = c->rd_stream[k & 1];
         hipError_t he = hipEventRecord(c->ev_et[slot][0], c->copy_stream);
         if (he == hipSuccess)
             he = hipMemcpyAsync(c->gp_d_ecs[slot], c->gp_h_ecs[slot], (size_t)cnt * R, hipMemcpyHostToDevice, c->copy_stream);
         if (he == hipSuccess)
             he = hipMemcpyAsync(dm, hm, ((size_t)2 * C + 1 + subs) * sizeof(unsigned), hipMemcpyHostToDevice, c->copy_stream);
         if (he == hipSuccess) he = hipEventRecord(c->ev_h2d[slot], c->copy_stream);
-        if (he == hipSuccess) he = hipStreamWaitEvent(compute, c->ev_h2d[slot], 0);
-        if (he == hipSuccess) he = hipEventRecord(c->ev_et[slot][1], compute);
-        if (he == hipSuccess) he = gd_enqueue(P, 4, compute);
+        // (the slot's records and index arrays are free: the verdict above waited for chunk k - NB's block stage)
+        if (he == hipSuccess) he = hipStreamWaitEvent(rs, c->ev_h2d[slot], 0);
+        if (he == hipSuccess) he = hipEventRecord(c->ev_et[slot][1], rs);
+        if (he == hipSuccess) he = gd_enqueue(P, 4, rs);
         if (he == hipSuccess) // changed + status -> the pinned copy of the index arrays
-            he = hipMemcpyAsync(hm + (meta_words - 2), P.changed, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, compute);
+            he = hipMemcpyAsync(hm + (meta_words - 2), P.changed, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, rs);
+        if (he == hipSuccess) he = hipEventRecord(c->ev_rd[slot], rs);
+        if (he == hipSuccess) he = hipStreamWaitEvent(compute, c->ev_rd[slot], 0);
         if (he != hipSuccess) { rc = fail_hip(c, he); break; }
         uint8_t *dst = where == HVC_MEM_DEVICE ? pixels + (size_t)first * pixel_fs : (uint8_t *)c->d_oring[slot];
         const size_t dst_fs = where == HVC_MEM_DEVICE ? pixel_fs : out_bytes;
@@ -1590,6 +1617,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         cv.notify_all();
     }
     for (auto &t : pool) t.join();
+    for (int i = 0; i < 2; i++) (void)hipStreamSynchronize(c->rd_stream[i]);
     (void)hipStreamSynchronize(compute);
     (void)hipStreamSynchronize(c->copy_stream);
     if (rc == HVC_OK && error.load()) rc = error.load();

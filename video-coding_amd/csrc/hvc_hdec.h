@@ -35,7 +35,7 @@ struct HdSpec {
     uint16_t t[2][2][1024 + HVC_HD_SUBTABLES * 64]; // [slot][0 = DC, 1 = AC]
 };
 // slot of every component, or false when the frame uses more than two different (DC, AC) table pairs
-bool make_spec(const HdTables &t, int n_comp, HdSpec &out, unsigned char slot_of_comp[4]);
+bool make_spec(const HdTables &t, int n_comp, HdSpec &out, unsigned char slot_of_comp[4], unsigned char slot_rep[2]);
 
 #ifndef HVC_HD_SUBSEQ_BITS
 #define HVC_HD_SUBSEQ_BITS 1024 /* bits per lane in the synchronisation rounds (a multiple of 128) */
@@ -59,6 +59,7 @@ struct HdParams {
     const HdTables *tables;    // device
     const HdSpec *spec;        // device, or null: synchronise with k_hd_round only
     unsigned slotmask;         // bit b = table slot (HdSpec) of block b of an MCU
+    unsigned char slot_rep[2]; // a component whose tables the slot stands for
     int n_frames;
     unsigned total_sub;
     int n_comp, blocks_per_mcu, mbs_wide, mbs_high;

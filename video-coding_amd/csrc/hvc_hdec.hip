@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
 // that take as long as ever -- eight rounds cost eight passes where three passes' worth of lanes are busy.
 // k_hd_sync answers the three of them:
 //   * the walk reads HdSpec entries -- bits to skip, index advance, end of block -- and nothing else;
-//   * every lane's subsequence is staged in LDS (rows of 37 dwords, an odd stride: no bank conflicts), bytes
+//   * every lane's subsequence is staged in LDS (rows of 33 dwords, an odd stride: no bank conflicts), bytes
 //     already swapped, and read through a 64-bit window of two registers that v_alignbit_b32 looks into:
 //     no 64-bit shifts, no global loads inside the loop;
 //   * the rounds are level-synchronous with WORK LISTS: round 0 walks every subsequence from the guessed
@@ -301,8 +301,23 @@ __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
 // verifies every hand-over and keeps going where a stream needs more rounds (smooth content with its periodic
 // bit patterns can take hundreds), and the write pass compares the exit of its own walk with the recorded one.
 constexpr int SYNC_ROUNDS = 12;
-constexpr int SROW = S / 32 + 5; // the subsequence, 16 bytes of overshoot, one pad dword
+// A staged subsequence: its S / 32 dwords and one more.  A symbol starts before bit S and is at most 32 bits long
+// (code <= 16, magnitude <= 16), so bit S + 31 is the last one any walk looks at.  S / 32 + 1 is odd: lanes reading
+// the same dword index of their rows hit different LDS banks.
+constexpr int SROW = S / 32 + 1;
 static_assert((SROW & 1) == 1, "odd row stride");
+__device__ __forceinline__ void stage_row(unsigned *row, const uint8_t *seg) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(seg);
+#pragma unroll
+    for (int q = 0; q < S / 128; q++) {
+        const uint4 v = src[q];
+        row[4 * q + 0] = __builtin_bswap32(v.x);
+        row[4 * q + 1] = __builtin_bswap32(v.y);
+        row[4 * q + 2] = __builtin_bswap32(v.z);
+        row[4 * q + 3] = __builtin_bswap32(v.w);
+    }
+    row[S / 32] = __builtin_bswap32(reinterpret_cast<const unsigned *>(seg)[S / 32]); // the segment buffer has 16 bytes past every frame
+}
 constexpr int SPEC_T = 1024 + HVC_HD_SUBTABLES * 64;
 
 __device__ __forceinline__ void spec_walk(const unsigned *row, const uint16_t *sp, unsigned slotmask, int B, unsigned base,
@@ -312,9 +327,9 @@ __device__ __forceinline__ void spec_walk(const unsigned *row, const uint16_t *s
     unsigned ni = off >> 5;             // next dword of the row
     int s = (32 - (int)(off & 31u)) & 31; // bits of `hi` not yet consumed, 0..31; the window is {hi, lo} >> s
     unsigned hi = 0;
-    if (s) hi = row[min(ni++, (unsigned)(SROW - 2))];
-    unsigned lo = row[min(ni++, (unsigned)(SROW - 2))];
-    unsigned nx = row[min(ni, (unsigned)(SROW - 2))];
+    if (s) hi = row[min(ni++, (unsigned)(SROW - 1))];
+    unsigned lo = row[min(ni++, (unsigned)(SROW - 1))];
+    unsigned nx = row[min(ni, (unsigned)(SROW - 1))];
     const uint16_t *bt = sp + ((slotmask >> b) & 1u) * (2 * SPEC_T);
     while (p < limit) {
         const unsigned w = __builtin_amdgcn_alignbit(hi, lo, (unsigned)s); // the next 32 bits
@@ -330,7 +345,7 @@ __device__ __forceinline__ void spec_walk(const unsigned *row, const uint16_t *s
             lo = nx;
             s += 32;
             ni++;
-            nx = row[min(ni, (unsigned)(SROW - 2))];
+            nx = row[min(ni, (unsigned)(SROW - 1))];
         }
         if ((e & 0x800u) || k >= 64) { // EOB, index 63 written, or past it (the model raises: the true parse never gets here)
             k = 0;
@@ -344,6 +359,10 @@ __device__ __forceinline__ void spec_walk(const unsigned *row, const uint16_t *s
 __global__ __launch_bounds__(256) void k_hd_sync(HdParams P, int round) {
     __shared__ uint16_t sp[2 * 2 * SPEC_T];
     __shared__ unsigned rows[4][64 * SROW];
+#ifdef HVC_SYNC_PAD
+    __shared__ unsigned padlds[HVC_SYNC_PAD];
+    if (P.total_sub == 0xffffffffu) padlds[threadIdx.x] = 1, P.list_n[15] = padlds[threadIdx.x ^ 1];
+#endif
     {
         const unsigned *src = reinterpret_cast<const unsigned *>(P.spec);
         unsigned *dst = reinterpret_cast<unsigned *>(sp);
@@ -368,16 +387,7 @@ __global__ __launch_bounds__(256) void k_hd_sync(HdParams P, int round) {
         const bool go = valid && (round == 0 || st != P.start_used[i]);
         bool push = false;
         if (go) {
-            // this lane's bytes: 128 + 16 of overshoot (the segment buffer has them, hvc_capi.hip)
-            const uint4 *src = reinterpret_cast<const uint4 *>(P.ecs + P.ecs_off[f] + (size_t)j * (S / 8));
-#pragma unroll
-            for (int q = 0; q < S / 128 + 1; q++) {
-                const uint4 v = src[q];
-                row[4 * q + 0] = __builtin_bswap32(v.x);
-                row[4 * q + 1] = __builtin_bswap32(v.y);
-                row[4 * q + 2] = __builtin_bswap32(v.z);
-                row[4 * q + 3] = __builtin_bswap32(v.w);
-            }
+            stage_row(row, P.ecs + P.ecs_off[f] + (size_t)j * (S / 8));
             unsigned p = (unsigned)st, nb = 0;
             int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
             spec_walk(row, sp, P.slotmask, P.blocks_per_mcu, base, p, k, b, nb);
@@ -468,6 +478,196 @@ __global__ __launch_bounds__(256) void k_hd_write(HdParams P, int final_round) {
     if (err) atomicOr(P.status, err);
 }
 
+// The write pass in its fast form (needs HdSpec's slots: at most two table sets).
+//   * Subsequences staged in LDS and read through the two-register window, like k_hd_sync.
+//   * A block belongs to the lane it STARTS in: that lane decodes on past the end of its subsequence (into the
+//     rows of its neighbours, up to three of them: 64 symbols of at most 32 bits) until the block ends, and a lane
+//     that starts in the middle of a block walks to its end without storing.  Every block leaves whole.
+//   * Coefficients are assembled in a 128-byte LDS buffer per lane; finished blocks are stored by the WAVEFRONT:
+//     the lanes concerned put (place in the records, lane) on a small list, then eight lanes per block move one
+//     16-byte piece each from LDS to the record and clear it.  (The loop is therefore wavefront-uniform: no lane
+//     leaves before the last one is done.)
+//   * Block ends are batched: see WR_BATCH below.
+// 81.4 KB of LDS per workgroup: two workgroups per CU.
+constexpr int WR_EXTRA = 3; // rows staged past the workgroup's own, for the last lanes' overrun
+constexpr int WR_BATCH = 12; // block ends handled together
+
+__global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) {
+    __shared__ uint16_t tv[2 * 2 * SPEC_T]; // value tables of the two slots: [slot][DC, AC]
+    __shared__ HdGeo G;
+    __shared__ unsigned rows[(256 + WR_EXTRA) * SROW];
+    __shared__ uint4 lbuf[256 * 8]; // 64 int16 per lane
+    __shared__ uint2 flist[4][64];  // per wavefront: blocks to store (offset in the batch's records in 16-byte units, lane)
+    load_geo(P, G);
+    {
+        // value tables in the form the loop below wants: bits 0-4 code length (0: no code), 5-9 magnitude bits,
+        // 10-13 run of zeros, bit 14 EOB; 0x8000 | n (first level only) = continue in sub-table n
+        for (int sl = 0; sl < 2; sl++)
+            for (int cls = 0; cls < 2; cls++) {
+                const HdTable *src_t = cls ? &P.tables->ac[P.slot_rep[sl]] : &P.tables->dc[P.slot_rep[sl]];
+                const uint16_t *src = reinterpret_cast<const uint16_t *>(src_t);
+                for (unsigned i = threadIdx.x; i < sizeof(HdTable) / 2; i += 256) {
+                    const unsigned e = src[i];
+                    unsigned o = e;
+                    if (!(e & 0x8000u) && e) {
+                        const unsigned len = e >> 8, val = e & 0xffu;
+                        // a DC category above 31 cannot be coded here; it is an error like every category above 16
+                        o = cls ? (len | ((val & 15u) << 5) | ((val >> 4) << 10) | (val ? 0u : 0x4000u)) : (len | (min(val, 31u) << 5));
+                    }
+                    tv[(sl * 2 + cls) * SPEC_T + i] = (uint16_t)o;
+                }
+            }
+#pragma unroll
+        for (int q = 0; q < 8; q++) lbuf[threadIdx.x * 8 + q] = make_uint4(0, 0, 0, 0);
+    }
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const unsigned i = blockIdx.x * 256u + (unsigned)tid;
+    const bool valid = i < P.total_sub;
+    const unsigned f = valid ? P.frame_of[i] : 0u, j = valid ? i - P.sub_off[f] : 0u;
+    if (valid) stage_row(rows + tid * SROW, P.ecs + P.ecs_off[f] + (size_t)j * (S / 8));
+    if (tid < WR_EXTRA) {
+        const unsigned i2 = blockIdx.x * 256u + 256u + (unsigned)tid;
+        if (i2 < P.total_sub) {
+            const unsigned f2 = P.frame_of[i2];
+            stage_row(rows + (256 + tid) * SROW, P.ecs + P.ecs_off[f2] + (size_t)(i2 - P.sub_off[f2]) * (S / 8));
+        }
+    }
+    __syncthreads();
+    const unsigned *row = rows + tid * SROW;
+    // dword ni of the stream from this lane's subsequence on: rows are consecutive subsequences, SROW = S / 32 + 1
+    auto rd = [&](unsigned ni) -> unsigned { ni = min(ni, (unsigned)((WR_EXTRA + 1) * (S / 32) - 1)); return row[ni + ni / (unsigned)(S / 32)]; };
+    int16_t *lb = reinterpret_cast<int16_t *>(lbuf + tid * 8);
+    const int B = P.blocks_per_mcu;
+    const unsigned base = j * (unsigned)S, limit = base + (unsigned)S, hard = limit + (unsigned)(WR_EXTRA * S);
+    unsigned bi = valid ? P.nblk[i] : 0xffffffffu; // the block this subsequence starts in
+    bool act = valid && bi < P.blocks_per_frame;   // past the last coded block: the model never reads this far
+    const unsigned long long st = act ? P.start_used[i] : 0ull;
+    unsigned p = act ? (unsigned)st : 0u;
+    int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
+    bool skipping = k > 0; // the block in progress belongs to the lane it started in
+    unsigned err = 0;
+    const unsigned mcu = (act ? bi : 0u) / (unsigned)B;
+    unsigned my = mcu / (unsigned)P.mbs_wide, mx = mcu - my * (unsigned)P.mbs_wide; // advance by counting
+    // 16-byte units from P.coefs: records are multiples of 8 coefficients apart, planes of 64 (launch_hd_finish checks the range)
+    const unsigned frame_unit0 = (unsigned)(((size_t)f * P.coef_fs) >> 3);
+    auto block_no = [&](int bb) -> unsigned {
+        const int comp = G.b2comp[bb];
+        return frame_unit0 + (G.coef_off[comp] >> 3) +
+               ((my * (unsigned)G.v[comp] + G.b2sy[bb]) * (unsigned)G.bw[comp] + (mx * (unsigned)G.h[comp] + G.b2sx[bb])) * 8u;
+    };
+    const unsigned off = p - base;
+    unsigned ni = off >> 5;
+    int s = (32 - (int)(off & 31u)) & 31;
+    unsigned hi = 0;
+    if (s) hi = rd(ni++);
+    unsigned lo = rd(ni++);
+    unsigned nx = rd(ni);
+    const uint16_t *bt = tv + ((P.slotmask >> b) & 1u) * (2 * SPEC_T);
+    unsigned long long exit_state = 0;
+    bool exit_seen = false;
+    // What happens at the end of a block -- store it, find the next one's place -- costs more than a symbol, and in
+    // a wavefront some lane ends a block in almost every iteration.  A lane that ends a block therefore WAITS
+    // (pending) until WR_BATCH lanes do, or nobody else can go on; then the wavefront does all of them at once.
+    bool pending = false, flush = false;
+    unsigned cur_block = (act && !skipping) ? block_no(b) : 0u; // where the block in progress goes
+    while (__any(act)) {
+        if (act && !pending) {
+            const bool live = !skipping && bi < P.blocks_per_frame; // coefficients are stored, errors count
+            const unsigned w = __builtin_amdgcn_alignbit(hi, lo, (unsigned)s); // the next 32 bits: a whole symbol
+            const uint16_t *t = bt + (k ? SPEC_T : 0);
+            unsigned e = t[w >> 22];
+            if (e & 0x8000u) e = t[1024u + (e & 0x7fffu) * 64u + ((w >> 16) & 63u)];
+            // One path for DC and AC symbols (a DC symbol is "run 0" at index 0), no branches but the store:
+            const unsigned len = e & 31u, size = (e >> 5) & 31u, run = (e >> 10) & 15u;
+            const bool bad = !e || size > 16u; // "Can't find dc / ac code" (one bit further) / DC category above 16 (the code is skipped)
+            const unsigned used = bad ? max(len, 1u) : len + size;
+            // decoder.ml:73-79 mag': `size` bits after the code; a leading 0 bit means negative
+            const unsigned mbits = __builtin_amdgcn_ubfe(w, 32u - len - size, size);
+            const unsigned full = (1u << size) - 1u;
+            const int mag = (int)mbits - (mbits <= (full >> 1) ? (int)full : 0);
+            const int kk = k + (int)run; // the index this symbol's coefficient has
+            const bool eob = (e & 0x4000u) != 0u;
+            if (live) {
+                if (bad || (kk >= 64 && !eob)) err |= 1u; // ... / "coefficient index out of range"
+                else if (size) {
+                    lb[kk] = (int16_t)mag;
+                    if (size == 16u && (mag < -32768 || mag > 32767)) err |= 2u; // only a DC difference can be this long
+                }
+            }
+            const bool end_block = !bad && (eob || kk >= 63);
+            if (!bad) k = kk + 1;
+            p += (unsigned)used;
+            s -= used;
+            if (s < 0) {
+                hi = lo;
+                lo = nx;
+                s += 32;
+                ni++;
+                nx = rd(ni);
+            }
+            if (end_block) {
+                pending = true;
+                flush = live;
+                k = 0;
+            }
+            if (!exit_seen && p >= limit) { // where k_hd_sync's walk of this subsequence stopped
+                exit_seen = true;
+                exit_state = pack_state(p, k, end_block ? (b + 1 == B ? 0 : b + 1) : b);
+            }
+            if (p >= limit && !end_block) {
+                // a block in progress is finished here unless it is not this lane's (or nobody's: past the frame)
+                const bool mine = k > 0 && !skipping && bi < P.blocks_per_frame;
+                if (!mine) act = false;
+                else if (p >= hard) { // cannot happen: 64 symbols of <= 32 bits end a block
+                    err |= 1u;
+                    act = false;
+                }
+            }
+        }
+        const unsigned long long mp = __ballot(pending);
+        if (mp && ((int)__popcll(mp) >= WR_BATCH || !__any(act && !pending))) { // wavefront-uniform: every lane is here
+            const unsigned long long m = __ballot(flush);
+            asm volatile("" ::: "memory"); // the int16 stores above and the 16-byte reads below meet in LDS, not in the type system
+            const unsigned n = (unsigned)__popcll(m);
+            if (flush) flist[wave][__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(cur_block, (unsigned)(wave * 64 + lane));
+            for (unsigned g = 0; g < n; g += 8) {
+                const unsigned en = g + ((unsigned)lane >> 3);
+                if (en < n) {
+                    const uint2 fe = flist[wave][en];
+                    uint4 *src = lbuf + fe.y * 8u + ((unsigned)lane & 7u);
+#ifndef HVC_WR_NOSTORE
+                    reinterpret_cast<uint4 *>(P.coefs)[(size_t)fe.x + ((unsigned)lane & 7u)] = *src;
+#endif
+                    *src = make_uint4(0, 0, 0, 0);
+                }
+            }
+            asm volatile("" ::: "memory");
+            if (pending) { // on to the next block
+                pending = false;
+                flush = false;
+                skipping = false;
+                b = b + 1 == B ? 0 : b + 1;
+                bi++;
+                bt = tv + ((P.slotmask >> b) & 1u) * (2 * SPEC_T);
+                if (b == 0) { // next MCU
+                    mx++;
+                    if (mx == (unsigned)P.mbs_wide) {
+                        mx = 0;
+                        my++;
+                    }
+                }
+                if (p >= limit) act = false; // the next block starts in another lane's subsequence
+                else cur_block = block_no(b);
+            }
+        }
+    }
+    if (valid && exit_seen) {
+        const unsigned long long *fin = (final_round & 1) ? P.exit_a : P.exit_b; // launch final_round - 1 wrote it
+        if (exit_state != fin[i]) err |= 8u;
+    }
+    if (err) atomicOr(P.status, err);
+}
+
 // DC differences -> DC values (decoder.ml:143): inclusive prefix sum over the component's blocks in scan
 // order, one workgroup per (component, frame).
 __global__ __launch_bounds__(1024) void k_hd_dc(HdParams P) {
@@ -515,7 +715,7 @@ __global__ __launch_bounds__(1024) void k_hd_dc(HdParams P) {
     if (bad) atomicOr(P.status, 2u);
 }
 
-bool make_spec(const HdTables &t, int n_comp, HdSpec &out, unsigned char slot_of_comp[4]) {
+bool make_spec(const HdTables &t, int n_comp, HdSpec &out, unsigned char slot_of_comp[4], unsigned char slot_rep[2]) {
     if (n_comp < 1 || n_comp > 3) return false;
     int rep[2] = {0, -1}; // the component whose tables a slot holds
     for (int c = 0; c < 4; c++) slot_of_comp[c] = 0;
@@ -526,6 +726,8 @@ bool make_spec(const HdTables &t, int n_comp, HdSpec &out, unsigned char slot_of
         if (!same(rep[1])) return false;
         slot_of_comp[c] = 1;
     }
+    slot_rep[0] = 0;
+    slot_rep[1] = (unsigned char)(rep[1] < 0 ? 0 : rep[1]);
     std::memset(&out, 0, sizeof out);
     auto conv = [](uint16_t e, bool dc) -> uint16_t {
         if (e & 0x8000u) return e;             // continues in a sub-table
@@ -570,7 +772,10 @@ hipError_t launch_hd_round(const HdParams &P, int round, hipStream_t s) {
 hipError_t launch_hd_finish(const HdParams &P, int rounds_done, hipStream_t s) {
     if (P.total_sub == 0) return hipSuccess;
     hipLaunchKernelGGL(k_hd_scan, dim3((unsigned)P.n_frames), dim3(1024), 0, s, P);
-    hipLaunchKernelGGL(k_hd_write, dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, rounds_done);
+    if (P.spec && (unsigned long long)P.n_frames * P.coef_fs < (1ull << 35)) // k_hd_write2 addresses the records in 32 bits
+        hipLaunchKernelGGL(k_hd_write2, dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, rounds_done);
+    else
+        hipLaunchKernelGGL(k_hd_write, dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, rounds_done);
     hipLaunchKernelGGL(k_hd_dc, dim3((unsigned)P.n_comp, (unsigned)P.n_frames), dim3(1024), 0, s, P);
     return hipGetLastError();
 }
