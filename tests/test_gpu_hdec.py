@@ -107,3 +107,34 @@ def test_streams_the_model_treats_specially_fall_back_to_the_host_decoder(ctx):
                 ctx.jpeg_entropy_decode_gpu([b])
             assert e2.value.code == err, it
     assert agree > 40
+
+
+def test_the_general_kernels_alone_give_the_same_records():
+    """HVC_HD_CLASSIC=1 keeps the reader to k_hd_round / k_hd_write -- the kernels that frames with three
+    different Huffman table sets get, and the ones that verify and finish what k_hd_sync starts.  The
+    variable is read once per process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, "tests")
+import numpy as np
+from test_gpu_hdec import make_jpeg
+from conftest import golden_bytes
+import video_coding_amd as hvc
+c = hvc.Context(0)
+jobs = [[golden_bytes("mini.jpg")], [golden_bytes("Mouse480.jpg")],
+        [make_jpeg(900 + f, 480, 320, 420, 60) for f in range(3)], [make_jpeg(950 + f, 200, 120, 444, 95) for f in range(2)]]
+for files in jobs:
+    _, got, used = c.jpeg_entropy_decode_gpu(files, device=True)
+    assert used == 1
+    for f, j in enumerate(files):
+        _, want = hvc.hvc.jpeg_entropy_decode(j)
+        assert np.array_equal(got[f], want)
+print("classic ok")
+'''
+    env = dict(os.environ, HVC_HD_CLASSIC="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "classic ok" in r.stdout, r.stdout + r.stderr

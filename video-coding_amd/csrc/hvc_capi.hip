@@ -58,8 +58,8 @@ struct hvc_ctx {
     void *gp_h_ecs[RING] = {}, *gp_d_ecs[RING] = {}, *gp_h_meta[RING] = {}, *gp_d_meta[RING] = {};
     size_t gp_ecs_bytes = 0, gp_meta_bytes = 0;
     // GPU Huffman decoder (hvc_jpeg_entropy_decode_gpu): device scratch, grown on demand
-    void *gd_ecs = nullptr, *gd_meta = nullptr, *gd_state = nullptr, *gd_tables = nullptr, *gd_coefs = nullptr;
-    size_t gd_ecs_cap = 0, gd_meta_cap = 0, gd_state_cap = 0, gd_tables_cap = 0, gd_coefs_cap = 0;
+    void *gd_ecs = nullptr, *gd_meta = nullptr, *gd_state = nullptr, *gd_tables = nullptr, *gd_coefs = nullptr, *gd_dcd = nullptr;
+    size_t gd_ecs_cap = 0, gd_meta_cap = 0, gd_state_cap = 0, gd_tables_cap = 0, gd_coefs_cap = 0, gd_dcd_cap = 0;
     // GPU Huffman coder (hvc_huffman_encode_frames): tables + scratch, grown on demand
     unsigned *hd_tables = nullptr;
     void *hd_lens = nullptr, *hd_meta = nullptr, *hd_bitbuf = nullptr, *hd_ff = nullptr, *hd_out = nullptr;
@@ -254,6 +254,7 @@ void hvc_destroy(hvc_ctx *c) {
     if (c->gd_state) (void)hipFree(c->gd_state);
     if (c->gd_tables) (void)hipFree(c->gd_tables);
     if (c->gd_coefs) (void)hipFree(c->gd_coefs);
+    if (c->gd_dcd) (void)hipFree(c->gd_dcd);
     if (c->hd_tables) (void)hipFree(c->hd_tables);
     if (c->hd_lens) (void)hipFree(c->hd_lens);
     if (c->hd_meta) (void)hipFree(c->hd_meta);
@@ -1243,6 +1244,8 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
     if ((r = grow(c, &c->gd_ecs, &c->gd_ecs_cap, bytes))) return r;
     if ((r = grow(c, &c->gd_meta, &c->gd_meta_cap, meta_words * sizeof(unsigned) + 64))) return r;
     if ((r = grow(c, &c->gd_state, &c->gd_state_cap, HVC_HD_STATE_BYTES(subs)))) return r;
+    if ((r = grow(c, &c->gd_dcd, &c->gd_dcd_cap, (size_t)n_frames * P.blocks_per_frame * sizeof(int16_t)))) return r;
+    P.dcd = (int16_t *)c->gd_dcd;
     unsigned *m = (unsigned *)c->gd_meta;
     unsigned *d_ecs_off = m, *d_sub_off = m + n_frames, *d_frame_of = d_sub_off + n_frames + 1;
     unsigned *d_frame_blocks = d_frame_of + subs, *d_flags = d_frame_blocks + n_frames;
@@ -1464,6 +1467,8 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         if (!c->ev_rd[i]) HIPCHK(c, hipEventCreate(&c->ev_rd[i]));
     const size_t state_bytes = (HVC_HD_STATE_BYTES((size_t)C * nsub_max) + 255) & ~(size_t)255;
     if ((r = grow(c, &c->gd_state, &c->gd_state_cap, 2 * state_bytes))) return r;
+    const size_t dcd_elems = ((size_t)C * G.blocks_per_frame + 127) & ~(size_t)127;
+    if ((r = grow(c, &c->gd_dcd, &c->gd_dcd_cap, 2 * dcd_elems * sizeof(int16_t)))) return r;
     if ((r = gd_upload_tables(c, tables0, G, c->stream))) return r;
 
     // workers: header parse, table check, unstuffing into the pinned segment ring
@@ -1571,6 +1576,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         P.coefs = (int16_t *)c->d_ring[slot];
         P.coef_fs = info0.coef_count;
         gd_carve_state(P, (char *)c->gd_state + (size_t)(k & 1) * state_bytes, (size_t)C * nsub_max);
+        P.dcd = (int16_t *)c->gd_dcd + (size_t)(k & 1) * dcd_elems;
         hipStream_t rs = c->rd_stream[k & 1];
         hipError_t he = hipEventRecord(c->ev_et[slot][0], c->copy_stream);
         if (he == hipSuccess)

@@ -73,6 +73,7 @@ struct HdParams {
     // k_hd_sync only: second per-round exit buffer (exit_b is the first), the two work lists, list lengths per round
     unsigned long long *exit_c;
     unsigned *list0, *list1, *list_n; // [total_sub], [total_sub], [HVC_HD_LIST_N]
+    int16_t *dcd;              // [n_frames * blocks_per_frame] DC differences in scan order (k_hd_write2 -> k_hd_dc), or null
     unsigned *nblk;            // blocks completed inside the subsequence, then (scan) index of its first block
     unsigned *frame_blocks;    // [n_frames] blocks found in the whole segment
     unsigned *changed;         // [1]

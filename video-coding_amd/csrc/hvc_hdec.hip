@@ -356,19 +356,19 @@ __device__ __forceinline__ void spec_walk(const unsigned *row, const uint16_t *s
     }
 }
 
-__global__ __launch_bounds__(256) void k_hd_sync(HdParams P, int round) {
+// 512 lanes per workgroup: 12 KB of tables + 66 KB of rows = 78 KB, two workgroups = 16 wavefronts per CU.  (With
+// 256 lanes the tables weigh twice as much per lane and 12 wavefronts fit; the loop is latency-bound enough --
+// 8 wavefronts per CU were 1.4x slower -- for the 16 to show.)
+constexpr int SYNC_WG = 512;
+__global__ __launch_bounds__(SYNC_WG) void k_hd_sync(HdParams P, int round) {
     __shared__ uint16_t sp[2 * 2 * SPEC_T];
-    __shared__ unsigned rows[4][64 * SROW];
-#ifdef HVC_SYNC_PAD
-    __shared__ unsigned padlds[HVC_SYNC_PAD];
-    if (P.total_sub == 0xffffffffu) padlds[threadIdx.x] = 1, P.list_n[15] = padlds[threadIdx.x ^ 1];
-#endif
+    __shared__ unsigned rows[SYNC_WG / 64][64 * SROW];
     {
         const unsigned *src = reinterpret_cast<const unsigned *>(P.spec);
         unsigned *dst = reinterpret_cast<unsigned *>(sp);
-        for (unsigned i = threadIdx.x; i < sizeof(HdSpec) / 4; i += 256) dst[i] = src[i];
+        for (unsigned i = threadIdx.x; i < sizeof(HdSpec) / 4; i += SYNC_WG) dst[i] = src[i];
     }
-    __syncthreads(); // the tables; from here on the four wavefronts have nothing to do with one another
+    __syncthreads(); // the tables; from here on the wavefronts have nothing to do with one another
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned *row = rows[wave] + lane * SROW;
     const unsigned *list = (round & 1) ? P.list1 : P.list0; // rounds 0 and 1: every subsequence, no list
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void k_hd_sync(HdParams P, int round) {
     const unsigned count = round < 2 ? P.total_sub : P.list_n[round];
     const unsigned long long *pe = (round & 1) ? P.exit_b : P.exit_c; // exits of round - 1
     unsigned long long *ce = (round & 1) ? P.exit_c : P.exit_b;       // exits of this round
-    for (unsigned t0 = (blockIdx.x * 4u + (unsigned)wave) * 64u; t0 < count; t0 += gridDim.x * 256u) {
+    for (unsigned t0 = (blockIdx.x * (unsigned)(SYNC_WG / 64) + (unsigned)wave) * 64u; t0 < count; t0 += gridDim.x * (unsigned)SYNC_WG) {
         const unsigned t = t0 + (unsigned)lane;
         const bool valid = t < count;
         const unsigned i = !valid ? 0u : round < 2 ? t : list[t];
@@ -629,15 +629,16 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
             const unsigned long long m = __ballot(flush);
             asm volatile("" ::: "memory"); // the int16 stores above and the 16-byte reads below meet in LDS, not in the type system
             const unsigned n = (unsigned)__popcll(m);
-            if (flush) flist[wave][__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(cur_block, (unsigned)(wave * 64 + lane));
+            if (flush) {
+                flist[wave][__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(cur_block, (unsigned)(wave * 64 + lane));
+                P.dcd[(size_t)f * P.blocks_per_frame + bi] = lb[0]; // the DC difference once more, where k_hd_dc finds it without touching the records
+            }
             for (unsigned g = 0; g < n; g += 8) {
                 const unsigned en = g + ((unsigned)lane >> 3);
                 if (en < n) {
                     const uint2 fe = flist[wave][en];
                     uint4 *src = lbuf + fe.y * 8u + ((unsigned)lane & 7u);
-#ifndef HVC_WR_NOSTORE
                     reinterpret_cast<uint4 *>(P.coefs)[(size_t)fe.x + ((unsigned)lane & 7u)] = *src;
-#endif
                     *src = make_uint4(0, 0, 0, 0);
                 }
             }
@@ -679,6 +680,9 @@ __global__ __launch_bounds__(1024) void k_hd_dc(HdParams P) {
     const int hv = C.h * C.v;
     const unsigned n = (unsigned)P.mbs_wide * (unsigned)P.mbs_high * (unsigned)hv;
     int16_t *rec = P.coefs + (size_t)frame * P.coef_fs + C.coef_off;
+    // k_hd_write2 leaves the differences in block order of the scan, 2 bytes each (reading them out of the records
+    // costs a 128-byte line apiece: the records' size in traffic for 1/64 of their content)
+    const int16_t *dcd = P.dcd ? P.dcd + (size_t)frame * P.blocks_per_frame : nullptr;
     if (lane == 0) carry_s = 0;
     __syncthreads();
     bool bad = false;
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(1024) void k_hd_dc(HdParams P) {
             const unsigned sy = r / (unsigned)C.h, sx = r - sy * (unsigned)C.h;
             const unsigned my = m / (unsigned)P.mbs_wide, mx = m - my * (unsigned)P.mbs_wide;
             dcp = rec + ((size_t)(my * C.v + sy) * C.bw + (size_t)(mx * C.h + sx)) * 64;
-            v = *dcp;
+            v = dcd ? dcd[(size_t)m * (unsigned)P.blocks_per_mcu + (unsigned)C.mcu_base + r] : *dcp;
         }
         int incl = v;
 #pragma unroll
@@ -757,11 +761,11 @@ hipError_t launch_hd_round(const HdParams &P, int round, hipStream_t s) {
     if (round == 0 && P.spec) { // all the fast rounds; launches 1.. of k_hd_round verify and, if need be, continue
         hipError_t e = hipMemsetAsync(P.list_n, 0, (SYNC_ROUNDS + 2) * sizeof(unsigned), s);
         if (e != hipSuccess) return e;
-        const unsigned all = (P.total_sub + 255u) / 256u;
+        const unsigned all = (P.total_sub + (unsigned)SYNC_WG - 1u) / (unsigned)SYNC_WG;
         for (int r = 0; r < SYNC_ROUNDS; r++) {
             // the lists shrink by about half a round; a grid-stride loop takes whatever is there
-            const unsigned grid = r < 2 ? all : min(all, r < 4 ? 4096u : 768u);
-            hipLaunchKernelGGL(k_hd_sync, dim3(grid), dim3(256), 0, s, P, r);
+            const unsigned grid = r < 2 ? all : min(all, r < 4 ? 2048u : 512u);
+            hipLaunchKernelGGL(k_hd_sync, dim3(grid), dim3(SYNC_WG), 0, s, P, r);
         }
         return hipGetLastError();
     }
@@ -772,11 +776,14 @@ hipError_t launch_hd_round(const HdParams &P, int round, hipStream_t s) {
 hipError_t launch_hd_finish(const HdParams &P, int rounds_done, hipStream_t s) {
     if (P.total_sub == 0) return hipSuccess;
     hipLaunchKernelGGL(k_hd_scan, dim3((unsigned)P.n_frames), dim3(1024), 0, s, P);
-    if (P.spec && (unsigned long long)P.n_frames * P.coef_fs < (1ull << 35)) // k_hd_write2 addresses the records in 32 bits
+    HdParams Q = P;
+    if (P.spec && P.dcd && (unsigned long long)P.n_frames * P.coef_fs < (1ull << 35)) { // k_hd_write2 addresses the records in 32 bits
         hipLaunchKernelGGL(k_hd_write2, dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, rounds_done);
-    else
+    } else {
+        Q.dcd = nullptr; // k_hd_write leaves the differences in the records only
         hipLaunchKernelGGL(k_hd_write, dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, rounds_done);
-    hipLaunchKernelGGL(k_hd_dc, dim3((unsigned)P.n_comp, (unsigned)P.n_frames), dim3(1024), 0, s, P);
+    }
+    hipLaunchKernelGGL(k_hd_dc, dim3((unsigned)P.n_comp, (unsigned)P.n_frames), dim3(1024), 0, s, Q);
     return hipGetLastError();
 }
 
