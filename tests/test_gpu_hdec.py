@@ -138,3 +138,38 @@ print("classic ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "classic ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("w,h,chroma", [(64, 48, 420), (48, 32, 444), (64, 32, 422)])
+def test_constructed_records_blocks_longer_than_a_subsequence(ctx, w, h, chroma):
+    """Every AC at +-1023 (26 bits a symbol, 1.6 kbit a block: each block runs through two or three 1024-bit
+    subsequences, which k_hd_write2's lanes follow into their neighbours' rows), mixed with empty blocks,
+    lone last coefficients (ZRL chains) and DC swings -- records the host coder writes and the host reader
+    reads back, so the GPU reader has to as well."""
+    import video_coding_amd as hvc
+    info = hvc.hvc.jpeg_encoder_layout(w, h, chroma, 50)
+    rng = np.random.Generator(np.random.PCG64(w * 7 + h))
+    files = []
+    for variant in range(4):
+        rec = np.zeros(info.coef_count, np.int16).reshape(-1, 64)
+        n = rec.shape[0]
+        sign = np.where(rng.integers(0, 2, size=(n, 64)) == 0, -1, 1).astype(np.int16)
+        if variant == 0:            # all blocks as long as a block can be with the default tables
+            rec[:] = 1023 * sign
+        elif variant == 1:          # long and empty blocks alternate
+            rec[::2] = 1023 * sign[::2]
+        elif variant == 2:          # long blocks, lone coefficient 63, lone DC
+            kind = rng.integers(0, 3, size=n)
+            rec[kind == 0] = (1023 * sign)[kind == 0]
+            rec[kind == 1, 63] = 5
+        else:                       # random lengths: a block ends anywhere in a subsequence
+            for b in range(n):
+                m = int(rng.integers(0, 64))
+                rec[b, 1:1 + m] = (1023 * sign)[b, 1:1 + m]
+        rec[:, 0] = rng.integers(-1000, 1001, size=n)   # DC differences of up to 11 bits
+        files.append(hvc.hvc.jpeg_entropy_encode(info, rec.reshape(-1)))
+    _, got, used = ctx.jpeg_entropy_decode_gpu(files, device=True)
+    assert used == 1
+    for f, j in enumerate(files):
+        _, want = hvc.hvc.jpeg_entropy_decode(j)
+        assert np.array_equal(got[f], want), f

@@ -243,7 +243,7 @@ def jpeg_encoder_layout(width, height, chroma, quality):
 def jpeg_entropy_encode(info, coefs):
     coefs = np.ascontiguousarray(coefs, dtype=np.int16)
     assert coefs.size == info.coef_count
-    cap = 2 * coefs.size + 4096
+    cap = 8 * coefs.size + 4096  # 26 bits per coefficient at worst, every byte stuffed
     out = np.empty(cap, dtype=np.uint8)
     n = C.c_size_t()
     _chk(lib().hvc_jpeg_entropy_encode(C.byref(info), coefs.ctypes.data, out.ctypes.data, cap, C.byref(n)),
