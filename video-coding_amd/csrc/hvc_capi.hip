@@ -769,9 +769,9 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
 // host decoder (nothing usable on the device then).
 static int single_frame_coefs_on_device(hvc_ctx *c, const uint8_t *jpeg, size_t n, const hvc_jpeg_info *info, int *used) {
     *used = 0;
-    // Below ~300 kB the host reader is done before the GPU decoder's launches and synchronisations are
-    // (measured on 1080p: 64 kB file 0.39 ms on the host vs 1.0 ms; 984 kB file 3.9 ms vs 1.7 ms).
-    if (n < 300u * 1024u) return HVC_OK;
+    // Below ~128 kB the host reader is done before the GPU decoder's launches and synchronisations are
+    // (tools/bench_single.py on 1080p: 64 kB file 0.39 ms on the host vs 0.8 ms; 228 kB 1.7 vs 0.8 ms; 967 kB 3.9 vs 1.6 ms).
+    if (n < 128u * 1024u) return HVC_OK;
     DeviceGuard g(c->device);
     if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
     int r = grow(c, &c->gd_coefs, &c->gd_coefs_cap, info->coef_count * sizeof(int16_t));
