@@ -19,6 +19,14 @@
 // Anything the model would raise on (invalid code, index past 63, DC category > 16 inside the coded
 // blocks), a DC outside int16 or a stream that ends before the frame is complete only raises a status
 // bit here: the caller then runs the host decoder, which reproduces the model's behaviour exactly.
+//
+// Two sets of kernels do this.  The general one -- k_hd_round (rounds inside a workgroup through LDS,
+// across workgroups through launches) and k_hd_write -- takes any frame the host side lets through.
+// The fast one -- k_hd_sync (level-synchronous rounds over work lists, skip-only tables, subsequences
+// staged in LDS) and k_hd_write2 (blocks owned by the lane they start in, wavefront-wide batched
+// stores) -- needs the components to share at most two (DC, AC) table pairs, as every baseline file's do;
+// launch_hd_round / launch_hd_finish pick it whenever HdParams::spec is set, and k_hd_round then only
+// verifies the hand-overs and finishes what takes more rounds than k_hd_sync is given.
 #include "hvc_hdec.h"
 
 #include <cstring>
@@ -490,7 +498,10 @@ __global__ __launch_bounds__(256) void k_hd_write(HdParams P, int final_round) {
 //   * Block ends are batched: see WR_BATCH below.
 // 81.4 KB of LDS per workgroup: two workgroups per CU.
 constexpr int WR_EXTRA = 3; // rows staged past the workgroup's own, for the last lanes' overrun
-constexpr int WR_BATCH = 12; // block ends handled together
+#ifndef HVC_WR_BATCH
+#define HVC_WR_BATCH 12
+#endif
+constexpr int WR_BATCH = HVC_WR_BATCH; // block ends handled together
 
 __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) {
     __shared__ uint16_t tv[2 * 2 * SPEC_T]; // value tables of the two slots: [slot][DC, AC]
