@@ -180,3 +180,29 @@ def test_two_contexts_on_two_host_threads():
                 want = orc.dequant_idct_recon(recs[f][off:off + n], qtabs[qt], bw, bh)
                 assert np.array_equal(out[f][s["plane_offset"]:s["plane_offset"] + n], want), (tid, rep, f)
                 off += n
+
+
+@pytest.mark.parametrize("pad", [0, 4096])
+def test_host_buffers_in_four_overlapped_parts_equal_the_device_path(ctx, pad):
+    """hvc_decode_frames with host memory: batches above 64 MB go up, through the kernels and down in four parts
+    on two streams.  Same bytes as the resident path, the caller's bytes between records untouched (pad),
+    blocks outside the packed kernel's range included (they take the fix-up kernel in every part)."""
+    import torch
+    import video_coding_amd as hvc
+    planes = [(240, 136, 0), (120, 68, 1), (120, 68, 1)]
+    n = 24
+    recs, qtabs, _ = make_records(planes, 4, seed=1300)
+    specs, cfs, pfs = hvc.hvc.frame_layout(planes)
+    comps = hvc.hvc.components(specs)
+    batch = np.ascontiguousarray(recs[np.arange(n) % 4])
+    for f in (0, 7, 13, 23):   # a few blocks with large coefficients
+        batch[f, 64 * (1000 + f):64 * (1000 + f) + 64] = 1023
+    d_pix = torch.zeros((n, pfs), dtype=torch.uint8, device="cuda")
+    ctx.decode_frames(torch.from_numpy(batch).cuda(), cfs, qtabs, comps, n, d_pix, pfs)
+    ctx.synchronize()
+    want = d_pix.cpu().numpy()
+    fs = pfs + pad
+    host = np.full((n, fs), 0xA5, dtype=np.uint8)
+    ctx.decode_frames(batch, cfs, qtabs, comps, n, host, fs)
+    assert np.array_equal(host[:, :pfs], want)
+    assert (host[:, pfs:] == 0xA5).all()

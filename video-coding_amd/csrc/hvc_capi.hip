@@ -478,18 +478,94 @@ int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const ui
     if (r) return r;
     r = grow(c, &c->d_out, &c->out_cap, pbytes);
     if (r) return r;
+    // copy back only the pixels the kernels wrote (the caller's padding stays untouched).  Tight planes that
+    // follow one another -- the usual record -- are one stretch per frame, or one for the whole batch.
+    size_t run0 = 0, run = 0; // [run0, run0 + run): the planes as one byte range of the record, if they are one
+    {
+        bool tight = true;
+        int order[4] = {0, 1, 2, 3};
+        for (int i = 0; i < n_comp; i++)
+            for (int j = i + 1; j < n_comp; j++)
+                if (comps[order[j]].plane_offset < comps[order[i]].plane_offset) std::swap(order[i], order[j]);
+        size_t at = comps[order[0]].plane_offset;
+        run0 = at;
+        for (int i = 0; i < n_comp && tight; i++) {
+            const hvc_component &k = comps[order[i]];
+            tight = k.plane_offset == at && k.stride == (size_t)k.blocks_w * 8;
+            at += (size_t)k.blocks_w * 8 * (size_t)k.blocks_h * 8;
+        }
+        run = tight ? at - run0 : 0;
+    }
+    // Large batches in that usual form go in four parts: while part k + 1 is uploaded, part k is decoded and
+    // downloaded (a second thread and stream: copies to and from pageable memory hold their caller), so the
+    // link carries both directions at once.
+    if (run && n_frames >= 8 && cbytes >= ((size_t)64 << 20)) {
+        constexpr int K = 4;
+        if (!c->down_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
+        for (int i = 0; i < K; i++)
+            if (!c->ev_t[i]) HIPCHK(c, hipEventCreate(&c->ev_t[i]));
+        std::atomic<int> launched{0}, herr{0};
+        std::thread down([&] {
+            if (hipSetDevice(c->device) != hipSuccess) { herr.store((int)hipErrorInvalidDevice); return; }
+            for (int k = 0; k < K; k++) {
+                while (launched.load(std::memory_order_acquire) <= k && !herr.load()) std::this_thread::yield();
+                if (herr.load()) return;
+                const int f0 = (int)((long long)n_frames * k / K), cnt = (int)((long long)n_frames * (k + 1) / K) - f0;
+                const size_t off = (size_t)f0 * pixel_fs + run0;
+                hipError_t e = hipStreamWaitEvent(c->down_stream, c->ev_t[k], 0);
+                if (e == hipSuccess)
+                    e = pixel_fs == run ? hipMemcpyAsync(pixels + off, (uint8_t *)c->d_out + off, (size_t)cnt * run,
+                                                         hipMemcpyDeviceToHost, c->down_stream)
+                                        : hipMemcpy2DAsync(pixels + off, pixel_fs, (uint8_t *)c->d_out + off, pixel_fs, run,
+                                                           (size_t)cnt, hipMemcpyDeviceToHost, c->down_stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->down_stream);
+                if (e != hipSuccess) { herr.store((int)e); return; }
+            }
+        });
+        hipError_t e = hipSuccess;
+        for (int k = 0; k < K && e == hipSuccess && !herr.load(); k++) {
+            const int f0 = (int)((long long)n_frames * k / K), cnt = (int)((long long)n_frames * (k + 1) / K) - f0;
+            e = hipMemcpyAsync((int16_t *)c->d_in + (size_t)f0 * coef_fs, coefs + (size_t)f0 * coef_fs,
+                               ((size_t)(cnt - 1) * coef_fs + L.coef_span) * sizeof(int16_t), hipMemcpyHostToDevice, c->stream);
+            hvc::DecodeParams Pk = P;
+            Pk.coefs = (const int16_t *)c->d_in + (size_t)f0 * coef_fs;
+            Pk.pixels = (uint8_t *)c->d_out + (size_t)f0 * pixel_fs;
+            Pk.n_frames = cnt;
+            if (k > 0 && !wide_only) { // every launch consumes one fix-up counter and clears the other (as above)
+                Pk.fix_count = c->d_fix_count + c->fix_phase;
+                Pk.fix_count_next = c->d_fix_count + (c->fix_phase ^ 1);
+                c->fix_last = c->fix_phase;
+                c->fix_phase ^= 1;
+            }
+            if (e == hipSuccess) e = wide_only ? hvc::launch_decode_wide_only(Pk, c->stream) : hvc::launch_decode(Pk, c->stream);
+            if (e == hipSuccess) e = hipEventRecord(c->ev_t[k], c->stream);
+            if (e == hipSuccess) launched.store(k + 1, std::memory_order_release);
+        }
+        if (e != hipSuccess) herr.store((int)e);
+        down.join();
+        (void)hipStreamSynchronize(c->stream);
+        if (herr.load()) return fail_hip(c, (hipError_t)herr.load());
+        return HVC_OK;
+    }
     HIPCHK(c, hipMemcpyAsync(c->d_in, coefs, cbytes, hipMemcpyHostToDevice, c->stream));
     P.coefs = (const int16_t *)c->d_in;
     P.pixels = (uint8_t *)c->d_out;
     HIPCHK(c, wide_only ? hvc::launch_decode_wide_only(P, c->stream) : hvc::launch_decode(P, c->stream));
-    // copy back only the pixels the kernels wrote (the caller's padding stays untouched)
-    for (int f = 0; f < n_frames; f++)
-        for (int i = 0; i < n_comp; i++) {
-            size_t off = (size_t)f * pixel_fs + comps[i].plane_offset;
-            HIPCHK(c, hipMemcpy2DAsync(pixels + off, comps[i].stride, (uint8_t *)c->d_out + off, comps[i].stride,
-                                       (size_t)comps[i].blocks_w * 8, (size_t)comps[i].blocks_h * 8,
-                                       hipMemcpyDeviceToHost, c->stream));
-        }
+    if (run && (n_frames == 1 || pixel_fs == run)) {
+        HIPCHK(c, hipMemcpyAsync(pixels + run0, (uint8_t *)c->d_out + run0, (size_t)(n_frames - 1) * pixel_fs + run,
+                                 hipMemcpyDeviceToHost, c->stream));
+    } else if (run) {
+        HIPCHK(c, hipMemcpy2DAsync(pixels + run0, pixel_fs, (uint8_t *)c->d_out + run0, pixel_fs, run, (size_t)n_frames,
+                                   hipMemcpyDeviceToHost, c->stream));
+    } else {
+        for (int f = 0; f < n_frames; f++)
+            for (int i = 0; i < n_comp; i++) {
+                size_t off = (size_t)f * pixel_fs + comps[i].plane_offset;
+                HIPCHK(c, hipMemcpy2DAsync(pixels + off, comps[i].stride, (uint8_t *)c->d_out + off, comps[i].stride,
+                                           (size_t)comps[i].blocks_w * 8, (size_t)comps[i].blocks_h * 8,
+                                           hipMemcpyDeviceToHost, c->stream));
+            }
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HVC_OK;
 }
