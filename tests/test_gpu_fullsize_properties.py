@@ -206,3 +206,27 @@ def test_host_buffers_in_four_overlapped_parts_equal_the_device_path(ctx, pad):
     ctx.decode_frames(batch, cfs, qtabs, comps, n, host, fs)
     assert np.array_equal(host[:, :pfs], want)
     assert (host[:, pfs:] == 0xA5).all()
+
+
+@pytest.mark.parametrize("pad", [0, 512])
+def test_host_pixel_records_encoded_in_four_overlapped_parts_equal_the_device_path(ctx, pad):
+    """hvc_encode_frames with host memory, a batch above 64 MB of coefficients: same records as the resident path,
+    the caller's elements between records untouched."""
+    import torch
+    import video_coding_amd as hvc
+    from video_coding_amd.synth import synth_frame_pixels
+    planes = [(240, 136, 0), (120, 68, 1), (120, 68, 1)]
+    n = 24
+    qtabs = np.stack([hvc.hvc.quant_table(0, 60), hvc.hvc.quant_table(1, 60)])
+    specs, cfs, pfs = hvc.hvc.frame_layout(planes)
+    comps = hvc.hvc.components(specs)
+    pix = np.stack([synth_frame_pixels(2000 + 5 * (f % 6), planes) for f in range(n)])
+    d_coefs = torch.zeros((n, cfs), dtype=torch.int16, device="cuda")
+    ctx.encode_frames(torch.from_numpy(pix).cuda(), pfs, qtabs, comps, n, d_coefs, cfs)
+    ctx.synchronize()
+    want = d_coefs.cpu().numpy()
+    fs = cfs + pad
+    host = np.full((n, fs), 0x5A5A, dtype=np.int16)
+    ctx.encode_frames(pix, pfs, qtabs, comps, n, host, fs)
+    assert np.array_equal(host[:, :cfs], want)
+    assert (host[:, cfs:] == 0x5A5A).all()

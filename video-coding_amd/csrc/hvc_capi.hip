@@ -158,6 +158,50 @@ int check_qtabs(const uint16_t *qtabs, int n_qtabs) {
     return HVC_OK;
 }
 
+// Host buffers, large batches: four parts; while part k + 1 is uploaded (c->stream), part k runs through the kernels
+// (c->stream) and is downloaded (a second thread on c->down_stream: copies to and from pageable memory hold
+// their caller), so the link carries both directions at once.  up(f0, cnt) / run(k, f0, cnt) enqueue on c->stream,
+// down(f0, cnt, stream) on the stream it is given.
+template <class Up, class Run, class Down>
+static int overlapped_parts(hvc_ctx *c, int n_frames, Up up, Run run, Down down) {
+    constexpr int K = 4;
+    if (!c->down_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
+    for (int i = 0; i < K; i++)
+        if (!c->ev_t[i]) HIPCHK(c, hipEventCreate(&c->ev_t[i]));
+    std::atomic<int> launched{0}, herr{0};
+    auto part = [&](int k, int &f0, int &cnt) {
+        f0 = (int)((long long)n_frames * k / K);
+        cnt = (int)((long long)n_frames * (k + 1) / K) - f0;
+    };
+    std::thread downloader([&] {
+        if (hipSetDevice(c->device) != hipSuccess) { herr.store((int)hipErrorInvalidDevice); return; }
+        for (int k = 0; k < K; k++) {
+            while (launched.load(std::memory_order_acquire) <= k && !herr.load()) std::this_thread::yield();
+            if (herr.load()) return;
+            int f0, cnt;
+            part(k, f0, cnt);
+            hipError_t e = hipStreamWaitEvent(c->down_stream, c->ev_t[k], 0);
+            if (e == hipSuccess) e = down(f0, cnt, c->down_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->down_stream);
+            if (e != hipSuccess) { herr.store((int)e); return; }
+        }
+    });
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < K && e == hipSuccess && !herr.load(); k++) {
+        int f0, cnt;
+        part(k, f0, cnt);
+        e = up(f0, cnt);
+        if (e == hipSuccess) e = run(k, f0, cnt);
+        if (e == hipSuccess) e = hipEventRecord(c->ev_t[k], c->stream);
+        if (e == hipSuccess) launched.store(k + 1, std::memory_order_release);
+    }
+    if (e != hipSuccess) herr.store((int)e);
+    downloader.join();
+    (void)hipStreamSynchronize(c->stream);
+    if (herr.load()) return fail_hip(c, (hipError_t)herr.load());
+    return HVC_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -496,57 +540,33 @@ int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const ui
         }
         run = tight ? at - run0 : 0;
     }
-    // Large batches in that usual form go in four parts: while part k + 1 is uploaded, part k is decoded and
-    // downloaded (a second thread and stream: copies to and from pageable memory hold their caller), so the
-    // link carries both directions at once.
-    if (run && n_frames >= 8 && cbytes >= ((size_t)64 << 20)) {
-        constexpr int K = 4;
-        if (!c->down_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
-        for (int i = 0; i < K; i++)
-            if (!c->ev_t[i]) HIPCHK(c, hipEventCreate(&c->ev_t[i]));
-        std::atomic<int> launched{0}, herr{0};
-        std::thread down([&] {
-            if (hipSetDevice(c->device) != hipSuccess) { herr.store((int)hipErrorInvalidDevice); return; }
-            for (int k = 0; k < K; k++) {
-                while (launched.load(std::memory_order_acquire) <= k && !herr.load()) std::this_thread::yield();
-                if (herr.load()) return;
-                const int f0 = (int)((long long)n_frames * k / K), cnt = (int)((long long)n_frames * (k + 1) / K) - f0;
+    if (run && n_frames >= 8 && cbytes >= ((size_t)64 << 20)) // large batches in that usual form: see overlapped_parts
+        return overlapped_parts(
+            c, n_frames,
+            [&](int f0, int cnt) {
+                return hipMemcpyAsync((int16_t *)c->d_in + (size_t)f0 * coef_fs, coefs + (size_t)f0 * coef_fs,
+                                      ((size_t)(cnt - 1) * coef_fs + L.coef_span) * sizeof(int16_t), hipMemcpyHostToDevice, c->stream);
+            },
+            [&](int k, int f0, int cnt) {
+                hvc::DecodeParams Pk = P;
+                Pk.coefs = (const int16_t *)c->d_in + (size_t)f0 * coef_fs;
+                Pk.pixels = (uint8_t *)c->d_out + (size_t)f0 * pixel_fs;
+                Pk.n_frames = cnt;
+                if (k > 0 && !wide_only) { // every launch consumes one fix-up counter and clears the other (as above)
+                    Pk.fix_count = c->d_fix_count + c->fix_phase;
+                    Pk.fix_count_next = c->d_fix_count + (c->fix_phase ^ 1);
+                    c->fix_last = c->fix_phase;
+                    c->fix_phase ^= 1;
+                }
+                return wide_only ? hvc::launch_decode_wide_only(Pk, c->stream) : hvc::launch_decode(Pk, c->stream);
+            },
+            [&](int f0, int cnt, hipStream_t st) {
                 const size_t off = (size_t)f0 * pixel_fs + run0;
-                hipError_t e = hipStreamWaitEvent(c->down_stream, c->ev_t[k], 0);
-                if (e == hipSuccess)
-                    e = pixel_fs == run ? hipMemcpyAsync(pixels + off, (uint8_t *)c->d_out + off, (size_t)cnt * run,
-                                                         hipMemcpyDeviceToHost, c->down_stream)
-                                        : hipMemcpy2DAsync(pixels + off, pixel_fs, (uint8_t *)c->d_out + off, pixel_fs, run,
-                                                           (size_t)cnt, hipMemcpyDeviceToHost, c->down_stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(c->down_stream);
-                if (e != hipSuccess) { herr.store((int)e); return; }
-            }
-        });
-        hipError_t e = hipSuccess;
-        for (int k = 0; k < K && e == hipSuccess && !herr.load(); k++) {
-            const int f0 = (int)((long long)n_frames * k / K), cnt = (int)((long long)n_frames * (k + 1) / K) - f0;
-            e = hipMemcpyAsync((int16_t *)c->d_in + (size_t)f0 * coef_fs, coefs + (size_t)f0 * coef_fs,
-                               ((size_t)(cnt - 1) * coef_fs + L.coef_span) * sizeof(int16_t), hipMemcpyHostToDevice, c->stream);
-            hvc::DecodeParams Pk = P;
-            Pk.coefs = (const int16_t *)c->d_in + (size_t)f0 * coef_fs;
-            Pk.pixels = (uint8_t *)c->d_out + (size_t)f0 * pixel_fs;
-            Pk.n_frames = cnt;
-            if (k > 0 && !wide_only) { // every launch consumes one fix-up counter and clears the other (as above)
-                Pk.fix_count = c->d_fix_count + c->fix_phase;
-                Pk.fix_count_next = c->d_fix_count + (c->fix_phase ^ 1);
-                c->fix_last = c->fix_phase;
-                c->fix_phase ^= 1;
-            }
-            if (e == hipSuccess) e = wide_only ? hvc::launch_decode_wide_only(Pk, c->stream) : hvc::launch_decode(Pk, c->stream);
-            if (e == hipSuccess) e = hipEventRecord(c->ev_t[k], c->stream);
-            if (e == hipSuccess) launched.store(k + 1, std::memory_order_release);
-        }
-        if (e != hipSuccess) herr.store((int)e);
-        down.join();
-        (void)hipStreamSynchronize(c->stream);
-        if (herr.load()) return fail_hip(c, (hipError_t)herr.load());
-        return HVC_OK;
-    }
+                return pixel_fs == run ? hipMemcpyAsync(pixels + off, (uint8_t *)c->d_out + off, (size_t)cnt * run,
+                                                        hipMemcpyDeviceToHost, st)
+                                       : hipMemcpy2DAsync(pixels + off, pixel_fs, (uint8_t *)c->d_out + off, pixel_fs, run, (size_t)cnt,
+                                                          hipMemcpyDeviceToHost, st);
+            });
     HIPCHK(c, hipMemcpyAsync(c->d_in, coefs, cbytes, hipMemcpyHostToDevice, c->stream));
     P.coefs = (const int16_t *)c->d_in;
     P.pixels = (uint8_t *)c->d_out;
@@ -754,11 +774,49 @@ int hvc_encode_frames(hvc_ctx *c, const uint8_t *pixels, size_t pixel_fs, const 
     if (r) return r;
     r = grow(c, &c->d_out, &c->out_cap, cbytes);
     if (r) return r;
+    // copy back only the coefficient planes (gaps in the caller's records stay untouched); planes that follow one
+    // another -- the usual record -- are one stretch per frame
+    size_t run0 = 0, run = 0; // in int16 elements
+    {
+        bool adjacent = true;
+        int order[4] = {0, 1, 2, 3};
+        for (int i = 0; i < n_comp; i++)
+            for (int j = i + 1; j < n_comp; j++)
+                if (comps[order[j]].coef_offset < comps[order[i]].coef_offset) std::swap(order[i], order[j]);
+        size_t at = comps[order[0]].coef_offset;
+        run0 = at;
+        for (int i = 0; i < n_comp && adjacent; i++) {
+            adjacent = comps[order[i]].coef_offset == at;
+            at += (size_t)comps[order[i]].blocks_w * comps[order[i]].blocks_h * 64;
+        }
+        run = adjacent ? at - run0 : 0;
+    }
+    if (run && n_frames >= 8 && cbytes >= ((size_t)64 << 20)) // large batches in that usual form: see overlapped_parts
+        return overlapped_parts(
+            c, n_frames,
+            [&](int f0, int cnt) {
+                return hipMemcpyAsync((uint8_t *)c->d_in + (size_t)f0 * pixel_fs, pixels + (size_t)f0 * pixel_fs,
+                                      (size_t)(cnt - 1) * pixel_fs + L.pixel_span, hipMemcpyHostToDevice, c->stream);
+            },
+            [&](int, int f0, int cnt) {
+                hvc::EncodeParams Pk = P;
+                Pk.pixels = (const uint8_t *)c->d_in + (size_t)f0 * pixel_fs;
+                Pk.coefs = (int16_t *)c->d_out + (size_t)f0 * coef_fs;
+                Pk.n_frames = cnt;
+                return hvc::launch_encode(Pk, c->stream);
+            },
+            [&](int f0, int cnt, hipStream_t st) {
+                const size_t off = (size_t)f0 * coef_fs + run0;
+                return coef_fs == run ? hipMemcpyAsync(coefs + off, (int16_t *)c->d_out + off, (size_t)cnt * run * sizeof(int16_t),
+                                                       hipMemcpyDeviceToHost, st)
+                                      : hipMemcpy2DAsync(coefs + off, coef_fs * sizeof(int16_t), (int16_t *)c->d_out + off,
+                                                         coef_fs * sizeof(int16_t), run * sizeof(int16_t), (size_t)cnt,
+                                                         hipMemcpyDeviceToHost, st);
+            });
     HIPCHK(c, hipMemcpyAsync(c->d_in, pixels, pbytes, hipMemcpyHostToDevice, c->stream));
     P.pixels = (const uint8_t *)c->d_in;
     P.coefs = (int16_t *)c->d_out;
     HIPCHK(c, hvc::launch_encode(P, c->stream));
-    // copy back only the coefficient planes (gaps in the caller's records stay untouched)
     for (int f = 0; f < n_frames; f++)
         for (int i = 0; i < n_comp; i++) {
             size_t off = (size_t)f * coef_fs + comps[i].coef_offset;
