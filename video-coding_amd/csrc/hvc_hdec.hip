@@ -522,8 +522,10 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
                     unsigned o = e;
                     if (!(e & 0x8000u) && e) {
                         const unsigned len = e >> 8, val = e & 0xffu;
-                        // a DC category above 31 cannot be coded here; it is an error like every category above 16
-                        o = cls ? (len | ((val & 15u) << 5) | ((val >> 4) << 10) | (val ? 0u : 0x4000u)) : (len | (min(val, 31u) << 5));
+                        // DC: categories above 16 are errors (decoder.ml:73-79 has no such magnitude) and so, here, is 16
+                        // itself: its differences (|d| >= 32768, or -32768) leave int16 or the range a JPEG DC can have,
+                        // so the stream goes to the host decoder either way and the loop needs no range check
+                        o = cls ? (len | ((val & 15u) << 5) | ((val >> 4) << 10) | (val ? 0u : 0x4000u)) : (len | ((val >= 16u ? 31u : val) << 5));
                     }
                     tv[(sl * 2 + cls) * SPEC_T + i] = (uint16_t)o;
                 }
@@ -555,7 +557,9 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
     const unsigned long long st = act ? P.start_used[i] : 0ull;
     unsigned p = act ? (unsigned)st : 0u;
     int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
-    bool skipping = k > 0; // the block in progress belongs to the lane it started in
+    // live: the block in progress is this lane's (it started here) and inside the frame -- its coefficients are stored,
+    // its errors count.  A lane that starts in the middle of a block (k > 0) only walks that one to its end.
+    bool live = act && k == 0;
     unsigned err = 0;
     const unsigned mcu = (act ? bi : 0u) / (unsigned)B;
     unsigned my = mcu / (unsigned)P.mbs_wide, mx = mcu - my * (unsigned)P.mbs_wide; // advance by counting
@@ -574,23 +578,21 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
     unsigned lo = rd(ni++);
     unsigned nx = rd(ni);
     const uint16_t *bt = tv + ((P.slotmask >> b) & 1u) * (2 * SPEC_T);
-    unsigned long long exit_state = 0;
-    bool exit_seen = false;
+    unsigned exit_p = 0, exit_kb = 0; // exit_p stays 0 for a lane that never gets that far
     // What happens at the end of a block -- store it, find the next one's place -- costs more than a symbol, and in
     // a wavefront some lane ends a block in almost every iteration.  A lane that ends a block therefore WAITS
     // (pending) until WR_BATCH lanes do, or nobody else can go on; then the wavefront does all of them at once.
-    bool pending = false, flush = false;
-    unsigned cur_block = (act && !skipping) ? block_no(b) : 0u; // where the block in progress goes
+    bool pending = false;
+    unsigned cur_block = live ? block_no(b) : 0u; // where the block in progress goes
     while (__any(act)) {
         if (act && !pending) {
-            const bool live = !skipping && bi < P.blocks_per_frame; // coefficients are stored, errors count
             const unsigned w = __builtin_amdgcn_alignbit(hi, lo, (unsigned)s); // the next 32 bits: a whole symbol
             const uint16_t *t = bt + (k ? SPEC_T : 0);
             unsigned e = t[w >> 22];
             if (e & 0x8000u) e = t[1024u + (e & 0x7fffu) * 64u + ((w >> 16) & 63u)];
             // One path for DC and AC symbols (a DC symbol is "run 0" at index 0), no branches but the store:
             const unsigned len = e & 31u, size = (e >> 5) & 31u, run = (e >> 10) & 15u;
-            const bool bad = !e || size > 16u; // "Can't find dc / ac code" (one bit further) / DC category above 16 (the code is skipped)
+            const bool bad = !e || size > 16u; // "Can't find dc / ac code" (one bit further) / DC category 16 and above (the code is skipped)
             const unsigned used = bad ? max(len, 1u) : len + size;
             // decoder.ml:73-79 mag': `size` bits after the code; a leading 0 bit means negative
             const unsigned mbits = __builtin_amdgcn_ubfe(w, 32u - len - size, size);
@@ -600,10 +602,7 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
             const bool eob = (e & 0x4000u) != 0u;
             if (live) {
                 if (bad || (kk >= 64 && !eob)) err |= 1u; // ... / "coefficient index out of range"
-                else if (size) {
-                    lb[kk] = (int16_t)mag;
-                    if (size == 16u && (mag < -32768 || mag > 32767)) err |= 2u; // only a DC difference can be this long
-                }
+                else if (size) lb[kk] = (int16_t)mag; // |mag| < 2^15: size <= 15
             }
             const bool end_block = !bad && (eob || kk >= 63);
             if (!bad) k = kk + 1;
@@ -618,16 +617,17 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
             }
             if (end_block) {
                 pending = true;
-                flush = live;
                 k = 0;
             }
-            if (!exit_seen && p >= limit) { // where k_hd_sync's walk of this subsequence stopped
-                exit_seen = true;
-                exit_state = pack_state(p, k, end_block ? (b + 1 == B ? 0 : b + 1) : b);
-            }
+            // where k_hd_sync's walk of this subsequence stopped: the one symbol that takes p across the limit
+            // (selects, no flag to carry: as a branch with a 64-bit state this check cost 13 % of the pass)
+            const bool cross = p - (unsigned)used < limit && p >= limit;
+            const int b_after = end_block ? (b + 1 == B ? 0 : b + 1) : b;
+            exit_p = cross ? p : exit_p;
+            exit_kb = cross ? (unsigned)k | ((unsigned)b_after << 8) : exit_kb;
             if (p >= limit && !end_block) {
                 // a block in progress is finished here unless it is not this lane's (or nobody's: past the frame)
-                const bool mine = k > 0 && !skipping && bi < P.blocks_per_frame;
+                const bool mine = k > 0 && live;
                 if (!mine) act = false;
                 else if (p >= hard) { // cannot happen: 64 symbols of <= 32 bits end a block
                     err |= 1u;
@@ -637,6 +637,7 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
         }
         const unsigned long long mp = __ballot(pending);
         if (mp && ((int)__popcll(mp) >= WR_BATCH || !__any(act && !pending))) { // wavefront-uniform: every lane is here
+            const bool flush = pending && live;
             const unsigned long long m = __ballot(flush);
             asm volatile("" ::: "memory"); // the int16 stores above and the 16-byte reads below meet in LDS, not in the type system
             const unsigned n = (unsigned)__popcll(m);
@@ -656,10 +657,9 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
             asm volatile("" ::: "memory");
             if (pending) { // on to the next block
                 pending = false;
-                flush = false;
-                skipping = false;
                 b = b + 1 == B ? 0 : b + 1;
                 bi++;
+                live = bi < P.blocks_per_frame;
                 bt = tv + ((P.slotmask >> b) & 1u) * (2 * SPEC_T);
                 if (b == 0) { // next MCU
                     mx++;
@@ -673,9 +673,9 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
             }
         }
     }
-    if (valid && exit_seen) {
+    if (valid && exit_p) {
         const unsigned long long *fin = (final_round & 1) ? P.exit_a : P.exit_b; // launch final_round - 1 wrote it
-        if (exit_state != fin[i]) err |= 8u;
+        if (pack_state(exit_p, (int)(exit_kb & 0xffu), (int)(exit_kb >> 8)) != fin[i]) err |= 8u;
     }
     if (err) atomicOr(P.status, err);
 }
