@@ -68,6 +68,11 @@ struct hvc_ctx {
 
 namespace {
 
+// pinned rings the host only ever writes (unstuffed segments, padded raw frames) and the copy engine reads
+#ifndef HVC_UPLOAD_RING_FLAGS
+#define HVC_UPLOAD_RING_FLAGS hipHostMallocDefault
+#endif
+
 struct DeviceGuard {
     int prev = -1;
     bool ok = true;
@@ -1552,7 +1557,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         }
         c->gp_ecs_bytes = c->gp_meta_bytes = 0;
         for (int i = 0; i < NB; i++)
-            if (hipHostMalloc(&c->gp_h_ecs[i], ecs_bytes, hipHostMallocDefault) != hipSuccess ||
+            if (hipHostMalloc(&c->gp_h_ecs[i], ecs_bytes, HVC_UPLOAD_RING_FLAGS) != hipSuccess ||
                 hipMalloc(&c->gp_d_ecs[i], ecs_bytes) != hipSuccess ||
                 hipHostMalloc(&c->gp_h_meta[i], meta_bytes, hipHostMallocDefault) != hipSuccess ||
                 hipMalloc(&c->gp_d_meta[i], meta_bytes) != hipSuccess)
@@ -1982,7 +1987,7 @@ static int encode_batch_impl(hvc_ctx *c, const uint8_t *const *frames, int n_fra
         }
         c->e_in_bytes = c->e_out_bytes = 0;
         for (int i = 0; i < NB; i++)
-            if (hipHostMalloc(&c->eh_in[i], in_bytes, hipHostMallocDefault) != hipSuccess ||
+            if (hipHostMalloc(&c->eh_in[i], in_bytes, HVC_UPLOAD_RING_FLAGS) != hipSuccess ||
                 hipHostMalloc(&c->eh_out[i], out_bytes, hipHostMallocDefault) != hipSuccess ||
                 hipMalloc(&c->ed_in[i], in_bytes) != hipSuccess || hipMalloc(&c->ed_out[i], out_bytes) != hipSuccess)
                 return HVC_E_OUT_OF_MEMORY;
