@@ -215,3 +215,27 @@ def test_single_frame_ignores_the_frame_stride(ctx):
     out = np.zeros(3 * width * height, dtype=np.uint8)
     ctx.decode_frames_yuv444(rec, cfs, qt, specs, 1, width, height, out, 16)  # host buffers, stride < frame
     assert np.array_equal(out, expected444(rec, planes, qt, width, height))
+
+
+@pytest.mark.parametrize("pad", [0, 1000])
+def test_host_buffers_in_four_overlapped_parts_equal_the_device_path(ctx, pad):
+    """hvc_decode_frames_yuv444 with host memory, a batch above 64 MB of coefficients (uploaded, decoded and
+    downloaded in four parts on two streams): same frames as the resident path, the caller's bytes between
+    frames untouched."""
+    import torch
+    import video_coding_amd as hvc
+    width, height = 1920, 1080
+    planes, qt = geometry420(width, height), tables()
+    specs, cfs, pfs = hvc.hvc.frame_layout(planes)
+    base = [make_record(161 + f, planes, qt) for f in range(3)]
+    n = 24
+    batch = np.ascontiguousarray(np.stack(base)[np.arange(n) % 3])
+    d_o = torch.zeros((n, 3 * width * height), dtype=torch.uint8, device="cuda")
+    ctx.decode_frames_yuv444(torch.from_numpy(batch).cuda(), cfs, qt, specs, n, width, height, d_o)
+    ctx.synchronize()
+    want = d_o.cpu().numpy()
+    fs = 3 * width * height + pad
+    host = np.full((n, fs), 0x3C, dtype=np.uint8)
+    ctx.decode_frames_yuv444(batch, cfs, qt, specs, n, width, height, host, frame_stride=fs)
+    assert np.array_equal(host[:, :3 * width * height], want)
+    assert (host[:, 3 * width * height:] == 0x3C).all()

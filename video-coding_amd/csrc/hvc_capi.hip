@@ -692,6 +692,31 @@ int hvc_decode_frames_yuv444(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, c
     if (r) return r;
     r = grow(c, &c->d_out, &c->out_cap, obytes);
     if (r) return r;
+    if (n_frames >= 8 && cbytes >= ((size_t)64 << 20)) // large batches: see overlapped_parts
+        return overlapped_parts(
+            c, n_frames,
+            [&](int f0, int cnt) {
+                return hipMemcpyAsync((int16_t *)c->d_in + (size_t)f0 * coef_fs, coefs + (size_t)f0 * coef_fs,
+                                      ((size_t)(cnt - 1) * coef_fs + L.coef_span) * sizeof(int16_t), hipMemcpyHostToDevice, c->stream);
+            },
+            [&](int k, int f0, int cnt) {
+                auto Pk = P;
+                Pk.coefs = (const int16_t *)c->d_in + (size_t)f0 * coef_fs;
+                Pk.out = (uint8_t *)c->d_out + (size_t)f0 * frame_stride;
+                Pk.n_frames = cnt;
+                if (k > 0 && !wide_only) { // every launch consumes one fix-up counter and clears the other
+                    Pk.fix_count = c->d_fix_count + c->fix_phase;
+                    Pk.fix_count_next = c->d_fix_count + (c->fix_phase ^ 1);
+                    c->fix_last = c->fix_phase;
+                    c->fix_phase ^= 1;
+                }
+                return hvc::launch_decode_444(Pk, wide_only, c->stream);
+            },
+            [&](int f0, int cnt, hipStream_t st) {
+                const size_t off = (size_t)f0 * frame_stride;
+                return hipMemcpy2DAsync(frames + off, frame_stride, (uint8_t *)c->d_out + off, frame_stride, out_span, (size_t)cnt,
+                                        hipMemcpyDeviceToHost, st);
+            });
     HIPCHK(c, hipMemcpyAsync(c->d_in, coefs, cbytes, hipMemcpyHostToDevice, c->stream));
     P.coefs = (const int16_t *)c->d_in;
     P.out = (uint8_t *)c->d_out;
