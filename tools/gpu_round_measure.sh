@@ -15,6 +15,12 @@ python tools/bench_configs.py --config 7 > gpurun_out/m_c7.json 2> gpurun_out/m_
 python tools/bench_configs.py --config 2 > gpurun_out/m_k2.json 2> gpurun_out/m_k2.err
 python tools/bench_configs.py --config 8 > gpurun_out/m_c5_files.json 2> gpurun_out/m_c5_files.err
 HVC_DECODE_KERNEL=q16 python bench.py --no-cpu-baseline > gpurun_out/m_bench_q16.json 2> gpurun_out/m_bench_q16.err
+# the file-level pipelines with the entropy stages on the GPU, the GPU Huffman coder alone, one file at a time
+python tools/bench_configs.py --config 3 --frames 1024 --threads 16 --gpu-entropy --chunk 64 > gpurun_out/m_c3_gpu_entropy.json 2> gpurun_out/m_c3g.err
+python tools/bench_configs.py --config 3 --frames 4096 --threads 16 --gpu-entropy --chunk 256 > gpurun_out/m_c3_gpu_entropy_4096.json 2>> gpurun_out/m_c3g.err
+python tools/bench_configs.py --config 8 --gpu-entropy > gpurun_out/m_c5_files_gpu_entropy.json 2> gpurun_out/m_c5g.err
+python tools/bench_configs.py --config 9 > gpurun_out/m_huffman_gpu.json 2> gpurun_out/m_huffman_gpu.err
+python tools/bench_single.py > gpurun_out/m_single_file.jsonl 2> gpurun_out/m_single_file.err
 echo "configs done"
 bash tools/gpu_profile.sh ${TAG}_decode
 echo "decode profile done"
@@ -22,3 +28,5 @@ bash tools/gpu_profile_cmd.sh ${TAG}_444 tools/bench_configs.py --config 7 --ste
 echo "444 profile done"
 bash tools/gpu_profile_cmd.sh ${TAG}_encode tools/bench_configs.py --config 5 --steps 10
 echo "encode profile done"
+bash tools/gpu_profile_cmd.sh ${TAG}_c3g tools/bench_configs.py --config 3 --frames 512 --threads 16 --gpu-entropy --chunk 256 --steps 2
+echo "reader profile done"
