@@ -37,7 +37,10 @@ def config3(args):
         jpegs.append(ctx.jpeg_encode(y, u, v, W, H, 420, 75))
     batch = [jpegs[i % len(jpegs)] for i in range(args.frames)]
     info = hvc.hvc.jpeg_read_header(batch[0])
-    d_pix = torch.zeros(args.frames * info.pixel_bytes, dtype=torch.uint8, device="cuda")
+    if args.host_out:   # decoded frames back in (pageable) host memory: the other PCIe direction joins in
+        d_pix = np.zeros(args.frames * info.pixel_bytes, dtype=np.uint8)
+    else:
+        d_pix = torch.zeros(args.frames * info.pixel_bytes, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     gpu = bool(getattr(args, "gpu_entropy", False))
     ctx.jpeg_decode_batch(batch[:min(64, args.frames)], d_pix, info.pixel_bytes, threads=args.threads,
@@ -53,7 +56,7 @@ def config3(args):
     dt, st = best
     jpeg_bytes = sum(len(j) for j in batch)
     print(json.dumps({
-        "config": "3-gpu-entropy" if gpu else 3,
+        "config": ("3-gpu-entropy" if gpu else "3") + ("-host-out" if args.host_out else ""),
         "metric": "Mpixel/s decoded, " + ("host unstuffing + H2D of segments + GPU Huffman + GPU block stage"
                                           if gpu else "host Huffman + H2D + GPU block stage") + " overlapped",
         "host_prep_thread_ms_sum": round(st.host_prep_ms_sum, 1),
@@ -66,7 +69,8 @@ def config3(args):
         "kernel_ms_sum": round(st.kernel_ms_sum, 2),
         "overlap": "sum of stage times / wall = %.2f" % ((st.entropy_ms_sum / args.threads + st.h2d_ms_sum +
                                                           st.kernel_ms_sum) / (dt * 1e3)),
-        "bound": "host Huffman (entropy time / threads ~ wall)"}))
+        "bound": ("GPU reader kernels / upload" if gpu else "host Huffman (entropy time / threads ~ wall)") +
+                 (", download of the frames" if args.host_out else "")}))
     ctx.close()
 
 
@@ -340,7 +344,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--threads", type=int, default=min(16, os.cpu_count() or 16))
     ap.add_argument("--chunk", type=int, default=32)
-    ap.add_argument("--gpu-entropy", action="store_true", help="config 8: Huffman coding on the GPU as well")
+    ap.add_argument("--gpu-entropy", action="store_true", help="configs 3 / 8: Huffman decoding / coding on the GPU as well")
+    ap.add_argument("--host-out", action="store_true", help="config 3: decoded frames to host memory instead of HBM")
     args = ap.parse_args()
     if args.config == 2:  # K2 upsample (optional output stage)
         args.frames = args.frames or 256

@@ -1621,6 +1621,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     // stretches that are slow to synchronise, each round a full kernel's latency) overlap with the next chunk's
     // first ones, which fill the GPU.
     static_assert(hvc_ctx::RING <= 3, "ev_rd");
+    if (where == HVC_MEM_HOST && !c->down_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
     if (!c->rd_stream[0]) {
         // two streams of the same priority can end up on one hardware queue (they did: no overlap at all);
         // streams of different priorities never share one
@@ -1689,6 +1690,37 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     std::vector<std::thread> pool;
     for (int t = 0; t < threads; t++) pool.emplace_back(worker);
 
+    // Host output: a thread of its own downloads chunk after chunk on c->down_stream (copies to pageable memory hold
+    // their caller -- issued from the loop below they kept the next chunk's launches waiting, and on the block
+    // stage's stream its kernels too: 18 Gpixel/s, 33 with this).
+    std::atomic<int> stage_done{0}, dl_abort{0}, dl_err{0}; // chunks whose block stage is enqueued
+    std::vector<char> downloaded((size_t)n_chunks, 0);
+    std::thread downloader;
+    if (where == HVC_MEM_HOST) {
+        downloader = std::thread([&] {
+            if (hipSetDevice(c->device) != hipSuccess) { dl_err.store((int)hipErrorInvalidDevice); return; }
+            for (int k = 0; k < n_chunks; k++) {
+                while (stage_done.load(std::memory_order_acquire) <= k && !dl_abort.load()) std::this_thread::yield();
+                if (dl_abort.load()) return;
+                const int slot = k % NB, first = k * C, cnt = (first + C <= n_frames) ? C : n_frames - first;
+                hipError_t e = hipStreamWaitEvent(c->down_stream, c->ev_et[slot][2], 0);
+                if (e == hipSuccess)
+                    e = hipMemcpy2DAsync(pixels + (size_t)first * pixel_fs, pixel_fs, c->d_oring[slot], out_bytes, out_bytes,
+                                         (size_t)cnt, hipMemcpyDeviceToHost, c->down_stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->down_stream);
+                if (e != hipSuccess) dl_err.store((int)e);
+                std::lock_guard<std::mutex> lk(mu);
+                downloaded[(size_t)k] = 1;
+                cv.notify_all();
+                if (e != hipSuccess) return;
+            }
+        });
+    }
+    auto stop_downloader = [&] {
+        dl_abort.store(1);
+        if (downloader.joinable()) downloader.join();
+    };
+
     int rc = HVC_OK;
     bool fallback = false;
     double h2d_ms = 0, k_ms = 0;
@@ -1701,7 +1733,14 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         const int v = it - NB;
         if (v >= 0) {
             const int slot = v % NB;
-            hipError_t he = hipEventSynchronize(c->ev_kern[slot]);
+            hipError_t he = hipSuccess;
+            if (where == HVC_MEM_HOST) { // the slot's frames have left the device
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return downloaded[(size_t)v] != 0 || dl_err.load(); });
+                if (dl_err.load()) he = (hipError_t)dl_err.load();
+            } else {
+                he = hipEventSynchronize(c->ev_kern[slot]);
+            }
             if (he != hipSuccess) { rc = fail_hip(c, he); break; }
             const unsigned *flags = (const unsigned *)c->gp_h_meta[slot] + (meta_words - 2);
             if (flags[0] || flags[1]) { fallback = true; break; } // not settled / the model raises / truncated
@@ -1769,11 +1808,8 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
                                         info0.n_comp, cnt, dst, dst_fs, HVC_MEM_DEVICE);
         if (rc) break;
         he = hipEventRecord(c->ev_et[slot][2], compute);
-        if (he == hipSuccess && where == HVC_MEM_HOST)
-            for (int f = 0; f < cnt && he == hipSuccess; f++)
-                he = hipMemcpyAsync(pixels + (size_t)(first + f) * pixel_fs, dst + (size_t)f * dst_fs, out_bytes,
-                                    hipMemcpyDeviceToHost, compute);
-        if (he == hipSuccess) he = hipEventRecord(c->ev_kern[slot], compute);
+        if (he == hipSuccess && where == HVC_MEM_HOST) stage_done.store(k + 1, std::memory_order_release); // the downloader takes over
+        if (he == hipSuccess && where != HVC_MEM_HOST) he = hipEventRecord(c->ev_kern[slot], compute);
         // hand the pinned segment slot to chunk k + NB once this chunk's upload is through
         if (he == hipSuccess) he = hipEventSynchronize(c->ev_h2d[slot]);
         if (he != hipSuccess) { rc = fail_hip(c, he); break; }
@@ -1790,6 +1826,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         if (fallback) need_host.store(1);
         cv.notify_all();
     }
+    stop_downloader(); // (after a complete run it has finished: the last verdicts waited for its last chunks)
     for (auto &t : pool) t.join();
     for (int i = 0; i < 3; i++) (void)hipStreamSynchronize(c->rd_stream[i]);
     (void)hipStreamSynchronize(compute);
