@@ -1700,7 +1700,10 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         downloader = std::thread([&] {
             if (hipSetDevice(c->device) != hipSuccess) { dl_err.store((int)hipErrorInvalidDevice); return; }
             for (int k = 0; k < n_chunks; k++) {
-                while (stage_done.load(std::memory_order_acquire) <= k && !dl_abort.load()) std::this_thread::yield();
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stage_done.load() > k || dl_abort.load(); });
+                }
                 if (dl_abort.load()) return;
                 const int slot = k % NB, first = k * C, cnt = (first + C <= n_frames) ? C : n_frames - first;
                 hipError_t e = hipStreamWaitEvent(c->down_stream, c->ev_et[slot][2], 0);
@@ -1717,7 +1720,11 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         });
     }
     auto stop_downloader = [&] {
-        dl_abort.store(1);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            dl_abort.store(1);
+            cv.notify_all();
+        }
         if (downloader.joinable()) downloader.join();
     };
 
@@ -1808,7 +1815,11 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
                                         info0.n_comp, cnt, dst, dst_fs, HVC_MEM_DEVICE);
         if (rc) break;
         he = hipEventRecord(c->ev_et[slot][2], compute);
-        if (he == hipSuccess && where == HVC_MEM_HOST) stage_done.store(k + 1, std::memory_order_release); // the downloader takes over
+        if (he == hipSuccess && where == HVC_MEM_HOST) { // the downloader takes over
+            std::lock_guard<std::mutex> lk(mu);
+            stage_done.store(k + 1);
+            cv.notify_all();
+        }
         if (he == hipSuccess && where != HVC_MEM_HOST) he = hipEventRecord(c->ev_kern[slot], compute);
         // hand the pinned segment slot to chunk k + NB once this chunk's upload is through
         if (he == hipSuccess) he = hipEventSynchronize(c->ev_h2d[slot]);
