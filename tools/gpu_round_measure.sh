@@ -30,3 +30,9 @@ bash tools/gpu_profile_cmd.sh ${TAG}_encode tools/bench_configs.py --config 5 --
 echo "encode profile done"
 bash tools/gpu_profile_cmd.sh ${TAG}_c3g tools/bench_configs.py --config 3 --frames 512 --threads 16 --gpu-entropy --chunk 256 --steps 2
 echo "reader profile done"
+# summaries here, databases deleted: gpurun only brings back 64 MiB
+for d in gpurun_out/prof_${TAG}_*; do
+    python tools/rocpd_summary.py $d > gpurun_out/$(basename $d | sed 's/^prof_//')_rocprofv3.txt 2>&1 || true
+    find $d -name '*.db' -delete
+done
+echo "summaries done"
