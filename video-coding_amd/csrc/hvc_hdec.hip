@@ -309,6 +309,8 @@ __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
 // verifies every hand-over and keeps going where a stream needs more rounds (smooth content with its periodic
 // bit patterns can take hundreds), and the write pass compares the exit of its own walk with the recorded one.
 constexpr int SYNC_ROUNDS = 12;
+constexpr unsigned SYNC_TAIL_MAX_SUB = 32768; // up to four 1080p files of 1 MB: k_hd_sync_tail
+constexpr int SYNC_TAIL_FROM = 5;
 // A staged subsequence: its S / 32 dwords and one more.  A symbol starts before bit S and is at most 32 bits long
 // (code <= 16, magnitude <= 16), so bit S + 31 is the last one any walk looks at.  S / 32 + 1 is odd: lanes reading
 // the same dword index of their rows hit different LDS banks.
@@ -368,6 +370,28 @@ __device__ __forceinline__ void spec_walk(const unsigned *row, const uint16_t *s
 // 256 lanes the tables weigh twice as much per lane and 12 wavefronts fit; the loop is latency-bound enough --
 // 8 wavefronts per CU were 1.4x slower -- for the 16 to show.)
 constexpr int SYNC_WG = 512;
+// One subsequence of one round: true when its successor has to start again.
+__device__ __forceinline__ bool sync_one(const HdParams &P, int round, bool valid, unsigned i, unsigned *row, const uint16_t *sp,
+                                         const unsigned long long *pe, unsigned long long *ce) {
+    const unsigned f = P.frame_of[i], j = i - P.sub_off[f];
+    const unsigned base = j * (unsigned)S;
+    unsigned long long st = pack_state(base, 0, 0); // the guess; the truth for j == 0
+    if (round > 0 && j > 0) st = pe[i - 1];
+    if (!(valid && (round == 0 || st != P.start_used[i]))) return false;
+    stage_row(row, P.ecs + P.ecs_off[f] + (size_t)j * (S / 8));
+    unsigned p = (unsigned)st, nb = 0;
+    int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
+    spec_walk(row, sp, P.slotmask, P.blocks_per_mcu, base, p, k, b, nb);
+    const unsigned long long ex = pack_state(p, k, b);
+    const bool differs = round == 0 || ex != P.exit_a[i];
+    P.exit_a[i] = ex;
+    ce[i] = ex;
+    P.start_used[i] = st;
+    P.nblk[i] = nb;
+    // the successor (same frame) has to start again; after round 0 everybody does, no list needed
+    return round > 0 && differs && i + 1 < P.sub_off[f + 1];
+}
+
 __global__ __launch_bounds__(SYNC_WG) void k_hd_sync(HdParams P, int round) {
     __shared__ uint16_t sp[2 * 2 * SPEC_T];
     __shared__ unsigned rows[SYNC_WG / 64][64 * SROW];
@@ -388,26 +412,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_hd_sync(HdParams P, int round) {
         const unsigned t = t0 + (unsigned)lane;
         const bool valid = t < count;
         const unsigned i = !valid ? 0u : round < 2 ? t : list[t];
-        const unsigned f = P.frame_of[i], j = i - P.sub_off[f];
-        const unsigned base = j * (unsigned)S;
-        unsigned long long st = pack_state(base, 0, 0); // the guess; the truth for j == 0
-        if (round > 0 && j > 0) st = pe[i - 1];
-        const bool go = valid && (round == 0 || st != P.start_used[i]);
-        bool push = false;
-        if (go) {
-            stage_row(row, P.ecs + P.ecs_off[f] + (size_t)j * (S / 8));
-            unsigned p = (unsigned)st, nb = 0;
-            int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
-            spec_walk(row, sp, P.slotmask, P.blocks_per_mcu, base, p, k, b, nb);
-            const unsigned long long ex = pack_state(p, k, b);
-            const bool differs = round == 0 || ex != P.exit_a[i];
-            P.exit_a[i] = ex;
-            ce[i] = ex;
-            P.start_used[i] = st;
-            P.nblk[i] = nb;
-            // the successor (same frame) has to start again; after round 0 everybody does, no list needed
-            push = round > 0 && differs && i + 1 < P.sub_off[f + 1];
-        }
+        const bool push = sync_one(P, round, valid, i, row, sp, pe, ce);
         const unsigned long long m = __ballot(push);
         if (m) { // one atomic per wavefront
             unsigned at = 0;
@@ -415,6 +420,53 @@ __global__ __launch_bounds__(SYNC_WG) void k_hd_sync(HdParams P, int round) {
             at = __shfl(at, 0);
             if (push) next[at + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = i + 1;
         }
+    }
+}
+
+// The same rounds for a handful of files (one at a time is how the model's decode_a_frame is called): from round 5
+// on the lists hold a few hundred subsequences, and what a round costs is a launch and the latency of one walk.  One
+// workgroup keeps the tables and goes from round to round by itself -- a barrier instead of a launch, the list lengths
+// in LDS -- until a list is empty (or last_round: k_hd_round then continues).  A workgroup's own stores are visible to
+// its own later loads (one CU, one L1), so the per-round buffers work as they do across launches.
+__global__ __launch_bounds__(SYNC_WG) void k_hd_sync_tail(HdParams P, int first_round, int last_round) {
+    __shared__ uint16_t sp[2 * 2 * SPEC_T];
+    __shared__ unsigned rows[SYNC_WG / 64][64 * SROW];
+    __shared__ unsigned cnt_s[2];
+    {
+        const unsigned *src = reinterpret_cast<const unsigned *>(P.spec);
+        unsigned *dst = reinterpret_cast<unsigned *>(sp);
+        for (unsigned i = threadIdx.x; i < sizeof(HdSpec) / 4; i += SYNC_WG) dst[i] = src[i];
+    }
+    if (threadIdx.x == 0) {
+        cnt_s[first_round & 1] = P.list_n[first_round];
+        cnt_s[(first_round + 1) & 1] = 0;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned *row = rows[wave] + lane * SROW;
+    for (int round = first_round; round <= last_round; round++) {
+        const unsigned count = cnt_s[round & 1];
+        if (count == 0) break; // (the same value in every lane)
+        const unsigned *list = (round & 1) ? P.list1 : P.list0;
+        unsigned *next = (round & 1) ? P.list0 : P.list1;
+        const unsigned long long *pe = (round & 1) ? P.exit_b : P.exit_c;
+        unsigned long long *ce = (round & 1) ? P.exit_c : P.exit_b;
+        for (unsigned t0 = (unsigned)wave * 64u; t0 < count; t0 += (unsigned)SYNC_WG) {
+            const unsigned t = t0 + (unsigned)lane;
+            const bool valid = t < count;
+            const unsigned i = valid ? list[t] : 0u;
+            const bool push = sync_one(P, round, valid, i, row, sp, pe, ce);
+            const unsigned long long m = __ballot(push);
+            if (m) {
+                unsigned at = 0;
+                if (lane == 0) at = atomicAdd(&cnt_s[(round + 1) & 1], (unsigned)__popcll(m));
+                at = __shfl(at, 0);
+                if (push) next[at + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = i + 1;
+            }
+        }
+        __syncthreads(); // this round's stores before the next round's loads
+        if (threadIdx.x == 0) cnt_s[round & 1] = 0; // the counter of round + 2
+        __syncthreads();
     }
 }
 
@@ -773,6 +825,11 @@ hipError_t launch_hd_round(const HdParams &P, int round, hipStream_t s) {
         hipError_t e = hipMemsetAsync(P.list_n, 0, (SYNC_ROUNDS + 2) * sizeof(unsigned), s);
         if (e != hipSuccess) return e;
         const unsigned all = (P.total_sub + (unsigned)SYNC_WG - 1u) / (unsigned)SYNC_WG;
+        if (P.total_sub <= SYNC_TAIL_MAX_SUB) { // a few files: five rounds as launches, the rest inside one workgroup
+            for (int r = 0; r < SYNC_TAIL_FROM; r++) hipLaunchKernelGGL(k_hd_sync, dim3(all), dim3(SYNC_WG), 0, s, P, r);
+            hipLaunchKernelGGL(k_hd_sync_tail, dim3(1), dim3(SYNC_WG), 0, s, P, SYNC_TAIL_FROM, SYNC_TAIL_FROM + 200);
+            return hipGetLastError();
+        }
         // (fewer list rounds for a single file's few thousand subsequences -- leaving the slow stretches to
         // k_hd_round's inner rounds earlier -- was tried: 10-25 % slower)
         for (int r = 0; r < SYNC_ROUNDS; r++) {
