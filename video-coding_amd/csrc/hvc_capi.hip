@@ -59,6 +59,9 @@ struct hvc_ctx {
     size_t gp_ecs_bytes = 0, gp_meta_bytes = 0;
     // GPU Huffman decoder (hvc_jpeg_entropy_decode_gpu): device scratch, grown on demand
     void *gd_ecs = nullptr, *gd_meta = nullptr, *gd_state = nullptr, *gd_tables = nullptr, *gd_coefs = nullptr, *gd_dcd = nullptr;
+    hvc::HdTables *gd_tables_host = nullptr; // what gd_tables holds (value tables; the HdSpec behind them follows from these)
+    bool gd_tables_valid = false;
+    int gd_tables_ncomp = 0;
     size_t gd_ecs_cap = 0, gd_meta_cap = 0, gd_state_cap = 0, gd_tables_cap = 0, gd_coefs_cap = 0, gd_dcd_cap = 0;
     // GPU Huffman coder (hvc_huffman_encode_frames): tables + scratch, grown on demand
     unsigned *hd_tables = nullptr;
@@ -304,6 +307,7 @@ void hvc_destroy(hvc_ctx *c) {
     if (c->gd_tables) (void)hipFree(c->gd_tables);
     if (c->gd_coefs) (void)hipFree(c->gd_coefs);
     if (c->gd_dcd) (void)hipFree(c->gd_dcd);
+    delete c->gd_tables_host;
     if (c->hd_tables) (void)hipFree(c->hd_tables);
     if (c->hd_lens) (void)hipFree(c->hd_lens);
     if (c->hd_meta) (void)hipFree(c->hd_meta);
@@ -1335,10 +1339,19 @@ static int gd_upload_tables(hvc_ctx *c, const hvc::HdTables &t, hvc::HdParams &P
     unsigned char slot[4];
     static const bool classic = std::getenv("HVC_HD_CLASSIC") != nullptr; // tests: force k_hd_round / k_hd_write
     const bool have_spec = hvc::make_spec(t, P.n_comp, spec, slot, P.slot_rep) && !classic;
-    HIPCHK(c, hipMemcpyAsync(c->gd_tables, &t, sizeof t, hipMemcpyHostToDevice, st));
-    if (have_spec)
-        HIPCHK(c, hipMemcpyAsync((char *)c->gd_tables + sizeof t, &spec, sizeof spec, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st)); // both sources live on a stack frame
+    // file after file with the same tables (the usual case: an encoder's fixed set) finds them on the device already
+    if (!c->gd_tables_host) c->gd_tables_host = new (std::nothrow) hvc::HdTables;
+    if (!c->gd_tables_host) return HVC_E_OUT_OF_MEMORY;
+    if (!(c->gd_tables_valid && c->gd_tables_ncomp == P.n_comp && !std::memcmp(c->gd_tables_host, &t, sizeof t))) {
+        c->gd_tables_valid = false;
+        HIPCHK(c, hipMemcpyAsync(c->gd_tables, &t, sizeof t, hipMemcpyHostToDevice, st));
+        if (have_spec)
+            HIPCHK(c, hipMemcpyAsync((char *)c->gd_tables + sizeof t, &spec, sizeof spec, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st)); // both sources live on a stack frame
+        std::memcpy(c->gd_tables_host, &t, sizeof t);
+        c->gd_tables_ncomp = P.n_comp;
+        c->gd_tables_valid = true;
+    }
     P.tables = (const hvc::HdTables *)c->gd_tables;
     P.spec = have_spec ? (const hvc::HdSpec *)((char *)c->gd_tables + sizeof t) : nullptr;
     P.slotmask = 0;
@@ -1398,13 +1411,17 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
     sub_off[(size_t)n_frames] = (unsigned)subs;
     P.total_sub = (unsigned)subs;
     std::vector<uint8_t> h_ecs(bytes, 0);
-    std::vector<unsigned> frame_of(subs);
+    // the index arrays (and the two flags behind them, as zeros) travel as one block
+    const size_t meta_words = (size_t)n_frames + ((size_t)n_frames + 1) + subs + (size_t)n_frames + 2;
+    std::vector<unsigned> h_meta(meta_words, 0u);
     for (int f = 0; f < n_frames; f++) {
         std::memcpy(h_ecs.data() + ecs_off[(size_t)f], ecs[(size_t)f].data(), ecs[(size_t)f].size());
-        for (unsigned k = sub_off[(size_t)f]; k < sub_off[(size_t)f + 1]; k++) frame_of[k] = (unsigned)f;
+        h_meta[(size_t)f] = ecs_off[(size_t)f];
+        h_meta[(size_t)n_frames + (size_t)f] = sub_off[(size_t)f];
+        for (unsigned k = sub_off[(size_t)f]; k < sub_off[(size_t)f + 1]; k++) h_meta[(size_t)2 * n_frames + 1 + k] = (unsigned)f;
     }
+    h_meta[(size_t)2 * n_frames] = sub_off[(size_t)n_frames];
     int r;
-    const size_t meta_words = (size_t)n_frames + ((size_t)n_frames + 1) + subs + (size_t)n_frames + 2;
     if ((r = grow(c, &c->gd_ecs, &c->gd_ecs_cap, bytes))) return r;
     if ((r = grow(c, &c->gd_meta, &c->gd_meta_cap, meta_words * sizeof(unsigned) + 64))) return r;
     if ((r = grow(c, &c->gd_state, &c->gd_state_cap, HVC_HD_STATE_BYTES(subs)))) return r;
@@ -1415,11 +1432,8 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
     unsigned *d_frame_blocks = d_frame_of + subs, *d_flags = d_frame_blocks + n_frames;
     hipStream_t st = c->stream;
     HIPCHK(c, hipMemcpyAsync(c->gd_ecs, h_ecs.data(), bytes, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_ecs_off, ecs_off.data(), (size_t)n_frames * sizeof(unsigned), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_sub_off, sub_off.data(), ((size_t)n_frames + 1) * sizeof(unsigned), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_frame_of, frame_of.data(), subs * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(m, h_meta.data(), meta_words * sizeof(unsigned), hipMemcpyHostToDevice, st));
     if ((r = gd_upload_tables(c, tables0, P, st))) return r;
-    HIPCHK(c, hipMemsetAsync(d_flags, 0, 2 * sizeof(unsigned), st));
     P.ecs = (const uint8_t *)c->gd_ecs;
     P.ecs_off = d_ecs_off;
     P.sub_off = d_sub_off;
@@ -1431,24 +1445,33 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
     P.changed = d_flags;
     P.status = d_flags + 1;
     // (no clearing of the records: the write pass stores every index of every coded block exactly once)
-    // synchronisation rounds: until a round changes no start state
-    int round = 0;
-    const int max_rounds = 48;
-    for (;; round++) {
-        if (round > 0) HIPCHK(c, hipMemsetAsync(P.changed, 0, sizeof(unsigned), st));
-        HIPCHK(c, hvc::launch_hd_round(P, round, st));
-        if (round >= 1) {
-            unsigned changed = 0;
-            HIPCHK(c, hipMemcpyAsync(&changed, P.changed, sizeof changed, hipMemcpyDeviceToHost, st));
-            HIPCHK(c, hipStreamSynchronize(st));
-            if (!changed) break;
-            if (round >= max_rounds) return HVC_OK; // does not settle: let the host decoder handle it
-        }
-    }
-    HIPCHK(c, hvc::launch_hd_finish(P, round + 1, st)); // launches 0..round have run
-    unsigned status = 0;
-    HIPCHK(c, hipMemcpyAsync(&status, P.status, sizeof status, hipMemcpyDeviceToHost, st));
+    // Everything in one go, as the batch pipeline does: four synchronisation launches (all of k_hd_sync's rounds count
+    // as the first), the finish passes, one look at the two flags.  Only a stream that has not settled by then -- smooth
+    // content can take hundreds of rounds -- is done again round by round.
+    HIPCHK(c, gd_enqueue(P, 4, st)); // clears the flags first
+    unsigned flags[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(flags, P.changed, sizeof flags, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    if (flags[0]) { // (the finish passes have turned the block counts into block indices: the rounds start over)
+        const int max_rounds = 48;
+        int round = 0;
+        HIPCHK(c, hipMemsetAsync(P.changed, 0, 2 * sizeof(unsigned), st));
+        for (;; round++) {
+            if (round > 0) HIPCHK(c, hipMemsetAsync(P.changed, 0, sizeof(unsigned), st));
+            HIPCHK(c, hvc::launch_hd_round(P, round, st));
+            if (round >= 4) {
+                unsigned changed = 0;
+                HIPCHK(c, hipMemcpyAsync(&changed, P.changed, sizeof changed, hipMemcpyDeviceToHost, st));
+                HIPCHK(c, hipStreamSynchronize(st));
+                if (!changed) break;
+                if (round >= max_rounds) return HVC_OK; // does not settle: let the host decoder handle it
+            }
+        }
+        HIPCHK(c, hvc::launch_hd_finish(P, round + 1, st)); // launches 0..round have run
+        HIPCHK(c, hipMemcpyAsync(flags + 1, P.status, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+    const unsigned status = flags[1];
     if (status) return HVC_OK; // the model raises / range / truncated stream: the host decoder reproduces it exactly
     *used_gpu = 1;
     return HVC_OK;
