@@ -23,8 +23,8 @@
 // Two sets of kernels do this.  The general one -- k_hd_round (rounds inside a workgroup through LDS,
 // across workgroups through launches) and k_hd_write -- takes any frame the host side lets through.
 // The fast one -- k_hd_sync (level-synchronous rounds over work lists, skip-only tables, subsequences
-// staged in LDS) and k_hd_write2 (blocks owned by the lane they start in, wavefront-wide batched
-// stores) -- needs the components to share at most two (DC, AC) table pairs, as every baseline file's do;
+// staged in LDS; k_hd_sync_tail: the late rounds of a few files inside one workgroup) and k_hd_write2
+// (blocks owned by the lane they start in, wavefront-wide batched stores) -- needs the components to share at most two (DC, AC) table pairs, as every baseline file's do;
 // launch_hd_round / launch_hd_finish pick it whenever HdParams::spec is set, and k_hd_round then only
 // verifies the hand-overs and finishes what takes more rounds than k_hd_sync is given.
 #include "hvc_hdec.h"
