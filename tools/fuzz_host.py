@@ -36,3 +36,24 @@ for it in range(6000):
     except hvc.HvcError:
         err += 1
 print("decoded", ok, "rejected", err)
+# the host coder with arbitrary int16 records (values without a code must be refused, never written past a buffer)
+enc_ok = enc_err = 0
+for it in range(300):
+    chroma = int(rng.choice([420, 422, 444]))
+    w, h = int(rng.integers(1, 20)) * 2, int(rng.integers(1, 20)) * 2
+    try:
+        info = hvc.hvc.jpeg_encoder_layout(w, h, chroma, int(rng.integers(1, 101)))
+    except hvc.HvcError:
+        continue
+    lim = int(rng.choice([2, 64, 1024, 2048, 32768]))
+    rec = rng.integers(-lim, lim, size=info.coef_count).astype(np.int16)
+    if it % 3 == 0:
+        rec[rng.integers(0, 2, size=rec.size) == 0] = 0
+    try:
+        jpg = hvc.hvc.jpeg_entropy_encode(info, rec)
+        _, back = hvc.hvc.jpeg_entropy_decode(jpg)
+        assert np.array_equal(back, rec), "coder / reader round trip"
+        enc_ok += 1
+    except hvc.HvcError:
+        enc_err += 1
+print("encoded", enc_ok, "refused", enc_err)
