@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Randomised sweep over the file-level decode pipelines: hvc_jpeg_decode_batch_gpu (GPU Huffman reader, two reader
+streams, downloader thread) against hvc_jpeg_decode_batch (host reader) -- both product paths, the second pinned to
+the model restatement by the test suite -- over batch sizes, chunk sizes, thread counts, host / device output and
+the fused 4:4:4 form.  One summary line; exit code 1 on a mismatch.
+
+    python tools/stress_pipeline.py [--cases 60] [--seed 3]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import video_coding_amd as hvc  # noqa: E402
+from video_coding_amd.synth import synth_pixels  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=3)
+    args = ap.parse_args()
+    import torch
+    rng = np.random.Generator(np.random.PCG64(args.seed))
+    ctx = hvc.Context(0)
+    bad = 0
+    for case in range(args.cases):
+        w = int(rng.integers(1, 30)) * 16
+        h = int(rng.integers(1, 20)) * 16
+        q = int(rng.choice([10, 50, 75, 95]))
+        n_distinct = int(rng.integers(1, 5))
+        files = []
+        for d in range(n_distinct):
+            s = int(rng.integers(0, 1 << 30))
+            files.append(ctx.jpeg_encode(synth_pixels(s, h, w), synth_pixels(s + 1, h // 2, w // 2), synth_pixels(s + 2, h // 2, w // 2),
+                                         w, h, 420, q))
+        n = int(rng.integers(1, 41))
+        batch = [files[int(rng.integers(0, n_distinct))] for _ in range(n)]
+        info = hvc.hvc.jpeg_read_header(batch[0])
+        yuv444 = bool(rng.integers(0, 2))
+        fs = 3 * w * h if yuv444 else info.pixel_bytes
+        chunk = int(rng.integers(1, 10))
+        threads = int(rng.integers(1, 9))
+        host_out = bool(rng.integers(0, 2))
+        if host_out:
+            a = np.zeros(n * fs, np.uint8)
+            b = np.zeros(n * fs, np.uint8)
+        else:
+            a = torch.zeros(n * fs, dtype=torch.uint8, device="cuda")
+            b = torch.zeros(n * fs, dtype=torch.uint8, device="cuda")
+        ctx.jpeg_decode_batch(batch, a, fs, threads=threads, frames_per_chunk=chunk, yuv444=yuv444, gpu_entropy=True)
+        ctx.jpeg_decode_batch(batch, b, fs, threads=threads, frames_per_chunk=chunk, yuv444=yuv444, gpu_entropy=False)
+        same = np.array_equal(a, b) if host_out else bool(torch.equal(a, b))
+        if not same:
+            bad += 1
+            print("MISMATCH", case, (w, h, q, n, chunk, threads, host_out, yuv444), file=sys.stderr)
+    print({"cases": args.cases, "mismatches": bad})
+    ctx.close()
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
