@@ -1674,7 +1674,6 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     int released_upto = NB - 1;
     std::atomic<long long> prep_ns{0};
     auto worker = [&]() {
-        std::vector<uint8_t> ecs;
         hvc::HdTables t;
         for (;;) {
             const int f = next_frame.fetch_add(1);
@@ -1693,14 +1692,14 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
                        std::memcmp(fi.qtabs, info0.qtabs, sizeof fi.qtabs)))
                 e = HVC_E_INVALID_ARG; // a batch shares one geometry and one set of tables
             bool ok = false;
-            if (!e) e = hvc::prepare_gpu_decode(jpegs[f], sizes[f], &fi, t, ecs, ok);
-            if (!e && (!ok || std::memcmp(&t, &tables0, sizeof t) || ecs.size() > (nsub_max - 1) * SB)) need_host.store(1);
+            uint8_t *dst = (uint8_t *)c->gp_h_ecs[slot] + (size_t)(f - k * C) * R; // unstuffed straight into the pinned slot
+            size_t got = 0;
+            if (!e) e = hvc::prepare_gpu_decode_to(jpegs[f], sizes[f], &fi, t, dst, (nsub_max - 1) * SB, &got, ok);
+            if (!e && (!ok || std::memcmp(&t, &tables0, sizeof t))) need_host.store(1);
             if (!e && !need_host.load()) {
-                uint8_t *dst = (uint8_t *)c->gp_h_ecs[slot] + (size_t)(f - k * C) * R;
-                std::memcpy(dst, ecs.data(), ecs.size());
-                const size_t used = ((ecs.size() + SB - 1) / SB + 1) * SB + 16; // this frame's subsequences + overshoot
-                std::memset(dst + ecs.size(), 0, used - ecs.size());
-                ecs_size[(size_t)f] = (unsigned)ecs.size();
+                const size_t used = ((got + SB - 1) / SB + 1) * SB + 16; // this frame's subsequences + overshoot
+                std::memset(dst + got, 0, used - got);
+                ecs_size[(size_t)f] = (unsigned)got;
             }
             prep_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
             std::lock_guard<std::mutex> lk(mu);

@@ -692,23 +692,43 @@ void default_enc_tables(uint32_t (*out)[16 + 256]) {
 
 // ECS extraction shared by the host decoder and the GPU decoder: extract_entropy_coded_bits
 // (decoder.ml:261-281): up to the first marker, 0xff00 -> 0xff
-static void extract_ecs(const uint8_t *data, size_t n, size_t pos, std::vector<uint8_t> &ecs) {
-    ecs.clear();
-    ecs.reserve((n > pos ? n - pos : 0) + 16);
+// The entropy-coded segment without its stuffing (0xFF 0x00 -> 0xFF), up to the first marker, into dst[0, cap):
+// the number of bytes, or SIZE_MAX when cap is too small.
+static size_t extract_ecs_to(const uint8_t *data, size_t n, size_t pos, uint8_t *dst, size_t cap) {
+    size_t out = 0;
     while (pos < n) {
         const uint8_t *ff = (const uint8_t *)std::memchr(data + pos, 0xff, n - pos);
         const size_t stop = ff ? (size_t)(ff - data) : n;
-        ecs.insert(ecs.end(), data + pos, data + stop);
+        if (stop - pos > cap - out) return SIZE_MAX;
+        std::memcpy(dst + out, data + pos, stop - pos);
+        out += stop - pos;
         if (!ff) break;
         const int next = stop + 1 < n ? data[stop + 1] : 0;
         if (next != 0x00) break;
-        ecs.push_back(0xff);
+        if (out == cap) return SIZE_MAX;
+        dst[out++] = 0xff;
         pos = stop + 2;
     }
+    return out;
+}
+static void extract_ecs(const uint8_t *data, size_t n, size_t pos, std::vector<uint8_t> &ecs) {
+    ecs.resize((n > pos ? n - pos : 0) + 1); // unstuffing only ever shortens
+    const size_t got = extract_ecs_to(data, n, pos, ecs.data(), ecs.size());
+    ecs.resize(got == SIZE_MAX ? 0 : got);
 }
 
+static int prepare_gpu_decode_impl(const uint8_t *jpeg, size_t n, const ::hvc_jpeg_info *info, HdTables &t,
+                                   std::vector<uint8_t> *ecs, uint8_t *dst, size_t cap, size_t *ecs_size, bool &gpu_ok);
 int prepare_gpu_decode(const uint8_t *jpeg, size_t n, const ::hvc_jpeg_info *info, HdTables &t, std::vector<uint8_t> &ecs,
                        bool &gpu_ok) {
+    return prepare_gpu_decode_impl(jpeg, n, info, t, &ecs, nullptr, 0, nullptr, gpu_ok);
+}
+int prepare_gpu_decode_to(const uint8_t *jpeg, size_t n, const ::hvc_jpeg_info *info, HdTables &t, uint8_t *dst, size_t cap,
+                          size_t *ecs_size, bool &gpu_ok) {
+    return prepare_gpu_decode_impl(jpeg, n, info, t, nullptr, dst, cap, ecs_size, gpu_ok);
+}
+static int prepare_gpu_decode_impl(const uint8_t *jpeg, size_t n, const ::hvc_jpeg_info *info, HdTables &t,
+                                   std::vector<uint8_t> *ecs, uint8_t *dst, size_t cap, size_t *ecs_size, bool &gpu_ok) {
     gpu_ok = false;
     Header h;
     int r = parse_header(jpeg, n, h);
@@ -758,10 +778,18 @@ int prepare_gpu_decode(const uint8_t *jpeg, size_t n, const ::hvc_jpeg_info *inf
             ok = ok && fill(h.dht[ai].spec, t.ac[i]);
         }
     }
-    extract_ecs(jpeg, n, h.ecs_pos, ecs);
+    size_t got;
+    if (ecs) {
+        extract_ecs(jpeg, n, h.ecs_pos, *ecs);
+        got = ecs->size();
+    } else {
+        got = extract_ecs_to(jpeg, n, h.ecs_pos, dst, cap); // SIZE_MAX: does not fit (the caller sized cap from the file sizes)
+        *ecs_size = got == SIZE_MAX ? 0 : got;
+        ok = ok && got != SIZE_MAX;
+    }
     int per_mcu = 0;
     for (int i = 0; i < info->n_comp; i++) per_mcu += info->comp[i].hscale * info->comp[i].vscale;
-    gpu_ok = ok && info->n_comp <= 3 && per_mcu <= HVC_HD_MAX_MCU_BLOCKS && ecs.size() < (1u << 28);
+    gpu_ok = ok && info->n_comp <= 3 && per_mcu <= HVC_HD_MAX_MCU_BLOCKS && got < (1u << 28);
     return HVC_OK;
 }
 } // namespace hvc

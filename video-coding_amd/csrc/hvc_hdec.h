@@ -89,6 +89,9 @@ hipError_t launch_hd_finish(const HdParams &P, int rounds_done, hipStream_t s); 
 // gpu_ok = false when the stream needs the host decoder (tables that are no prefix code, > 16 blocks per MCU)
 int prepare_gpu_decode(const uint8_t *jpeg, size_t n, const ::hvc_jpeg_info *info, HdTables &t, std::vector<uint8_t> &ecs,
                        bool &gpu_ok);
+// the same, unstuffing straight into dst[0, cap) (a pinned ring slot); a segment that does not fit clears gpu_ok
+int prepare_gpu_decode_to(const uint8_t *jpeg, size_t n, const ::hvc_jpeg_info *info, HdTables &t, uint8_t *dst, size_t cap,
+                          size_t *ecs_size, bool &gpu_ok);
 
 } // namespace hvc
 #endif
