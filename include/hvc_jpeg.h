@@ -263,8 +263,10 @@ HVC_API int hvc_jpeg_encoder_layout(int width, int height, int chroma, int quali
 /* hvc_jpeg_decode_batch (or _yuv444 when yuv444 != 0) with the Huffman reader on the GPU as well
  * (hvc_jpeg_entropy_decode_gpu below): host threads only parse headers and unstuff the entropy-coded
  * segments into a pinned ring, ~1 MB per 1080p frame crosses PCIe instead of 6 MB of coefficients, and
- * the coefficient records are produced where the block stage reads them.  If any file needs the host
- * decoder (see below) the whole call is redone by the host-decoder pipeline: same output, same errors.
+ * the coefficient records are produced where the block stage reads them.  Chunks holding a file that needs
+ * the host decoder (see below), or whose Huffman tables differ from the first file's, are redone by the
+ * host-decoder pipeline once the others are through: same output, same errors (stats->entropy_ms_sum is
+ * the host decoding time spent on them, 0 when the GPU reader did everything).
  * frames_per_chunk < 1 = a quarter of the batch, between 64 and 256 (what measured best). */
 HVC_API int hvc_jpeg_decode_batch_gpu(hvc_ctx *ctx, const uint8_t *const *jpegs, const size_t *sizes, int n_frames,
                                       int threads, int frames_per_chunk, uint8_t *pixels,

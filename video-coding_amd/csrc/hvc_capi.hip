@@ -1668,7 +1668,10 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     std::condition_variable cv;
     std::atomic<int> next_frame{0};
     std::atomic<int> error{0};
-    std::atomic<int> need_host{0};
+    // chunks the GPU reader cannot or must not do (a file with other Huffman tables, tables that are no prefix code, a
+    // stream the model raises on or that ends early, rounds that do not settle): skipped here or found out at the
+    // verdict, and redone by the host-reader pipeline once this one has drained -- chunk by chunk, not the whole call
+    std::vector<char> chunk_host((size_t)n_chunks, 0), skipped((size_t)n_chunks, 0);
     std::vector<int> done_in_chunk((size_t)n_chunks, 0);
     std::vector<unsigned> ecs_size((size_t)n_frames, 0);
     int released_upto = NB - 1;
@@ -1677,13 +1680,13 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         hvc::HdTables t;
         for (;;) {
             const int f = next_frame.fetch_add(1);
-            if (f >= n_frames || error.load() || need_host.load()) return;
+            if (f >= n_frames || error.load()) return;
             const int k = f / C, slot = k % NB;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return k <= released_upto || error.load() || need_host.load(); });
+                cv.wait(lk, [&] { return k <= released_upto || error.load(); });
             }
-            if (error.load() || need_host.load()) return;
+            if (error.load()) return;
             const auto t0 = std::chrono::steady_clock::now();
             hvc_jpeg_info fi;
             int e = hvc_jpeg_read_header(jpegs[f], sizes[f], &fi);
@@ -1695,8 +1698,8 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
             uint8_t *dst = (uint8_t *)c->gp_h_ecs[slot] + (size_t)(f - k * C) * R; // unstuffed straight into the pinned slot
             size_t got = 0;
             if (!e) e = hvc::prepare_gpu_decode_to(jpegs[f], sizes[f], &fi, t, dst, (nsub_max - 1) * SB, &got, ok);
-            if (!e && (!ok || std::memcmp(&t, &tables0, sizeof t))) need_host.store(1);
-            if (!e && !need_host.load()) {
+            const bool unfit = !e && (!ok || std::memcmp(&t, &tables0, sizeof t));
+            if (!e && !unfit) {
                 const size_t used = ((got + SB - 1) / SB + 1) * SB + 16; // this frame's subsequences + overshoot
                 std::memset(dst + got, 0, used - got);
                 ecs_size[(size_t)f] = (unsigned)got;
@@ -1704,6 +1707,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
             prep_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
             std::lock_guard<std::mutex> lk(mu);
             if (e) error.store(e);
+            if (unfit) chunk_host[(size_t)k] = 1;
             done_in_chunk[(size_t)k]++;
             cv.notify_all();
         }
@@ -1727,6 +1731,14 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
                     cv.wait(lk, [&] { return stage_done.load() > k || dl_abort.load(); });
                 }
                 if (dl_abort.load()) return;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (skipped[(size_t)k]) { // nothing was decoded here: the host-reader pipeline fills it in later
+                        downloaded[(size_t)k] = 1;
+                        cv.notify_all();
+                        continue;
+                    }
+                }
                 const int slot = k % NB, first = k * C, cnt = (first + C <= n_frames) ? C : n_frames - first;
                 hipError_t e = hipStreamWaitEvent(c->down_stream, c->ev_et[slot][2], 0);
                 if (e == hipSuccess)
@@ -1751,16 +1763,15 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     };
 
     int rc = HVC_OK;
-    bool fallback = false;
     double h2d_ms = 0, k_ms = 0;
     uint64_t ecs_total = 0;
     hipStream_t compute = c->stream;
     const bool prof_saved = c->profiling;
     c->profiling = false;
-    for (int it = 0; it < n_chunks + NB && rc == HVC_OK && !fallback; it++) {
+    for (int it = 0; it < n_chunks + NB && rc == HVC_OK; it++) {
         // verdict on chunk it - NB's slot before it is overwritten (and on the last chunks at the end)
         const int v = it - NB;
-        if (v >= 0) {
+        if (v >= 0 && !skipped[(size_t)v]) {
             const int slot = v % NB;
             hipError_t he = hipSuccess;
             if (where == HVC_MEM_HOST) { // the slot's frames have left the device
@@ -1772,7 +1783,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
             }
             if (he != hipSuccess) { rc = fail_hip(c, he); break; }
             const unsigned *flags = (const unsigned *)c->gp_h_meta[slot] + (meta_words - 2);
-            if (flags[0] || flags[1]) { fallback = true; break; } // not settled / the model raises / truncated
+            if (flags[0] || flags[1]) chunk_host[(size_t)v] = 1; // not settled / the model raises / truncated: what was decoded is redone
             float ms = 0; // stage times of the chunk that just finished (read late so that nothing waits for them)
             if (hipEventElapsedTime(&ms, c->ev_et[slot][0], c->ev_h2d[slot]) == hipSuccess) h2d_ms += ms;
             if (hipEventElapsedTime(&ms, c->ev_et[slot][1], c->ev_et[slot][2]) == hipSuccess) k_ms += ms;
@@ -1781,10 +1792,21 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         const int k = it, slot = k % NB, first = k * C, cnt = (first + C <= n_frames) ? C : n_frames - first;
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return done_in_chunk[(size_t)k] == cnt || error.load() || need_host.load(); });
+            cv.wait(lk, [&] { return done_in_chunk[(size_t)k] == cnt || error.load(); });
         }
         if (error.load()) { rc = error.load(); break; }
-        if (need_host.load()) { fallback = true; break; }
+        bool skip;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            skip = chunk_host[(size_t)k] != 0;
+            if (skip) { // no GPU work for this chunk; its pinned slot goes to chunk k + NB, the downloader moves on
+                skipped[(size_t)k] = 1;
+                released_upto = k + NB;
+                stage_done.store(k + 1);
+                cv.notify_all();
+            }
+        }
+        if (skip) continue;
         // the chunk's index arrays
         unsigned *hm = (unsigned *)c->gp_h_meta[slot];
         unsigned *h_ecs_off = hm, *h_sub_off = hm + C, *h_frame_of = h_sub_off + C + 1;
@@ -1856,7 +1878,6 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     {
         std::lock_guard<std::mutex> lk(mu);
         if (rc != HVC_OK) error.store(rc);
-        if (fallback) need_host.store(1);
         cv.notify_all();
     }
     stop_downloader(); // (after a complete run it has finished: the last verdicts waited for its last chunks)
@@ -1865,10 +1886,18 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     (void)hipStreamSynchronize(compute);
     (void)hipStreamSynchronize(c->copy_stream);
     if (rc == HVC_OK && error.load()) rc = error.load();
-    if (rc == HVC_OK && (fallback || need_host.load())) return host_pipeline();
+    double host_entropy_ms = 0;
+    for (int k = 0; k < n_chunks && rc == HVC_OK; k++) // everything has drained: the chunks left to the host reader
+        if (chunk_host[(size_t)k]) {
+            const int first = k * C, cnt = (first + C <= n_frames) ? C : n_frames - first;
+            hvc_batch_stats hs;
+            rc = decode_batch_impl(c, jpegs + first, sizes + first, cnt, threads, 0, pixels + (size_t)first * pixel_fs, pixel_fs,
+                                   where, &hs, yuv444);
+            host_entropy_ms += hs.entropy_ms_sum;
+        }
     if (stats) {
         stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-        stats->entropy_ms_sum = 0; // no host entropy decoding
+        stats->entropy_ms_sum = host_entropy_ms; // host entropy decoding: only for the chunks that fell to the host reader
         stats->host_prep_ms_sum = (double)prep_ns.load() * 1e-6;
         stats->h2d_ms_sum = h2d_ms;
         stats->kernel_ms_sum = k_ms;
