@@ -1,40 +1,48 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X JPEG block-transform path.
 
-Workload (BASELINE.json configs[1]): 1080p 4:2:0 baseline frames, synthetic
-*valid* coefficient blocks (Huffman bypassed), resident in HBM; one "step" is
-one pass of the decode hot path (dequantise -> inverse zig-zag -> Chen-Wang
-IDCT -> clip/level shift -> plane store) over one batch of frames through the
-C ABI (hvc_decode_frames).  Metric: Mpixel/s decoded (cropped 1920x1080 luma
-pixels per frame).
+    python bench.py --gpus N --steps K --warmup W [--config 2|4]
 
-    python bench.py --gpus N --steps K --warmup W
+--config 2 (default; BASELINE.json configs[1], the configuration the metric is quoted on):
+    1080p 4:2:0 baseline frames, synthetic *valid* coefficient blocks (Huffman bypassed), resident in
+    HBM; one "step" = one pass of the decode hot path (dequantise -> inverse zig-zag -> Chen-Wang IDCT ->
+    clip / level shift -> plane store) over one batch of --frames frames per GPU through the C ABI
+    (hvc_decode_frames).  Metric: Mpixel/s decoded (cropped 1920x1080 luma pixels per frame).
+--config 4 (BASELINE.json configs[3]: 16384 x 4K 4:4:4 sharded over 8 GPUs = 2048 frames per GPU):
+    one "step" = one pass over the rank's whole shard, --shard frames in launches of --frames (128) frames;
+    the shard is resident in HBM (102 GB of coefficients + 51 GB of pixels per GPU) when the device has the
+    room, otherwise one resident launch-sized chunk is processed shard / frames times (said in `config`).
 
-Setup (untimed, before the W warm-up steps): input generation on the GPU and eight launches of the
-step itself (page touch + clock ramp).  N > 1 is launched by the driver with torch.distributed.run
-(one rank per GPU);
-the path shards as independent frame batches: no data-path collective, weak
-scaling (per-GPU batch fixed).  The barrier / max-over-ranks reduction below is
-timing closure only.
+N > 1: one process per GPU.  The driver starts the ranks with torch.distributed.run; typed by hand,
+`python bench.py --gpus N` starts them itself -- N fresh child processes, before this process has made any
+HIP or torch.cuda call -- and relays rank 0's JSON line.  The path shards as independent frame batches:
+no data-path collective, weak scaling (per-GPU work fixed); the barrier / MAX-over-ranks reduction is timing
+closure only.  HVC_BENCH_REHEARSAL=1 puts every rank on cuda:0 with gloo (a one-GPU box can rehearse the
+whole N-rank flow; never a measurement, the line says so).
 
-Inputs: seeded synthetic pixel frames (video-coding_amd/synth.py) pushed through
-this library's OWN forward path (k_encode, quality 75) on the GPU, outside the
-timed region -- so the coefficients are encoder-producible.  (tests/test_gpu_fullsize_properties.py
-checks this very batch shape against the oracle and across four implementations.)
+Setup (untimed, before the W warm-up steps): input generation on the GPU and a few launches of the step
+itself (page touch + clock ramp).  Inputs: seeded synthetic pixel frames (video-coding_amd/synth.py) pushed
+through this library's OWN forward path (k_encode, quality 75) on the GPU, outside the timed region -- so the
+coefficients are encoder-producible.
 
 The JSON line also carries
-  roofline      achieved algorithmic GB/s of the dominant kernel (k_decode_packed:
-                192 B per 8x8 block = 128 B int16 coefficients read + 64 B pixels
-                written) over its HIP-event-timed duration, against 8 TB/s HBM;
-                `traffic` = the HBM bytes of the committed rocprofv3 PMC passes;
-  cpu_baseline  the CPU oracle (oracle/hvc_oracle.c, the restated model path,
-                scalar, 1 thread) timed on this host on a bounded sample of the
-                same workload.  The oracle is the checker, timed as a baseline
-                only: this leg is its only use here (parity is the job of tests/).
+  roofline      achieved algorithmic GB/s of the dominant kernel (k_decode_packed: 192 B per 8x8 block =
+                128 B int16 coefficients read + 64 B pixels written) over its HIP-event-timed duration (events
+                recorded inside the library on the kernel's own stream), against 8 TB/s HBM; `traffic` = the
+                HBM bytes of the committed rocprofv3 PMC passes, `traffic_source` says which;
+  checksum      K5 (hvc_checksum_records) over the decoded DISTINCT frames, on the device, compared with the
+                values tests/golden/bench_checksums.json holds for these seeds -- which the CPU suite
+                reproduces from the model restatement (tests/test_bench_checksums.py): the timed output is
+                the model's output, not just fast;
+  cpu_baseline  the CPU restatement of the model path (oracle/hvc_oracle.c, scalar, 1 thread) timed on this
+                host on a bounded sample of the same workload.  The oracle is the checker, timed as a
+                baseline only: this leg is its only use here (parity is the job of tests/).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -43,23 +51,37 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W, H = 1920, 1080
-# Decoder.init geometry (decoder.ml:304-345) for 4:2:0: rounded to 16 -> 1920x1088
-PLANES = [(240, 136, 0), (120, 68, 1), (120, 68, 1)]  # (blocks_w, blocks_h, qtab)
-BLOCKS_PER_FRAME = sum(bw * bh for bw, bh, _ in PLANES)  # 48960
 ALGO_BYTES_PER_BLOCK = 192  # 128 B read + 64 B written
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 
+# Decoder.init geometry (decoder.ml:304-345): (blocks_w, blocks_h, qtab) per component
+WORKLOADS = {
+    2: dict(name="1080p 4:2:0 baseline, synthetic valid coefficient blocks (Huffman bypassed), HBM-resident",
+            W=1920, H=1080, planes=[(240, 136, 0), (120, 68, 1), (120, 68, 1)],  # rounded to 16 -> 1920x1088
+            frames=1024, shard=None, steps=50, seed=0x4A504547, metric="Mpixel/s decoded (1080p 4:2:0 batch)"),
+    4: dict(name="4K 4:4:4 baseline, synthetic valid coefficient blocks, one GPU's 2048-frame shard of the 16384-frame batch",
+            W=3840, H=2160, planes=[(480, 270, 0), (480, 270, 1), (480, 270, 1)],
+            frames=128, shard=2048, steps=3, seed=0x4A504547 + 400, metric="Mpixel/s decoded (4K 4:4:4 batch)"),
+}
+# kept for callers of the N > 1 helpers (tests/test_distributed_cpu.py)
+W, H = WORKLOADS[2]["W"], WORKLOADS[2]["H"]
+PLANES = WORKLOADS[2]["planes"]
+BLOCKS_PER_FRAME = sum(bw * bh for bw, bh, _ in PLANES)  # 48960
 
-def make_distinct_frames(ctx, hvc, n_distinct, seed):
+
+def distinct_seed(base_seed, rank, f):
+    return base_seed + 1000 * rank + 16 * f
+
+
+def make_distinct_frames(ctx, hvc, planes, n_distinct, base_seed, rank):
     """Coefficient records of n_distinct synthetic frames via the library's own forward path
     (hvc_encode_frames on the GPU, Quant_tables.scale 75).  Returns (device int16 tensor
     [n_distinct, coef_count], qtabs uint16 [2, 64])."""
     import torch
     from video_coding_amd.synth import synth_frame_pixels
     qtabs = np.stack([hvc.hvc.quant_table(0, 75), hvc.hvc.quant_table(1, 75)])
-    specs, cfs, pfs = hvc.hvc.frame_layout(PLANES)
-    pix = np.stack([synth_frame_pixels(seed + 16 * f, PLANES) for f in range(n_distinct)])
+    specs, cfs, pfs = hvc.hvc.frame_layout(planes)
+    pix = np.stack([synth_frame_pixels(distinct_seed(base_seed, rank, f), planes) for f in range(n_distinct)])
     d_pix = torch.from_numpy(pix).cuda()
     d_coefs = torch.zeros((n_distinct, cfs), dtype=torch.int16, device="cuda")
     torch.cuda.synchronize()
@@ -68,15 +90,15 @@ def make_distinct_frames(ctx, hvc, n_distinct, seed):
     return d_coefs, qtabs
 
 
-def _oracle_frame(orc, rec, qtabs):
+def _oracle_frame(orc, rec, qtabs, planes):
     off = 0
-    for bw, bh, qt in PLANES:
+    for bw, bh, qt in planes:
         n = bw * bh * 64
         orc.dequant_idct_recon(rec[off:off + n], qtabs[qt], bw, bh)
         off += n
 
 
-def cpu_baseline(frames, qtabs, min_seconds=10.0):
+def cpu_baseline(frames, qtabs, planes, pixels_per_frame, min_seconds=10.0):
     """Oracle block stage (scalar C, int64, one block at a time) on the same frames: (i) one thread
     -- the model's CPU path as restated; (ii) the same code frame-sharded over the host cores this
     process may use (ctypes releases the GIL), SURVEY.md 8(d)."""
@@ -84,7 +106,7 @@ def cpu_baseline(frames, qtabs, min_seconds=10.0):
     from oracle import orc
     done, t0 = 0, time.perf_counter()
     while True:
-        _oracle_frame(orc, frames[done % len(frames)], qtabs)
+        _oracle_frame(orc, frames[done % len(frames)], qtabs, planes)
         done += 1
         dt = time.perf_counter() - t0
         if dt >= min_seconds:
@@ -95,28 +117,43 @@ def cpu_baseline(frames, qtabs, min_seconds=10.0):
 
     def worker(k):
         for i in range(per_thread):
-            _oracle_frame(orc, frames[(k + i) % len(frames)], qtabs)
+            _oracle_frame(orc, frames[(k + i) % len(frames)], qtabs, planes)
 
     t1 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
         list(ex.map(worker, range(cores)))
     dtm = time.perf_counter() - t1
-    return {"value": round(done * W * H / dt / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of the same 1080p 4:2:0 workload, %.1f s, oracle/hvc_oracle.c "
+    return {"value": round(done * pixels_per_frame / dt / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": "port",
+            "sample": "%d frames of the same workload, %.1f s, oracle/hvc_oracle.c "
                       "orc_dequant_idct_recon, 1 thread" % (done, dt),
-            "all_cores": {"value": round(cores * per_thread * W * H / dtm / 1e6, 3), "unit": "Mpixel/s", "cores": cores,
+            "all_cores": {"value": round(cores * per_thread * pixels_per_frame / dtm / 1e6, 3), "unit": "Mpixel/s", "cores": cores,
                           "sample": "%d frames, %.1f s, frame-sharded threads" % (cores * per_thread, dtm)}}
 
 
-def measured_traffic(frames):
+def measured_traffic(config, frames):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate --pmc runs of this very
     command and corrected as MI355X_MICROARCH.md prescribes).  bench.py cannot collect counters
-    itself; None when the profile is absent or was taken at another batch size."""
+    itself: (None, reason) when the profile is absent or was taken at another configuration."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
-        return round(t["hbm_bytes"]) if t.get("frames_per_launch") == frames else None
+        if t.get("frames_per_launch") == frames and t.get("config", 2) == config:
+            return round(t["hbm_bytes"]), "profiles/traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
+                                          "this command, not collected in this run" % t.get("session", "r01f")
+        return None, "no committed PMC pass for config %d at %d frames per launch" % (config, frames)
+    except (OSError, ValueError, KeyError):
+        return None, "profiles/traffic.json absent"
+
+
+def expected_checksums(config, n_distinct, rank):
+    """tests/golden/bench_checksums.json: the K5 checksums of the decoded distinct frames as the model
+    restatement gives them (made by tests/golden/make_bench_checksums.py, re-derived by the CPU suite)."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "bench_checksums.json")) as f:
+            g = json.load(f)
+        vals = g["bench_config%d" % config]["rank%d" % rank]
+        return [int(v, 16) for v in vals[:n_distinct]] if len(vals) >= n_distinct else None
     except (OSError, ValueError, KeyError):
         return None
 
@@ -166,28 +203,91 @@ def max_over_ranks(dt, world, dist=None, device="cpu"):
     return float(t.item())
 
 
-def whole_job_mpixels(world, frames_per_gpu, steps, dt):
-    """value = units ALL ranks processed / max-over-ranks time (weak scaling: per-GPU batch fixed)."""
-    return world * frames_per_gpu * steps * W * H / dt / 1e6
+def whole_job_mpixels(world, frames_per_gpu, steps, dt, pixels_per_frame=W * H):
+    """value = units ALL ranks processed / max-over-ranks time (weak scaling: per-GPU work fixed)."""
+    return world * frames_per_gpu * steps * pixels_per_frame / dt / 1e6
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` typed by hand: N fresh ranks through torch.distributed.run, started as
+    CHILD processes before this one has touched HIP or torch.cuda (a process that has must never be
+    replaced or re-executed); the ranks inherit stdout, so rank 0's JSON line is this command's output."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)  # the first launches after idle run off-clock (DVFS)
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per launch (9.6 GB of coefficients + pixels)")
+    ap.add_argument("--shard", type=int, default=None, help="config 4: frames per GPU per step (launches of --frames)")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames (replicated)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    args = ap.parse_args(argv)
+    wl = WORKLOADS[args.config]
+    args.frames = args.frames or wl["frames"]
+    args.shard = args.shard or wl["shard"] or args.frames
+    if args.shard % args.frames:
+        ap.error("--shard must be a multiple of --frames")
+    args.steps = args.steps if args.steps is not None else wl["steps"]
+    args.warmup = args.warmup if args.warmup is not None else (10 if args.config == 2 else 1)
+    return args
+
+
+def run_without_gpu(args, rank, world):
+    """HVC_BENCH_NO_GPU=1: the launch path alone (self-launch, rendezvous, barriers, MAX over ranks, one JSON
+    line from rank 0) with a sleep standing in for the step -- what tests/test_distributed_cpu.py drives on a
+    machine without a GPU.  Nothing is decoded and the line says so; it is never a measurement."""
+    dist = dist_init(world, "gloo")
+    calls = []
+
+    def step():
+        calls.append(1)
+        time.sleep(0.001 * (rank + 1))
+
+    dt = max_over_ranks(timed_steps(step, args.steps, args.warmup, lambda: None, world, dist), world, dist, "cpu")
+    if rank == 0:
+        wl = WORKLOADS[args.config]
+        print(json.dumps({"metric": wl["metric"], "value": round(whole_job_mpixels(world, args.shard, args.steps, dt, wl["W"] * wl["H"]), 1),
+                          "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "int32",
+                          "data": "none: launch-path rehearsal without a GPU (HVC_BENCH_NO_GPU=1), nothing decoded, not a measurement",
+                          "config": {"workload": wl["name"], "step_calls_rank0": len(calls)}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)  # the first launches after idle run off-clock (DVFS)
-    ap.add_argument("--frames", type=int, default=1024, help="frames per GPU per step (9.6 GB of coefficients + pixels)")
-    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames (replicated to --frames)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    args = ap.parse_args()
+    args = parse_args()
+    rank, world, local_rank = dist_env()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))  # (no HIP / torch.cuda call has happened in this process)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (set by the launcher): they must agree" % (args.gpus, world))
+    if os.environ.get("HVC_BENCH_NO_GPU") == "1":
+        return run_without_gpu(args, rank, world)
 
     import torch
     import video_coding_amd as hvc
 
-    rank, world, local_rank = dist_env()
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    wl = WORKLOADS[args.config]
+    planes, PW, PH = wl["planes"], wl["W"], wl["H"]
+    blocks_per_frame = sum(bw * bh for bw, bh, _ in planes)
     # Rehearsal on a one-GPU box (never the measured configuration): HVC_BENCH_REHEARSAL=1 puts every
     # rank on cuda:0 and closes the timing with gloo instead of RCCL (which refuses two ranks per GPU).
     rehearsal = os.environ.get("HVC_BENCH_REHEARSAL") == "1"
@@ -198,22 +298,33 @@ def main():
 
     ctx = hvc.Context(local_rank)  # raises without a gfx950 GPU: there is no CPU fallback
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    d_distinct, qtabs = make_distinct_frames(ctx, hvc, args.distinct, seed=0x4A504547 + 1000 * rank)
-    specs, cfs, pfs = hvc.hvc.frame_layout(PLANES)
-    reps = (args.frames + args.distinct - 1) // args.distinct
-    d_coefs = d_distinct.repeat(reps, 1)[:args.frames].contiguous()
-    d_pix = torch.zeros((args.frames, pfs), dtype=torch.uint8, device="cuda")
+    d_distinct, qtabs = make_distinct_frames(ctx, hvc, planes, args.distinct, wl["seed"], rank)
+    specs, cfs, pfs = hvc.hvc.frame_layout(planes)
     comps = hvc.hvc.components(specs)
+    launches = args.shard // args.frames
+    # the shard resident as a whole when the device has the room (config 4: 153 GB per GPU); otherwise one
+    # launch-sized chunk, processed `launches` times per step
+    need = args.shard * (cfs * 2 + pfs)
+    free_b, _ = torch.cuda.mem_get_info()
+    resident = launches == 1 or (not rehearsal and need + (8 << 30) < free_b)
+    held = args.shard if resident else args.frames
+    d_coefs = torch.empty((held, cfs), dtype=torch.int16, device="cuda")
+    for f0 in range(0, held, args.distinct):  # replicate the distinct frames
+        n = min(args.distinct, held - f0)
+        d_coefs[f0:f0 + n] = d_distinct[:n]
+    d_pix = torch.zeros((held, pfs), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     ctx.set_profiling(True)
 
     def step():
-        ctx.decode_frames(d_coefs, cfs, qtabs, comps, args.frames, d_pix, pfs)
+        for k in range(launches):
+            f0 = k * args.frames if resident else 0
+            ctx.decode_frames(d_coefs[f0:f0 + args.frames], cfs, qtabs, comps, args.frames, d_pix[f0:f0 + args.frames], pfs)
 
     # Setup, not measurement: a few launches so that the output buffer's pages are touched and the chip
     # is on its sustained clock even when the caller asks for very few warm-up steps (the first launches
     # after idle run off the sustained rate in either direction).
-    for _ in range(8):
+    for _ in range(8 if launches == 1 else 1):
         step()
     torch.cuda.synchronize()
     ctx.set_profiling(True)  # restart the event ring: only warm-up and timed steps are recorded from here
@@ -221,38 +332,62 @@ def main():
     dt = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, world, dist)
     dt = max_over_ranks(dt, world, dist, "cpu" if rehearsal else "cuda")
 
-    # HIP events recorded around k_decode_packed inside the timed region (one pair per step)
-    kernel_ms = ctx.kernel_ms_history(min(args.steps, 64))
+    # HIP events recorded around k_decode_packed inside the timed region (one pair per launch, ring of 64)
+    kernel_ms = ctx.kernel_ms_history(min(args.steps * launches, 64))
     wide = ctx.last_wide_blocks()
+    # K5: what was decoded -- the distinct frames' pixel records, checksummed where they are
+    sums = [int(x) for x in ctx.checksum_records(d_pix, pfs, min(args.distinct, held))]
+    want = expected_checksums(args.config, len(sums), rank) if args.distinct <= 8 else None
     frames_host = d_distinct.cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    ok_local = want is not None and sums == want
+    if world > 1:  # every rank's output is verified; rank 0 reports how many were
+        t = torch.tensor([1.0 if ok_local else 0.0], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        ranks_ok = int(t.item())
+    else:
+        ranks_ok = int(ok_local)
 
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
-        algo_bytes = args.frames * BLOCKS_PER_FRAME * ALGO_BYTES_PER_BLOCK
+        algo_bytes = args.frames * blocks_per_frame * ALGO_BYTES_PER_BLOCK
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        traffic, traffic_source = measured_traffic(args.config, args.frames)
         out = {
-            "metric": "Mpixel/s decoded (1080p 4:2:0 batch)",
-            "value": round(whole_job_mpixels(world, args.frames, args.steps, dt), 1),
+            "metric": wl["metric"],
+            "value": round(whole_job_mpixels(world, args.shard, args.steps, dt, PW * PH), 1),
             "unit": "Mpixel/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "timed_region_s": round(dt, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic" + (" (REHEARSAL: all ranks share cuda:0, gloo)" if rehearsal else ""),
-            "config": {"workload": "1080p 4:2:0 baseline, synthetic valid coefficient blocks (Huffman bypassed), "
-                                   "HBM-resident, %d frames/GPU/step" % args.frames,
-                       "frames_per_gpu_per_step": args.frames, "blocks_per_frame": BLOCKS_PER_FRAME,
+            "config": {"workload": "%s, %d frames/GPU/step%s" % (
+                           wl["name"], args.shard,
+                           "" if launches == 1 else " in %d launches of %d frames, %s" % (
+                               launches, args.frames, "whole shard resident in HBM (%.0f GB/GPU)" % (need / 1e9) if resident
+                               else "one resident %d-frame chunk re-used (the shard's %.0f GB did not fit next to other users of the device)"
+                               % (args.frames, need / 1e9))),
+                       "baseline_config": args.config,
+                       "frames_per_gpu_per_step": args.shard, "frames_per_launch": args.frames,
+                       "blocks_per_frame": blocks_per_frame,
                        "parallelism": "independent frame batch per GPU, no collective",
                        "wide_path_blocks": int(wide)},
             "roofline": {"bound": "hbm", "kernel": "k_decode_packed", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": measured_traffic(args.frames), "kernel_ms": round(k_ms, 4),
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": round(k_ms, 4),
+                         "kernel_ms_min_max": [round(float(np.min(kernel_ms)), 4), round(float(np.max(kernel_ms)), 4)],
+                         "launches_averaged": len(kernel_ms),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "arithmetic": "int32 with int16-pair dot products (v_dot2_i32_i16); int64 fix-up kernel "
                                        "for blocks outside the proven range"},
+            "checksum": {"kernel": "k_checksum (K5, hvc_checksum_records)", "frames": len(sums),
+                         "rank0": ["%016x" % s for s in sums],
+                         "expected": "tests/golden/bench_checksums.json" if want is not None else None,
+                         "verified": bool(ok_local) if want is not None else None,
+                         "ranks_verified": ranks_ok if want is not None else None},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames_host, qtabs, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(frames_host, qtabs, planes, PW * PH, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

@@ -334,6 +334,16 @@ HVC_API int hvc_jpeg_encode_batch_gpu(hvc_ctx *ctx, const uint8_t *const *frames
                                       uint8_t *const *jpegs, const size_t *caps, size_t *sizes,
                                       hvc_batch_stats *stats);
 
+/* K5 (no counterpart in the reference): what a benchmark or a pipeline produced, said in
+ * 64 bits per record without bringing the records back.  For r < n_records
+ *     sums[r] = SUM_i (byte_i + 1) * ((2 i + 1) * 0x9E3779B97F4A7C15)   mod 2^64,  i = byte index in record r
+ * over data + r * record_stride, record_bytes bytes each.  data lives where `where` says (host data is uploaded
+ * first); sums is host memory; the call returns when sums is complete.  The same 64 bits follow from three
+ * lines of numpy on any machine (tests/helpers.py checksum_records), which is how the CPU suite pins the
+ * benchmarks' outputs to the model. */
+HVC_API int hvc_checksum_records(hvc_ctx *ctx, const void *data, size_t record_bytes, size_t record_stride,
+                                 int n_records, uint64_t *sums, int where);
+
 /* Device memory helpers so that a binding needs no HIP of its own. */
 HVC_API int hvc_device_alloc(hvc_ctx *ctx, size_t bytes, void **out);
 HVC_API int hvc_device_free(hvc_ctx *ctx, void *p);

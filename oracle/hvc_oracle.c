@@ -862,6 +862,34 @@ ORC_API int orc_decoder_decode(orc_decoder *d) {
     }
 }
 
+/* Test harness around For_testing.Sequenced.decode (decoder.ml:433-435), no arithmetic of its own: runs the
+ * sequence to its end and collects every block's `coefs` (zig-zag order, decoder.ml:118-140) with coefs[0]
+ * replaced by the component's dc_pred after the block -- the absolute DC of decoder.ml:143 -- in the C ABI's
+ * record layout: component planes back to back, each [decoded_height/8][decoded_width/8][64].  int64, so a DC
+ * outside int16 (the model is 63-bit) is representable.  The planes are decoded as a side effect.  Returns 0,
+ * or the model's error (< -1) with the blocks decoded so far in place. */
+ORC_API int orc_decoder_coef_record(orc_decoder *d, i64 *out) {
+    size_t base[4], at = 0;
+    for (int i = 0; i < d->ncomp; i++) {
+        base[i] = at;
+        at += (size_t)(d->comp[i].decoded_width / 8) * (size_t)(d->comp[i].decoded_height / 8) * 64;
+    }
+    for (;;) {
+        int r = orc_decoder_next_block(d);
+        if (r == -1) return 0;
+        if (r < -1) return r;
+        const Component *c = &d->comp[r];
+        i64 *blk = out + base[r] + ((size_t)(c->y / 8) * (size_t)(c->decoded_width / 8) + (size_t)(c->x / 8)) * 64;
+        memcpy(blk, c->coefs, sizeof c->coefs);
+        blk[0] = c->dc_pred;
+    }
+}
+ORC_API i64 orc_decoder_coef_count(const orc_decoder *d) {
+    i64 n = 0;
+    for (int i = 0; i < d->ncomp; i++) n += (i64)(d->comp[i].decoded_width / 8) * (d->comp[i].decoded_height / 8) * 64;
+    return n;
+}
+
 ORC_API int orc_decoder_ncomp(const orc_decoder *d) { return d->ncomp; }
 ORC_API int orc_decoder_width(const orc_decoder *d) { return d->header.frame.width; }
 ORC_API int orc_decoder_height(const orc_decoder *d) { return d->header.frame.height; }

@@ -43,6 +43,9 @@ def lib():
                   "orc_decoder_width", "orc_decoder_height"):
             getattr(L, f).argtypes = [C.c_void_p]
         L.orc_decoder_destroy.restype = None
+        L.orc_decoder_coef_record.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_decoder_coef_count.restype = C.c_int64
+        L.orc_decoder_coef_count.argtypes = [C.c_void_p]
         L.orc_decoder_component_info.argtypes = [C.c_void_p, C.c_int, i64p]
         L.orc_decoder_component_array.restype = i64p
         L.orc_decoder_component_array.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -185,6 +188,16 @@ class Decoder:
         if r < -1:
             raise ValueError("decode error %d" % r)
         return r
+
+    def coef_record(self):
+        """Sequenced.decode to the end: the frame's coefficient record in the C ABI's layout (component
+        planes back to back, [bh][bw][64] zig-zag, DC absolute = dc_pred after the block) as int64 -- the
+        model's ints, so a DC outside int16 shows as such.  Decodes the planes as a side effect."""
+        out = np.zeros(lib().orc_decoder_coef_count(self._d), dtype=np.int64)
+        r = lib().orc_decoder_coef_record(self._d, _ptr(out))
+        if r:
+            raise ValueError("decode error %d" % r)
+        return out
 
     def decode(self):
         r = lib().orc_decoder_decode(self._d)

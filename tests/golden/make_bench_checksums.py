@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/bench_checksums.json: the K5 checksums (include/hvc_jpeg.h hvc_checksum_records) of what
+the benchmarks decode, computed with the CPU restatement of the model on the benchmarks' own seeded inputs.
+
+    bench.py --config 2 / 4    distinct frame f of rank r: synth_frame_pixels(seed + 1000 r + 16 f) ->
+                               Encoder block stage at quality 75 (encoder.ml:81-108) -> Decoder block stage
+                               (decoder.ml:142-149, 213-224) -> padded pixel record
+    tools/bench_configs.py     config 3 (files -> padded planes), 4, 5 (pixels -> coefficient records), 7 (fused 4:4:4)
+
+bench.py and tools/bench_configs.py read the file (data, not the oracle) and report `verified`;
+tests/test_bench_checksums.py re-derives entries from the oracle on every CPU run."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench  # noqa: E402
+from helpers import checksum_records  # noqa: E402
+from oracle import orc  # noqa: E402
+from video_coding_amd.synth import synth_frame_pixels, synth_pixels  # noqa: E402
+
+QL = orc.quant_scale(orc.quant_luma(), 75).astype(np.uint16)
+QC = orc.quant_scale(orc.quant_chroma(), 75).astype(np.uint16)
+
+
+def coef_record(pix_record, planes):
+    """Encoder block stage of one tight pixel record -> coefficient record (int16, C-ABI layout)"""
+    out, off = [], 0
+    for bw, bh, qt in planes:
+        n = bw * bh * 64
+        out.append(orc.fdct_quant(pix_record[off:off + n].reshape(bh * 8, bw * 8), QC if qt else QL, bw, bh).reshape(-1))
+        off += n
+    return np.concatenate(out).astype(np.int16)
+
+
+def pixel_record(coefs, planes):
+    out, off = [], 0
+    for bw, bh, qt in planes:
+        n = bw * bh * 64
+        out.append(orc.dequant_idct_recon(coefs[off:off + n], QC if qt else QL, bw, bh).reshape(-1))
+        off += n
+    return np.concatenate(out)
+
+
+def bench_frames(config, rank, n_distinct):
+    wl = bench.WORKLOADS[config]
+    for f in range(n_distinct):
+        pix = synth_frame_pixels(bench.distinct_seed(wl["seed"], rank, f), wl["planes"])
+        yield pixel_record(coef_record(pix, wl["planes"]), wl["planes"])
+
+
+def bench_entry(config, ranks, n_distinct=8):
+    return {"rank%d" % r: ["%016x" % int(checksum_records(rec[None, :])[0]) for rec in bench_frames(config, r, n_distinct)]
+            for r in ranks}
+
+
+# -- tools/bench_configs.py -------------------------------------------------------------------------------
+def c3_jpeg(f):
+    """the files of tools/bench_configs.py --config 3 (hvc_jpeg_encode = Encoder.encode_420 ~quality:75)"""
+    W, H = 1920, 1080
+    y = synth_pixels(10 + f, 1088, 1920)[:H]
+    u = synth_pixels(20 + f, 544, 960)[:H // 2]
+    v = synth_pixels(30 + f, 544, 960)[:H // 2]
+    return orc.encode_yuv(y, u, v, W, H, 420, 75)
+
+
+def c3_entry(n_distinct=4):
+    out = []
+    for f in range(n_distinct):
+        d = orc.Decoder(c3_jpeg(f))
+        d.decode()
+        out.append("%016x" % int(checksum_records(np.concatenate([d.plane(i).reshape(-1) for i in range(3)])[None, :])[0]))
+    return out
+
+
+def resident_entry(planes, seed0, n_distinct=4):
+    """tools/bench_configs.py resident_decode: frames synth_frame_pixels(seed0 + 8 f) -> encode -> decode"""
+    return ["%016x" % int(checksum_records(pixel_record(coef_record(synth_frame_pixels(seed0 + 8 * f, planes), planes), planes)[None, :])[0])
+            for f in range(n_distinct)]
+
+
+def c5_entry(n_distinct=4):
+    planes = [(480, 270, 0), (240, 135, 1), (240, 135, 1)]
+    return ["%016x" % int(checksum_records(coef_record(synth_frame_pixels(60 + 8 * f, planes), planes).view(np.uint8)[None, :])[0])
+            for f in range(n_distinct)]
+
+
+def c7_entry(n_distinct=4):
+    """fused 4:4:4: decode -> crop to 1920x1080 / 960x540 -> supersample_hv2 (planar_444.ml:82-131)"""
+    planes = [(240, 136, 0), (120, 68, 1), (120, 68, 1)]
+    W, H = 1920, 1080
+    out = []
+    for f in range(n_distinct):
+        rec = pixel_record(coef_record(synth_frame_pixels(90 + 8 * f, planes), planes), planes)
+        y = rec[:1920 * 1088].reshape(1088, 1920)[:H]
+        u = rec[1920 * 1088:1920 * 1088 + 960 * 544].reshape(544, 960)[:H // 2]
+        v = rec[1920 * 1088 + 960 * 544:].reshape(544, 960)[:H // 2]
+        frame = np.concatenate([y.reshape(-1), orc.supersample_hv2(u).reshape(-1), orc.supersample_hv2(v).reshape(-1)])
+        out.append("%016x" % int(checksum_records(frame[None, :])[0]))
+    return out
+
+
+def main():
+    g = {"comment": "K5 checksums of the benchmarks' decoded distinct frames per the CPU restatement of the model; "
+                    "written by tests/golden/make_bench_checksums.py",
+         "bench_config2": bench_entry(2, range(8)),
+         "bench_config4": bench_entry(4, range(8)),
+         "configs_c3": c3_entry(), "configs_c4": resident_entry([(480, 270, 0), (480, 270, 1), (480, 270, 1)], 40),
+         "configs_c5": c5_entry(), "configs_c7": c7_entry()}
+    with open(os.path.join(ROOT, "tests", "golden", "bench_checksums.json"), "w") as f:
+        json.dump(g, f, indent=1)
+    print("written")
+
+
+if __name__ == "__main__":
+    main()

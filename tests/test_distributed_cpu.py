@@ -56,3 +56,55 @@ def test_single_rank_needs_no_process_group():
     dt = bench.timed_steps(lambda: n.append(1), steps=3, warmup=1, sync=lambda: None, world=1)
     assert len(n) == 4 and dt >= 0
     assert bench.max_over_ranks(dt, 1) == dt
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MASTER_ADDR="127.0.0.1", **extra)
+    return env
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout  # ONE line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_typed_by_hand_launches_its_own_ranks():
+    """`python bench.py --gpus 2`, no launcher around it: bench.py starts two fresh ranks itself (child processes
+    of torch.distributed.run, before any HIP call), they rendezvous, run W + K steps between barriers, and rank 0
+    prints the one JSON line.  HVC_BENCH_NO_GPU=1 replaces the step with a sleep (this machine has no GPU): the
+    launch path is the thing under test, and the line says that nothing was decoded."""
+    for config, extra in ((2, []), (4, ["--shard", "256"])):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                              "--config", str(config)] + extra,
+                             capture_output=True, text=True, env=_clean_env(HVC_BENCH_NO_GPU="1"), timeout=300, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-3000:]
+        rec = _json_line(out.stdout)
+        assert rec["n_gpus"] == 2 and rec["steps"] == 4 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+        assert rec["config"]["step_calls_rank0"] == 5
+        assert "not a measurement" in rec["data"]
+        # the slow rank (2 ms a step) bounds the job; the value is the whole job's: both ranks' frames
+        assert rec["ms_per_step"] >= 2.0
+        frames = 1024 if config == 2 else 256
+        px = 1920 * 1080 if config == 2 else 3840 * 2160
+        assert abs(rec["value"] - 2 * frames * px / (rec["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * rec["value"]
+
+
+def test_bench_under_the_drivers_launcher_and_alone():
+    """the driver's own command line for N > 1 (torch.distributed.run around bench.py) and the plain N = 1 form"""
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "0"],
+                         capture_output=True, text=True, env=_clean_env(HVC_BENCH_NO_GPU="1"), timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert _json_line(out.stdout)["n_gpus"] == 2
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "0"],
+                         capture_output=True, text=True, env=_clean_env(HVC_BENCH_NO_GPU="1"), timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert _json_line(out.stdout)["n_gpus"] == 1
+    # a launcher whose world size contradicts --gpus is an error, not a silent re-interpretation
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "4"], capture_output=True, text=True, env=_clean_env(HVC_BENCH_NO_GPU="1"), timeout=300, cwd=ROOT)
+    assert out.returncode != 0

@@ -1,0 +1,130 @@
+"""K5 (hvc_checksum_records) against its three-line numpy definition, the benchmarks' verified output, the
+N-rank launch path of bench.py on the GPU box, and contexts opened by device index."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from helpers import checksum_records, synth_coefs
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import video_coding_amd as hvc
+    c = hvc.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("n,size,stride", [(1, 1, 1), (3, 15, 15), (5, 16, 16), (4, 1000, 1024), (2, 4097, 4099),
+                                           (7, 3133440, 3133440), (1, 40_000_003, 40_000_003), (300, 64, 64)])
+def test_checksum_kernel_equals_its_definition(ctx, n, size, stride):
+    import torch
+    rng = np.random.Generator(np.random.PCG64(n * 131 + size))
+    buf = rng.integers(0, 256, size=(n - 1) * stride + size, dtype=np.uint8)
+    recs = np.stack([buf[r * stride:r * stride + size] for r in range(n)])
+    want = checksum_records(recs)
+    assert np.array_equal(ctx.checksum_records(buf, size, n, stride), want)            # host data
+    d = torch.from_numpy(buf).cuda()
+    torch.cuda.synchronize()
+    assert np.array_equal(ctx.checksum_records(d, size, n, stride), want)              # device data
+    if size > 40:  # unaligned records take the byte path
+        assert np.array_equal(ctx.checksum_records(d[3:], size - 3, 1, stride), checksum_records(recs[:1, 3:]))
+    assert ctx.checksum_records(d, size, 0).size == 0
+
+
+def test_checksum_of_decoded_frames_is_the_models(ctx):
+    """the benchmarks' chain in small: coefficients -> hvc_decode_frames (device) -> K5 == checksum of the
+    model restatement's planes"""
+    import torch
+    import video_coding_amd as hvc
+    q = orc.quant_scale(orc.quant_luma(), 75).astype(np.uint16)
+    bw, bh, n = 40, 23, 6
+    coefs = np.stack([synth_coefs(300 + i, bh, bw, q)[0] for i in range(n)])
+    want = checksum_records(orc.dequant_idct_recon(coefs, q, bw, bh, n_planes=n).reshape(n, -1))
+    d_c = torch.from_numpy(coefs).cuda()
+    d_p = torch.zeros((n, bh * 8 * bw * 8), dtype=torch.uint8, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.dequant_idct_recon(d_c, q, bw, bh, n, d_p)
+        assert np.array_equal(ctx.checksum_records(d_p, bh * 8 * bw * 8, n), want)
+    finally:
+        ctx.reset_stream()
+
+
+def _run_bench(args, **env):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    e.update(env)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=e,
+                         timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_is_verified_against_the_golden_checksums():
+    """python bench.py (config 2, small batch): the line carries roofline + cpu_baseline + a checksum that equals
+    tests/golden/bench_checksums.json -- entries the CPU suite derives from the model restatement."""
+    rec = _run_bench(["--steps", "3", "--warmup", "1", "--frames", "64", "--cpu-seconds", "1"])
+    with open(os.path.join(GOLDEN, "bench_checksums.json")) as f:
+        g = json.load(f)
+    assert rec["checksum"]["verified"] is True and rec["checksum"]["rank0"] == g["bench_config2"]["rank0"]
+    assert rec["n_gpus"] == 1 and rec["roofline"]["bound"] == "hbm" and 0 < rec["roofline"]["frac"] < 1
+    assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["cores"] == 1
+    assert rec["timed_region_s"] > 0 and rec["roofline"]["traffic_source"]
+    assert rec["config"]["wide_path_blocks"] == 0
+
+
+def test_bench_n_rank_path_on_one_gpu():
+    """HVC_BENCH_REHEARSAL=1 python bench.py --gpus 2, as typed: bench.py starts the two ranks itself (both on
+    cuda:0, gloo for the timing closure), each decodes its own shard, both outputs are verified."""
+    rec = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "64"], HVC_BENCH_REHEARSAL="1")
+    assert rec["n_gpus"] == 2 and "REHEARSAL" in rec["data"]
+    assert rec["checksum"]["verified"] is True and rec["checksum"]["ranks_verified"] == 2
+    rec = _run_bench(["--gpus", "2", "--config", "4", "--steps", "1", "--warmup", "0", "--frames", "8", "--shard", "16"],
+                     HVC_BENCH_REHEARSAL="1")
+    assert rec["n_gpus"] == 2 and rec["config"]["baseline_config"] == 4 and rec["checksum"]["ranks_verified"] == 2
+    assert rec["config"]["frames_per_gpu_per_step"] == 16 and rec["config"]["frames_per_launch"] == 8
+
+
+def test_contexts_by_device_index():
+    """hvc_create(device): one context per visible GPU (whatever their number on this machine: 1 on a one-GPU
+    box, 8 on a node), each decoding on ITS device; an index past the last one is HVC_E_NO_DEVICE."""
+    import torch
+    import video_coding_amd as hvc
+    n_dev = torch.cuda.device_count()
+    assert n_dev >= 1
+    q = orc.quant_scale(orc.quant_chroma(), 60).astype(np.uint16)
+    bw, bh = 33, 9
+    coefs, _ = synth_coefs(4242, bh, bw, q)
+    want = orc.dequant_idct_recon(coefs, q, bw, bh).reshape(bh * 8, bw * 8)
+    ctxs = [hvc.Context(dev) for dev in range(n_dev)] + [hvc.Context(n_dev - 1)]  # and a second one on the last device
+    try:
+        for i, c in enumerate(ctxs):
+            dev = min(i, n_dev - 1)
+            with torch.cuda.device(dev):
+                d_c = torch.from_numpy(coefs).to("cuda:%d" % dev)
+                d_p = torch.zeros((bh * 8, bw * 8), dtype=torch.uint8, device="cuda:%d" % dev)
+                torch.cuda.synchronize(dev)
+            c.dequant_idct_recon(d_c, q, bw, bh, 1, d_p)  # called with ANOTHER device current: the context switches itself
+            c.synchronize()
+            assert np.array_equal(d_p.cpu().numpy(), want), dev
+            out = np.zeros((bh * 8, bw * 8), dtype=np.uint8)
+            c.dequant_idct_recon(coefs, q, bw, bh, 1, out)
+            assert np.array_equal(out, want), dev
+    finally:
+        for c in ctxs:
+            c.close()
+    for bad in (n_dev, n_dev + 7, -1):
+        with pytest.raises(hvc.HvcError) as e:
+            hvc.Context(bad)
+        assert e.value.code == -2

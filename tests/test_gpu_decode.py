@@ -277,3 +277,46 @@ def test_frame_count_limits(ctx):
     ctx.dequant_idct_recon(c2, q, 1, 1, m, out)
     want2 = orc.dequant_idct_recon(c2.reshape(1, m, 64), q, m, 1).reshape(8, m, 8).transpose(1, 0, 2).reshape(m, 64)
     assert np.array_equal(out, want2)
+
+
+def test_failed_call_between_wide_decodes_leaves_no_stale_fixups(ctx):
+    """A decode with fix-up blocks, then a call that fails after its argument checks (misaligned device
+    pointer), then a decode of a smaller geometry: the failed call must not hand the next one a
+    fix-up counter that still holds the first call's count (its int64 kernel would re-process old
+    block ids under the new geometry).  Device memory on both sides, so a stray write would land in the
+    canary rows around the small plane."""
+    import torch
+    import video_coding_amd as hvc
+    rng = np.random.Generator(np.random.PCG64(2025))
+    q = np.full(64, 255, dtype=np.uint16)
+    bw, bh = 64, 40                      # 2560 blocks, every one of them through the int64 kernel
+    adv = rng.integers(-2047, 2048, size=(bh, bw, 64)).astype(np.int16)
+    d_adv = torch.from_numpy(adv).cuda()
+    d_big = torch.zeros((bh * 8, bw * 8), dtype=torch.uint8, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        for fused_fail in (False, True):
+            ctx.dequant_idct_recon(d_adv, q, bw, bh, 1, d_big)
+            assert ctx.last_wide_blocks() > 0
+            with pytest.raises(hvc.HvcError) as e:  # fails at the alignment check, after the geometry checks
+                if fused_fail:
+                    specs, cfs, _ = hvc.hvc.frame_layout([(2, 2, 0), (1, 1, 0), (1, 1, 0)])
+                    ctx.decode_frames_yuv444(d_adv.data_ptr() + 2, cfs, q, specs, 1, 16, 16, d_big.data_ptr())
+                else:
+                    ctx.dequant_idct_recon(d_adv.data_ptr() + 2, q, bw, bh, 1, d_big.data_ptr())
+            assert e.value.code == -4
+            # smaller geometry, valid data, canary rows on both sides of the plane
+            sbw, sbh = 3, 2
+            small, _ = synth_coefs(77, sbh, sbw, q)
+            d_small = torch.from_numpy(small).cuda()
+            guard = 64
+            d_pix = torch.full(((sbh * 8 + 2 * guard), sbw * 8), 0x5A, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            ctx.dequant_idct_recon(d_small, q, sbw, sbh, 1, d_pix[guard:guard + sbh * 8])
+            ctx.synchronize()
+            got = d_pix.cpu().numpy()
+            assert ctx.last_wide_blocks() == 0
+            assert np.array_equal(got[guard:guard + sbh * 8], orc.dequant_idct_recon(small, q, sbw, sbh).reshape(sbh * 8, sbw * 8))
+            assert (got[:guard] == 0x5A).all() and (got[guard + sbh * 8:] == 0x5A).all()
+    finally:
+        ctx.reset_stream()

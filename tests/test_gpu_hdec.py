@@ -1,12 +1,28 @@
 """hvc_jpeg_entropy_decode_gpu: the Huffman reader as a self-synchronising parallel decoder on the GPU.
-Its coefficient records must equal the host front end's (itself equal to the model restatement) on every
-file; whatever it cannot or must not handle goes to the host decoder, with the same records / errors."""
+Its coefficient records must equal the ORACLE's -- Decoder.huffman_decode + the DC predictor
+(jpeg/model/src/decoder.ml:118-140, 143) run block by block through For_testing.Sequenced.decode,
+collected by orc.Decoder.coef_record -- and, as a second opinion, the product's own host reader;
+whatever the GPU reader cannot or must not handle goes to the host reader, with the same records / errors."""
 import numpy as np
 import pytest
 
 from conftest import golden_bytes
-from helpers import synth_pixels
+from helpers import jpeg_optimised_tables, synth_pixels
 from oracle import orc
+
+
+def oracle_record(jpeg):
+    """the model's coefficient record of one file (int64: the model's ints), checked to fit the ABI's int16"""
+    rec = orc.Decoder(jpeg).coef_record()
+    assert rec.min() >= -32768 and rec.max() <= 32767
+    return rec.astype(np.int16)
+
+
+def check_records(jpegs, got):
+    import video_coding_amd as hvc
+    for f, j in enumerate(jpegs):
+        assert np.array_equal(got[f], oracle_record(j)), "file %d differs from the oracle" % f
+        assert np.array_equal(got[f], hvc.hvc.jpeg_entropy_decode(j)[1]), "file %d differs from the host reader" % f
 
 pytestmark = pytest.mark.gpu
 
@@ -31,25 +47,22 @@ def make_jpeg(seed, w, h, chroma, q):
 @pytest.mark.parametrize("fn", ["mini.jpg", "Mouse480.jpg"])
 @pytest.mark.parametrize("device", [False, True])
 def test_reference_files(ctx, fn, device):
-    import video_coding_amd as hvc
     data = golden_bytes(fn)
     info, got, used = ctx.jpeg_entropy_decode_gpu([data], device=device)
-    _, want = hvc.hvc.jpeg_entropy_decode(data)
     assert used == 1
-    assert np.array_equal(got[0], want)
+    check_records([data], got)
 
 
 @pytest.mark.parametrize("w,h,chroma,q", [(64, 64, 420, 75), (52, 44, 420, 95), (130, 70, 422, 40), (33, 17, 444, 80),
                                           (16, 8, 420, 50), (480, 320, 420, 20), (1920, 1080, 420, 75), (200, 120, 444, 100),
                                           (96, 64, 422, 1), (2048, 16, 420, 90), (16, 1024, 444, 60)])
 def test_batches_equal_the_host_decoder(ctx, w, h, chroma, q):
-    import video_coding_amd as hvc
     jpegs = [make_jpeg(500 + 7 * f, w, h, chroma, q) for f in range(4)]
     info, got, used = ctx.jpeg_entropy_decode_gpu(jpegs, device=True)
     assert used == 1
+    check_records(jpegs if w * h < 1 << 20 else jpegs[:2], got)  # (the oracle takes seconds per 1080p file)
     for f, j in enumerate(jpegs):
-        _, want = hvc.hvc.jpeg_entropy_decode(j)
-        assert np.array_equal(got[f], want), f
+        assert np.array_equal(got[f], __import__("video_coding_amd").hvc.jpeg_entropy_decode(j)[1]), f
 
 
 def test_smooth_content_with_long_zero_runs_and_tiny_blocks(ctx):
@@ -62,8 +75,8 @@ def test_smooth_content_with_long_zero_runs_and_tiny_blocks(ctx):
     v = np.full((h // 2, w // 2), 90, np.uint8)
     j = orc.encode_yuv(y, u, v, w, h, 420, 85)
     info, got, used = ctx.jpeg_entropy_decode_gpu([j, j], device=True)
-    _, want = hvc.hvc.jpeg_entropy_decode(j)
-    assert used == 1 and np.array_equal(got[0], want) and np.array_equal(got[1], want)
+    assert used == 1
+    check_records([j, j], got)
 
 
 def test_streams_the_model_treats_specially_fall_back_to_the_host_decoder(ctx):
@@ -71,16 +84,25 @@ def test_streams_the_model_treats_specially_fall_back_to_the_host_decoder(ctx):
     data = golden_bytes("mini.jpg")
     info = hvc.hvc.jpeg_read_header(data)
     # truncated entropy segment (EOI kept): the model reads zero bits past the end
-    cut = data[:info.ecs_offset + 40] + b"\\xff\\xd9"
-    try:
-        _, want = hvc.hvc.jpeg_entropy_decode(cut)
-    except hvc.HvcError as e:
-        with pytest.raises(hvc.HvcError) as e2:
-            ctx.jpeg_entropy_decode_gpu([cut])
-        assert e2.value.code == e.code
-    else:
-        _, got, used = ctx.jpeg_entropy_decode_gpu([cut])
-        assert np.array_equal(got[0], want)
+    for keep in (40, 41, 100, 333):
+        cut = data[:info.ecs_offset + keep] + b"\xff\xd9"
+        assert cut[-2:] == bytes([0xFF, 0xD9])
+        # the model: Bits.show / get past the end read zeros until they raise (bitstream_reader.ml:19-46)
+        try:
+            want = orc.Decoder(cut).coef_record()
+        except ValueError:
+            want = None
+        try:
+            _, host = hvc.hvc.jpeg_entropy_decode(cut)
+        except hvc.HvcError as e:
+            assert want is None, "the host reader refuses what the model decodes"
+            with pytest.raises(hvc.HvcError) as e2:
+                ctx.jpeg_entropy_decode_gpu([cut])
+            assert e2.value.code == e.code
+        else:
+            assert want is not None and np.array_equal(host, want)
+            _, got, used = ctx.jpeg_entropy_decode_gpu([cut])
+            assert np.array_equal(got[0], want)
     # random mutations: same records or same error code as the host decoder
     rng = np.random.Generator(np.random.PCG64(77))
     agree = 0
@@ -170,6 +192,26 @@ def test_constructed_records_blocks_longer_than_a_subsequence(ctx, w, h, chroma)
         files.append(hvc.hvc.jpeg_entropy_encode(info, rec.reshape(-1)))
     _, got, used = ctx.jpeg_entropy_decode_gpu(files, device=True)
     assert used == 1
-    for f, j in enumerate(files):
-        _, want = hvc.hvc.jpeg_entropy_decode(j)
-        assert np.array_equal(got[f], want), f
+    check_records(files, got)
+
+
+@pytest.mark.parametrize("w,h,chroma,q,table_sets", [(64, 64, 420, 75, 2), (130, 70, 422, 40, 2), (33, 17, 444, 80, 2),
+                                                     (640, 352, 420, 75, 2), (200, 120, 444, 95, 3), (96, 64, 420, 30, 1),
+                                                     (480, 320, 420, 60, 3)])
+def test_files_with_their_own_optimised_tables(ctx, w, h, chroma, q, table_sets):
+    """Every file carries Huffman tables optimised for its own statistics (what libjpeg -optimize, cameras and
+    most web encoders write) -- other tables than the model's defaults, and other tables in every file of the
+    batch.  The reader takes its tables from the DHT segments (decoder.ml:238-259), per file."""
+    qt = np.stack([orc.quant_scale(orc.quant_luma(), q), orc.quant_scale(orc.quant_chroma(), q)])
+    files = []
+    for f in range(5):
+        rec = orc.Decoder(make_jpeg(700 + 11 * f, w, h, chroma, q if f != 3 else max(1, q - 25))).coef_record()
+        files.append(jpeg_optimised_tables(w, h, chroma, qt, rec, table_sets))
+    assert len({j[:600] for j in files}) == len(files)  # the headers (tables) really differ
+    one_by_one = [ctx.jpeg_entropy_decode_gpu([j], device=True) for j in files]
+    for j, (_, got, used) in zip(files, one_by_one):
+        assert used == 1
+        check_records([j], got)
+    _, got, used = ctx.jpeg_entropy_decode_gpu(files, device=True)  # the batch form: a table set per frame
+    check_records(files, got)
+    assert used == 1

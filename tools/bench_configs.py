@@ -7,8 +7,10 @@
   --config 5   encoder: forward 8x8 DCT + quantise, 4K 4:2:0, HBM-resident (hvc_encode_frames)
 
 Each prints one JSON line.  Inputs are synthetic and are prepared with the library's own paths
-(hvc_jpeg_encode / hvc_encode_frames) outside every timed region; nothing here touches the oracle
-(parity at these shapes is checked by tests/).
+(hvc_jpeg_encode / hvc_encode_frames) outside every timed region; nothing here touches the oracle.
+What a configuration produced is checksummed on the device after the timed region (K5, hvc_checksum_records;
+EVERY output record, not a sample) and compared with tests/golden/bench_checksums.json -- values the CPU suite
+derives from the model restatement on the same seeds (tests/test_bench_checksums.py): `verified` in the line.
 """
 import argparse
 import json
@@ -21,6 +23,21 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def verify(ctx, data, record_bytes, n_records, key, distinct):
+    """K5 over all n_records output records (record r holds distinct frame r % distinct) against the golden values"""
+    sums = ["%016x" % int(x) for x in ctx.checksum_records(data, record_bytes, n_records)]
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "bench_checksums.json")) as f:
+            want = json.load(f)[key]
+    except (OSError, ValueError, KeyError):
+        want = None
+    ok = None
+    if want is not None and distinct <= len(want):
+        ok = all(sums[r] == want[r % distinct] for r in range(n_records))
+    return {"checksum": {"records": n_records, "distinct": sums[:distinct], "expected": "tests/golden/bench_checksums.json:" + key,
+                         "verified": ok}}
 
 
 def config3(args):
@@ -56,6 +73,7 @@ def config3(args):
     dt, st = best
     jpeg_bytes = sum(len(j) for j in batch)
     print(json.dumps({
+        **verify(ctx, d_pix, info.pixel_bytes, args.frames, "configs_c3", args.distinct),
         "config": ("3-gpu-entropy" if gpu else "3") + ("-host-out" if args.host_out else ""),
         "metric": "Mpixel/s decoded, " + ("host unstuffing + H2D of segments + GPU Huffman + GPU block stage"
                                           if gpu else "host Huffman + H2D + GPU block stage") + " overlapped",
@@ -102,7 +120,8 @@ def resident_decode(args, planes, W, H, tag):
     k_ms = float(np.mean(ctx.kernel_ms_history(min(args.steps, 64))))
     blocks = sum(bw * bh for bw, bh, _ in planes)
     algo = args.frames * blocks * 192
-    print(json.dumps({"config": tag, "metric": "Mpixel/s decoded", "value": round(args.frames * args.steps * W * H / dt / 1e6, 1),
+    print(json.dumps({**verify(ctx, d_pix, pfs, args.frames, "configs_c%d" % tag, args.distinct),
+                      "config": tag, "metric": "Mpixel/s decoded", "value": round(args.frames * args.steps * W * H / dt / 1e6, 1),
                       "unit": "Mpixel/s", "frames": args.frames, "blocks_per_frame": blocks, "kernel_ms": round(k_ms, 4),
                       "algorithmic_GBps": round(algo / (k_ms * 1e-3) / 1e9, 1), "frac_of_8TBps": round(algo / (k_ms * 1e-3) / 8e12, 4),
                       "wide_path_blocks": int(ctx.last_wide_blocks())}))
@@ -137,7 +156,8 @@ def config5(args):
     k_ms = float(np.mean(ctx.kernel_ms_history(min(args.steps, 64))))
     blocks = sum(bw * bh for bw, bh, _ in planes)
     algo = args.frames * blocks * 192
-    print(json.dumps({"config": 5, "metric": "Mpixel/s encoded (fDCT + quantise, 4K 4:2:0)",
+    print(json.dumps({**verify(ctx, d_coefs, cfs * 2, args.frames, "configs_c5", args.distinct),
+                      "config": 5, "metric": "Mpixel/s encoded (fDCT + quantise, 4K 4:2:0)",
                       "value": round(args.frames * args.steps * W * H / dt / 1e6, 1), "unit": "Mpixel/s",
                       "frames": args.frames, "blocks_per_frame": blocks, "kernel_ms": round(k_ms, 4),
                       "algorithmic_GBps": round(algo / (k_ms * 1e-3) / 1e9, 1),
@@ -216,7 +236,9 @@ def config_444(args):
         res[name] = ctx.timer_end() / args.steps
     blocks_needed = 240 * 135 + 2 * 120 * 68
     algo = n * (blocks_needed * 128 + 3 * W * H)
-    print(json.dumps({"config": "444", "metric": "Mpixel/s decoded to 4:4:4 (1080p 4:2:0 in)", "frames": n,
+    ctx.decode_frames_yuv444(d_coefs, cfs, qtabs, comps, n, W, H, d_out)  # (the separate path ran last: the fused output once more)
+    print(json.dumps({**verify(ctx, d_out, 3 * W * H, n, "configs_c7", args.distinct),
+                      "config": "444", "metric": "Mpixel/s decoded to 4:4:4 (1080p 4:2:0 in)", "frames": n,
                       "fused_ms": round(res["fused"], 4), "separate_ms": round(res["separate"], 4),
                       "value": round(n * W * H / (res["fused"] * 1e-3) / 1e6, 1), "unit": "Mpixel/s",
                       "speedup_vs_separate": round(res["separate"] / res["fused"], 3),

@@ -37,8 +37,8 @@ struct hvc_ctx {
     int fix_last = 0;                // index of the counter the last decode call used
     unsigned *d_fix_list = nullptr;
     size_t fix_cap = 0; // entries
-    void *d_in = nullptr, *d_out = nullptr;
-    size_t in_cap = 0, out_cap = 0;
+    void *d_in = nullptr, *d_out = nullptr, *d_sums = nullptr;
+    size_t in_cap = 0, out_cap = 0, sums_cap = 0;
     int last_hip = 0;
     // hvc_jpeg_decode_batch: copy stream + ring of pinned host / device coefficient chunks
     static constexpr int RING = 3;
@@ -116,6 +116,25 @@ int grow(hvc_ctx *c, void **p, size_t *cap, size_t need) {
     }
     *cap = want;
     return HVC_OK;
+}
+
+// The two fix-up counters alternate between launches: a launch appends to counter fix_phase and its wide kernel
+// clears the other one for the launch after it (no memset node).  The roles change hands only once a launch has
+// been enqueued: a call that fails before or while launching leaves fix_phase where it was and, if anything may
+// have reached the stream, both counters are cleared -- the next call must never find a stale count (its wide kernel
+// would re-process old list entries under the new geometry).
+template <class Params>
+static void fix_assign(const hvc_ctx *c, Params &P) {
+    P.fix_count = c->d_fix_count + c->fix_phase;
+    P.fix_count_next = c->d_fix_count + (c->fix_phase ^ 1);
+    P.fix_list = c->d_fix_list;
+}
+static void fix_commit(hvc_ctx *c) {
+    c->fix_last = c->fix_phase;
+    c->fix_phase ^= 1;
+}
+static void fix_reset(hvc_ctx *c) { // after a failed launch: both counters to zero, in stream order
+    (void)hipMemsetAsync(c->d_fix_count, 0, 2 * sizeof(unsigned), c->stream);
 }
 
 // Geometry of one call -> CompK[]; shared by decode and encode.
@@ -265,11 +284,19 @@ int hvc_create(hvc_ctx **out, int device) {
 void hvc_destroy(hvc_ctx *c) {
     if (!c) return;
     DeviceGuard g(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    // everything this context may still have in flight: the caller's stream (NULL is HIP's default stream -- a
+    // stream like any other), its own, and the pipelines' side streams
+    (void)hipStreamSynchronize(c->stream);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->down_stream) (void)hipStreamSynchronize(c->down_stream);
+    for (int i = 0; i < 3; i++)
+        if (c->rd_stream[i]) (void)hipStreamSynchronize(c->rd_stream[i]);
     if (c->d_fix_count) (void)hipFree(c->d_fix_count);
     if (c->d_fix_list) (void)hipFree(c->d_fix_list);
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_sums) (void)hipFree(c->d_sums);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (int i = 0; i < HVC_PROF_RING; i++) {
@@ -326,16 +353,25 @@ void hvc_destroy(hvc_ctx *c) {
 
 int hvc_last_hip_error(const hvc_ctx *c) { return c ? c->last_hip : 0; }
 
+// Work enqueued on the stream the context leaves is drained first: device-memory calls return while their kernels
+// run, the scratch they use (fix-up list and counters, staging buffers) is re-grown and re-used in the order of ONE
+// stream, and grow() only synchronises the current one.
+static int switch_stream(hvc_ctx *c, hipStream_t s) {
+    if (s == c->stream) return HVC_OK;
+    DeviceGuard g(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = s;
+    return HVC_OK;
+}
+
 int hvc_set_stream(hvc_ctx *c, void *s) {
     if (!c) return HVC_E_INVALID_ARG;
-    c->stream = (hipStream_t)s; // NULL is a stream too: HIP's default (null) stream
-    return HVC_OK;
+    return switch_stream(c, (hipStream_t)s); // NULL is a stream too: HIP's default (null) stream
 }
 
 int hvc_reset_stream(hvc_ctx *c) {
     if (!c) return HVC_E_INVALID_ARG;
-    c->stream = c->own_stream;
-    return HVC_OK;
+    return switch_stream(c, c->own_stream);
 }
 
 int hvc_synchronize(hvc_ctx *c) {
@@ -422,6 +458,31 @@ int hvc_memcpy_d2h(hvc_ctx *c, void *dst, const void *src, size_t bytes) {
     return HVC_OK;
 }
 
+int hvc_checksum_records(hvc_ctx *c, const void *data, size_t record_bytes, size_t record_stride, int n_records,
+                         uint64_t *sums, int where) {
+    if (!c || !sums || n_records < 0 || (!data && n_records && record_bytes)) return HVC_E_INVALID_ARG;
+    if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
+    if (n_records == 0) return HVC_OK;
+    if (n_records > 65535) return HVC_E_TOO_LARGE;
+    if (n_records > 1 && record_stride < record_bytes) return HVC_E_INVALID_ARG;
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
+    const size_t sum_bytes = (size_t)n_records * sizeof(unsigned long long);
+    const uint8_t *d = (const uint8_t *)data;
+    int r;
+    if (where == HVC_MEM_HOST) {
+        const size_t bytes = (size_t)(n_records - 1) * record_stride + record_bytes;
+        if ((r = grow(c, &c->d_in, &c->in_cap, bytes ? bytes : 1))) return r;
+        if (bytes) HIPCHK(c, hipMemcpyAsync(c->d_in, data, bytes, hipMemcpyHostToDevice, c->stream));
+        d = (const uint8_t *)c->d_in;
+    }
+    if ((r = grow(c, &c->d_sums, &c->sums_cap, sum_bytes))) return r;
+    HIPCHK(c, hvc::launch_checksum(d, record_bytes, record_stride, n_records, (unsigned long long *)c->d_sums, c->stream));
+    HIPCHK(c, hipMemcpyAsync(sums, c->d_sums, sum_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HVC_OK;
+}
+
 int hvc_last_wide_blocks(hvc_ctx *c, uint64_t *count) {
     if (!c || !count) return HVC_E_INVALID_ARG;
     DeviceGuard g(c->device);
@@ -496,9 +557,7 @@ int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const ui
     P.tiles_per_frame = L.tiles_per_frame;
     for (int i = 0; i < L.n_comp; i++) P.comp[i] = L.comp[i];
     prepare_tables(qtabs, n_qtabs, P.qt, P.ethr, P.ethr_packed, P.qpair);
-    P.fix_count = c->d_fix_count + c->fix_phase;
-    P.fix_count_next = c->d_fix_count + (c->fix_phase ^ 1);
-    P.fix_list = c->d_fix_list;
+    fix_assign(c, P);
 
     // 16-bit quantiser entries above 255 leave the fast kernel's proven range
     // (|coef * q| must stay below 2^23): such planes go straight to the wide kernel.
@@ -506,10 +565,15 @@ int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const ui
     for (int i = 0; i < n_qtabs * 64; i++) wide_only |= qtabs[i] > 255;
     wide_only |= c->decode_kernel == 2;
     P.kernel_sel = (c->decode_kernel == 1 || c->decode_kernel == 3) ? c->decode_kernel : 0;
-    if (!wide_only) { // this call consumes counter fix_phase; its wide kernel clears the other one
-        c->fix_last = c->fix_phase;
-        c->fix_phase ^= 1;
-    }
+    // one launch: consumes counter fix_phase, its wide kernel clears the other one (fix_assign / fix_commit above)
+    auto launch = [&](hvc::DecodeParams &Q, hipEvent_t k0, hipEvent_t k1) -> hipError_t {
+        if (wide_only) return hvc::launch_decode_wide_only(Q, c->stream);
+        fix_assign(c, Q);
+        const hipError_t e = hvc::launch_decode(Q, c->stream, k0, k1);
+        if (e == hipSuccess) fix_commit(c);
+        else fix_reset(c);
+        return e;
+    };
 
     if (where == HVC_MEM_DEVICE) {
         if (((uintptr_t)coefs & 15) || ((uintptr_t)pixels & 7)) return HVC_E_ALIGNMENT;
@@ -517,9 +581,7 @@ int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const ui
         P.pixels = pixels;
         const bool prof = c->profiling && !wide_only;
         const int slot = (int)(c->k_calls % HVC_PROF_RING);
-        HIPCHK(c, wide_only ? hvc::launch_decode_wide_only(P, c->stream)
-                            : hvc::launch_decode(P, c->stream, prof ? c->k0[slot] : nullptr,
-                                                 prof ? c->k1[slot] : nullptr));
+        HIPCHK(c, launch(P, prof ? c->k0[slot] : nullptr, prof ? c->k1[slot] : nullptr));
         if (prof) c->k_calls++;
         return HVC_OK;
     }
@@ -556,18 +618,12 @@ int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const ui
                 return hipMemcpyAsync((int16_t *)c->d_in + (size_t)f0 * coef_fs, coefs + (size_t)f0 * coef_fs,
                                       ((size_t)(cnt - 1) * coef_fs + L.coef_span) * sizeof(int16_t), hipMemcpyHostToDevice, c->stream);
             },
-            [&](int k, int f0, int cnt) {
+            [&](int, int f0, int cnt) {
                 hvc::DecodeParams Pk = P;
                 Pk.coefs = (const int16_t *)c->d_in + (size_t)f0 * coef_fs;
                 Pk.pixels = (uint8_t *)c->d_out + (size_t)f0 * pixel_fs;
                 Pk.n_frames = cnt;
-                if (k > 0 && !wide_only) { // every launch consumes one fix-up counter and clears the other (as above)
-                    Pk.fix_count = c->d_fix_count + c->fix_phase;
-                    Pk.fix_count_next = c->d_fix_count + (c->fix_phase ^ 1);
-                    c->fix_last = c->fix_phase;
-                    c->fix_phase ^= 1;
-                }
-                return wide_only ? hvc::launch_decode_wide_only(Pk, c->stream) : hvc::launch_decode(Pk, c->stream);
+                return launch(Pk, nullptr, nullptr);
             },
             [&](int f0, int cnt, hipStream_t st) {
                 const size_t off = (size_t)f0 * pixel_fs + run0;
@@ -579,7 +635,7 @@ int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const ui
     HIPCHK(c, hipMemcpyAsync(c->d_in, coefs, cbytes, hipMemcpyHostToDevice, c->stream));
     P.coefs = (const int16_t *)c->d_in;
     P.pixels = (uint8_t *)c->d_out;
-    HIPCHK(c, wide_only ? hvc::launch_decode_wide_only(P, c->stream) : hvc::launch_decode(P, c->stream));
+    HIPCHK(c, launch(P, nullptr, nullptr));
     if (run && (n_frames == 1 || pixel_fs == run)) {
         HIPCHK(c, hipMemcpyAsync(pixels + run0, (uint8_t *)c->d_out + run0, (size_t)(n_frames - 1) * pixel_fs + run,
                                  hipMemcpyDeviceToHost, c->stream));
@@ -672,12 +728,14 @@ int hvc_decode_frames_yuv444(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, c
     bool wide_only = c->decode_kernel == 2;
     for (int i = 0; i < n_qtabs * 64; i++) wide_only |= qtabs[i] > 255;
     P.fix_list = c->d_fix_list;
-    if (!wide_only) {
-        P.fix_count = c->d_fix_count + c->fix_phase;
-        P.fix_count_next = c->d_fix_count + (c->fix_phase ^ 1);
-        c->fix_last = c->fix_phase;
-        c->fix_phase ^= 1;
-    }
+    auto launch = [&](hvc::Decode444Params &Q, hipEvent_t k0, hipEvent_t k1) -> hipError_t {
+        if (wide_only) return hvc::launch_decode_444(Q, true, c->stream, k0, k1); // no list, no counters
+        fix_assign(c, Q);
+        const hipError_t e = hvc::launch_decode_444(Q, false, c->stream, k0, k1);
+        if (e == hipSuccess) fix_commit(c);
+        else fix_reset(c);
+        return e;
+    };
 
     if (where == HVC_MEM_DEVICE) {
         if ((uintptr_t)coefs & 15) return HVC_E_ALIGNMENT;
@@ -685,8 +743,7 @@ int hvc_decode_frames_yuv444(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, c
         P.out = frames;
         const bool prof = c->profiling && !wide_only;
         const int slot = (int)(c->k_calls % HVC_PROF_RING);
-        HIPCHK(c, hvc::launch_decode_444(P, wide_only, c->stream, prof ? c->k0[slot] : nullptr,
-                                         prof ? c->k1[slot] : nullptr));
+        HIPCHK(c, launch(P, prof ? c->k0[slot] : nullptr, prof ? c->k1[slot] : nullptr));
         if (prof) c->k_calls++;
         return HVC_OK;
     }
@@ -703,18 +760,12 @@ int hvc_decode_frames_yuv444(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, c
                 return hipMemcpyAsync((int16_t *)c->d_in + (size_t)f0 * coef_fs, coefs + (size_t)f0 * coef_fs,
                                       ((size_t)(cnt - 1) * coef_fs + L.coef_span) * sizeof(int16_t), hipMemcpyHostToDevice, c->stream);
             },
-            [&](int k, int f0, int cnt) {
+            [&](int, int f0, int cnt) {
                 auto Pk = P;
                 Pk.coefs = (const int16_t *)c->d_in + (size_t)f0 * coef_fs;
                 Pk.out = (uint8_t *)c->d_out + (size_t)f0 * frame_stride;
                 Pk.n_frames = cnt;
-                if (k > 0 && !wide_only) { // every launch consumes one fix-up counter and clears the other
-                    Pk.fix_count = c->d_fix_count + c->fix_phase;
-                    Pk.fix_count_next = c->d_fix_count + (c->fix_phase ^ 1);
-                    c->fix_last = c->fix_phase;
-                    c->fix_phase ^= 1;
-                }
-                return hvc::launch_decode_444(Pk, wide_only, c->stream);
+                return launch(Pk, nullptr, nullptr);
             },
             [&](int f0, int cnt, hipStream_t st) {
                 const size_t off = (size_t)f0 * frame_stride;
@@ -724,7 +775,7 @@ int hvc_decode_frames_yuv444(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, c
     HIPCHK(c, hipMemcpyAsync(c->d_in, coefs, cbytes, hipMemcpyHostToDevice, c->stream));
     P.coefs = (const int16_t *)c->d_in;
     P.out = (uint8_t *)c->d_out;
-    HIPCHK(c, hvc::launch_decode_444(P, wide_only, c->stream));
+    HIPCHK(c, launch(P, nullptr, nullptr));
     if (n_frames == 1) // frame_stride is irrelevant for a single frame (and may be smaller than the frame)
         HIPCHK(c, hipMemcpyAsync(frames, c->d_out, out_span, hipMemcpyDeviceToHost, c->stream));
     else

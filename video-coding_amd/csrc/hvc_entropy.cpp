@@ -629,6 +629,13 @@ int hvc_jpeg_encoder_check(const hvc_jpeg_info *info) {
         if (mbs_wide * info->comp[i].hscale > info->layout[i].blocks_w ||
             mbs_high * info->comp[i].vscale > info->layout[i].blocks_h)
             return HVC_E_INVALID_ARG;
+    // The encoder writes the two default table sets only (write_dht, encoder.ml:236-264: luma = 0, chroma = 1) and
+    // codes a component's DC and AC symbols with the same set (Component.t, encoder.ml:287-345); the header holds two
+    // quantiser tables.  An info from hvc_jpeg_read_header may carry other selectors: refused, not guessed at.
+    for (int i = 0; i < 3; i++) {
+        const int dt = info->comp[i].dc_table, at = info->comp[i].ac_table, qt = info->layout[i].qtab;
+        if (dt < 0 || dt > 1 || at != dt || qt < 0 || qt > 1) return HVC_E_INVALID_ARG;
+    }
     return HVC_OK;
 }
 

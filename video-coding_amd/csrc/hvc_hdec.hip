@@ -522,6 +522,10 @@ __global__ __launch_bounds__(256) void k_hd_write(HdParams P, int final_round) {
     const unsigned f = valid ? P.frame_of[i] : 0u, j = valid ? i - P.sub_off[f] : 0u;
     const unsigned *slot = reinterpret_cast<const unsigned *>(P.ecs + P.ecs_off[f] + (size_t)j * (S / 8));
     __syncthreads();
+    // Launched behind the synchronisation rounds without a look at their verdict (no host round trip): when the last
+    // round still changed something the hand-overs are not consistent, block indices and states need not agree, and
+    // nothing may be stored -- the caller sees the flag and redoes the chunk (k_hd_write2 and k_hd_dc likewise).
+    if (*P.changed) return;
     if (!valid) return;
     const unsigned first_block = P.nblk[i];
     if (first_block >= P.blocks_per_frame) return; // past the last coded block: the model never reads this far
@@ -529,6 +533,10 @@ __global__ __launch_bounds__(256) void k_hd_write(HdParams P, int final_round) {
     unsigned p = (unsigned)st;
     int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
     unsigned nb = 0, err = 0;
+    if ((unsigned)b != first_block % (unsigned)P.blocks_per_mcu) { // the MCU coordinates below count from first_block, the
+        atomicOr(P.status, 8u);                                    // block-in-MCU index from the state: they must agree
+        return;
+    }
     const unsigned base = j * (unsigned)S;
     walk<true>(P, G, T, slot, base, base + (unsigned)S, p, k, b, nb, first_block, P.coefs + (size_t)f * P.coef_fs, err,
                reinterpret_cast<int16_t *>(lbuf + threadIdx.x * 8));
@@ -589,6 +597,7 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
     const unsigned i = blockIdx.x * 256u + (unsigned)tid;
     const bool valid = i < P.total_sub;
     const unsigned f = valid ? P.frame_of[i] : 0u, j = valid ? i - P.sub_off[f] : 0u;
+    if (*P.changed) return; // not settled: nothing is stored (see k_hd_write); uniform, before any barrier
     if (valid) stage_row(rows + tid * SROW, P.ecs + P.ecs_off[f] + (size_t)j * (S / 8));
     if (tid < WR_EXTRA) {
         const unsigned i2 = blockIdx.x * 256u + 256u + (unsigned)tid;
@@ -611,8 +620,12 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
     int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
     // live: the block in progress is this lane's (it started here) and inside the frame -- its coefficients are stored,
     // its errors count.  A lane that starts in the middle of a block (k > 0) only walks that one to its end.
-    bool live = act && k == 0;
     unsigned err = 0;
+    if (act && (unsigned)b != bi % (unsigned)B) { // MCU coordinates count from bi, the block-in-MCU index comes from the
+        err |= 8u;                                // state: a lane where they disagree must not store anything
+        act = false;
+    }
+    bool live = act && k == 0;
     const unsigned mcu = (act ? bi : 0u) / (unsigned)B;
     unsigned my = mcu / (unsigned)P.mbs_wide, mx = mcu - my * (unsigned)P.mbs_wide; // advance by counting
     // 16-byte units from P.coefs: records are multiples of 8 coefficients apart, planes of 64 (launch_hd_finish checks the range)
@@ -738,7 +751,7 @@ __global__ __launch_bounds__(1024) void k_hd_dc(HdParams P) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int comp = blockIdx.x, frame = blockIdx.y, lane = threadIdx.x, wave = lane >> 6, wl = lane & 63;
-    if (comp >= P.n_comp) return;
+    if (comp >= P.n_comp || *P.changed) return; // (not settled: the write pass stored nothing)
     const HdComp &C = P.comp[comp];
     const int hv = C.h * C.v;
     const unsigned n = (unsigned)P.mbs_wide * (unsigned)P.mbs_high * (unsigned)hv;

@@ -776,6 +776,7 @@ __global__ __launch_bounds__(64) void k_decode_wide(DecodeParams P, const unsign
         unsigned long long t = id / HVC_TILE;
         int tile = (int)(t % (unsigned)P.tiles_per_frame);
         int frame = (int)(t / (unsigned)P.tiles_per_frame);
+        if (frame >= P.n_frames) continue; // an id from another geometry must never turn into an address
         BlockRef br;
         if (!locate(P, frame, tile, lane, br)) continue;
         const int *q = P.qt + br.qtab * 64;
@@ -1015,6 +1016,7 @@ __global__ __launch_bounds__(64) void k_decode_wide_444(Decode444Params P, const
         const unsigned long long t = id / HVC_TILE;
         const int tile = (int)(t % (unsigned)P.tiles_per_frame);
         const size_t frame = (size_t)(t / (unsigned)P.tiles_per_frame);
+        if (frame >= (size_t)P.n_frames) continue; // an id from another geometry must never turn into an address
         const Ref444 r = locate444(P, tile, lane);
         if (!r.store) continue;
         const Plane444K &K = P.pl[r.p];
@@ -1118,6 +1120,7 @@ __global__ __launch_bounds__(256) void k_reinterp_444(Decode444Params P, const u
         const unsigned long long t = id / HVC_TILE;
         const int tile = (int)(t % (unsigned)P.tiles_per_frame);
         const size_t f = (size_t)(t / (unsigned)P.tiles_per_frame);
+        if (f >= (size_t)P.n_frames) continue;
         const Ref444 rr = locate444(P, tile, lane);
         if (!rr.store || rr.p == 0) continue;
         const int c = rr.bx * 8 - 1 + k % 9, r = rr.by * 8 - 1 + k / 9;
@@ -1384,6 +1387,56 @@ __global__ __launch_bounds__(256) void k_upsample420_x8(UpsampleParams P) {
     const unsigned m1 = last ? 0xff000000u : 0u;
     const RowQ cur = rowq<0>(a.x, a.y, an, 0u, m1), nxt = rowq<0>(b.x, b.y, bn, 0u, m1);
     emit_rows444<true>(dst + (size_t)(2 * row) * P.dst_stride, P.dst_stride, 16 * g, cur, nxt, false);
+}
+
+// ---------------------------------------------------------------------------
+// K5: checksum of byte records on the device, so that a benchmark can say WHAT it produced without
+// bringing the frames back (no counterpart in the reference; SURVEY.md section 2 "K5").
+//   sum[r] = SUM_i (byte_i + 1) * ((2 i + 1) * HVC_CHECKSUM_MUL)   (mod 2^64), i = byte index inside the record
+// -- position-weighted (odd weights: a changed byte always changes the sum, swapped bytes do unless equal) and
+// a plain sum, hence order-free: any split into partial sums gives the same 64 bits, on the host too
+// (numpy uint64 arithmetic wraps the same way).  One pass over the data, 16 bytes per lane per
+// iteration, one 64-bit atomic per wavefront.
+__global__ __launch_bounds__(256) void k_checksum(const uint8_t *data, size_t record_bytes, size_t record_stride,
+                                                  unsigned long long *sums) {
+    const uint8_t *rec = data + (size_t)blockIdx.y * record_stride;
+    const size_t vec = ((uintptr_t)rec & 15) == 0 ? record_bytes / 16 : 0; // 16-byte pieces (aligned records only)
+    unsigned long long acc = 0;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < vec; v += (size_t)gridDim.x * 256) {
+        const uint4 q = reinterpret_cast<const uint4 *>(rec)[v];
+        const unsigned w[4] = {q.x, q.y, q.z, q.w};
+        // SUM (b_k + 1) * (2 (i0 + k) + 1) M = M * [ (2 i0 + 1) * S0 + 2 * S1 ],  S0 = SUM (b_k + 1), S1 = SUM k (b_k + 1)
+        unsigned s0 = 0, s1 = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const unsigned b = ((w[k >> 2] >> (8 * (k & 3))) & 0xffu) + 1u;
+            s0 += b;
+            s1 += (unsigned)k * b;
+        }
+        acc += (2ull * (16ull * v) + 1ull) * s0 + 2ull * s1;
+    }
+    if (blockIdx.x == 0) // the bytes the 16-byte pieces do not cover
+        for (size_t i = vec * 16 + threadIdx.x; i < record_bytes; i += 256) acc += (2ull * i + 1ull) * ((unsigned long long)rec[i] + 1ull);
+    acc *= HVC_CHECKSUM_MUL;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&sums[blockIdx.y], acc);
+}
+
+hipError_t launch_checksum(const uint8_t *data, size_t record_bytes, size_t record_stride, int n_records,
+                           unsigned long long *sums, hipStream_t s) {
+    if (n_records <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(sums, 0, (size_t)n_records * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    if (record_bytes == 0) return hipSuccess;
+    // enough workgroups to fill the chip however few records there are; a grid-stride loop takes the rest
+    const size_t pieces = (record_bytes / 16 + 255) / 256;
+    size_t gx = pieces < 1 ? 1 : pieces;
+    const size_t want = (size_t)(4096 + n_records - 1) / (size_t)n_records;
+    if (gx > want) gx = want;
+    hipLaunchKernelGGL(k_checksum, dim3((unsigned)gx, (unsigned)n_records, 1), dim3(256), 0, s, data, record_bytes,
+                       record_stride, sums);
+    return hipGetLastError();
 }
 
 hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0, hipEvent_t k1) {

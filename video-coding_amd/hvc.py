@@ -21,6 +21,7 @@ SYMBOLS = [
     "hvc_jpeg_read_header", "hvc_jpeg_entropy_decode", "hvc_jpeg_get_yuv_frame", "hvc_jpeg_decode",
     "hvc_jpeg_decode_batch", "hvc_quant_table", "hvc_jpeg_encoder_layout", "hvc_jpeg_entropy_encode",
     "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444", "hvc_jpeg_decode_yuv444", "hvc_compare_planes", "hvc_jpeg_encode_batch", "hvc_jpeg_decode_batch_yuv444", "hvc_jpeg_encoder_check", "hvc_huffman_encode_frames", "hvc_jpeg_header", "hvc_jpeg_encode_batch_gpu", "hvc_jpeg_entropy_decode_gpu", "hvc_jpeg_decode_batch_gpu",
+    "hvc_checksum_records",
 ]
 
 
@@ -139,6 +140,7 @@ def lib():
         L.hvc_jpeg_encoder_layout.argtypes = [i, i, i, i, ip]
         L.hvc_jpeg_entropy_encode.argtypes = [ip, vp, vp, sz, C.POINTER(sz)]
         L.hvc_jpeg_encode.argtypes = [vp, vp, vp, vp, i, i, i, i, vp, sz, C.POINTER(sz)]
+        L.hvc_checksum_records.argtypes = [vp, vp, sz, sz, i, vp, i]
         L.hvc_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
         L.hvc_device_free.argtypes = [vp, vp]
         L.hvc_memcpy_h2d.argtypes = [vp, vp, vp, sz]
@@ -307,6 +309,15 @@ class Context:
         arr = (C.c_float * n)()
         _chk(lib().hvc_kernel_ms_history(self._h, arr, n))
         return list(arr)
+
+    def checksum_records(self, data, record_bytes, n_records, record_stride=None):
+        """K5: position-weighted 64-bit checksum per record (numpy uint64 array); data: numpy (host) or a
+        device tensor / address."""
+        a, where = _addr(data)
+        sums = np.zeros(max(n_records, 1), dtype=np.uint64)
+        _chk(lib().hvc_checksum_records(self._h, a, record_bytes, record_bytes if record_stride is None else record_stride,
+                                        n_records, sums.ctypes.data, where), "hvc_checksum_records")
+        return sums[:n_records]
 
     def last_wide_blocks(self):
         n = C.c_uint64()
