@@ -20,8 +20,17 @@
  *  - an hvc_ctx is bound to ONE GPU and is NOT thread-safe: one per host
  *    thread / GPU.  There is no CPU backend: hvc_create fails with
  *    HVC_E_NO_DEVICE when no gfx950 device is usable.
- *  - all results are bit-exact to the OCaml model for every input the model
- *    accepts (int16 coefficients, 8- or 16-bit quantiser entries).
+ *  - all results are bit-exact to the OCaml model for every input that fits the
+ *    coefficient record: int16 coefficients (DC absolute), 8- or 16-bit quantiser
+ *    entries.  ONE class of streams the model decodes is outside that: the model's
+ *    ints are 63-bit (decoder.ml:143 `dc = coefs.(0) + dc_pred` never wraps), so a
+ *    malformed-but-decodable stream whose DC differences pile up to an absolute DC
+ *    beyond +-32767 (17 blocks of +2047 in a row do it; no encoder writes that: a
+ *    baseline DC is within +-2047 after an 8-bit forward DCT) still decodes there --
+ *    to saturated blocks.  The entropy front end refuses such a stream with
+ *    HVC_E_RANGE instead of wrapping; the int16 record cannot carry it.
+ *    tests/test_host_entropy.py::test_dc_beyond_int16_is_refused_not_wrapped pins
+ *    the model's output next to the refusal.
  *
  * Data layouts
  *  - coefficients: int16, [plane][blocks_h][blocks_w][64], each block in
@@ -54,7 +63,7 @@ typedef enum hvc_status {
     HVC_E_NO_DEVICE = -2,    /* no usable gfx950 GPU / HIP runtime error at create */
     HVC_E_HIP = -3,          /* a HIP call failed; hvc_last_hip_error() has the code */
     HVC_E_ALIGNMENT = -4,    /* plane pointer/stride not 8-byte aligned, coefs not 16-byte aligned */
-    HVC_E_RANGE = -5,        /* quantiser entry 0, or encoder output outside int16 */
+    HVC_E_RANGE = -5,        /* quantiser entry 0, encoder output outside int16, or a decoded absolute DC outside int16 */
     HVC_E_OUT_OF_MEMORY = -6,
     HVC_E_TOO_LARGE = -7,    /* plane geometry beyond the kernel's index range */
     HVC_E_BAD_JPEG = -8,     /* the model would raise: missing frame/scan/table, invalid Huffman code,
@@ -178,6 +187,20 @@ HVC_API int hvc_encode_frames(hvc_ctx *ctx, const uint8_t *pixels, size_t pixel_
                               const uint16_t *qtabs, int n_qtabs, const hvc_component *comps,
                               int n_comp, int n_frames, int16_t *coefs, size_t coef_frame_stride,
                               int where);
+
+/* hvc_encode_frames plus the debugging tail of Encoder.encode_block (encoder.ml:195-205) that an encoder created
+ * with ~compute_reconstruction_error:true runs on every block -- from the block's quantised coefficients
+ *     Encoder.dequant   encoder.ml:110-117   quant.(i) * table.(i) through Zigzag.inverse
+ *     Encoder.idct      encoder.ml:94-96     Dct.Chen.inverse_8x8
+ *     Encoder.recon     encoder.ml:119-125   recon = max 0 (min 255 (idct + 128)); error = abs (recon - input pixel)
+ * recon and error (either may be NULL) are pixel records with the layout of `pixels` (same comps, strides and
+ * frame stride; bytes outside the component planes are not touched): Block.Decoded.recon / .error of every
+ * block at the block's place.  max 0 (min 255 (x + 128)) is the decoder's clip + level shift (decoder.ml:213-224),
+ * so recon is also exactly what Decoder.decode will make of the file. */
+HVC_API int hvc_encode_frames_recon(hvc_ctx *ctx, const uint8_t *pixels, size_t pixel_frame_stride,
+                                    const uint16_t *qtabs, int n_qtabs, const hvc_component *comps, int n_comp,
+                                    int n_frames, int16_t *coefs, size_t coef_frame_stride, uint8_t *recon,
+                                    uint8_t *error, int where);
 
 /* ------------------------------------------------------------------------- */
 /* 4:2:0 -> 4:4:4 chroma upsample, tools/src/planar_444.ml:82-103

@@ -355,6 +355,44 @@ ORC_API int orc_fdct_quant(const uint8_t *plane, size_t stride, size_t plane_str
     return 0;
 }
 
+/* encoder.ml:110-125 + 94-96 + 195-205: the debugging tail of Encoder.encode_block when the encoder was
+ * created with ~compute_reconstruction_error:true -- from the block's quantised coefficients
+ *   dequant :110-117  c = quant.(i) * table.(i) -> dequant / idct .(Zigzag.inverse.(i))
+ *   idct    :94-96    Dct.Chen.inverse_8x8
+ *   recon   :119-125  recon.(i) = max 0 (min 255 (idct.(i) + 128)); error.(i) = abs (recon.(i) - input_pixels.(i))
+ * on the C-ABI batch layout of orc_fdct_quant; recon / error planes have the layout of `plane`. */
+ORC_API int orc_encode_recon(const uint8_t *plane, size_t stride, size_t plane_stride, const uint16_t *qtab, int bw,
+                             int bh, int n_planes, int16_t *coefs, uint8_t *recon, uint8_t *error) {
+    init_tables();
+    i64 q[64], fd[64], qu[64], idct[64];
+    for (int i = 0; i < 64; i++) q[i] = qtab[i];
+    for (int p = 0; p < n_planes; p++) {
+        const uint8_t *pl = plane + (size_t)p * plane_stride;
+        for (int by = 0; by < bh; by++)
+            for (int bx = 0; bx < bw; bx++) {
+                int16_t *dst = coefs + (((size_t)p * bh + by) * bw + bx) * 64;
+                encode_block_stage(pl, stride, bx * 8, by * 8, q, fd, qu);
+                for (int i = 0; i < 64; i++) {
+                    if (qu[i] < -32768 || qu[i] > 32767) return -1;
+                    dst[i] = (int16_t)qu[i];
+                }
+                for (int i = 0; i < 64; i++) idct[ZZ_INV[i]] = qu[i] * q[i];       /* dequant */
+                orc_idct_8x8(idct);                                                /* idct */
+                for (int y = 0; y < 8; y++)
+                    for (int x = 0; x < 8; x++) {                                  /* recon */
+                        const size_t at = (size_t)p * plane_stride + (size_t)(by * 8 + y) * stride + (size_t)(bx * 8 + x);
+                        i64 r = idct[y * 8 + x] + 128;
+                        r = r > 255 ? 255 : r;
+                        r = r < 0 ? 0 : r;
+                        i64 e = r - (i64)plane[at];
+                        recon[at] = (uint8_t)r;
+                        error[at] = (uint8_t)(e < 0 ? -e : e);
+                    }
+            }
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* common/src/bitstream_reader.ml:7-57                                        */
 typedef struct {

@@ -61,6 +61,8 @@ def lib():
                                              C.c_size_t, C.c_size_t]
         L.orc_fdct_quant.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p]
+        L.orc_encode_recon.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_max_difference.restype = C.c_int64
         L.orc_square_error.restype = C.c_int64
         L.orc_max_difference.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -149,6 +151,22 @@ def fdct_quant(planes, qtab, bw, bh, n_planes=1, stride=None, plane_stride=None)
     if r:
         raise RuntimeError("orc_fdct_quant: %d" % r)
     return out
+
+
+def encode_recon(planes, qtab, bw, bh, n_planes=1):
+    """Encoder.encode_block with ~compute_reconstruction_error:true on tight planes uint8 [n_planes][bh*8][bw*8]:
+    (quantised coefficients int16 [n][bh][bw][64], recon uint8, error uint8), encoder.ml:81-125."""
+    planes = np.ascontiguousarray(planes, dtype=np.uint8)
+    assert planes.size == n_planes * bh * bw * 64
+    qtab = np.ascontiguousarray(qtab, dtype=np.uint16)
+    coefs = np.zeros(n_planes * bh * bw * 64, dtype=np.int16)
+    recon = np.zeros(planes.size, dtype=np.uint8)
+    error = np.zeros(planes.size, dtype=np.uint8)
+    r = lib().orc_encode_recon(_ptr(planes), bw * 8, bw * 8 * bh * 8, _ptr(qtab), bw, bh, n_planes, _ptr(coefs), _ptr(recon),
+                               _ptr(error))
+    if r:
+        raise RuntimeError("orc_encode_recon: %d" % r)
+    return coefs, recon, error
 
 
 class Decoder:

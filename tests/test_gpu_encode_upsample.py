@@ -166,3 +166,66 @@ def test_encoder_rejects_wide_tables(ctx):
     with pytest.raises(hvc.HvcError) as e:
         ctx.fdct_quant(np.zeros((8, 8), dtype=np.uint8), q, 1, 1, 1, np.zeros(64, dtype=np.int16))
     assert e.value.code == -5
+
+
+@pytest.mark.parametrize("quality", [1, 30, 75, 100])
+@pytest.mark.parametrize("device", [False, True])
+def test_encoder_reconstruction_error_path(ctx, quality, device):
+    """a16: Encoder.encode_block with ~compute_reconstruction_error:true (encoder.ml:110-125, 195-205) --
+    hvc_encode_frames_recon's coefficients, recon planes (max 0 (min 255 (idct + 128))) and per-sample error
+    (abs (recon - input)) against the restated Encoder.dequant / idct / recon, on a 4:2:0 frame batch with
+    padded strides (bytes outside the planes must stay untouched), incl. saturating content at quality 1."""
+    import torch
+    import video_coding_amd as hvc
+    planes = [(6, 4, 0), (3, 2, 1), (3, 2, 1)]
+    pad = 16
+    specs, co, po = [], 0, 0
+    for bw, bh, qt in planes:
+        specs.append(dict(blocks_w=bw, blocks_h=bh, qtab=qt, coef_offset=co, plane_offset=po, stride=bw * 8 + pad))
+        co += bw * bh * 64
+        po += (bw * 8 + pad) * bh * 8
+    cfs, pfs, n = co + 64, po + 40, 3
+    qtabs = np.stack([orc.quant_scale(orc.quant_luma(), quality), orc.quant_scale(orc.quant_chroma(), quality)]).astype(np.uint16)
+    pix = np.full(n * pfs, 0xEE, dtype=np.uint8)
+    want = []
+    for f in range(n):
+        for i, (s, (bw, bh, qt)) in enumerate(zip(specs, planes)):
+            p = synth_pixels(40 * f + i, bh * 8, bw * 8)
+            if f == 2:  # hard edges: the reconstruction overshoots 0 / 255 and the clamp of Encoder.recon acts
+                p = np.where(p > 127, 255, 0).astype(np.uint8)
+            v = pix[f * pfs + s["plane_offset"]:][:(bw * 8 + pad) * bh * 8].reshape(bh * 8, bw * 8 + pad)
+            v[:, :bw * 8] = p
+            want.append(orc.encode_recon(p, qtabs[qt], bw, bh))
+    coefs = np.zeros(n * cfs, dtype=np.int16)
+    recon = np.full(n * pfs, 0x11, dtype=np.uint8)
+    err = np.full(n * pfs, 0x22, dtype=np.uint8)
+    if device:
+        d = [torch.from_numpy(a).cuda() for a in (pix, coefs, recon, err)]
+        torch.cuda.synchronize()
+        ctx.encode_frames_recon(d[0], pfs, qtabs, specs, n, d[1], cfs, d[2], d[3])
+        ctx.synchronize()
+        coefs, recon, err = (t.cpu().numpy() for t in d[1:])
+        # the error plane alone: the reconstruction goes to scratch
+        e2 = torch.full((n * pfs,), 0x22, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ctx.encode_frames_recon(d[0], pfs, qtabs, specs, n, d[1], cfs, None, e2)
+        ctx.synchronize()
+        assert np.array_equal(e2.cpu().numpy(), err)
+    else:
+        ctx.encode_frames_recon(pix, pfs, qtabs, specs, n, coefs, cfs, recon, err)
+    k, clamped = 0, False
+    for f in range(n):
+        for s, (bw, bh, qt) in zip(specs, planes):
+            wc, wr, we = want[k]
+            k += 1
+            assert np.array_equal(coefs[f * cfs + s["coef_offset"]:][:bw * bh * 64], wc), (f, s)
+            for got, w, fill in ((recon, wr, 0x11), (err, we, 0x22)):
+                v = got[f * pfs + s["plane_offset"]:][:(bw * 8 + pad) * bh * 8].reshape(bh * 8, bw * 8 + pad)
+                assert np.array_equal(v[:, :bw * 8], w.reshape(bh * 8, bw * 8)), (f, s)
+                assert (v[:, bw * 8:] == fill).all()
+            clamped |= bool((wr == 0).any() and (wr == 255).any())
+    assert clamped
+    # the reconstruction is what the decoder makes of these coefficients
+    f0 = specs[0]
+    got = recon[f0["plane_offset"]:][:(6 * 8 + pad) * 32].reshape(32, 6 * 8 + pad)[:, :48]
+    assert np.array_equal(got, orc.dequant_idct_recon(coefs[:6 * 4 * 64], qtabs[0], 6, 4).reshape(32, 48))

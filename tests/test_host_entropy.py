@@ -287,3 +287,31 @@ def test_geometries_where_the_model_raises_are_refused(hvc, w, h, chroma, ok):
             hvc.jpeg_entropy_encode(info, rec)
         with pytest.raises(RuntimeError):
             orc.encode_yuv(y, u, v, w, h, chroma, 75)
+
+
+def test_dc_beyond_int16_is_refused_not_wrapped(hvc):
+    """The contract edge include/hvc_jpeg.h states: the model's ints are 63-bit (decoder.ml:143), so DC differences
+    that pile up beyond int16 decode there; the int16 coefficient record cannot carry them and the entropy front end
+    says HVC_E_RANGE -- it never wraps.  Pinned from both sides: the model's output for the stream (a ramp of
+    absolute DCs up to 131 008 in the luma plane, every block saturated white after the 17th), the refusal, and a
+    stream that stops one block short of the limit, which must decode and agree."""
+    from helpers import jpeg_optimised_tables
+    w = h = 64
+    qt = np.stack([orc.quant_scale(orc.quant_luma(), 75), orc.quant_scale(orc.quant_chroma(), 75)])
+    rec = np.zeros(3 * 64 * 64, dtype=np.int64).reshape(3, 64, 64)
+    rec[0, :, 0] = 2047 * (np.arange(64) + 1)        # differences of +2047: category 11, what baseline tables can code
+    rec[0, :, 5] = 3
+    jpg = jpeg_optimised_tables(w, h, 444, qt, rec.reshape(-1), table_sets=2)
+    d = orc.Decoder(jpg)
+    model = d.coef_record()                           # the model decodes it ...
+    assert model.max() == 2047 * 64 and np.array_equal(model, rec.reshape(-1))
+    y = d.plane(0)
+    assert (y[16:] == 255).all()                      # ... block 17 on (rows 16..): DC * q far beyond the clip
+    with pytest.raises(hvc.HvcError) as e:            # the library refuses, loudly and specifically
+        hvc.jpeg_entropy_decode(jpg)
+    assert e.value.code == -5
+    ok = rec.copy()
+    ok[0, 16:, 0] = 32767                             # 16 steps of +2047 = 32752, then +15 and flat: still inside int16
+    jpg2 = jpeg_optimised_tables(w, h, 444, qt, ok.reshape(-1), table_sets=2)
+    _, got = hvc.jpeg_entropy_decode(jpg2)
+    assert np.array_equal(got, orc.Decoder(jpg2).coef_record()) and got.max() == 32767

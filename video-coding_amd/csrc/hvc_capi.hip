@@ -37,8 +37,8 @@ struct hvc_ctx {
     int fix_last = 0;                // index of the counter the last decode call used
     unsigned *d_fix_list = nullptr;
     size_t fix_cap = 0; // entries
-    void *d_in = nullptr, *d_out = nullptr, *d_sums = nullptr;
-    size_t in_cap = 0, out_cap = 0, sums_cap = 0;
+    void *d_in = nullptr, *d_out = nullptr, *d_sums = nullptr, *d_aux = nullptr, *d_aux2 = nullptr;
+    size_t in_cap = 0, out_cap = 0, sums_cap = 0, aux_cap = 0, aux2_cap = 0;
     int last_hip = 0;
     // hvc_jpeg_decode_batch: copy stream + ring of pinned host / device coefficient chunks
     static constexpr int RING = 3;
@@ -297,6 +297,8 @@ void hvc_destroy(hvc_ctx *c) {
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_sums) (void)hipFree(c->d_sums);
+    if (c->d_aux) (void)hipFree(c->d_aux);
+    if (c->d_aux2) (void)hipFree(c->d_aux2);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (int i = 0; i < HVC_PROF_RING; i++) {
@@ -908,6 +910,80 @@ int hvc_encode_frames(hvc_ctx *c, const uint8_t *pixels, size_t pixel_fs, const 
             size_t n = (size_t)comps[i].blocks_w * comps[i].blocks_h * 64;
             HIPCHK(c, hipMemcpyAsync(coefs + off, (int16_t *)c->d_out + off, n * sizeof(int16_t),
                                      hipMemcpyDeviceToHost, c->stream));
+        }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HVC_OK;
+}
+
+// Encoder.encode_block with compute_reconstruction_error (encoder.ml:195-205): K3, then K1 on the coefficients it
+// wrote, then the error plane.  A debugging path in the model and here: three launches, nothing fused.
+int hvc_encode_frames_recon(hvc_ctx *c, const uint8_t *pixels, size_t pixel_fs, const uint16_t *qtabs, int n_qtabs,
+                            const hvc_component *comps, int n_comp, int n_frames, int16_t *coefs, size_t coef_fs,
+                            uint8_t *recon, uint8_t *error, int where) {
+    if (!c || !coefs || !pixels || n_frames < 0) return HVC_E_INVALID_ARG;
+    if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
+    Layout L;
+    int r = check_qtabs(qtabs, n_qtabs);
+    if (!r) r = make_layout(comps, n_comp, n_qtabs, L);
+    if (r) return r;
+    if (n_frames == 0) return HVC_OK;
+    if (n_frames > 1 && (coef_fs < L.coef_span || pixel_fs < L.pixel_span)) return HVC_E_INVALID_ARG;
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
+    const size_t pbytes = (size_t)(n_frames - 1) * pixel_fs + L.pixel_span;
+    const size_t cbytes = ((size_t)(n_frames - 1) * coef_fs + L.coef_span) * sizeof(int16_t);
+    const bool prof_saved = c->profiling;
+    struct Restore {
+        hvc_ctx *c;
+        bool p;
+        ~Restore() { c->profiling = p; }
+    } restore{c, prof_saved};
+    c->profiling = false;
+    // device pointers of the three pixel-layout records and of the coefficients
+    const uint8_t *d_pix = pixels;
+    int16_t *d_coefs = coefs;
+    uint8_t *d_recon = recon, *d_error = error;
+    if (where == HVC_MEM_HOST) { // [pixels | recon | error] in one scratch allocation, coefficients in another
+        const size_t slot = (pbytes + 255) & ~(size_t)255;
+        if ((r = grow(c, &c->d_aux, &c->aux_cap, 3 * slot))) return r;
+        if ((r = grow(c, &c->d_aux2, &c->aux2_cap, cbytes))) return r;
+        d_pix = (const uint8_t *)c->d_aux;
+        d_recon = (uint8_t *)c->d_aux + slot;
+        d_error = (uint8_t *)c->d_aux + 2 * slot;
+        d_coefs = (int16_t *)c->d_aux2;
+        HIPCHK(c, hipMemcpyAsync(c->d_aux, pixels, pbytes, hipMemcpyHostToDevice, c->stream));
+    } else if (!recon) { // the error plane needs the reconstruction somewhere
+        if ((r = grow(c, &c->d_aux, &c->aux_cap, pbytes))) return r;
+        d_recon = (uint8_t *)c->d_aux;
+    }
+    if ((r = hvc_encode_frames(c, d_pix, pixel_fs, qtabs, n_qtabs, comps, n_comp, n_frames, d_coefs, coef_fs, HVC_MEM_DEVICE)))
+        return r;
+    if ((r = hvc_decode_frames(c, d_coefs, coef_fs, qtabs, n_qtabs, comps, n_comp, n_frames, d_recon, pixel_fs, HVC_MEM_DEVICE)))
+        return r;
+    if (error || where == HVC_MEM_HOST) {
+        hvc::EncodeParams P;
+        std::memset(&P, 0, sizeof P);
+        P.pixels = d_pix;
+        P.pixel_fs = pixel_fs;
+        P.n_frames = n_frames;
+        P.n_comp = L.n_comp;
+        P.tiles_per_frame = L.tiles_per_frame;
+        for (int i = 0; i < L.n_comp; i++) P.comp[i] = L.comp[i];
+        HIPCHK(c, hvc::launch_abs_error(P, d_recon, d_error, c->stream));
+    }
+    if (where == HVC_MEM_DEVICE) return HVC_OK;
+    for (int f = 0; f < n_frames; f++) // back to the caller: the component planes only (padding stays as it was)
+        for (int i = 0; i < n_comp; i++) {
+            const size_t coff = (size_t)f * coef_fs + comps[i].coef_offset, cn = (size_t)comps[i].blocks_w * comps[i].blocks_h * 64;
+            HIPCHK(c, hipMemcpyAsync(coefs + coff, d_coefs + coff, cn * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+            const size_t poff = (size_t)f * pixel_fs + comps[i].plane_offset;
+            uint8_t *const dst[2] = {recon, error};
+            const uint8_t *const src[2] = {d_recon, d_error};
+            for (int k = 0; k < 2; k++)
+                if (dst[k])
+                    HIPCHK(c, hipMemcpy2DAsync(dst[k] + poff, comps[i].stride, src[k] + poff, comps[i].stride,
+                                               (size_t)comps[i].blocks_w * 8, (size_t)comps[i].blocks_h * 8,
+                                               hipMemcpyDeviceToHost, c->stream));
         }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HVC_OK;

@@ -112,6 +112,8 @@ hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0 = n
 hipError_t launch_decode_wide_only(const DecodeParams &P, hipStream_t s);
 hipError_t launch_encode(const EncodeParams &P, hipStream_t s, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr);
 hipError_t launch_upsample420(const UpsampleParams &P, hipStream_t s);
+// error = |recon - P.pixels| per sample of the component planes (Encoder.recon, encoder.ml:119-125); P.coefs unused
+hipError_t launch_abs_error(const EncodeParams &P, const uint8_t *recon, uint8_t *error, hipStream_t s);
 // K5: sums[r] (device, n_records entries, cleared here) = position-weighted 64-bit checksum of record r
 #define HVC_CHECKSUM_MUL 0x9E3779B97F4A7C15ull
 hipError_t launch_checksum(const uint8_t *data, size_t record_bytes, size_t record_stride, int n_records,

@@ -1390,6 +1390,36 @@ __global__ __launch_bounds__(256) void k_upsample420_x8(UpsampleParams P) {
 }
 
 // ---------------------------------------------------------------------------
+// Encoder.recon's error plane (encoder.ml:119-125): error.(i) = abs (recon.(i) - input_pixels.(i)), block per
+// lane with K3's load shape (8 rows x 8 B; a wave's row accesses are 512 contiguous bytes).  `pixels` of the
+// EncodeParams = the encoder's input, `recon` = what the block stage rebuilt from the quantised coefficients
+// (K1's output: max 0 (min 255 (idct + 128)) is K1's clip + level shift), both in the pixel-record layout.
+__device__ __forceinline__ unsigned absdiff_u8x4(unsigned a, unsigned b) {
+    unsigned r = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int d = (int)((a >> (8 * k)) & 0xffu) - (int)((b >> (8 * k)) & 0xffu);
+        r |= (unsigned)(d < 0 ? -d : d) << (8 * k);
+    }
+    return r;
+}
+__global__ __launch_bounds__(HVC_TILE) void k_abs_error(EncodeParams P, const uint8_t *recon, uint8_t *error) {
+    BlockRef br;
+    if (!locate(P, blockIdx.y, blockIdx.x, threadIdx.x, br)) return;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const size_t at = br.pix_idx + (size_t)j * br.stride;
+        const uint2 a = *reinterpret_cast<const uint2 *>(P.pixels + at), b = *reinterpret_cast<const uint2 *>(recon + at);
+        *reinterpret_cast<uint2 *>(error + at) = make_uint2(absdiff_u8x4(b.x, a.x), absdiff_u8x4(b.y, a.y));
+    }
+}
+hipError_t launch_abs_error(const EncodeParams &P, const uint8_t *recon, uint8_t *error, hipStream_t s) {
+    if (P.n_frames <= 0 || P.tiles_per_frame <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_abs_error, dim3((unsigned)P.tiles_per_frame, (unsigned)P.n_frames, 1), dim3(HVC_TILE), 0, s, P, recon, error);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // K5: checksum of byte records on the device, so that a benchmark can say WHAT it produced without
 // bringing the frames back (no counterpart in the reference; SURVEY.md section 2 "K5").
 //   sum[r] = SUM_i (byte_i + 1) * ((2 i + 1) * HVC_CHECKSUM_MUL)   (mod 2^64), i = byte index inside the record

@@ -21,7 +21,7 @@ SYMBOLS = [
     "hvc_jpeg_read_header", "hvc_jpeg_entropy_decode", "hvc_jpeg_get_yuv_frame", "hvc_jpeg_decode",
     "hvc_jpeg_decode_batch", "hvc_quant_table", "hvc_jpeg_encoder_layout", "hvc_jpeg_entropy_encode",
     "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444", "hvc_jpeg_decode_yuv444", "hvc_compare_planes", "hvc_jpeg_encode_batch", "hvc_jpeg_decode_batch_yuv444", "hvc_jpeg_encoder_check", "hvc_huffman_encode_frames", "hvc_jpeg_header", "hvc_jpeg_encode_batch_gpu", "hvc_jpeg_entropy_decode_gpu", "hvc_jpeg_decode_batch_gpu",
-    "hvc_checksum_records",
+    "hvc_checksum_records", "hvc_encode_frames_recon",
 ]
 
 
@@ -141,6 +141,7 @@ def lib():
         L.hvc_jpeg_entropy_encode.argtypes = [ip, vp, vp, sz, C.POINTER(sz)]
         L.hvc_jpeg_encode.argtypes = [vp, vp, vp, vp, i, i, i, i, vp, sz, C.POINTER(sz)]
         L.hvc_checksum_records.argtypes = [vp, vp, sz, sz, i, vp, i]
+        L.hvc_encode_frames_recon.argtypes = [vp, vp, sz, vp, i, C.POINTER(Component), i, i, vp, sz, vp, vp, i]
         L.hvc_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
         L.hvc_device_free.argtypes = [vp, vp]
         L.hvc_memcpy_h2d.argtypes = [vp, vp, vp, sz]
@@ -486,6 +487,19 @@ class Context:
         arr = comps if not isinstance(comps, list) else components(comps)
         _chk(lib().hvc_encode_frames(self._h, pa, pixel_frame_stride, q.ctypes.data, q.shape[0], arr, len(arr),
                                      n_frames, ca, coef_frame_stride, w1))
+
+    def encode_frames_recon(self, pixels, pixel_frame_stride, qtabs, comps, n_frames, coefs, coef_frame_stride, recon=None,
+                            error=None):
+        """Encoder.encode_block with ~compute_reconstruction_error:true: coefficients + recon / error records"""
+        pa, w1 = _addr(pixels)
+        ca, w2 = _addr(coefs)
+        ra = _addr(recon)[0] if recon is not None else None
+        ea = _addr(error)[0] if error is not None else None
+        assert w1 == w2
+        q = np.ascontiguousarray(qtabs, dtype=np.uint16).reshape(-1, 64)
+        arr = comps if not isinstance(comps, list) else components(comps)
+        _chk(lib().hvc_encode_frames_recon(self._h, pa, pixel_frame_stride, q.ctypes.data, q.shape[0], arr, len(arr), n_frames,
+                                           ca, coef_frame_stride, ra, ea, w1), "hvc_encode_frames_recon")
 
     def upsample420(self, src, cw, ch, dst, n_planes=1, src_stride=None, dst_stride=None, src_plane_stride=0,
                     dst_plane_stride=0):
