@@ -162,6 +162,94 @@ let compare_planes =
     (ptr char @-> ptr char @-> size_t @-> ptr int @-> ptr uint64_t @-> ptr uint64_t @-> returning int)
 ;;
 
+(* int hvc_encode_frames(ctx, pixels, pixel_frame_stride, qtabs, n_qtabs, comps, n_comp, n_frames, coefs,
+                         coef_frame_stride, where)                            encoder.ml:81-108 for a frame batch *)
+let encode_frames =
+  foreign
+    "hvc_encode_frames"
+    ~release_runtime_lock:true
+    (ctx @-> ptr char @-> size_t @-> ptr uint16_t @-> int @-> ptr Component.t @-> int @-> int
+    @-> ptr int16_t @-> size_t @-> int @-> returning int)
+;;
+
+(* int hvc_encode_frames_recon(ctx, pixels, pixel_frame_stride, qtabs, n_qtabs, comps, n_comp, n_frames, coefs,
+                               coef_frame_stride, recon, error, where)
+   Encoder.encode_block with ~compute_reconstruction_error:true: encoder.ml:110-125, 195-205 *)
+let encode_frames_recon =
+  foreign
+    "hvc_encode_frames_recon"
+    ~release_runtime_lock:true
+    (ctx @-> ptr char @-> size_t @-> ptr uint16_t @-> int @-> ptr Component.t @-> int @-> int
+    @-> ptr int16_t @-> size_t @-> ptr char @-> ptr char @-> int @-> returning int)
+;;
+
+(* int hvc_jpeg_entropy_decode(jpeg, n, info, coefs)                         decoder.ml:118-140, 143, 362-395 *)
+let jpeg_entropy_decode =
+  foreign
+    "hvc_jpeg_entropy_decode"
+    (string @-> size_t @-> ptr Jpeg_info.t @-> ptr int16_t @-> returning int)
+;;
+
+(* int hvc_jpeg_decode_yuv444(ctx, jpeg, n, info, frame, frame_cap)          decode_a_frame + Planar_444.of_420 *)
+let jpeg_decode_yuv444 =
+  foreign
+    "hvc_jpeg_decode_yuv444"
+    ~release_runtime_lock:true
+    (ctx @-> string @-> size_t @-> ptr Jpeg_info.t @-> ptr char @-> size_t @-> returning int)
+;;
+
+(* typedef struct hvc_batch_stats { double wall_ms, entropy_ms_sum, h2d_ms_sum, kernel_ms_sum, d2h_ms_sum;
+     int chunks, threads, frames_per_chunk; uint64_t coef_bytes; double host_prep_ms_sum; } *)
+module Batch_stats = struct
+  type t
+
+  let t : t structure typ = structure "hvc_batch_stats"
+  let wall_ms = field t "wall_ms" double
+  let entropy_ms_sum = field t "entropy_ms_sum" double
+  let h2d_ms_sum = field t "h2d_ms_sum" double
+  let kernel_ms_sum = field t "kernel_ms_sum" double
+  let d2h_ms_sum = field t "d2h_ms_sum" double
+  let chunks = field t "chunks" int
+  let threads = field t "threads" int
+  let frames_per_chunk = field t "frames_per_chunk" int
+  let coef_bytes = field t "coef_bytes" uint64_t
+  let host_prep_ms_sum = field t "host_prep_ms_sum" double
+  let () = seal t
+end
+
+(* int hvc_jpeg_decode_batch(ctx, jpegs, sizes, n_frames, threads, frames_per_chunk, pixels, pixel_frame_stride,
+                             where, stats)                                    BASELINE config 3 *)
+let jpeg_decode_batch =
+  foreign
+    "hvc_jpeg_decode_batch"
+    ~release_runtime_lock:true
+    (ctx @-> ptr string @-> ptr size_t @-> int @-> int @-> int @-> ptr char @-> size_t @-> int
+    @-> ptr Batch_stats.t @-> returning int)
+;;
+
+(* int hvc_jpeg_decode_batch_gpu(ctx, jpegs, sizes, n_frames, threads, frames_per_chunk, pixels,
+                                 pixel_frame_stride, where, yuv444, stats) *)
+let jpeg_decode_batch_gpu =
+  foreign
+    "hvc_jpeg_decode_batch_gpu"
+    ~release_runtime_lock:true
+    (ctx @-> ptr string @-> ptr size_t @-> int @-> int @-> int @-> ptr char @-> size_t @-> int @-> int
+    @-> ptr Batch_stats.t @-> returning int)
+;;
+
+(* int hvc_checksum_records(ctx, data, record_bytes, record_stride, n_records, sums, where)   K5 *)
+let checksum_records =
+  foreign
+    "hvc_checksum_records"
+    ~release_runtime_lock:true
+    (ctx @-> ptr void @-> size_t @-> size_t @-> int @-> ptr uint64_t @-> int @-> returning int)
+;;
+
+(* int hvc_set_stream(ctx, hip_stream); int hvc_reset_stream(ctx); int hvc_synchronize(ctx) *)
+let set_stream = foreign "hvc_set_stream" (ctx @-> ptr void @-> returning int)
+let reset_stream = foreign "hvc_reset_stream" (ctx @-> returning int)
+let synchronize = foreign "hvc_synchronize" ~release_runtime_lock:true (ctx @-> returning int)
+
 (* Plane.t (common/src/plane.ml:4-9) is a Base_bigstring = (char, int8_unsigned_elt, c_layout) Array1:
    its data pointer is passed zero-copy.  (Needs [Plane.plane : t -> Base_bigstring.t] exposed.) *)
 let plane_ptr (p : Hardcaml_video_common.Plane.t) =

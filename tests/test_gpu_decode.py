@@ -320,3 +320,82 @@ def test_failed_call_between_wide_decodes_leaves_no_stale_fixups(ctx):
             assert (got[:guard] == 0x5A).all() and (got[guard + sbh * 8:] == 0x5A).all()
     finally:
         ctx.reset_stream()
+
+
+def test_a_million_blocks_within_one_per_cent_of_each_guard_limit(ctx):
+    """The int32 kernel's guards (hvc_idct_spec.h: coefficient energy, row-output energy, the 181 * y arguments of
+    the row and of the column pass) decide per block between the packed int32 path and the int64 kernel.  2 500
+    random base blocks, each scaled so that ONE of the four guarded quantities lands at 100 different places within
+    +-1 % of its limit: 10^6 blocks that sit right on the boundaries, on either side.  Every one must equal the
+    model restatement (int64) -- whichever path it took -- and the int64-only kernel; both paths must have been
+    taken."""
+    from test_guard_bounds import idct_spec, model_pass
+    c, _ = idct_spec()
+    rng = np.random.Generator(np.random.PCG64(424242))
+    zi = orc.zigzag_inverse()
+    tables = [np.ones(64, np.uint16), orc.quant_scale(orc.quant_luma(), 75).astype(np.uint16),
+              orc.quant_scale(orc.quant_chroma(), 30).astype(np.uint16), np.full(64, 255, np.uint16)]
+
+    def guarded_quantities(block_zz, q):
+        """(E, row-output energy, max |y| of the row passes, max |y| of the column passes) of one block, exact ints"""
+        d = [0] * 64
+        for k in range(64):
+            d[zi[k]] = int(block_zz[k]) * int(q[k])
+
+        def ys(b, col):  # the two arguments of the 181-products (dct.ml:41-42 / 83-84), via the butterfly's odd half
+            r, s = (4, 3) if col else (0, 0)
+            x4, x5, x6, x7 = b[1], b[7], b[5], b[3]
+            t = 565 * (x4 + x5) + r
+            x4, x5 = (t + (2841 - 565) * x4) >> s, (t - (2841 + 565) * x5) >> s
+            t = 2408 * (x6 + x7) + r
+            x6, x7 = (t - (2408 - 1609) * x6) >> s, (t - (2408 + 1609) * x7) >> s
+            a, b2 = x4 - x6, x5 - x7
+            return max(abs(a + b2), abs(a - b2))
+        rows = [model_pass(d[8 * r:8 * r + 8], False) for r in range(8)]
+        yr = max(ys(d[8 * r:8 * r + 8], False) for r in range(8))
+        cols = [[rows[r][cc] for r in range(8)] for cc in range(8)]
+        yc = max(ys(col, True) for col in cols)
+        return (sum(int(v) ** 2 for v in block_zz), sum(v * v for row in rows for v in row), yr, yc)
+
+    n_base, n_eps = 2500, 100
+    eps = np.linspace(-0.01, 0.01, n_eps)
+    blocks, qsel = [], []
+    for i in range(n_base):
+        ti = i % len(tables)
+        q = tables[ti]
+        dens = (1, 4, 16, 64)[(i // 4) % 4]   # from a lone coefficient to a dense block
+        base = np.zeros(64, np.int64)
+        idx = rng.choice(64, size=dens, replace=False)
+        base[idx] = rng.integers(-200, 201, size=dens)
+        base[idx] += np.where(base[idx] == 0, 7, 0)
+        E1, R1, Yr1, Yc1 = guarded_quantities(base, q)
+        qmax = int(q.max())
+        limits = ((E1, (c["HVC_GUARD_D_PACKED"] // qmax) ** 2, 0.5), (R1, c["HVC_GUARD_RE"], 0.5),
+                  (Yr1, c["HVC_GUARD_Y"], 1.0), (Yc1, c["HVC_GUARD_Y"], 1.0))
+        for val, lim, power in limits:
+            s0 = (lim / max(val, 1)) ** power
+            for e in eps:   # quantity ~ s^(1/power): (1 + e) on the quantity is (1 + e)^power on the scale
+                blocks.append(np.clip(np.rint(base * s0 * (1.0 + e) ** power), -32768, 32767).astype(np.int16))
+                qsel.append(ti)
+    blocks = np.stack(blocks)
+    qsel = np.array(qsel)
+    assert blocks.shape[0] == 1_000_000
+    took_wide = took_fast = 0
+    for ti, q in enumerate(tables):
+        sel = blocks[qsel == ti]
+        n = sel.shape[0]
+        assert n == 250_000
+        coefs = np.ascontiguousarray(sel.reshape(500, 500, 64))
+        want = orc.dequant_idct_recon(coefs, q, 500, 500).reshape(4000, 4000)
+        got = gpu_decode_plane(ctx, coefs, q)
+        wide = ctx.last_wide_blocks()
+        assert np.array_equal(got, want), ti
+        took_wide += wide
+        took_fast += n - wide
+        ctx.set_decode_kernel(2)
+        try:
+            assert np.array_equal(gpu_decode_plane(ctx, coefs, q), want), ti
+        finally:
+            ctx.set_decode_kernel(0)
+    # the boundaries really were straddled: a good share of the blocks on each side
+    assert took_wide > 100_000 and took_fast > 100_000, (took_wide, took_fast)

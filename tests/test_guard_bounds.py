@@ -66,9 +66,10 @@ def kernel_constants():
     src = open(os.path.join(csrc, "hvc_kernels.hip")).read()
     hdr = open(os.path.join(csrc, "hvc_kernels.h")).read()
     out = {}
-    for name in ("GUARD_R", "GUARD_Y"):
-        m = re.search(r"constexpr int %s = \(1 << (\d+)\) - 1;" % name, src)
-        out[name] = (1 << int(m.group(1))) - 1
+    m = re.search(r"constexpr int GUARD_R = \(1 << (\d+)\) - 1;", src)
+    out["GUARD_R"] = (1 << int(m.group(1))) - 1
+    assert "constexpr int GUARD_Y = HVC_GUARD_Y;" in src
+    out["GUARD_Y"] = idct_spec()[0]["HVC_GUARD_Y"]
     m = re.search(r"#define HVC_GUARD_D \(\(1 << (\d+)\) - 1\)", hdr)
     out["GUARD_D"] = (1 << int(m.group(1))) - 1
     assert "constexpr int GUARD_D = HVC_GUARD_D;" in src
@@ -201,47 +202,150 @@ def dot2(pair, k, add=0):
     return Iv(pa[0] + pb[0] + add, pa[1] + pb[1] + add, "dot2")
 
 
-def idct_1d_packed(A, B, C, Z, col, guard_y):
-    s, rnd, add0 = (256, 4, 8192 + (128 << 14)) if col else (2048, 0, 128)
-    rs = 3 if col else 0
-    n4, n5 = dot2(A, (W1, W7), rnd).asr(rs), dot2(A, (W7, -W1), rnd).asr(rs)
-    n6, n7 = dot2(B, (W5, W3), rnd).asr(rs), dot2(B, (W3, -W5), rnd).asr(rs)
-    n3, n2 = dot2(C, (W2, W6), rnd).asr(rs), dot2(C, (W6, -W2), rnd).asr(rs)
-    x8, x0 = dot2(Z, (s, s), add0), dot2(Z, (s, -s), add0)
-    x1, x6 = n4 + n6, n5 + n7
-    x4, x5 = n4 - n6, n5 - n7
-    x7 = x8 + n3
-    x8 = x8 - n3
-    x3 = x0 + n2
-    x0 = x0 - n2
-    ys = (x4 + x5).clampto(-guard_y, guard_y)
-    yd = (x4 - x5).clampto(-guard_y, guard_y)
-    x2 = mad24(181, ys, 128).asr(8)
-    x4 = mad24(181, yd, 128).asr(8)
-    S = 0 if col else 8
-    return [o.asr(S) for o in (x7 + x1, x3 + x2, x0 + x4, x8 + x6, x8 - x6, x0 - x4, x3 - x2, x7 - x1)]
+# The packed kernel's pass is not mirrored here by hand: video-coding_amd/csrc/hvc_idct_spec.h holds it as data
+# (constants + one operation list), hvc_kernels.hip expands that list into the kernel's statements, and this
+# file parses the same header and replays the same list on intervals.
+def idct_spec():
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-coding_amd", "csrc")
+    text = open(os.path.join(csrc, "hvc_idct_spec.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)          # comments out
+    text = text.replace("\\\n", " ")                            # line continuations joined
+    consts = {}
+    ops = None
+    for m in re.finditer(r"^#define[ \t]+(\w+)(\([^)]*\))?[ \t]+(.*)$", text, flags=re.M):
+        name, params, body = m.group(1), m.group(2), m.group(3).strip()
+        if name == "HVC_IDCT_PASS":
+            assert params.replace(" ", "") == "(ROT,ZDOT,ADD,SUB,GUARDY,M181,OUTADD,OUTSUB)"
+            ops = [(o.group(1), [a.strip() for a in o.group(2).split(",")]) for o in re.finditer(r"(\w+)\(([^()]*)\)", body)]
+        elif params is None and body and name != "HVC_IDCT_SPEC_H":
+            assert re.fullmatch(r"[\w\s()+\-*<]+", body), (name, body)  # integer expressions of earlier names only
+            consts[name] = int(eval(body, {"__builtins__": {}}, dict(consts)))
+    assert ops and len(ops) == 29, ops
+    return consts, ops
+
+
+def replay_pass(consts, ops, pairs, col, guard_y):
+    """the operation list of hvc_idct_spec.h on intervals; pairs = {"A": (lo, hi), ...} of Iv operands"""
+    pre = "HVC_COL_" if col else "HVC_ROW_"
+    K = lambda n: consts[pre + n]
+    val = lambda t: consts[t] if t in consts else (-consts[t[1:]] if t.startswith("-") and t[1:] in consts else int(t))
+    env, out = {}, [None] * 8
+    for op, a in ops:
+        if op == "ROT":
+            env[a[0]] = dot2(pairs[a[1]], (val(a[2]), val(a[3])), K("RADD")).asr(K("RSHIFT"))
+        elif op == "ZDOT":
+            env[a[0]] = dot2(pairs[a[1]], (val(a[2]) * K("ZSCALE"), val(a[3]) * K("ZSCALE")), K("ZADD"))
+        elif op == "ADD":
+            env[a[0]] = env[a[1]] + env[a[2]]
+        elif op == "SUB":
+            env[a[0]] = env[a[1]] - env[a[2]]
+        elif op == "GUARDY":   # g.y2(): a block whose value lies outside goes to the int64 kernel
+            for n in a:
+                env[n] = env[n].clampto(-guard_y, guard_y)
+        elif op == "M181":
+            env[a[0]] = mad24(consts["HVC_M181_MUL"], env[a[1]], consts["HVC_M181_ADD"]).asr(consts["HVC_M181_SHIFT"])
+        elif op == "OUTADD":
+            out[int(a[0])] = (env[a[1]] + env[a[2]]).asr(K("OSHIFT"))
+        elif op == "OUTSUB":
+            out[int(a[0])] = (env[a[1]] - env[a[2]]).asr(K("OSHIFT"))
+        else:
+            raise AssertionError("unknown operation %s in hvc_idct_spec.h" % op)
+    assert all(o is not None for o in out)
+    return out
+
+
+def test_spec_header_is_what_the_kernel_compiles():
+    """hvc_kernels.hip must take its packed passes from the list (no hand-written second copy), the host side its
+    pair order, and the constants must be the model's (dct.ml:4-9, :11-98)."""
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-coding_amd", "csrc")
+    src = open(os.path.join(csrc, "hvc_kernels.hip")).read()
+    capi = open(os.path.join(csrc, "hvc_capi.hip")).read()
+    row = src[src.index("void idct_row_packed("):src.index("// saturating pack of two row outputs")]
+    col = src[src.index("void idct_col_packed("):src.index("// two adjacent pixels of a row")]
+    assert "HVC_EXPAND_PASS(ROW)" in row and "HVC_EXPAND_PASS(COL)" in col
+    for body in (row, col):   # no arithmetic of its own next to the expansion
+        assert "dot2<" not in body and "mad24(" not in body and " >> " not in body
+    assert "HVC_IDCT_PASS(HVC_OP_ROT_##PASS" in src and "HVC_PAIR_A_LO, HVC_PAIR_A_HI" in capi
+    assert "constexpr int GUARD_RE = HVC_GUARD_RE;" in src and "constexpr int GUARD_Y = HVC_GUARD_Y;" in src
+    c, ops = idct_spec()
+    assert [c["HVC_W%d" % i] for i in (1, 2, 3, 5, 6, 7)] == [W1, W2, W3, W5, W6, W7]
+    assert (c["HVC_ROW_ZSCALE"], c["HVC_ROW_ZADD"], c["HVC_ROW_OSHIFT"]) == (1 << 11, 128, 8)            # dct.ml:14-15, 45-53
+    assert (c["HVC_COL_ZSCALE"], c["HVC_COL_RADD"], c["HVC_COL_RSHIFT"]) == (1 << 8, 4, 3)               # dct.ml:59-60, 67-76
+    assert c["HVC_COL_ZADD"] == 8192 + (128 << c["HVC_COL_PACK_SHIFT"]) and c["HVC_COL_PACK_SHIFT"] == 14  # :59, 89-97 + recon's 128
+    # the list computes the model's pass: exact integers on a block of values (against the literal dct.ml butterfly)
+    import random
+    rnd = random.Random(5)
+    for colpass in (False, True):
+        for _ in range(200):
+            b = [rnd.randint(-900, 900) for _ in range(8)]
+            P = lambda lo, hi: (Iv(b[lo], b[lo]), Iv(b[hi], b[hi]))
+            pairs = {k: P(c["HVC_PAIR_%s_LO" % k], c["HVC_PAIR_%s_HI" % k]) for k in "ABCZ"}
+            got = [o.lo for o in replay_pass(c, ops, pairs, colpass, c["HVC_GUARD_Y"])]
+            want = model_pass(b, colpass)
+            if colpass:  # the list leaves the column outputs unshifted, with recon's 128 riding along
+                got = [(g >> 14) - 128 for g in got]
+            assert got == want, (colpass, b)
+
+
+def model_pass(b, col):
+    """dct.ml:11-54 (row) / :56-98 (column), literally"""
+    if col:
+        x0, x1 = (b[0] << 8) + 8192, b[4] << 8
+    else:
+        x0, x1 = (b[0] << 11) + 128, b[4] << 11
+    x2, x3, x4, x5, x6, x7 = b[6], b[2], b[1], b[7], b[5], b[3]
+    r, s = (4, 3) if col else (0, 0)
+    x8 = W7 * (x4 + x5) + r
+    x4 = (x8 + (W1 - W7) * x4) >> s
+    x5 = (x8 - (W1 + W7) * x5) >> s
+    x8 = W3 * (x6 + x7) + r
+    x6 = (x8 - (W3 - W5) * x6) >> s
+    x7 = (x8 - (W3 + W5) * x7) >> s
+    x8 = x0 + x1
+    x0 = x0 - x1
+    x1 = W6 * (x3 + x2) + r
+    x2 = (x1 - (W2 + W6) * x2) >> s
+    x3 = (x1 + (W2 - W6) * x3) >> s
+    x1 = x4 + x6
+    x4 = x4 - x6
+    x6 = x5 + x7
+    x5 = x5 - x7
+    x7 = x8 + x3
+    x8 = x8 - x3
+    x3 = x0 + x2
+    x0 = x0 - x2
+    x2 = (181 * (x4 + x5) + 128) >> 8
+    x4 = (181 * (x4 - x5) + 128) >> 8
+    sh = 14 if col else 8
+    return [v >> sh for v in (x7 + x1, x3 + x2, x0 + x4, x8 + x6, x8 - x6, x0 - x4, x3 - x2, x7 - x1)]
 
 
 def test_packed_kernel_cannot_overflow_under_its_guard():
     """E <= (32767/qmax)^2 => every dequantised coefficient is an exact int16 (v_pk_mul_lo_u16 keeps
     the low 16 bits of c*q, which are the value itself when it fits); the row outputs may be anything
     in int32 (they are saturate-packed), and the row-energy guard renergy < 32767^2 -- computed on
-    the saturated values, so one clipped value alone reaches it -- leaves |r| < 32767: exact pairs."""
-    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-coding_amd", "csrc")
-    src = open(os.path.join(csrc, "hvc_kernels.hip")).read()
-    hdr = open(os.path.join(csrc, "hvc_kernels.h")).read()
-    assert "#define HVC_GUARD_D_PACKED 32767" in hdr and "constexpr int GUARD_RE = 32767 * 32767;" in src
-    gy = kernel_constants()["GUARD_Y"]
-    d = Iv(-32767, 32767)
-    rows = idct_1d_packed((d, d), (d, d), (d, d), (d, d), col=False, guard_y=gy)
+    the saturated values, so one clipped value alone reaches it -- leaves |r| < 32767: exact pairs.
+    The operations replayed are the ones hvc_idct_spec.h lists, i.e. the ones the kernel executes."""
+    c, ops = idct_spec()
+    assert c["HVC_GUARD_D_PACKED"] == 32767 and c["HVC_GUARD_RE"] == 32767 * 32767 and c["HVC_GUARD_Y"] == (1 << 23) - 1
+    gy = c["HVC_GUARD_Y"]
+    d = Iv(-c["HVC_GUARD_D_PACKED"], c["HVC_GUARD_D_PACKED"])
+    rows = replay_pass(c, ops, {k: (d, d) for k in "ABCZ"}, False, gy)
     for o in rows:  # v_cvt_pk_i16_i32 saturates any int32
         assert I32[0] <= o.lo and o.hi <= I32[1]
     # a saturated half is +-32767/-32768 and contributes >= 32767^2 to renergy: flagged
-    assert 32767 * 32767 >= 32767 * 32767 and 32768 * 32768 >= 32767 * 32767
-    r = Iv(-32766, 32766)
-    cols = idct_1d_packed((r, r), (r, r), (r, r), (r, r), col=True, guard_y=gy)
+    assert 32767 * 32767 >= c["HVC_GUARD_RE"] and 32768 * 32768 >= c["HVC_GUARD_RE"]
+    rmax = math_isqrt(c["HVC_GUARD_RE"] - 1)      # largest |r| an accepted block can hold
+    assert rmax == 32766
+    r = Iv(-rmax, rmax)
+    cols = replay_pass(c, ops, {k: (r, r) for k in "ABCZ"}, True, gy)
     for o in cols:  # consumed by v_ashr_pk_u8_i32
         assert I32[0] <= o.lo and o.hi <= I32[1]
+
+
+def math_isqrt(n):
+    import math
+    return math.isqrt(n)
 
 
 def test_packed_energy_thresholds():

@@ -509,7 +509,8 @@ static void prepare_tables(const uint16_t *qtabs, int n_qtabs, int *qt, int *eth
         m = HVC_GUARD_D_PACKED / qmax;
         thr = m * m;
         ethr_packed[t] = thr > 0x7ffffffeull ? 0x7ffffffe : (int)thr;
-        static const int PAIRS[4][2] = {{1, 7}, {5, 3}, {2, 6}, {0, 4}};
+        static const int PAIRS[4][2] = {{HVC_PAIR_A_LO, HVC_PAIR_A_HI}, {HVC_PAIR_B_LO, HVC_PAIR_B_HI},
+                                        {HVC_PAIR_C_LO, HVC_PAIR_C_HI}, {HVC_PAIR_Z_LO, HVC_PAIR_Z_HI}}; // hvc_idct_spec.h
         for (int r = 0; r < 8; r++)
             for (int k = 0; k < 4; k++) {
                 unsigned lo = qtabs[t * 64 + hvc::HVC_ZF[8 * r + PAIRS[k][0]]];

@@ -11,7 +11,7 @@
 #define HVC_GUARD_D ((1 << 17) - 1) /* fast kernel: largest |dequantised coefficient| it is proved for */
 #define HVC_TILE 256 /* blocks per workgroup = threads per workgroup (one block per lane) */
 
-#define HVC_GUARD_D_PACKED 32767 /* packed kernel: |dequantised coefficient| must fit int16 */
+#include "hvc_idct_spec.h" /* HVC_GUARD_D_PACKED: packed kernel, |dequantised coefficient| must fit int16; the pair order */
 
 namespace hvc {
 

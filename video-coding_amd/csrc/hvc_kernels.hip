@@ -24,6 +24,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "hvc_idct_spec.h"
 #include "hvc_kernels.h"
 
 #ifndef HVC_FAST_LB
@@ -46,7 +47,7 @@ __device__ constexpr int ZF[64] = {
     21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
 
 // dct.ml:4-9
-constexpr int W1 = 2841, W2 = 2676, W3 = 2408, W5 = 1609, W6 = 1108, W7 = 565;
+constexpr int W1 = HVC_W1, W2 = HVC_W2, W3 = HVC_W3, W5 = HVC_W5, W6 = HVC_W6, W7 = HVC_W7;
 
 // ---------------------------------------------------------------------------
 // Range guard of the int32 fast path (proved by tests/test_guard_bounds.py with
@@ -58,7 +59,7 @@ constexpr int W1 = 2841, W2 = 2676, W3 = 2408, W5 = 1609, W6 = 1108, W7 = 565;
 // operand lies in [-2^23, 2^23).
 [[maybe_unused]] constexpr int GUARD_D = HVC_GUARD_D;
 constexpr int GUARD_R = (1 << 18) - 1;
-constexpr int GUARD_Y = (1 << 23) - 1;
+constexpr int GUARD_Y = HVC_GUARD_Y;
 
 struct Guard {
     // |dequantised coefficient| is bounded a priori: every |c[k] * q[k]| <= qmax * sqrt(E) with
@@ -396,43 +397,40 @@ struct PackedGuard {
     int energy = 0;   // sum of squared quantised coefficients (saturating)
     int renergy = 0;  // sum of squared (saturated) row outputs (saturating)
     int ymax = 0, ymin = 0;
-    int k128 = 128, kcol = 8192 + (128 << 14); // wave-uniform addends of the (b0, b4) dot products, kept in VGPRs
+    int k128 = HVC_ROW_ZADD, kcol = HVC_COL_ZADD; // wave-uniform addends of the (b0, b4) dot products, kept in VGPRs
     __device__ __forceinline__ void y2(int a, int b) { ymax = max(max(ymax, a), b); ymin = min(min(ymin, a), b); }
 };
-constexpr int GUARD_RE = 32767 * 32767; // renergy >= this  <=>  some |r| may have reached 32767
+constexpr int GUARD_RE = HVC_GUARD_RE; // renergy >= this  <=>  some |r| may have reached 32767
+
+// The statements of a pass are the expansion of HVC_IDCT_PASS (hvc_idct_spec.h): the operation list that
+// tests/test_guard_bounds.py replays on intervals.  PASS = ROW or COL picks the parameter set (the wave-uniform
+// addend of the (b0, b4) dot products sits in a VGPR of the guard struct: g.k128 / g.kcol).
+#define HVC_EXPAND_PASS(PASS)                                                                                           \
+    HVC_IDCT_PASS(HVC_OP_ROT_##PASS, HVC_OP_ZDOT_##PASS, HVC_OP_ADD, HVC_OP_SUB, HVC_OP_GUARDY, HVC_OP_M181,            \
+                  HVC_OP_OUTADD_##PASS, HVC_OP_OUTSUB_##PASS)
+#define HVC_OP_ROT_ROW(d, P, klo, khi) const int d = dot2<HVC_ROW_RADD>(P, pk(klo, khi)) >> HVC_ROW_RSHIFT;
+#define HVC_OP_ROT_COL(d, P, klo, khi) const int d = dot2<HVC_COL_RADD>(P, pk(klo, khi)) >> HVC_COL_RSHIFT;
+#define HVC_OP_ZDOT_ROW(d, P, slo, shi) const int d = dot2v(P, pk((slo) * HVC_ROW_ZSCALE, (shi) * HVC_ROW_ZSCALE), g.k128);
+#define HVC_OP_ZDOT_COL(d, P, slo, shi) const int d = dot2v(P, pk((slo) * HVC_COL_ZSCALE, (shi) * HVC_COL_ZSCALE), g.kcol);
+#define HVC_OP_ADD(d, a, b) const int d = a + b;
+#define HVC_OP_SUB(d, a, b) const int d = a - b;
+#define HVC_OP_GUARDY(a, b) g.y2(a, b);
+#define HVC_OP_M181(d, a) const int d = mad24(HVC_M181_MUL, a, HVC_M181_ADD) >> HVC_M181_SHIFT;
+#define HVC_OP_OUTADD_ROW(i, a, b) o[i] = (a + b) >> HVC_ROW_OSHIFT;
+#define HVC_OP_OUTSUB_ROW(i, a, b) o[i] = (a - b) >> HVC_ROW_OSHIFT;
+#define HVC_OP_OUTADD_COL(i, a, b) o[i] = (a + b) >> HVC_COL_OSHIFT;
+#define HVC_OP_OUTSUB_COL(i, a, b) o[i] = (a - b) >> HVC_COL_OSHIFT;
 
 // Row pass (dct.ml:11-54) of row R from the coefficient dwords; the eight outputs (>> 8) are returned
-// in o[0..7].  qp = the row's four packed quantiser pairs, in the order (1,7) (5,3) (2,6) (0,4).
+// in o[0..7].  qp = the row's four packed quantiser pairs, in the order A, B, C, Z of hvc_idct_spec.h.
 template <int R>
 __device__ __forceinline__ void idct_row_packed(const unsigned (&w)[32], const unsigned *__restrict__ qp, int (&o)[8],
                                                 PackedGuard &g) {
-    const unsigned A = pk_mul_lo(gather_pair<8 * R + 1, 8 * R + 7>(w), qp[0]); // (x4, x5)
-    const unsigned B = pk_mul_lo(gather_pair<8 * R + 5, 8 * R + 3>(w), qp[1]); // (x6, x7)
-    const unsigned C = pk_mul_lo(gather_pair<8 * R + 2, 8 * R + 6>(w), qp[2]); // (x3, x2)
-    const unsigned Z = pk_mul_lo(gather_pair<8 * R + 0, 8 * R + 4>(w), qp[3]); // (b0, b4)
-    const int n4 = dot2<0>(A, pk(W1, W7)), n5 = dot2<0>(A, pk(W7, -W1));
-    const int n6 = dot2<0>(B, pk(W5, W3)), n7 = dot2<0>(B, pk(W3, -W5));
-    const int n3 = dot2<0>(C, pk(W2, W6)), n2 = dot2<0>(C, pk(W6, -W2));
-    int x8 = dot2v(Z, pk(2048, 2048), g.k128);  // x0 + x1
-    int x0 = dot2v(Z, pk(2048, -2048), g.k128); // x0 - x1
-    const int x1 = n4 + n6, x6 = n5 + n7;
-    int x4 = n4 - n6, x5 = n5 - n7;
-    const int x7 = x8 + n3;
-    x8 = x8 - n3;
-    const int x3 = x0 + n2;
-    x0 = x0 - n2;
-    const int ys = x4 + x5, yd = x4 - x5;
-    g.y2(ys, yd);
-    const int x2 = mad24(181, ys, 128) >> 8;
-    x4 = mad24(181, yd, 128) >> 8;
-    o[0] = (x7 + x1) >> 8;
-    o[1] = (x3 + x2) >> 8;
-    o[2] = (x0 + x4) >> 8;
-    o[3] = (x8 + x6) >> 8;
-    o[4] = (x8 - x6) >> 8;
-    o[5] = (x0 - x4) >> 8;
-    o[6] = (x3 - x2) >> 8;
-    o[7] = (x7 - x1) >> 8;
+    const unsigned A = pk_mul_lo(gather_pair<8 * R + HVC_PAIR_A_LO, 8 * R + HVC_PAIR_A_HI>(w), qp[0]); // (x4, x5)
+    const unsigned B = pk_mul_lo(gather_pair<8 * R + HVC_PAIR_B_LO, 8 * R + HVC_PAIR_B_HI>(w), qp[1]); // (x6, x7)
+    const unsigned C = pk_mul_lo(gather_pair<8 * R + HVC_PAIR_C_LO, 8 * R + HVC_PAIR_C_HI>(w), qp[2]); // (x3, x2)
+    const unsigned Z = pk_mul_lo(gather_pair<8 * R + HVC_PAIR_Z_LO, 8 * R + HVC_PAIR_Z_HI>(w), qp[3]); // (b0, b4)
+    HVC_EXPAND_PASS(ROW)
 }
 
 // saturating pack of two row outputs into one column-pass operand pair + its share of the energy
@@ -443,41 +441,19 @@ __device__ __forceinline__ unsigned pack_rows(int lo, int hi, PackedGuard &g) {
 }
 
 // Column pass (dct.ml:56-98) from the four operand pairs of one column; outputs unshifted, with the
-// +128 level shift of recon folded into the rounding constant (see k_decode_fast).
+// +128 level shift of recon folded into the rounding constant (see k_decode_fast, hvc_idct_spec.h).
 __device__ __forceinline__ void idct_col_packed(unsigned A, unsigned B, unsigned C, unsigned Z, int (&o)[8],
                                                 PackedGuard &g) {
-    const int n4 = dot2<4>(A, pk(W1, W7)) >> 3, n5 = dot2<4>(A, pk(W7, -W1)) >> 3;
-    const int n6 = dot2<4>(B, pk(W5, W3)) >> 3, n7 = dot2<4>(B, pk(W3, -W5)) >> 3;
-    const int n3 = dot2<4>(C, pk(W2, W6)) >> 3, n2 = dot2<4>(C, pk(W6, -W2)) >> 3;
-    int x8 = dot2v(Z, pk(256, 256), g.kcol);
-    int x0 = dot2v(Z, pk(256, -256), g.kcol);
-    const int x1 = n4 + n6, x6 = n5 + n7;
-    int x4 = n4 - n6, x5 = n5 - n7;
-    const int x7 = x8 + n3;
-    x8 = x8 - n3;
-    const int x3 = x0 + n2;
-    x0 = x0 - n2;
-    const int ys = x4 + x5, yd = x4 - x5;
-    g.y2(ys, yd);
-    const int x2 = mad24(181, ys, 128) >> 8;
-    x4 = mad24(181, yd, 128) >> 8;
-    o[0] = x7 + x1;
-    o[1] = x3 + x2;
-    o[2] = x0 + x4;
-    o[3] = x8 + x6;
-    o[4] = x8 - x6;
-    o[5] = x0 - x4;
-    o[6] = x3 - x2;
-    o[7] = x7 - x1;
+    HVC_EXPAND_PASS(COL)
 }
 
 // two adjacent pixels of a row: sat_u8(a >> 14) | sat_u8(b >> 14) << 8 into one half of dst
 template <int HALF>
 __device__ __forceinline__ void ashr14_sat_pack2(unsigned &dst, int a, int b) {
     if (HALF == 0)
-        asm("v_ashr_pk_u8_i32 %0, %1, %2, 14" : "=v"(dst) : "v"(a), "v"(b));
+        asm("v_ashr_pk_u8_i32 %0, %1, %2, %3" : "=v"(dst) : "v"(a), "v"(b), "n"(HVC_COL_PACK_SHIFT));
     else
-        asm("v_ashr_pk_u8_i32 %0, %1, %2, 14 op_sel:[0,0,0,1]" : "+v"(dst) : "v"(a), "v"(b));
+        asm("v_ashr_pk_u8_i32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(dst) : "v"(a), "v"(b), "n"(HVC_COL_PACK_SHIFT));
 }
 
 #ifndef HVC_PACKED_LB
@@ -508,17 +484,17 @@ __device__ __forceinline__ void ashr14_sat_pack2(unsigned &dst, int a, int b) {
         unsigned cA[8], cB[8], cC[8], cZ[8];                                                            \
         {                                                                                               \
             int ra[8], rb[8];                                                                           \
-            idct_row_packed<1>(w, (QP) + 4 * 1, ra, (G));                                               \
-            idct_row_packed<7>(w, (QP) + 4 * 7, rb, (G));                                               \
+            idct_row_packed<HVC_PAIR_A_LO>(w, (QP) + 4 * HVC_PAIR_A_LO, ra, (G));                       \
+            idct_row_packed<HVC_PAIR_A_HI>(w, (QP) + 4 * HVC_PAIR_A_HI, rb, (G));                       \
             _Pragma("unroll") for (int c = 0; c < 8; c++) cA[c] = pack_rows(ra[c], rb[c], (G)); /* (x4, x5) = (r1, r7) */ \
-            idct_row_packed<5>(w, (QP) + 4 * 5, ra, (G));                                               \
-            idct_row_packed<3>(w, (QP) + 4 * 3, rb, (G));                                               \
+            idct_row_packed<HVC_PAIR_B_LO>(w, (QP) + 4 * HVC_PAIR_B_LO, ra, (G));                       \
+            idct_row_packed<HVC_PAIR_B_HI>(w, (QP) + 4 * HVC_PAIR_B_HI, rb, (G));                       \
             _Pragma("unroll") for (int c = 0; c < 8; c++) cB[c] = pack_rows(ra[c], rb[c], (G)); /* (x6, x7) = (r5, r3) */ \
-            idct_row_packed<2>(w, (QP) + 4 * 2, ra, (G));                                               \
-            idct_row_packed<6>(w, (QP) + 4 * 6, rb, (G));                                               \
+            idct_row_packed<HVC_PAIR_C_LO>(w, (QP) + 4 * HVC_PAIR_C_LO, ra, (G));                       \
+            idct_row_packed<HVC_PAIR_C_HI>(w, (QP) + 4 * HVC_PAIR_C_HI, rb, (G));                       \
             _Pragma("unroll") for (int c = 0; c < 8; c++) cC[c] = pack_rows(ra[c], rb[c], (G)); /* (x3, x2) = (r2, r6) */ \
-            idct_row_packed<0>(w, (QP) + 4 * 0, ra, (G));                                               \
-            idct_row_packed<4>(w, (QP) + 4 * 4, rb, (G));                                               \
+            idct_row_packed<HVC_PAIR_Z_LO>(w, (QP) + 4 * HVC_PAIR_Z_LO, ra, (G));                       \
+            idct_row_packed<HVC_PAIR_Z_HI>(w, (QP) + 4 * HVC_PAIR_Z_HI, rb, (G));                       \
             _Pragma("unroll") for (int c = 0; c < 8; c++) cZ[c] = pack_rows(ra[c], rb[c], (G)); /* (b0, b4) = (r0, r4) */ \
         }                                                                                               \
         /* columns two at a time: 16 results -> 8 row halves of the output dwords */                   \
