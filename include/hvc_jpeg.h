@@ -286,17 +286,19 @@ HVC_API int hvc_jpeg_encoder_layout(int width, int height, int chroma, int quali
 /* hvc_jpeg_decode_batch (or _yuv444 when yuv444 != 0) with the Huffman reader on the GPU as well
  * (hvc_jpeg_entropy_decode_gpu below): host threads only parse headers and unstuff the entropy-coded
  * segments into a pinned ring, ~1 MB per 1080p frame crosses PCIe instead of 6 MB of coefficients, and
- * the coefficient records are produced where the block stage reads them.  Chunks holding a file that needs
- * the host decoder (see below), or whose Huffman tables differ from the first file's, are redone by the
- * host-decoder pipeline once the others are through: same output, same errors (stats->entropy_ms_sum is
- * the host decoding time spent on them, 0 when the GPU reader did everything).
+ * the coefficient records are produced where the block stage reads them.  Every file is read with ITS OWN
+ * Huffman tables (decoder.ml:238-259: the DHT segments of the file): a chunk whose files all carry the first
+ * file's tables runs with them in LDS, any other chunk with per-frame tables in device memory -- a batch of files
+ * with per-file optimised tables stays on the GPU.  Chunks holding a file that needs the host decoder (see
+ * below) are redone by the host-decoder pipeline once the others are through: same output, same errors
+ * (stats->entropy_ms_sum is the host decoding time spent on them, 0 when the GPU reader did everything).
  * frames_per_chunk < 1 = a quarter of the batch, between 64 and 256 (what measured best). */
 HVC_API int hvc_jpeg_decode_batch_gpu(hvc_ctx *ctx, const uint8_t *const *jpegs, const size_t *sizes, int n_frames,
                                       int threads, int frames_per_chunk, uint8_t *pixels,
                                       size_t pixel_frame_stride, int where, int yuv444, hvc_batch_stats *stats);
 
 /* Huffman DEcoding on the GPU (csrc/hvc_hdec.hip): the entropy-coded segments of n_frames files (one
- * geometry, one set of Huffman tables, as in hvc_jpeg_decode_batch) -> coefficient records exactly as
+ * geometry; Huffman tables per file) -> coefficient records exactly as
  * hvc_jpeg_entropy_decode writes them.  The segment is cut into 1024-bit subsequences, one lane each;
  * lanes start from guessed states, adopt their predecessor's exit state round after round until nothing
  * changes (Huffman streams re-synchronise), then decode once more writing coefficients; a prefix sum

@@ -363,3 +363,58 @@ def test_gpu_batch_redoes_only_what_it_must_with_the_host_reader(ctx, device, yu
     ctx.jpeg_decode_batch(jpegs, b, fs, threads=3, frames_per_chunk=2, yuv444=yuv444, gpu_entropy=False)
     assert st.entropy_ms_sum > 0 and st.host_prep_ms_sum > 0   # both readers had a part in it
     assert (torch.equal(a, b) if device else np.array_equal(a, b))
+
+
+def _optimised(jpeg, w, h, q, table_sets=2):
+    from helpers import jpeg_optimised_tables
+    qt = np.stack([orc.quant_scale(orc.quant_luma(), q), orc.quant_scale(orc.quant_chroma(), q)])
+    return jpeg_optimised_tables(w, h, 420, qt, orc.Decoder(jpeg).coef_record(), table_sets)
+
+
+@pytest.mark.parametrize("device", [False, True])
+@pytest.mark.parametrize("yuv444", [False, True])
+def test_gpu_batch_with_per_file_huffman_tables_stays_on_the_gpu(ctx, device, yuv444):
+    """Every file of the batch carries Huffman tables optimised for itself (libjpeg -optimize style), two files
+    the model's default tables, one three table sets -- hvc_jpeg_decode_batch_gpu keeps all of them with the GPU
+    reader (per-frame tables, PF mode: no chunk falls to the host reader) and every frame equals the model's."""
+    import torch
+    import video_coding_amd as hvc
+    w, h, q = 640, 352, 80
+    plain = _make_jpegs(11, w, h, q=q)
+    jpegs = [_optimised(j, w, h, q, 3 if f == 7 else 2) if f not in (2, 5) else j for f, j in enumerate(plain)]
+    assert len({j[:700] for j in jpegs}) >= 10
+    info = hvc.hvc.jpeg_read_header(jpegs[0])
+    fs = 3 * w * h if yuv444 else info.pixel_bytes
+    for chunk in (2, 4):
+        out = torch.zeros(len(jpegs) * fs, dtype=torch.uint8, device="cuda") if device else np.zeros(len(jpegs) * fs, np.uint8)
+        st = ctx.jpeg_decode_batch(jpegs, out, fs, threads=3, frames_per_chunk=chunk, yuv444=yuv444, gpu_entropy=True)
+        assert st.entropy_ms_sum == 0, "a chunk fell to the host reader"
+        got = out.cpu().numpy() if device else out
+        for f, j in enumerate(jpegs):
+            d = orc.Decoder(j)
+            d.decode()
+            if yuv444:
+                y, u, v = d.get_yuv_frame()
+                want = np.concatenate([y.reshape(-1), orc.supersample_hv2(u).reshape(-1), orc.supersample_hv2(v).reshape(-1)])
+                assert np.array_equal(got[f * fs:(f + 1) * fs], want), (chunk, f)
+            else:
+                for i, plane in enumerate(info.planes(got[f * fs:(f + 1) * fs])):
+                    assert np.array_equal(plane, d.plane(i)), (chunk, f, i)
+
+
+def test_gpu_batch_whose_first_file_has_three_table_sets(ctx):
+    """the first file sets the batch's reference tables: three different (DC, AC) pairs do not fit the two LDS
+    slots, so every chunk runs with per-component tables from device memory -- still on the GPU"""
+    import video_coding_amd as hvc
+    w, h, q = 96, 64, 60
+    jpegs = [_optimised(j, w, h, q, 3) for j in _make_jpegs(7, w, h, q=q)]
+    info = hvc.hvc.jpeg_read_header(jpegs[0])
+    fs = info.pixel_bytes
+    out = np.zeros(len(jpegs) * fs, np.uint8)
+    st = ctx.jpeg_decode_batch(jpegs, out, fs, threads=2, frames_per_chunk=3, gpu_entropy=True)
+    assert st.entropy_ms_sum == 0
+    for f, j in enumerate(jpegs):
+        d = orc.Decoder(j)
+        d.decode()
+        for i, plane in enumerate(info.planes(out[f * fs:(f + 1) * fs])):
+            assert np.array_equal(plane, d.plane(i)), (f, i)

@@ -22,7 +22,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def verify(ctx, data, record_bytes, n_records, key, distinct):
@@ -52,6 +52,13 @@ def config3(args):
         u = synth_pixels(20 + f, 544, 960)[:H // 2]
         v = synth_pixels(30 + f, 544, 960)[:H // 2]
         jpegs.append(ctx.jpeg_encode(y, u, v, W, H, 420, 75))
+    if getattr(args, "own_tables", False):
+        # every distinct file re-written with Huffman tables optimised for its own statistics (what libjpeg -optimize
+        # writes): other tables than the model's defaults AND other tables from file to file -- same coefficients,
+        # same decoded frames, so the golden checksums still apply
+        from jpeg_opt_writer import jpeg_optimised_tables
+        qt = np.stack([hvc.hvc.quant_table(0, 75), hvc.hvc.quant_table(1, 75)])
+        jpegs = [jpeg_optimised_tables(W, H, 420, qt, hvc.hvc.jpeg_entropy_decode(j)[1]) for j in jpegs]
     batch = [jpegs[i % len(jpegs)] for i in range(args.frames)]
     info = hvc.hvc.jpeg_read_header(batch[0])
     if args.host_out:   # decoded frames back in (pageable) host memory: the other PCIe direction joins in
@@ -74,7 +81,8 @@ def config3(args):
     jpeg_bytes = sum(len(j) for j in batch)
     print(json.dumps({
         **verify(ctx, d_pix, info.pixel_bytes, args.frames, "configs_c3", args.distinct),
-        "config": ("3-gpu-entropy" if gpu else "3") + ("-host-out" if args.host_out else ""),
+        "config": ("3-gpu-entropy" if gpu else "3") + ("-host-out" if args.host_out else "") +
+                  ("-own-tables" if getattr(args, "own_tables", False) else ""),
         "metric": "Mpixel/s decoded, " + ("host unstuffing + H2D of segments + GPU Huffman + GPU block stage"
                                           if gpu else "host Huffman + H2D + GPU block stage") + " overlapped",
         "host_prep_thread_ms_sum": round(st.host_prep_ms_sum, 1),
@@ -368,6 +376,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=32)
     ap.add_argument("--gpu-entropy", action="store_true", help="configs 3 / 8: Huffman decoding / coding on the GPU as well")
     ap.add_argument("--host-out", action="store_true", help="config 3: decoded frames to host memory instead of HBM")
+    ap.add_argument("--own-tables", action="store_true", help="config 3: every file with Huffman tables optimised for itself")
     args = ap.parse_args()
     if args.config == 2:  # K2 upsample (optional output stage)
         args.frames = args.frames or 256

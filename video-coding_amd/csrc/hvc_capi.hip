@@ -56,9 +56,12 @@ struct hvc_ctx {
     size_t e_seg_bytes = 0, e_off_bytes = 0;
     // hvc_jpeg_decode_batch_gpu: pinned / device rings of unstuffed segments and their index arrays
     void *gp_h_ecs[RING] = {}, *gp_d_ecs[RING] = {}, *gp_h_meta[RING] = {}, *gp_d_meta[RING] = {};
-    size_t gp_ecs_bytes = 0, gp_meta_bytes = 0;
+    void *gp_h_ftabs[RING] = {}, *gp_d_ftabs[RING] = {}; // ... and of per-frame Huffman tables (hvc::HdFrameTabs, PF mode)
+    size_t gp_ecs_bytes = 0, gp_meta_bytes = 0, gp_ftabs_bytes = 0;
     // GPU Huffman decoder (hvc_jpeg_entropy_decode_gpu): device scratch, grown on demand
     void *gd_ecs = nullptr, *gd_meta = nullptr, *gd_state = nullptr, *gd_tables = nullptr, *gd_coefs = nullptr, *gd_dcd = nullptr;
+    void *gd_ftabs = nullptr; // per-frame tables of hvc_jpeg_entropy_decode_gpu (PF mode)
+    size_t gd_ftabs_cap = 0;
     hvc::HdTables *gd_tables_host = nullptr; // what gd_tables holds (value tables; the HdSpec behind them follows from these)
     bool gd_tables_valid = false;
     int gd_tables_ncomp = 0;
@@ -324,6 +327,8 @@ void hvc_destroy(hvc_ctx *c) {
         if (c->gp_d_ecs[i]) (void)hipFree(c->gp_d_ecs[i]);
         if (c->gp_h_meta[i]) (void)hipHostFree(c->gp_h_meta[i]);
         if (c->gp_d_meta[i]) (void)hipFree(c->gp_d_meta[i]);
+        if (c->gp_h_ftabs[i]) (void)hipHostFree(c->gp_h_ftabs[i]);
+        if (c->gp_d_ftabs[i]) (void)hipFree(c->gp_d_ftabs[i]);
         if (c->ed_seg[i]) (void)hipFree(c->ed_seg[i]);
         if (c->ed_off[i]) (void)hipFree(c->ed_off[i]);
         if (c->eh_off[i]) (void)hipHostFree(c->eh_off[i]);
@@ -336,6 +341,7 @@ void hvc_destroy(hvc_ctx *c) {
     if (c->gd_tables) (void)hipFree(c->gd_tables);
     if (c->gd_coefs) (void)hipFree(c->gd_coefs);
     if (c->gd_dcd) (void)hipFree(c->gd_dcd);
+    if (c->gd_ftabs) (void)hipFree(c->gd_ftabs);
     delete c->gd_tables_host;
     if (c->hd_tables) (void)hipFree(c->hd_tables);
     if (c->hd_lens) (void)hipFree(c->hd_lens);
@@ -1482,9 +1488,21 @@ static int gd_upload_tables(hvc_ctx *c, const hvc::HdTables &t, hvc::HdParams &P
     }
     P.tables = (const hvc::HdTables *)c->gd_tables;
     P.spec = have_spec ? (const hvc::HdSpec *)((char *)c->gd_tables + sizeof t) : nullptr;
-    P.slotmask = 0;
-    for (int b = 0; b < P.blocks_per_mcu; b++) P.slotmask |= (unsigned)slot[P.b2comp[b]] << b;
+    P.ftabs = nullptr;
+    P.tabset_of = nullptr;
+    P.slotmask = P.selmask = 0;
+    for (int b = 0; b < P.blocks_per_mcu; b++) {
+        P.slotmask |= (unsigned)slot[P.b2comp[b]] << b;
+        P.selmask |= (unsigned)slot[P.b2comp[b]] << (2 * b);
+    }
     return HVC_OK;
+}
+
+// PF mode (per-frame Huffman tables, hvc_hdec.h): which tables block b of an MCU reads = its component
+static unsigned gd_component_selmask(const hvc::HdParams &P) {
+    unsigned m = 0;
+    for (int b = 0; b < P.blocks_per_mcu; b++) m |= (unsigned)P.b2comp[b] << (2 * b);
+    return m;
 }
 
 // Enqueue the whole decode on `st`: flags cleared, `rounds` synchronisation launches, finish passes.
@@ -1506,21 +1524,37 @@ static hipError_t gd_enqueue(const hvc::HdParams &P, int rounds, hipStream_t st)
 static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *sizes, int n_frames,
                               const hvc_jpeg_info &info0, int16_t *d_coefs, size_t coef_fs, int *used_gpu) {
     *used_gpu = 0;
-    hvc::HdTables tables0, t;
+    // Huffman tables per file (decoder.ml:238-259 picks them from the file's own DHT segments): the distinct sets of
+    // the batch and which one every frame uses.  One set that fits two slots = the fast LDS-table kernels; anything
+    // else = per-frame tables in device memory (PF mode, hvc_hdec.h).
+    std::vector<hvc::HdTables> sets;
+    std::vector<unsigned> tabset_of((size_t)n_frames, 0u);
     std::vector<std::vector<uint8_t>> ecs((size_t)n_frames);
-    for (int f = 0; f < n_frames; f++) {
-        hvc_jpeg_info fi;
-        int r = hvc_jpeg_read_header(jpegs[f], sizes[f], &fi);
-        if (r) return r;
-        if (fi.n_comp != info0.n_comp || fi.coef_count != info0.coef_count || std::memcmp(fi.layout, info0.layout, sizeof fi.layout) ||
-            std::memcmp(fi.comp, info0.comp, sizeof fi.comp))
-            return HVC_E_INVALID_ARG; // a batch shares one geometry
-        bool ok = false;
-        r = hvc::prepare_gpu_decode(jpegs[f], sizes[f], &fi, f == 0 ? tables0 : t, ecs[(size_t)f], ok);
-        if (r) return r;
-        if (!ok) return HVC_OK;
-        if (f > 0 && std::memcmp(&t, &tables0, sizeof t)) return HVC_OK; // different Huffman tables: host path
+    try {
+        hvc::HdTables t;
+        for (int f = 0; f < n_frames; f++) {
+            hvc_jpeg_info fi;
+            int r = hvc_jpeg_read_header(jpegs[f], sizes[f], &fi);
+            if (r) return r;
+            if (fi.n_comp != info0.n_comp || fi.coef_count != info0.coef_count || std::memcmp(fi.layout, info0.layout, sizeof fi.layout) ||
+                std::memcmp(fi.comp, info0.comp, sizeof fi.comp))
+                return HVC_E_INVALID_ARG; // a batch shares one geometry
+            bool ok = false;
+            r = hvc::prepare_gpu_decode(jpegs[f], sizes[f], &fi, t, ecs[(size_t)f], ok);
+            if (r) return r;
+            if (!ok) return HVC_OK;
+            size_t k = sets.size(); // newest first: files of one source tend to come in runs
+            while (k > 0 && std::memcmp(&sets[k - 1], &t, sizeof t)) k--;
+            if (k == 0) {
+                sets.push_back(t);
+                k = sets.size();
+            }
+            tabset_of[(size_t)f] = (unsigned)(k - 1);
+        }
+    } catch (const std::bad_alloc &) {
+        return HVC_E_OUT_OF_MEMORY;
     }
+    const hvc::HdTables &tables0 = sets[0];
     hvc::HdParams P;
     if (!gd_geometry(info0, P)) return HVC_OK;
     P.n_frames = n_frames;
@@ -1561,7 +1595,32 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
     hipStream_t st = c->stream;
     HIPCHK(c, hipMemcpyAsync(c->gd_ecs, h_ecs.data(), bytes, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(m, h_meta.data(), meta_words * sizeof(unsigned), hipMemcpyHostToDevice, st));
-    if ((r = gd_upload_tables(c, tables0, P, st))) return r;
+    std::vector<hvc::HdFrameTabs> ftabs; // (lives until the synchronisation below: the upload reads it)
+    bool pf = sets.size() > 1;
+    if (!pf) {
+        if ((r = gd_upload_tables(c, tables0, P, st))) return r;
+        static const bool classic = std::getenv("HVC_HD_CLASSIC") != nullptr;
+        pf = !P.spec && !classic; // one set, but three different table pairs in it: no slots for that, per-component tables
+    }
+    P.coef_fs = coef_fs;
+    if (pf) {
+        if (!hvc::hd_write2_fits(P)) return HVC_OK; // (PF mode has the fast write pass only)
+        try {
+            ftabs.resize(sets.size());
+        } catch (const std::bad_alloc &) {
+            return HVC_E_OUT_OF_MEMORY;
+        }
+        for (size_t k = 0; k < sets.size(); k++) hvc::make_frame_tabs(sets[k], P.n_comp, ftabs[k]);
+        const size_t tb = sets.size() * sizeof(hvc::HdFrameTabs);
+        if ((r = grow(c, &c->gd_ftabs, &c->gd_ftabs_cap, tb + (size_t)n_frames * sizeof(unsigned)))) return r;
+        HIPCHK(c, hipMemcpyAsync(c->gd_ftabs, ftabs.data(), tb, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync((char *)c->gd_ftabs + tb, tabset_of.data(), (size_t)n_frames * sizeof(unsigned), hipMemcpyHostToDevice, st));
+        P.tables = nullptr;
+        P.spec = nullptr;
+        P.ftabs = (const hvc::HdFrameTabs *)c->gd_ftabs;
+        P.tabset_of = (const unsigned *)((char *)c->gd_ftabs + tb);
+        P.selmask = gd_component_selmask(P);
+    }
     P.ecs = (const uint8_t *)c->gd_ecs;
     P.ecs_off = d_ecs_off;
     P.sub_off = d_sub_off;
@@ -1704,8 +1763,10 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     const size_t R = nsub_max * SB + 16;                   // bytes per frame in the segment ring (16-byte multiple)
     if ((size_t)C * nsub_max >= (1ull << 31) || (size_t)C * R >= (1ull << 31)) return host_pipeline();
     const size_t ecs_bytes = (size_t)C * R;
-    const size_t meta_words = (size_t)C + ((size_t)C + 1) + (size_t)C * nsub_max + (size_t)C + 2;
+    // index arrays of a chunk: [ecs_off C][sub_off C + 1][tabset_of C][frame_of C * nsub_max][frame_blocks C][changed, status]
+    const size_t meta_words = (size_t)C + ((size_t)C + 1) + (size_t)C + (size_t)C * nsub_max + (size_t)C + 2;
     const size_t meta_bytes = meta_words * sizeof(unsigned);
+    const size_t ftabs_bytes = ((size_t)C + 1) * sizeof(hvc::HdFrameTabs); // record 0: the first file's tables, 1 + f: frame f's own
     const size_t coef_chunk = info0.coef_count * sizeof(int16_t) * (size_t)C;
     const size_t oring_bytes = where == HVC_MEM_HOST ? out_bytes * (size_t)C : 0;
 
@@ -1721,7 +1782,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     for (int i = 0; i < NB; i++)
         for (int k = 0; k < 3; k++)
             if (!c->ev_et[i][k]) HIPCHK(c, hipEventCreate(&c->ev_et[i][k])); // per-slot stage timers
-    if (ecs_bytes > c->gp_ecs_bytes || meta_bytes > c->gp_meta_bytes) {
+    if (ecs_bytes > c->gp_ecs_bytes || meta_bytes > c->gp_meta_bytes || ftabs_bytes > c->gp_ftabs_bytes) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipStreamSynchronize(c->copy_stream));
         for (int i = 0; i < NB; i++) {
@@ -1729,17 +1790,22 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
             if (c->gp_d_ecs[i]) (void)hipFree(c->gp_d_ecs[i]);
             if (c->gp_h_meta[i]) (void)hipHostFree(c->gp_h_meta[i]);
             if (c->gp_d_meta[i]) (void)hipFree(c->gp_d_meta[i]);
-            c->gp_h_ecs[i] = c->gp_d_ecs[i] = c->gp_h_meta[i] = c->gp_d_meta[i] = nullptr;
+            if (c->gp_h_ftabs[i]) (void)hipHostFree(c->gp_h_ftabs[i]);
+            if (c->gp_d_ftabs[i]) (void)hipFree(c->gp_d_ftabs[i]);
+            c->gp_h_ecs[i] = c->gp_d_ecs[i] = c->gp_h_meta[i] = c->gp_d_meta[i] = c->gp_h_ftabs[i] = c->gp_d_ftabs[i] = nullptr;
         }
-        c->gp_ecs_bytes = c->gp_meta_bytes = 0;
+        c->gp_ecs_bytes = c->gp_meta_bytes = c->gp_ftabs_bytes = 0;
         for (int i = 0; i < NB; i++)
             if (hipHostMalloc(&c->gp_h_ecs[i], ecs_bytes, HVC_UPLOAD_RING_FLAGS) != hipSuccess ||
                 hipMalloc(&c->gp_d_ecs[i], ecs_bytes) != hipSuccess ||
                 hipHostMalloc(&c->gp_h_meta[i], meta_bytes, hipHostMallocDefault) != hipSuccess ||
-                hipMalloc(&c->gp_d_meta[i], meta_bytes) != hipSuccess)
+                hipMalloc(&c->gp_d_meta[i], meta_bytes) != hipSuccess ||
+                hipHostMalloc(&c->gp_h_ftabs[i], ftabs_bytes, HVC_UPLOAD_RING_FLAGS) != hipSuccess ||
+                hipMalloc(&c->gp_d_ftabs[i], ftabs_bytes) != hipSuccess)
                 return HVC_E_OUT_OF_MEMORY;
         c->gp_ecs_bytes = ecs_bytes;
         c->gp_meta_bytes = meta_bytes;
+        c->gp_ftabs_bytes = ftabs_bytes;
     }
     if (coef_chunk > c->ring_bytes) { // the device coefficient ring of the host-decoder pipeline is reused
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1790,6 +1856,15 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     const size_t dcd_elems = ((size_t)C * G.blocks_per_frame + 127) & ~(size_t)127;
     if ((r = grow(c, &c->gd_dcd, &c->gd_dcd_cap, NRD * dcd_elems * sizeof(int16_t)))) return r;
     if ((r = gd_upload_tables(c, tables0, G, c->stream))) return r;
+    // A chunk whose files all carry the first file's tables (and those fit two slots) runs on the LDS-table kernels;
+    // any other chunk in PF mode (hvc_hdec.h): per-frame tables in device memory, record 0 of every ring slot = the
+    // first file's, record 1 + f = frame f's own (written by the worker that unstuffs the file).
+    const bool uniform_ok = G.spec != nullptr;
+    const bool pf_fits = (unsigned long long)C * info0.coef_count < (1ull << 35); // hvc::hd_write2_fits for a full chunk
+    if (!uniform_ok && !pf_fits) return host_pipeline();
+    for (int i = 0; i < NB; i++) hvc::make_frame_tabs(tables0, G.n_comp, *(hvc::HdFrameTabs *)c->gp_h_ftabs[i]);
+    const unsigned comp_selmask = gd_component_selmask(G);
+    std::vector<char> frame_pf((size_t)n_frames, 0); // the frame has tables of its own
 
     // workers: header parse, table check, unstuffing into the pinned segment ring
     std::mutex mu;
@@ -1826,7 +1901,12 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
             uint8_t *dst = (uint8_t *)c->gp_h_ecs[slot] + (size_t)(f - k * C) * R; // unstuffed straight into the pinned slot
             size_t got = 0;
             if (!e) e = hvc::prepare_gpu_decode_to(jpegs[f], sizes[f], &fi, t, dst, (nsub_max - 1) * SB, &got, ok);
-            const bool unfit = !e && (!ok || std::memcmp(&t, &tables0, sizeof t));
+            const bool own_tables = !e && ok && std::memcmp(&t, &tables0, sizeof t) != 0;
+            const bool unfit = !e && (!ok || (own_tables && !pf_fits));
+            if (own_tables && !unfit) { // its own Huffman tables: a record of its own
+                hvc::make_frame_tabs(t, info0.n_comp, ((hvc::HdFrameTabs *)c->gp_h_ftabs[slot])[1 + (f - k * C)]);
+                frame_pf[(size_t)f] = 1;
+            }
             if (!e && !unfit) {
                 const size_t used = ((got + SB - 1) / SB + 1) * SB + 16; // this frame's subsequences + overshoot
                 std::memset(dst + got, 0, used - got);
@@ -1937,10 +2017,13 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         if (skip) continue;
         // the chunk's index arrays
         unsigned *hm = (unsigned *)c->gp_h_meta[slot];
-        unsigned *h_ecs_off = hm, *h_sub_off = hm + C, *h_frame_of = h_sub_off + C + 1;
+        unsigned *h_ecs_off = hm, *h_sub_off = hm + C, *h_tabset_of = h_sub_off + C + 1, *h_frame_of = h_tabset_of + C;
         unsigned subs = 0;
+        bool pf = !uniform_ok;
         for (int f = 0; f < cnt; f++) {
             const unsigned nsub = (ecs_size[(size_t)(first + f)] + SB - 1) / SB + 1;
+            h_tabset_of[f] = frame_pf[(size_t)(first + f)] ? 1u + (unsigned)f : 0u;
+            pf |= frame_pf[(size_t)(first + f)] != 0;
             h_ecs_off[f] = (unsigned)((size_t)f * R);
             h_sub_off[f] = subs;
             for (unsigned q = 0; q < nsub; q++) h_frame_of[subs + q] = (unsigned)f;
@@ -1955,7 +2038,14 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         P.ecs = (const uint8_t *)c->gp_d_ecs[slot];
         P.ecs_off = dm;
         P.sub_off = dm + C;
-        P.frame_of = dm + C + C + 1;
+        P.frame_of = dm + C + C + 1 + C;
+        if (pf) {
+            P.tables = nullptr;
+            P.spec = nullptr;
+            P.ftabs = (const hvc::HdFrameTabs *)c->gp_d_ftabs[slot];
+            P.tabset_of = dm + C + C + 1;
+            P.selmask = comp_selmask;
+        }
         P.frame_blocks = dm + (meta_words - 2 - C);
         P.changed = dm + (meta_words - 2);
         P.status = dm + (meta_words - 1);
@@ -1968,7 +2058,10 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         if (he == hipSuccess)
             he = hipMemcpyAsync(c->gp_d_ecs[slot], c->gp_h_ecs[slot], (size_t)cnt * R, hipMemcpyHostToDevice, c->copy_stream);
         if (he == hipSuccess)
-            he = hipMemcpyAsync(dm, hm, ((size_t)2 * C + 1 + subs) * sizeof(unsigned), hipMemcpyHostToDevice, c->copy_stream);
+            he = hipMemcpyAsync(dm, hm, ((size_t)3 * C + 1 + subs) * sizeof(unsigned), hipMemcpyHostToDevice, c->copy_stream);
+        if (he == hipSuccess && pf) // the tables of the chunk's frames (36 KB a frame against ~1 MB of segment)
+            he = hipMemcpyAsync(c->gp_d_ftabs[slot], c->gp_h_ftabs[slot], ((size_t)cnt + 1) * sizeof(hvc::HdFrameTabs),
+                                hipMemcpyHostToDevice, c->copy_stream);
         if (he == hipSuccess) he = hipEventRecord(c->ev_h2d[slot], c->copy_stream);
         // (the slot's records and index arrays are free: the verdict above waited for chunk k - NB's block stage)
         if (he == hipSuccess) he = hipStreamWaitEvent(rs, c->ev_h2d[slot], 0);

@@ -37,6 +37,18 @@ struct HdSpec {
 // slot of every component, or false when the frame uses more than two different (DC, AC) table pairs
 bool make_spec(const HdTables &t, int n_comp, HdSpec &out, unsigned char slot_of_comp[4], unsigned char slot_rep[2]);
 
+// PER-FRAME tables ("PF mode"): a batch in which the files carry different Huffman tables -- optimised per file, as
+// libjpeg -optimize, cameras and most web encoders write them -- or a frame with three different table sets.  One
+// record per table set in DEVICE memory (no room for them all in LDS), per COMPONENT rather than per slot; a frame
+// points at its record through HdParams::tabset_of.  The walks then read their tables through the L1 / L2 instead of
+// LDS: slower per symbol, but the batch stays on the GPU instead of dropping to the host reader.
+#define HVC_HD_SPEC_T (1024 + HVC_HD_SUBTABLES * 64)
+struct HdFrameTabs {
+    uint16_t spec[3][2][HVC_HD_SPEC_T]; // [component][0 = DC, 1 = AC] in HdSpec's entry format (synchronisation walk)
+    uint16_t val[3][2][HVC_HD_SPEC_T];  // the same tables in the write pass's format (k_hd_write2: length, size, run, EOB)
+};
+void make_frame_tabs(const HdTables &t, int n_comp, HdFrameTabs &out);
+
 #ifndef HVC_HD_SUBSEQ_BITS
 #define HVC_HD_SUBSEQ_BITS 1024 /* bits per lane in the synchronisation rounds (a multiple of 128) */
 #endif
@@ -58,6 +70,10 @@ struct HdParams {
     const unsigned *frame_of;  // [total_sub] frame of every subsequence
     const HdTables *tables;    // device
     const HdSpec *spec;        // device, or null: synchronise with k_hd_round only
+    const HdFrameTabs *ftabs;  // device, PF mode (then spec / tables are not used), or null
+    const unsigned *tabset_of; // [n_frames] PF mode: index of the frame's record in ftabs
+    unsigned selmask;          // 2 bits per block b of an MCU: which tables it reads -- the HdSpec slot (0 / 1), or in PF
+                               // mode its component (0..2)
     unsigned slotmask;         // bit b = table slot (HdSpec) of block b of an MCU
     unsigned char slot_rep[2]; // a component whose tables the slot stands for
     int n_frames;
@@ -83,6 +99,7 @@ struct HdParams {
 
 hipError_t launch_hd_round(const HdParams &P, int round, hipStream_t s);
 hipError_t launch_hd_finish(const HdParams &P, int rounds_done, hipStream_t s); // count scan, write pass, DC pass
+bool hd_write2_fits(const HdParams &P); // the fast write pass can address these records (PF mode needs it)
 
 // hvc_entropy.cpp: header parse + table preparation + unstuffing for one file
 // returns HVC_OK, or an hvc_status the host decoder would also return at this stage;

@@ -227,12 +227,16 @@ __device__ __forceinline__ void walk(const HdParams &P, const HdGeo &G, const Hd
 // LDS (exit of lane t - 1 -> start of lane t), so a launch settles whole workgroups and the launches only
 // have to carry states across workgroup boundaries.
 constexpr int INNER = 24;
+// PF (per-frame tables): the walk is spec_walk on the frame's own record in device memory, the bits come straight
+// from global memory as well (byte order restored on the way); no tables in LDS.
+template <bool PF>
 __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
-    __shared__ HdTables T;
+    __shared__ __attribute__((aligned(16))) unsigned char Traw[PF ? 16 : sizeof(HdTables)];
+    HdTables &T = *reinterpret_cast<HdTables *>(Traw);
     __shared__ HdGeo G;
     __shared__ unsigned long long exits[256];
     load_geo(P, G);
-    {
+    if (!PF) {
         const unsigned *src = reinterpret_cast<const unsigned *>(P.tables);
         unsigned *dst = reinterpret_cast<unsigned *>(&T);
         for (unsigned i = threadIdx.x; i < sizeof(HdTables) / 4; i += 256) dst[i] = src[i];
@@ -262,7 +266,11 @@ __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
             unsigned p = (unsigned)st, err = 0;
             int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
             nb = 0;
-            walk<false>(P, G, T, slot, base, base + (unsigned)S, p, k, b, nb, 0, nullptr, err);
+            if (PF)
+                spec_walk([slot](unsigned q) { return __builtin_bswap32(slot[q]); }, &P.ftabs[P.tabset_of[f]].spec[0][0][0],
+                          P.selmask, P.blocks_per_mcu, base, p, k, b, nb);
+            else
+                walk<false>(P, G, T, slot, base, base + (unsigned)S, p, k, b, nb, 0, nullptr, err);
             ex = pack_state(p, k, b);
             used = st;
             have = true;
@@ -328,19 +336,23 @@ __device__ __forceinline__ void stage_row(unsigned *row, const uint8_t *seg) {
     }
     row[S / 32] = __builtin_bswap32(reinterpret_cast<const unsigned *>(seg)[S / 32]); // the segment buffer has 16 bytes past every frame
 }
-constexpr int SPEC_T = 1024 + HVC_HD_SUBTABLES * 64;
+constexpr int SPEC_T = HVC_HD_SPEC_T;
 
-__device__ __forceinline__ void spec_walk(const unsigned *row, const uint16_t *sp, unsigned slotmask, int B, unsigned base,
-                                          unsigned &p, int &k, int &b, unsigned &nb) {
+// rd(i) = dword i of the subsequence, big-endian order restored (i <= S / 32: one dword past it).  sp = the tables of
+// the frame: [slot or component][DC, AC][SPEC_T] -- in LDS (one set for the whole batch) or, in PF mode, in device
+// memory (this frame's record); sel = HdParams::selmask.
+template <class RD>
+__device__ __forceinline__ void spec_walk(RD rd, const uint16_t *sp, unsigned sel, int B, unsigned base, unsigned &p, int &k,
+                                          int &b, unsigned &nb) {
     const unsigned limit = base + (unsigned)S;
     const unsigned off = p - base;      // < 32 + S
     unsigned ni = off >> 5;             // next dword of the row
     int s = (32 - (int)(off & 31u)) & 31; // bits of `hi` not yet consumed, 0..31; the window is {hi, lo} >> s
     unsigned hi = 0;
-    if (s) hi = row[min(ni++, (unsigned)(SROW - 1))];
-    unsigned lo = row[min(ni++, (unsigned)(SROW - 1))];
-    unsigned nx = row[min(ni, (unsigned)(SROW - 1))];
-    const uint16_t *bt = sp + ((slotmask >> b) & 1u) * (2 * SPEC_T);
+    if (s) hi = rd(min(ni++, (unsigned)(SROW - 1)));
+    unsigned lo = rd(min(ni++, (unsigned)(SROW - 1)));
+    unsigned nx = rd(min(ni, (unsigned)(SROW - 1)));
+    const uint16_t *bt = sp + ((sel >> (2 * b)) & 3u) * (2 * SPEC_T);
     while (p < limit) {
         const unsigned w = __builtin_amdgcn_alignbit(hi, lo, (unsigned)s); // the next 32 bits
         const uint16_t *t = bt + (k ? SPEC_T : 0);
@@ -355,13 +367,13 @@ __device__ __forceinline__ void spec_walk(const unsigned *row, const uint16_t *s
             lo = nx;
             s += 32;
             ni++;
-            nx = row[min(ni, (unsigned)(SROW - 1))];
+            nx = rd(min(ni, (unsigned)(SROW - 1)));
         }
         if ((e & 0x800u) || k >= 64) { // EOB, index 63 written, or past it (the model raises: the true parse never gets here)
             k = 0;
             b = b + 1 == B ? 0 : b + 1;
             nb++;
-            bt = sp + ((slotmask >> b) & 1u) * (2 * SPEC_T);
+            bt = sp + ((sel >> (2 * b)) & 3u) * (2 * SPEC_T);
         }
     }
 }
@@ -370,8 +382,10 @@ __device__ __forceinline__ void spec_walk(const unsigned *row, const uint16_t *s
 // 256 lanes the tables weigh twice as much per lane and 12 wavefronts fit; the loop is latency-bound enough --
 // 8 wavefronts per CU were 1.4x slower -- for the 16 to show.)
 constexpr int SYNC_WG = 512;
-// One subsequence of one round: true when its successor has to start again.
-__device__ __forceinline__ bool sync_one(const HdParams &P, int round, bool valid, unsigned i, unsigned *row, const uint16_t *sp,
+// One subsequence of one round: true when its successor has to start again.  PF: the frame's own tables, in device
+// memory (sp_lds unused); otherwise the batch's one set in LDS.
+template <bool PF>
+__device__ __forceinline__ bool sync_one(const HdParams &P, int round, bool valid, unsigned i, unsigned *row, const uint16_t *sp_lds,
                                          const unsigned long long *pe, unsigned long long *ce) {
     const unsigned f = P.frame_of[i], j = i - P.sub_off[f];
     const unsigned base = j * (unsigned)S;
@@ -381,7 +395,8 @@ __device__ __forceinline__ bool sync_one(const HdParams &P, int round, bool vali
     stage_row(row, P.ecs + P.ecs_off[f] + (size_t)j * (S / 8));
     unsigned p = (unsigned)st, nb = 0;
     int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
-    spec_walk(row, sp, P.slotmask, P.blocks_per_mcu, base, p, k, b, nb);
+    const uint16_t *sp = PF ? &P.ftabs[P.tabset_of[f]].spec[0][0][0] : sp_lds;
+    spec_walk([row](unsigned q) { return row[q]; }, sp, P.selmask, P.blocks_per_mcu, base, p, k, b, nb);
     const unsigned long long ex = pack_state(p, k, b);
     const bool differs = round == 0 || ex != P.exit_a[i];
     P.exit_a[i] = ex;
@@ -392,15 +407,16 @@ __device__ __forceinline__ bool sync_one(const HdParams &P, int round, bool vali
     return round > 0 && differs && i + 1 < P.sub_off[f + 1];
 }
 
+template <bool PF>
 __global__ __launch_bounds__(SYNC_WG) void k_hd_sync(HdParams P, int round) {
-    __shared__ uint16_t sp[2 * 2 * SPEC_T];
+    __shared__ uint16_t sp[PF ? 2 : 2 * 2 * SPEC_T];
     __shared__ unsigned rows[SYNC_WG / 64][64 * SROW];
-    {
+    if (!PF) {
         const unsigned *src = reinterpret_cast<const unsigned *>(P.spec);
         unsigned *dst = reinterpret_cast<unsigned *>(sp);
         for (unsigned i = threadIdx.x; i < sizeof(HdSpec) / 4; i += SYNC_WG) dst[i] = src[i];
+        __syncthreads(); // the tables; from here on the wavefronts have nothing to do with one another
     }
-    __syncthreads(); // the tables; from here on the wavefronts have nothing to do with one another
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned *row = rows[wave] + lane * SROW;
     const unsigned *list = (round & 1) ? P.list1 : P.list0; // rounds 0 and 1: every subsequence, no list
@@ -412,7 +428,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_hd_sync(HdParams P, int round) {
         const unsigned t = t0 + (unsigned)lane;
         const bool valid = t < count;
         const unsigned i = !valid ? 0u : round < 2 ? t : list[t];
-        const bool push = sync_one(P, round, valid, i, row, sp, pe, ce);
+        const bool push = sync_one<PF>(P, round, valid, i, row, sp, pe, ce);
         const unsigned long long m = __ballot(push);
         if (m) { // one atomic per wavefront
             unsigned at = 0;
@@ -428,11 +444,12 @@ __global__ __launch_bounds__(SYNC_WG) void k_hd_sync(HdParams P, int round) {
 // workgroup keeps the tables and goes from round to round by itself -- a barrier instead of a launch, the list lengths
 // in LDS -- until a list is empty (or last_round: k_hd_round then continues).  A workgroup's own stores are visible to
 // its own later loads (one CU, one L1), so the per-round buffers work as they do across launches.
+template <bool PF>
 __global__ __launch_bounds__(SYNC_WG) void k_hd_sync_tail(HdParams P, int first_round, int last_round) {
-    __shared__ uint16_t sp[2 * 2 * SPEC_T];
+    __shared__ uint16_t sp[PF ? 2 : 2 * 2 * SPEC_T];
     __shared__ unsigned rows[SYNC_WG / 64][64 * SROW];
     __shared__ unsigned cnt_s[2];
-    {
+    if (!PF) {
         const unsigned *src = reinterpret_cast<const unsigned *>(P.spec);
         unsigned *dst = reinterpret_cast<unsigned *>(sp);
         for (unsigned i = threadIdx.x; i < sizeof(HdSpec) / 4; i += SYNC_WG) dst[i] = src[i];
@@ -455,7 +472,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_hd_sync_tail(HdParams P, int first_
             const unsigned t = t0 + (unsigned)lane;
             const bool valid = t < count;
             const unsigned i = valid ? list[t] : 0u;
-            const bool push = sync_one(P, round, valid, i, row, sp, pe, ce);
+            const bool push = sync_one<PF>(P, round, valid, i, row, sp, pe, ce);
             const unsigned long long m = __ballot(push);
             if (m) {
                 unsigned at = 0;
@@ -563,8 +580,9 @@ constexpr int WR_EXTRA = 3; // rows staged past the workgroup's own, for the las
 #endif
 constexpr int WR_BATCH = HVC_WR_BATCH; // block ends handled together
 
+template <bool PF>
 __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) {
-    __shared__ uint16_t tv[2 * 2 * SPEC_T]; // value tables of the two slots: [slot][DC, AC]
+    __shared__ uint16_t tv[PF ? 2 : 2 * 2 * SPEC_T]; // value tables of the two slots: [slot][DC, AC] (PF: the frame's record in device memory instead)
     __shared__ HdGeo G;
     __shared__ unsigned rows[(256 + WR_EXTRA) * SROW];
     __shared__ uint4 lbuf[256 * 8]; // 64 int16 per lane
@@ -573,7 +591,8 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
     {
         // value tables in the form the loop below wants: bits 0-4 code length (0: no code), 5-9 magnitude bits,
         // 10-13 run of zeros, bit 14 EOB; 0x8000 | n (first level only) = continue in sub-table n
-        for (int sl = 0; sl < 2; sl++)
+        // (make_frame_tabs on the host writes the same form for PF mode)
+        for (int sl = 0; sl < (PF ? 0 : 2); sl++)
             for (int cls = 0; cls < 2; cls++) {
                 const HdTable *src_t = cls ? &P.tables->ac[P.slot_rep[sl]] : &P.tables->dc[P.slot_rep[sl]];
                 const uint16_t *src = reinterpret_cast<const uint16_t *>(src_t);
@@ -642,7 +661,8 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
     if (s) hi = rd(ni++);
     unsigned lo = rd(ni++);
     unsigned nx = rd(ni);
-    const uint16_t *bt = tv + ((P.slotmask >> b) & 1u) * (2 * SPEC_T);
+    const uint16_t *const tvb = PF ? &P.ftabs[P.tabset_of[f]].val[0][0][0] : tv;
+    const uint16_t *bt = tvb + ((P.selmask >> (2 * b)) & 3u) * (2 * SPEC_T);
     unsigned exit_p = 0, exit_kb = 0; // exit_p stays 0 for a lane that never gets that far
     // What happens at the end of a block -- store it, find the next one's place -- costs more than a symbol, and in
     // a wavefront some lane ends a block in almost every iteration.  A lane that ends a block therefore WAITS
@@ -725,7 +745,7 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
                 b = b + 1 == B ? 0 : b + 1;
                 bi++;
                 live = bi < P.blocks_per_frame;
-                bt = tv + ((P.slotmask >> b) & 1u) * (2 * SPEC_T);
+                bt = tvb + ((P.selmask >> (2 * b)) & 3u) * (2 * SPEC_T);
                 if (b == 0) { // next MCU
                     mx++;
                     if (mx == (unsigned)P.mbs_wide) {
@@ -795,6 +815,39 @@ __global__ __launch_bounds__(1024) void k_hd_dc(HdParams P) {
     if (bad) atomicOr(P.status, 2u);
 }
 
+// One Huffman table in the two forms the fast kernels read (SPEC_T entries each: first level, then the sub-tables).
+//   spec (synchronisation walk): see HdSpec
+//   val  (k_hd_write2): bits 0-4 code length (0: no code), 5-9 magnitude bits, 10-13 run of zeros, bit 14 EOB;
+//                       0x8000 | n (first level only) = continue in sub-table n
+static void convert_table(const HdTable &src, bool dc, uint16_t *spec, uint16_t *val) {
+    auto conv = [dc](uint16_t e) -> uint16_t {
+        if (e & 0x8000u) return e;             // continues in a sub-table
+        if (!e) return 1;                      // no code: one bit further, same state
+        const unsigned len = e >> 8, v = e & 0xffu;
+        if (dc) return (uint16_t)(v > 16 ? len : (len + v) | (1u << 6)); // category > 16: the index stays 0
+        const unsigned size = v & 15u, run = v >> 4;
+        if (!size && !run) return (uint16_t)(len | 0x800u);
+        return (uint16_t)((len + size) | ((run + 1u) << 6));
+    };
+    const uint16_t *all = reinterpret_cast<const uint16_t *>(&src); // fast[1024] then sub[HVC_HD_SUBTABLES * 64]
+    static_assert(sizeof(HdTable) == SPEC_T * sizeof(uint16_t), "HdTable = first level + sub-tables");
+    for (int q = 0; q < SPEC_T; q++) {
+        const uint16_t e = all[q];
+        if (spec) spec[q] = (q >= 1024 && (e & 0x8000u)) ? (uint16_t)1 : conv(e);
+        if (val) {
+            unsigned o = e;
+            if (!(e & 0x8000u) && e) {
+                const unsigned len = e >> 8, v = e & 0xffu;
+                // DC: categories above 16 are errors (decoder.ml:73-79 has no such magnitude) and so, here, is 16
+                // itself: its differences (|d| >= 32768, or -32768) leave int16 or the range a JPEG DC can have,
+                // so the stream goes to the host decoder either way and the loop needs no range check
+                o = dc ? (len | ((v >= 16u ? 31u : v) << 5)) : (len | ((v & 15u) << 5) | ((v >> 4) << 10) | (v ? 0u : 0x4000u));
+            }
+            val[q] = (uint16_t)o;
+        }
+    }
+}
+
 bool make_spec(const HdTables &t, int n_comp, HdSpec &out, unsigned char slot_of_comp[4], unsigned char slot_rep[2]) {
     if (n_comp < 1 || n_comp > 3) return false;
     int rep[2] = {0, -1}; // the component whose tables a slot holds
@@ -809,38 +862,31 @@ bool make_spec(const HdTables &t, int n_comp, HdSpec &out, unsigned char slot_of
     slot_rep[0] = 0;
     slot_rep[1] = (unsigned char)(rep[1] < 0 ? 0 : rep[1]);
     std::memset(&out, 0, sizeof out);
-    auto conv = [](uint16_t e, bool dc) -> uint16_t {
-        if (e & 0x8000u) return e;             // continues in a sub-table
-        if (!e) return 1;                      // no code: one bit further, same state
-        const unsigned len = e >> 8, val = e & 0xffu;
-        if (dc) return (uint16_t)(val > 16 ? len : (len + val) | (1u << 6)); // category > 16: the index stays 0
-        const unsigned size = val & 15u, run = val >> 4;
-        if (!size && !run) return (uint16_t)(len | 0x800u);
-        return (uint16_t)((len + size) | ((run + 1u) << 6));
-    };
     for (int sl = 0; sl < 2; sl++) {
         if (rep[sl] < 0) continue;
-        const HdTable *src[2] = {&t.dc[rep[sl]], &t.ac[rep[sl]]};
-        for (int cls = 0; cls < 2; cls++) {
-            for (int q = 0; q < 1024; q++) out.t[sl][cls][q] = conv(src[cls]->fast[q], cls == 0);
-            for (int q = 0; q < HVC_HD_SUBTABLES * 64; q++) {
-                const uint16_t e = src[cls]->sub[q];
-                out.t[sl][cls][1024 + q] = (e & 0x8000u) ? (uint16_t)1 : conv(e, cls == 0);
-            }
-        }
+        convert_table(t.dc[rep[sl]], true, out.t[sl][0], nullptr);
+        convert_table(t.ac[rep[sl]], false, out.t[sl][1], nullptr);
     }
     return true;
 }
 
-hipError_t launch_hd_round(const HdParams &P, int round, hipStream_t s) {
-    if (P.total_sub == 0) return hipSuccess;
-    if (round == 0 && P.spec) { // all the fast rounds; launches 1.. of k_hd_round verify and, if need be, continue
+void make_frame_tabs(const HdTables &t, int n_comp, HdFrameTabs &out) {
+    for (int c = 0; c < 3; c++) {
+        const int s = c < n_comp ? c : 0; // components the frame does not have: a copy, never read
+        convert_table(t.dc[s], true, out.spec[c][0], out.val[c][0]);
+        convert_table(t.ac[s], false, out.spec[c][1], out.val[c][1]);
+    }
+}
+
+template <bool PF>
+static hipError_t launch_hd_round_t(const HdParams &P, int round, hipStream_t s) {
+    if (round == 0 && (PF || P.spec)) { // all the fast rounds; launches 1.. of k_hd_round verify and, if need be, continue
         hipError_t e = hipMemsetAsync(P.list_n, 0, (SYNC_ROUNDS + 2) * sizeof(unsigned), s);
         if (e != hipSuccess) return e;
         const unsigned all = (P.total_sub + (unsigned)SYNC_WG - 1u) / (unsigned)SYNC_WG;
         if (P.total_sub <= SYNC_TAIL_MAX_SUB) { // a few files: five rounds as launches, the rest inside one workgroup
-            for (int r = 0; r < SYNC_TAIL_FROM; r++) hipLaunchKernelGGL(k_hd_sync, dim3(all), dim3(SYNC_WG), 0, s, P, r);
-            hipLaunchKernelGGL(k_hd_sync_tail, dim3(1), dim3(SYNC_WG), 0, s, P, SYNC_TAIL_FROM, SYNC_TAIL_FROM + 200);
+            for (int r = 0; r < SYNC_TAIL_FROM; r++) hipLaunchKernelGGL(k_hd_sync<PF>, dim3(all), dim3(SYNC_WG), 0, s, P, r);
+            hipLaunchKernelGGL(k_hd_sync_tail<PF>, dim3(1), dim3(SYNC_WG), 0, s, P, SYNC_TAIL_FROM, SYNC_TAIL_FROM + 200);
             return hipGetLastError();
         }
         // (fewer list rounds for a single file's few thousand subsequences -- leaving the slow stretches to
@@ -848,20 +894,31 @@ hipError_t launch_hd_round(const HdParams &P, int round, hipStream_t s) {
         for (int r = 0; r < SYNC_ROUNDS; r++) {
             // the lists shrink by about half a round; a grid-stride loop takes whatever is there
             const unsigned grid = r < 2 ? all : min(all, r < 4 ? 2048u : 512u);
-            hipLaunchKernelGGL(k_hd_sync, dim3(grid), dim3(SYNC_WG), 0, s, P, r);
+            hipLaunchKernelGGL(k_hd_sync<PF>, dim3(grid), dim3(SYNC_WG), 0, s, P, r);
         }
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_hd_round, dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, round);
+    hipLaunchKernelGGL(k_hd_round<PF>, dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, round);
     return hipGetLastError();
 }
+
+hipError_t launch_hd_round(const HdParams &P, int round, hipStream_t s) {
+    if (P.total_sub == 0) return hipSuccess;
+    return P.ftabs ? launch_hd_round_t<true>(P, round, s) : launch_hd_round_t<false>(P, round, s);
+}
+
+// k_hd_write2 addresses the records in 16-byte units with 32 bits
+bool hd_write2_fits(const HdParams &P) { return (unsigned long long)P.n_frames * P.coef_fs < (1ull << 35); }
 
 hipError_t launch_hd_finish(const HdParams &P, int rounds_done, hipStream_t s) {
     if (P.total_sub == 0) return hipSuccess;
     hipLaunchKernelGGL(k_hd_scan, dim3((unsigned)P.n_frames), dim3(1024), 0, s, P);
     HdParams Q = P;
-    if (P.spec && P.dcd && (unsigned long long)P.n_frames * P.coef_fs < (1ull << 35)) { // k_hd_write2 addresses the records in 32 bits
-        hipLaunchKernelGGL(k_hd_write2, dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, rounds_done);
+    if (P.ftabs) { // PF mode has no general write pass: the host side asks hd_write2_fits() before it chooses the mode
+        if (!P.dcd || !hd_write2_fits(P)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_hd_write2<true>, dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, rounds_done);
+    } else if (P.spec && P.dcd && hd_write2_fits(P)) {
+        hipLaunchKernelGGL(k_hd_write2<false>, dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, rounds_done);
     } else {
         Q.dcd = nullptr; // k_hd_write leaves the differences in the records only
         hipLaunchKernelGGL(k_hd_write, dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, rounds_done);

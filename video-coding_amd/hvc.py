@@ -412,10 +412,17 @@ class Context:
         used = C.c_int(-1)
         if device:
             import torch
-            out = torch.empty((n, info.coef_count), dtype=torch.int16, device="cuda")
+            # canary elements behind the last record: the reader's write passes must never store past the records,
+            # settled stream or not (this wrapper is the harness of the tests and of tools/stress_hdec.py)
+            guard = 8192
+            buf = torch.full((n * info.coef_count + guard,), 0x5A5A, dtype=torch.int16, device="cuda")
+            out = buf[:n * info.coef_count].view(n, info.coef_count)
             torch.cuda.synchronize()
             _chk(lib().hvc_jpeg_entropy_decode_gpu(self._h, ptrs, sizes, n, out.data_ptr(), info.coef_count, 1,
                                                    C.byref(info), C.byref(used)), "hvc_jpeg_entropy_decode_gpu")
+            torch.cuda.synchronize()
+            if not bool((buf[n * info.coef_count:] == 0x5A5A).all()):
+                raise RuntimeError("hvc_jpeg_entropy_decode_gpu wrote past the coefficient records")
             return info, out.cpu().numpy(), used.value
         out = np.empty((n, info.coef_count), dtype=np.int16)
         _chk(lib().hvc_jpeg_entropy_decode_gpu(self._h, ptrs, sizes, n, out.ctypes.data, info.coef_count, 0, C.byref(info),
