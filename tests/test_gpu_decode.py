@@ -397,5 +397,7 @@ def test_a_million_blocks_within_one_per_cent_of_each_guard_limit(ctx):
             assert np.array_equal(gpu_decode_plane(ctx, coefs, q), want), ti
         finally:
             ctx.set_decode_kernel(0)
-    # the boundaries really were straddled: a good share of the blocks on each side
-    assert took_wide > 100_000 and took_fast > 100_000, (took_wide, took_fast)
+    # the boundaries really were straddled.  (Scaled up to the limit of ONE guard a block has usually tripped another
+    # one already -- the coefficient energy binds first for most tables -- so the int64 side is the larger one: about
+    # 9 in 10; the blocks aimed at a block's binding guard land on both sides of it.)
+    assert took_wide > 50_000 and took_fast > 50_000, (took_wide, took_fast)

@@ -62,6 +62,8 @@ struct hvc_ctx {
     void *gd_ecs = nullptr, *gd_meta = nullptr, *gd_state = nullptr, *gd_tables = nullptr, *gd_coefs = nullptr, *gd_dcd = nullptr;
     void *gd_ftabs = nullptr; // per-frame tables of hvc_jpeg_entropy_decode_gpu (PF mode)
     size_t gd_ftabs_cap = 0;
+    void *gd_dcv = nullptr;   // batch pipeline: the blocks' DC values as a compact array (hvc::DecodeParams::dc_plane)
+    size_t gd_dcv_cap = 0;
     hvc::HdTables *gd_tables_host = nullptr; // what gd_tables holds (value tables; the HdSpec behind them follows from these)
     bool gd_tables_valid = false;
     int gd_tables_ncomp = 0;
@@ -342,6 +344,7 @@ void hvc_destroy(hvc_ctx *c) {
     if (c->gd_coefs) (void)hipFree(c->gd_coefs);
     if (c->gd_dcd) (void)hipFree(c->gd_dcd);
     if (c->gd_ftabs) (void)hipFree(c->gd_ftabs);
+    if (c->gd_dcv) (void)hipFree(c->gd_dcv);
     delete c->gd_tables_host;
     if (c->hd_tables) (void)hipFree(c->hd_tables);
     if (c->hd_lens) (void)hipFree(c->hd_lens);
@@ -527,9 +530,10 @@ static void prepare_tables(const uint16_t *qtabs, int n_qtabs, int *qt, int *eth
 }
 
 // ---------------------------------------------------------------------------
-int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const uint16_t *qtabs, int n_qtabs,
-                      const hvc_component *comps, int n_comp, int n_frames, uint8_t *pixels, size_t pixel_fs,
-                      int where) {
+// dc_plane (device memory calls only, default kernels only): see hvc::DecodeParams::dc_plane
+static int decode_frames_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const uint16_t *qtabs, int n_qtabs,
+                              const hvc_component *comps, int n_comp, int n_frames, uint8_t *pixels, size_t pixel_fs,
+                              int where, const int16_t *dc_plane, size_t dc_fs) {
     if (!c || !coefs || !pixels || n_frames < 0) return HVC_E_INVALID_ARG;
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
     int r = check_qtabs(qtabs, n_qtabs);
@@ -586,14 +590,18 @@ int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const ui
 
     if (where == HVC_MEM_DEVICE) {
         if (((uintptr_t)coefs & 15) || ((uintptr_t)pixels & 7)) return HVC_E_ALIGNMENT;
+        if (dc_plane && P.kernel_sel != 0) return HVC_E_INVALID_ARG;
         P.coefs = coefs;
         P.pixels = pixels;
+        P.dc_plane = dc_plane;
+        P.dc_fs = dc_fs;
         const bool prof = c->profiling && !wide_only;
         const int slot = (int)(c->k_calls % HVC_PROF_RING);
         HIPCHK(c, launch(P, prof ? c->k0[slot] : nullptr, prof ? c->k1[slot] : nullptr));
         if (prof) c->k_calls++;
         return HVC_OK;
     }
+    if (dc_plane) return HVC_E_INVALID_ARG;
 
     // host memory: mirror the caller's record layout on the device
     size_t cbytes = ((size_t)(n_frames - 1) * coef_fs + L.coef_span) * sizeof(int16_t);
@@ -664,11 +672,17 @@ int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const ui
     return HVC_OK;
 }
 
+int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const uint16_t *qtabs, int n_qtabs,
+                      const hvc_component *comps, int n_comp, int n_frames, uint8_t *pixels, size_t pixel_fs,
+                      int where) {
+    return decode_frames_impl(c, coefs, coef_fs, qtabs, n_qtabs, comps, n_comp, n_frames, pixels, pixel_fs, where, nullptr, 0);
+}
+
 // ---------------------------------------------------------------------------
 // 4:2:0 coefficient records -> tight 4:4:4 frames (block stage + crop + chroma upsample fused)
-int hvc_decode_frames_yuv444(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const uint16_t *qtabs, int n_qtabs,
-                             const hvc_component *comps, int n_comp, int n_frames, int width, int height,
-                             uint8_t *frames, size_t frame_stride, int where) {
+static int decode_frames_yuv444_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const uint16_t *qtabs, int n_qtabs,
+                                     const hvc_component *comps, int n_comp, int n_frames, int width, int height,
+                                     uint8_t *frames, size_t frame_stride, int where, const int16_t *dc_plane, size_t dc_fs) {
     if (!c || !coefs || !frames || !comps || n_frames < 0) return HVC_E_INVALID_ARG;
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
     int r = check_qtabs(qtabs, n_qtabs);
@@ -746,10 +760,13 @@ int hvc_decode_frames_yuv444(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, c
         return e;
     };
 
+    if (where == HVC_MEM_HOST && dc_plane) return HVC_E_INVALID_ARG;
     if (where == HVC_MEM_DEVICE) {
         if ((uintptr_t)coefs & 15) return HVC_E_ALIGNMENT;
         P.coefs = coefs;
         P.out = frames;
+        P.dc_plane = dc_plane;
+        P.dc_fs = dc_fs;
         const bool prof = c->profiling && !wide_only;
         const int slot = (int)(c->k_calls % HVC_PROF_RING);
         HIPCHK(c, launch(P, prof ? c->k0[slot] : nullptr, prof ? c->k1[slot] : nullptr));
@@ -792,6 +809,13 @@ int hvc_decode_frames_yuv444(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, c
                                    hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HVC_OK;
+}
+
+int hvc_decode_frames_yuv444(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const uint16_t *qtabs, int n_qtabs,
+                             const hvc_component *comps, int n_comp, int n_frames, int width, int height,
+                             uint8_t *frames, size_t frame_stride, int where) {
+    return decode_frames_yuv444_impl(c, coefs, coef_fs, qtabs, n_qtabs, comps, n_comp, n_frames, width, height, frames,
+                                     frame_stride, where, nullptr, 0);
 }
 
 int hvc_dequant_idct_recon(hvc_ctx *c, const int16_t *coefs, size_t coef_plane_stride, const uint16_t *qtab,
@@ -1419,6 +1443,21 @@ int hvc_jpeg_decode_batch_yuv444(hvc_ctx *c, const uint8_t *const *jpegs, const 
                              true);
 }
 
+// Two files of one batch: the same frame geometry (sizes, sampling, planes)?  The Huffman table selectors of the scan
+// may differ -- the GPU reader takes every file's tables from the file itself.
+static bool same_geometry(const hvc_jpeg_info &a, const hvc_jpeg_info &b) {
+    if (a.n_comp != b.n_comp || a.coef_count != b.coef_count || a.width != b.width || a.height != b.height ||
+        std::memcmp(a.layout, b.layout, sizeof a.layout))
+        return false;
+    for (int i = 0; i < a.n_comp; i++) {
+        const hvc_jpeg_component &x = a.comp[i], &y = b.comp[i];
+        if (x.identifier != y.identifier || x.hscale != y.hscale || x.vscale != y.vscale || x.decoded_width != y.decoded_width ||
+            x.decoded_height != y.decoded_height || x.actual_width != y.actual_width || x.actual_height != y.actual_height)
+            return false;
+    }
+    return true;
+}
+
 // Geometry part of the GPU Huffman decoder's parameter block; false = this frame layout needs the host decoder.
 static bool gd_geometry(const hvc_jpeg_info &info0, hvc::HdParams &P) {
     std::memset(&P, 0, sizeof P);
@@ -1536,9 +1575,7 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
             hvc_jpeg_info fi;
             int r = hvc_jpeg_read_header(jpegs[f], sizes[f], &fi);
             if (r) return r;
-            if (fi.n_comp != info0.n_comp || fi.coef_count != info0.coef_count || std::memcmp(fi.layout, info0.layout, sizeof fi.layout) ||
-                std::memcmp(fi.comp, info0.comp, sizeof fi.comp))
-                return HVC_E_INVALID_ARG; // a batch shares one geometry
+            if (!same_geometry(fi, info0)) return HVC_E_INVALID_ARG; // a batch shares one geometry
             bool ok = false;
             r = hvc::prepare_gpu_decode(jpegs[f], sizes[f], &fi, t, ecs[(size_t)f], ok);
             if (r) return r;
@@ -1855,6 +1892,13 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     if ((r = grow(c, &c->gd_state, &c->gd_state_cap, NRD * state_bytes))) return r;
     const size_t dcd_elems = ((size_t)C * G.blocks_per_frame + 127) & ~(size_t)127;
     if ((r = grow(c, &c->gd_dcd, &c->gd_dcd_cap, NRD * dcd_elems * sizeof(int16_t)))) return r;
+    // The DC values go from the reader's DC pass to the block stage through a compact array, one per ring slot (a
+    // chunk's block stage may still read it while the next chunk's DC pass runs), instead of 2 bytes into each
+    // 128-byte record -- unless a diagnostic kernel selection asks for the A/B alternates, which read the records.
+    const bool dc_compact = c->decode_kernel == 0 || c->decode_kernel == 2;
+    const size_t dcv_fs = info0.coef_count / 64; // (a tight record: whole blocks)
+    const size_t dcv_elems = ((size_t)C * dcv_fs + 127) & ~(size_t)127;
+    if (dc_compact && (r = grow(c, &c->gd_dcv, &c->gd_dcv_cap, (size_t)NB * dcv_elems * sizeof(int16_t)))) return r;
     if ((r = gd_upload_tables(c, tables0, G, c->stream))) return r;
     // A chunk whose files all carry the first file's tables (and those fit two slots) runs on the LDS-table kernels;
     // any other chunk in PF mode (hvc_hdec.h): per-frame tables in device memory, record 0 of every ring slot = the
@@ -1893,10 +1937,8 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
             const auto t0 = std::chrono::steady_clock::now();
             hvc_jpeg_info fi;
             int e = hvc_jpeg_read_header(jpegs[f], sizes[f], &fi);
-            if (!e && (fi.n_comp != info0.n_comp || fi.n_qtabs != info0.n_qtabs || fi.coef_count != info0.coef_count ||
-                       std::memcmp(fi.layout, info0.layout, sizeof fi.layout) || std::memcmp(fi.comp, info0.comp, sizeof fi.comp) ||
-                       std::memcmp(fi.qtabs, info0.qtabs, sizeof fi.qtabs)))
-                e = HVC_E_INVALID_ARG; // a batch shares one geometry and one set of tables
+            if (!e && (!same_geometry(fi, info0) || fi.n_qtabs != info0.n_qtabs || std::memcmp(fi.qtabs, info0.qtabs, sizeof fi.qtabs)))
+                e = HVC_E_INVALID_ARG; // a batch shares one geometry and one set of quantiser tables
             bool ok = false;
             uint8_t *dst = (uint8_t *)c->gp_h_ecs[slot] + (size_t)(f - k * C) * R; // unstuffed straight into the pinned slot
             size_t got = 0;
@@ -2053,6 +2095,8 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         P.coef_fs = info0.coef_count;
         gd_carve_state(P, (char *)c->gd_state + (size_t)(k % NRD) * state_bytes, (size_t)C * nsub_max);
         P.dcd = (int16_t *)c->gd_dcd + (size_t)(k % NRD) * dcd_elems;
+        P.dc_plane = dc_compact ? (int16_t *)c->gd_dcv + (size_t)slot * dcv_elems : nullptr;
+        P.dc_fs = dcv_fs;
         hipStream_t rs = c->rd_stream[k % NRD];
         hipError_t he = hipEventRecord(c->ev_et[slot][0], c->copy_stream);
         if (he == hipSuccess)
@@ -2074,10 +2118,11 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         if (he != hipSuccess) { rc = fail_hip(c, he); break; }
         uint8_t *dst = where == HVC_MEM_DEVICE ? pixels + (size_t)first * pixel_fs : (uint8_t *)c->d_oring[slot];
         const size_t dst_fs = where == HVC_MEM_DEVICE ? pixel_fs : out_bytes;
-        rc = yuv444 ? hvc_decode_frames_yuv444(c, P.coefs, info0.coef_count, &info0.qtabs[0][0], info0.n_qtabs, info0.layout,
-                                               info0.n_comp, cnt, info0.width, info0.height, dst, dst_fs, HVC_MEM_DEVICE)
-                    : hvc_decode_frames(c, P.coefs, info0.coef_count, &info0.qtabs[0][0], info0.n_qtabs, info0.layout,
-                                        info0.n_comp, cnt, dst, dst_fs, HVC_MEM_DEVICE);
+        rc = yuv444 ? decode_frames_yuv444_impl(c, P.coefs, info0.coef_count, &info0.qtabs[0][0], info0.n_qtabs, info0.layout,
+                                                info0.n_comp, cnt, info0.width, info0.height, dst, dst_fs, HVC_MEM_DEVICE,
+                                                P.dc_plane, P.dc_fs)
+                    : decode_frames_impl(c, P.coefs, info0.coef_count, &info0.qtabs[0][0], info0.n_qtabs, info0.layout,
+                                         info0.n_comp, cnt, dst, dst_fs, HVC_MEM_DEVICE, P.dc_plane, P.dc_fs);
         if (rc) break;
         he = hipEventRecord(c->ev_et[slot][2], compute);
         if (he == hipSuccess && where == HVC_MEM_HOST) { // the downloader takes over

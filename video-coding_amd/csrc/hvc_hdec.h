@@ -90,6 +90,9 @@ struct HdParams {
     unsigned long long *exit_c;
     unsigned *list0, *list1, *list_n; // [total_sub], [total_sub], [HVC_HD_LIST_N]
     int16_t *dcd;              // [n_frames * blocks_per_frame] DC differences in scan order (k_hd_write2 -> k_hd_dc), or null
+    int16_t *dc_plane;         // null: k_hd_dc puts the DC values into the records.  Otherwise into this compact array,
+    size_t dc_fs;              //   dc_plane[frame * dc_fs + (block's coefficient offset in the frame record) / 64] -- what
+                               //   DecodeParams::dc_plane reads; the records then keep the DC DIFFERENCE in coefficient 0
     unsigned *nblk;            // blocks completed inside the subsequence, then (scan) index of its first block
     unsigned *frame_blocks;    // [n_frames] blocks found in the whole segment
     unsigned *changed;         // [1]

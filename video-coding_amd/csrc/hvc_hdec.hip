@@ -29,6 +29,7 @@
 // verifies the hand-overs and finishes what takes more rounds than k_hd_sync is given.
 #include "hvc_hdec.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace hvc {
@@ -806,7 +807,10 @@ __global__ __launch_bounds__(1024) void k_hd_dc(HdParams P) {
         const int dc = carry_s + wbase + incl;
         if (o < n) {
             if (dc < -32768 || dc > 32767) bad = true;
-            *dcp = (int16_t)dc;
+            if (P.dc_plane) // 2 bytes into a compact array instead of 2 bytes into a 128-byte record (a partial-line write each)
+                P.dc_plane[(size_t)frame * P.dc_fs + (size_t)((dcp - (P.coefs + (size_t)frame * P.coef_fs)) >> 6)] = (int16_t)dc;
+            else
+                *dcp = (int16_t)dc;
         }
         __syncthreads();
         if (lane == 1023) carry_s = dc;
@@ -891,7 +895,13 @@ static hipError_t launch_hd_round_t(const HdParams &P, int round, hipStream_t s)
         }
         // (fewer list rounds for a single file's few thousand subsequences -- leaving the slow stretches to
         // k_hd_round's inner rounds earlier -- was tried: 10-25 % slower)
-        for (int r = 0; r < SYNC_ROUNDS; r++) {
+        // HVC_HD_SYNC_ROUNDS=n (experiments): fewer list rounds, leaving more to k_hd_round's inner rounds
+        static const int rounds = [] {
+            const char *v = getenv("HVC_HD_SYNC_ROUNDS");
+            const int n = v ? atoi(v) : SYNC_ROUNDS;
+            return n < 2 ? 2 : n > SYNC_ROUNDS ? SYNC_ROUNDS : n;
+        }();
+        for (int r = 0; r < rounds; r++) {
             // the lists shrink by about half a round; a grid-stride loop takes whatever is there
             const unsigned grid = r < 2 ? all : min(all, r < 4 ? 2048u : 512u);
             hipLaunchKernelGGL(k_hd_sync<PF>, dim3(grid), dim3(SYNC_WG), 0, s, P, r);

@@ -51,6 +51,12 @@ struct DecodeParams {
     unsigned *fix_count;       // device: number of entries in fix_list (this call's counter)
     unsigned *fix_count_next;  // device: the next call's counter, cleared by this call's wide kernel
     unsigned *fix_list;   // device: global block ids needing the wide kernel
+    // Optional (batch pipeline behind the GPU Huffman reader): the blocks' absolute DC values in a compact array,
+    // dc_plane[frame * dc_fs + (block's coefficient offset inside the frame record) / 64], read INSTEAD of coefficient
+    // 0 of the record (which then holds the DC difference as the reader's write pass left it): the reader's DC pass
+    // writes 2 bytes per block into a compact array instead of 2 bytes into every 128-byte record.
+    const int16_t *dc_plane;
+    size_t dc_fs;
 };
 
 struct EncodeParams {
@@ -102,6 +108,8 @@ struct Decode444Params {
     unsigned qpair[HVC_MAX_QTABS * 32];
     int ethr_packed[HVC_MAX_QTABS];
     unsigned *fix_count, *fix_count_next, *fix_list;
+    const int16_t *dc_plane; // as in DecodeParams
+    size_t dc_fs;
 };
 
 // k0/k1 (optional): events recorded right before / after the dominant kernel.

@@ -469,7 +469,8 @@ __device__ __forceinline__ void ashr14_sat_pack2(unsigned &dst, int a, int b) {
 // A macro, not a function: spelled inline, hipcc 7.2 schedules the kernel for <= 4 waves/SIMD
 // (116 VGPRs, rows interleaved); through an (always-inlined) function it settles on 64 VGPRs /
 // 8 waves, measured 6 % slower on the same box (1.764 vs 1.660 ms per 1024-frame launch).
-#define HVC_DECODE_BLOCK_PACKED(SRC, QP, OUT, G)                                                        \
+// PRE: statements run on the loaded dwords w[] before anything reads them (the DC override of DecodeParams::dc_plane).
+#define HVC_DECODE_BLOCK_PACKED(SRC, QP, OUT, G, PRE)                                                   \
     do {                                                                                                \
         unsigned w[32];                                                                                 \
         _Pragma("unroll") for (int j = 0; j < 8; j++) {                                                 \
@@ -479,6 +480,7 @@ __device__ __forceinline__ void ashr14_sat_pack2(unsigned &dst, int a, int b) {
             w[4 * j + 2] = t.z;                                                                         \
             w[4 * j + 3] = t.w;                                                                         \
         }                                                                                               \
+        PRE                                                                                             \
         _Pragma("unroll") for (int d = 0; d < 32; d++) (G).energy = dot2_sat(w[d], w[d], (G).energy);   \
         /* rows in the order that completes one column operand pair per two rows */                    \
         unsigned cA[8], cB[8], cC[8], cZ[8];                                                            \
@@ -515,6 +517,12 @@ __device__ __forceinline__ bool packed_guard_failed(const PackedGuard &g, int et
     return (g.energy > ethr) | (g.renergy >= GUARD_RE) | (g.ymax > GUARD_Y) | (g.ymin < -GUARD_Y);
 }
 
+// coefficient 0 (the low half of the first dword) replaced by the block's entry of the compact DC array
+__device__ __forceinline__ unsigned with_dc(unsigned w0, int16_t dc) { return (w0 & 0xffff0000u) | (unsigned)(unsigned short)dc; }
+
+// DCP: the DC comes from DecodeParams::dc_plane (the instantiation the batch pipeline behind the GPU Huffman reader
+// launches); the default instantiation is the kernel as it always was.
+template <bool DCP>
 __global__ __launch_bounds__(HVC_PACKED_LB) void k_decode_packed(DecodeParams P) {
     BlockRef br;
     const int lane = threadIdx.x;
@@ -523,7 +531,9 @@ __global__ __launch_bounds__(HVC_PACKED_LB) void k_decode_packed(DecodeParams P)
     const unsigned *__restrict__ qp = P.qpair + br.qtab * 32; // wave-uniform, kernarg segment
     PackedGuard g;
     unsigned out[8][2];
-    HVC_DECODE_BLOCK_PACKED(src, qp, out, g);
+    int16_t dcv = 0;
+    if (DCP) dcv = P.dc_plane[(size_t)blockIdx.y * P.dc_fs + ((br.coef_idx - (size_t)blockIdx.y * P.coef_fs) >> 6)];
+    HVC_DECODE_BLOCK_PACKED(src, qp, out, g, if (DCP) w[0] = with_dc(w[0], dcv););
 
     const bool bad = packed_guard_failed(g, P.ethr_packed[br.qtab]);
     if (active && !bad) {
@@ -759,6 +769,8 @@ __global__ __launch_bounds__(64) void k_decode_wide(DecodeParams P, const unsign
         int64_t v[64];
         const int16_t *cf = P.coefs + br.coef_idx;
         for (int k = 0; k < 64; k++) v[ZI[k]] = (int64_t)cf[k] * (int64_t)q[k];
+        if (P.dc_plane) // the DC lives in the compact array (DecodeParams::dc_plane)
+            v[0] = (int64_t)P.dc_plane[(size_t)frame * P.dc_fs + ((br.coef_idx - (size_t)frame * P.coef_fs) >> 6)] * (int64_t)q[0];
         for (int r = 0; r < 8; r++) idct_1d_wide<false>(v + r * 8, 1);
         for (int c = 0; c < 8; c++) idct_1d_wide<true>(v + c, 8);
         for (int j = 0; j < 8; j++)
@@ -893,19 +905,21 @@ __device__ __forceinline__ void emit_rows444(uint8_t *row_even, size_t W, int x0
                      __builtin_amdgcn_perm(q1, v1, LO), __builtin_amdgcn_perm(q1, v1, HI));
 }
 
-template <bool ALIGNED>
+template <bool ALIGNED, bool DCP>
 __global__ __launch_bounds__(HVC_PACKED_LB) void k_decode_444(Decode444Params P) {
     __shared__ uint4 edge[HVC_TILE]; // per lane: first row (x, y) and first column (z, w) of its chroma block
     const int lane = threadIdx.x;
     const bool chroma = (int)blockIdx.x >= P.y_tiles; // workgroup-uniform
     const Ref444 r = locate444(P, blockIdx.x, lane);
     const Plane444K &K = P.pl[r.p];
-    const uint4 *src = reinterpret_cast<const uint4 *>(P.coefs + (size_t)blockIdx.y * P.coef_fs + K.coef_off +
-                                                       ((size_t)r.by * K.bw + r.bx) * 64);
+    const size_t in_frame = K.coef_off + ((size_t)r.by * K.bw + r.bx) * 64; // the block's place in the frame record
+    const uint4 *src = reinterpret_cast<const uint4 *>(P.coefs + (size_t)blockIdx.y * P.coef_fs + in_frame);
     const unsigned *__restrict__ qp = P.qpair + K.qtab * 32;
     PackedGuard g;
     unsigned out[8][2];
-    HVC_DECODE_BLOCK_PACKED(src, qp, out, g);
+    int16_t dcv = 0;
+    if (DCP) dcv = P.dc_plane[(size_t)blockIdx.y * P.dc_fs + (in_frame >> 6)];
+    HVC_DECODE_BLOCK_PACKED(src, qp, out, g, if (DCP) w[0] = with_dc(w[0], dcv););
     const bool bad = packed_guard_failed(g, P.ethr_packed[K.qtab]);
 
     const size_t W = (size_t)P.width;
@@ -998,8 +1012,10 @@ __global__ __launch_bounds__(64) void k_decode_wide_444(Decode444Params P, const
         const Plane444K &K = P.pl[r.p];
         const int *q = P.qt + K.qtab * 64;
         int64_t v[64];
-        const int16_t *cf = P.coefs + frame * P.coef_fs + K.coef_off + ((size_t)r.by * K.bw + r.bx) * 64;
+        const size_t in_frame = K.coef_off + ((size_t)r.by * K.bw + r.bx) * 64;
+        const int16_t *cf = P.coefs + frame * P.coef_fs + in_frame;
         for (int k = 0; k < 64; k++) v[ZI[k]] = (int64_t)cf[k] * (int64_t)q[k];
+        if (P.dc_plane) v[0] = (int64_t)P.dc_plane[frame * P.dc_fs + (in_frame >> 6)] * (int64_t)q[0];
         for (int rr = 0; rr < 8; rr++) idct_1d_wide<false>(v + rr * 8, 1);
         for (int c = 0; c < 8; c++) idct_1d_wide<true>(v + c, 8);
         uint8_t *plane = P.out + frame * P.out_fs + K.out_off;
@@ -1457,12 +1473,15 @@ hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0, hi
         return !v ? 0 : (v[0] == 'v' && v[1] == '2') ? 1 : (v[0] == 'q') ? 3 : 0;
     }();
     const int sel = P.kernel_sel ? P.kernel_sel : env_sel;
+    if (P.dc_plane && sel != 0) return hipErrorInvalidValue; // (the A/B alternates read the DC from the record: hvc_capi.hip never combines them)
     if (sel == 3)
         hipLaunchKernelGGL(k_decode_q16, grid, dim3(HVC_TILE), 0, s, P);
     else if (sel == 1)
         hipLaunchKernelGGL(k_decode_fast, grid, dim3(HVC_TILE), 0, s, P);
+    else if (P.dc_plane)
+        hipLaunchKernelGGL(k_decode_packed<true>, grid, dim3(HVC_TILE), 0, s, P);
     else
-        hipLaunchKernelGGL(k_decode_packed, grid, dim3(HVC_TILE), 0, s, P);
+        hipLaunchKernelGGL(k_decode_packed<false>, grid, dim3(HVC_TILE), 0, s, P);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (k1 && (e = hipEventRecord(k1, s)) != hipSuccess) return e;
@@ -1497,10 +1516,14 @@ hipError_t launch_decode_444(const Decode444Params &P, bool wide_only, hipStream
     const size_t W = (size_t)P.width;
     const bool aligned = (W % 16 == 0) && (P.out_fs % 16 == 0) && ((uintptr_t)P.out % 16 == 0);
     if (k0) (void)hipEventRecord(k0, s);
-    if (aligned)
-        hipLaunchKernelGGL(k_decode_444<true>, grid, dim3(HVC_TILE), 0, s, P);
+    if (aligned && P.dc_plane)
+        hipLaunchKernelGGL((k_decode_444<true, true>), grid, dim3(HVC_TILE), 0, s, P);
+    else if (aligned)
+        hipLaunchKernelGGL((k_decode_444<true, false>), grid, dim3(HVC_TILE), 0, s, P);
+    else if (P.dc_plane)
+        hipLaunchKernelGGL((k_decode_444<false, true>), grid, dim3(HVC_TILE), 0, s, P);
     else
-        hipLaunchKernelGGL(k_decode_444<false>, grid, dim3(HVC_TILE), 0, s, P);
+        hipLaunchKernelGGL((k_decode_444<false, false>), grid, dim3(HVC_TILE), 0, s, P);
     if (k1) (void)hipEventRecord(k1, s);
     hipLaunchKernelGGL(k_decode_wide_444, dim3(256), dim3(64), 0, s, P, (const unsigned *)P.fix_count,
                        (const unsigned *)P.fix_list, 0ull);
