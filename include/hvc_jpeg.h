@@ -83,6 +83,18 @@ HVC_API const char *hvc_strerror(int code);
 HVC_API int hvc_last_hip_error(const hvc_ctx *ctx);
 HVC_API const char *hvc_version(void);
 
+/* The host threads of the batch pipelines (hvc_jpeg_decode_batch*, hvc_jpeg_encode_batch*, the download threads of
+ * the host-buffer entry points): which CPUs they may run on.  No counterpart in the reference (the model is one
+ * thread); it matters on a node with eight GPUs, where eight contexts each start `threads` workers: left alone they
+ * wander over both sockets, away from the pinned rings they fill and from their GPU's PCIe root.
+ *   cpulist  Linux list format, "0-15,32-47"; "auto" = the CPUs local to the context's GPU (the local_cpulist of its
+ *            PCI function in sysfs: its NUMA node); NULL or "" = no restriction (the default).
+ * CPUs outside the process's own affinity mask are dropped; HVC_E_INVALID_ARG for a malformed list or one that leaves
+ * nothing.  The environment variable HVC_HOST_CPUS, if set, is applied by hvc_create in the same way (an unusable
+ * value is ignored there).  hvc_get_host_cpus reports the list in force ("" = none) and the number of CPUs in it. */
+HVC_API int hvc_set_host_cpus(hvc_ctx *ctx, const char *cpulist);
+HVC_API int hvc_get_host_cpus(const hvc_ctx *ctx, char *out, size_t cap, int *n_cpus);
+
 /* Use an existing HIP stream (hipStream_t passed as void*) so that a host runtime can order this
  * library's kernels with its own work; torch.cuda.current_stream().cuda_stream is such a handle.
  * NULL is a stream too -- HIP's default (null) stream, which is what PyTorch's default stream is --

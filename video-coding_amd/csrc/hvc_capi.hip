@@ -2,6 +2,8 @@
 // Host-side plumbing only: argument checking, geometry -> kernel parameter
 // blocks, staging for host-memory callers, streams and events.
 #include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <sched.h>
 
 #include <atomic>
 #include <chrono>
@@ -64,6 +66,10 @@ struct hvc_ctx {
     size_t gd_ftabs_cap = 0;
     void *gd_dcv = nullptr;   // batch pipeline: the blocks' DC values as a compact array (hvc::DecodeParams::dc_plane)
     size_t gd_dcv_cap = 0;
+    // hvc_set_host_cpus: the CPUs the batch pipelines' host threads may run on (empty = no restriction)
+    bool have_cpus = false;
+    cpu_set_t cpus;
+    char cpulist[256] = "";
     hvc::HdTables *gd_tables_host = nullptr; // what gd_tables holds (value tables; the HdSpec behind them follows from these)
     bool gd_tables_valid = false;
     int gd_tables_ncomp = 0;
@@ -103,6 +109,39 @@ int fail_hip(hvc_ctx *c, hipError_t e) {
         hipError_t e_ = (call);                         \
         if (e_ != hipSuccess) return fail_hip((c), e_); \
     } while (0)
+
+// Every host thread a batch pipeline starts calls this first (hvc_set_host_cpus); false = the restriction could not
+// be applied (the batch call then fails rather than run somewhere it was told not to).
+bool pin_to_ctx_cpus(const hvc_ctx *c) {
+    if (!c->have_cpus) return true;
+    return pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &c->cpus) == 0;
+}
+
+// Linux cpulist format ("0-15,32-47") -> cpu_set_t; false on a syntax error, an empty set or a CPU beyond CPU_SETSIZE
+bool parse_cpulist(const char *s, cpu_set_t &set) {
+    CPU_ZERO(&set);
+    int n = 0;
+    while (*s) {
+        while (*s == ' ' || *s == '\n') s++;
+        if (!*s) break;
+        char *end = nullptr;
+        const long a = std::strtol(s, &end, 10);
+        if (end == s || a < 0) return false;
+        long b = a;
+        s = end;
+        if (*s == '-') {
+            b = std::strtol(s + 1, &end, 10);
+            if (end == s + 1 || b < a) return false;
+            s = end;
+        }
+        if (b >= CPU_SETSIZE) return false;
+        for (long k = a; k <= b; k++) CPU_SET((int)k, &set), n++;
+        while (*s == ' ' || *s == '\n') s++;
+        if (*s == ',') s++;
+        else if (*s) return false;
+    }
+    return n > 0;
+}
 
 int grow(hvc_ctx *c, void **p, size_t *cap, size_t need) {
     if (need <= *cap) return HVC_OK;
@@ -206,6 +245,7 @@ static int overlapped_parts(hvc_ctx *c, int n_frames, Up up, Run run, Down down)
         cnt = (int)((long long)n_frames * (k + 1) / K) - f0;
     };
     std::thread downloader([&] {
+        (void)pin_to_ctx_cpus(c);
         if (hipSetDevice(c->device) != hipSuccess) { herr.store((int)hipErrorInvalidDevice); return; }
         for (int k = 0; k < K; k++) {
             while (launched.load(std::memory_order_acquire) <= k && !herr.load()) std::this_thread::yield();
@@ -282,6 +322,7 @@ int hvc_create(hvc_ctx **out, int device) {
         return HVC_E_NO_DEVICE;
     }
     c->stream = c->own_stream;
+    if (const char *env = std::getenv("HVC_HOST_CPUS")) (void)hvc_set_host_cpus(c, env); // an unusable list leaves the threads unrestricted
     *out = c;
     return HVC_OK;
 }
@@ -363,6 +404,49 @@ void hvc_destroy(hvc_ctx *c) {
 }
 
 int hvc_last_hip_error(const hvc_ctx *c) { return c ? c->last_hip : 0; }
+
+int hvc_set_host_cpus(hvc_ctx *c, const char *cpulist) {
+    if (!c) return HVC_E_INVALID_ARG;
+    if (!cpulist || !*cpulist) {
+        c->have_cpus = false;
+        c->cpulist[0] = 0;
+        return HVC_OK;
+    }
+    char buf[sizeof c->cpulist];
+    if (!std::strcmp(cpulist, "auto")) { // the CPUs of the NUMA node the context's GPU hangs off (sysfs, through its PCI address)
+        DeviceGuard g(c->device);
+        char bus[64] = "", path[160];
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, c->device) != hipSuccess) return HVC_E_INVALID_ARG;
+        for (char *p = bus; *p; p++) *p = (char)((*p >= 'A' && *p <= 'Z') ? *p - 'A' + 'a' : *p); // sysfs spells it in lower case
+        std::snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bus);
+        FILE *f = std::fopen(path, "r");
+        if (!f) return HVC_E_INVALID_ARG;
+        const bool got = std::fgets(buf, (int)sizeof buf, f) != nullptr;
+        std::fclose(f);
+        if (!got) return HVC_E_INVALID_ARG;
+        cpulist = buf;
+    }
+    cpu_set_t set, allowed;
+    if (std::strlen(cpulist) >= sizeof c->cpulist || !parse_cpulist(cpulist, set)) return HVC_E_INVALID_ARG;
+    // only CPUs this process may use at all (a container's cpuset): an empty intersection is an error
+    if (sched_getaffinity(0, sizeof allowed, &allowed) == 0) {
+        CPU_AND(&set, &set, &allowed);
+        if (CPU_COUNT(&set) == 0) return HVC_E_INVALID_ARG;
+    }
+    c->cpus = set;
+    c->have_cpus = true;
+    std::snprintf(c->cpulist, sizeof c->cpulist, "%s", cpulist);
+    for (char *p = c->cpulist; *p; p++)
+        if (*p == '\n') *p = 0;
+    return HVC_OK;
+}
+
+int hvc_get_host_cpus(const hvc_ctx *c, char *out, size_t cap, int *n_cpus) {
+    if (!c || (!out && cap)) return HVC_E_INVALID_ARG;
+    if (out && cap) std::snprintf(out, cap, "%s", c->have_cpus ? c->cpulist : "");
+    if (n_cpus) *n_cpus = c->have_cpus ? CPU_COUNT(&c->cpus) : 0;
+    return HVC_OK;
+}
 
 // Work enqueued on the stream the context leaves is drained first: device-memory calls return while their kernels
 // run, the scratch they use (fix-up list and counters, staging buffers) is re-grown and re-used in the order of ONE
@@ -1315,6 +1399,7 @@ static int decode_batch_impl(hvc_ctx *c, const uint8_t *const *jpegs, const size
     int released_upto = NB - 1; // chunks 0..NB-1 may be written at once
     std::atomic<long long> entropy_ns{0};
     auto worker = [&]() {
+        if (!pin_to_ctx_cpus(c)) error.store(HVC_E_INVALID_ARG); // hvc_set_host_cpus
         for (;;) {
             const int f = next_frame.fetch_add(1);
             if (f >= n_frames || error.load()) return;
@@ -1925,6 +2010,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     std::atomic<long long> prep_ns{0};
     auto worker = [&]() {
         hvc::HdTables t;
+        if (!pin_to_ctx_cpus(c)) error.store(HVC_E_INVALID_ARG); // hvc_set_host_cpus
         for (;;) {
             const int f = next_frame.fetch_add(1);
             if (f >= n_frames || error.load()) return;
@@ -1974,6 +2060,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     std::thread downloader;
     if (where == HVC_MEM_HOST) {
         downloader = std::thread([&] {
+            (void)pin_to_ctx_cpus(c);
             if (hipSetDevice(c->device) != hipSuccess) { dl_err.store((int)hipErrorInvalidDevice); return; }
             for (int k = 0; k < n_chunks; k++) {
                 {
@@ -2398,6 +2485,7 @@ static int encode_batch_impl(hvc_ctx *c, const uint8_t *const *frames, int n_fra
     std::vector<int> pads_done((size_t)n_chunks, 0), ent_done((size_t)n_chunks, 0);
     std::atomic<long long> pad_ns{0}, ent_ns{0};
     auto worker = [&]() {
+        if (!pin_to_ctx_cpus(c)) error.store(HVC_E_INVALID_ARG); // hvc_set_host_cpus
         for (;;) {
             Task t;
             {

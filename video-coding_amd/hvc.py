@@ -21,7 +21,7 @@ SYMBOLS = [
     "hvc_jpeg_read_header", "hvc_jpeg_entropy_decode", "hvc_jpeg_get_yuv_frame", "hvc_jpeg_decode",
     "hvc_jpeg_decode_batch", "hvc_quant_table", "hvc_jpeg_encoder_layout", "hvc_jpeg_entropy_encode",
     "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444", "hvc_jpeg_decode_yuv444", "hvc_compare_planes", "hvc_jpeg_encode_batch", "hvc_jpeg_decode_batch_yuv444", "hvc_jpeg_encoder_check", "hvc_huffman_encode_frames", "hvc_jpeg_header", "hvc_jpeg_encode_batch_gpu", "hvc_jpeg_entropy_decode_gpu", "hvc_jpeg_decode_batch_gpu",
-    "hvc_checksum_records", "hvc_encode_frames_recon",
+    "hvc_checksum_records", "hvc_encode_frames_recon", "hvc_set_host_cpus", "hvc_get_host_cpus",
 ]
 
 
@@ -141,6 +141,8 @@ def lib():
         L.hvc_jpeg_entropy_encode.argtypes = [ip, vp, vp, sz, C.POINTER(sz)]
         L.hvc_jpeg_encode.argtypes = [vp, vp, vp, vp, i, i, i, i, vp, sz, C.POINTER(sz)]
         L.hvc_checksum_records.argtypes = [vp, vp, sz, sz, i, vp, i]
+        L.hvc_set_host_cpus.argtypes = [vp, C.c_char_p]
+        L.hvc_get_host_cpus.argtypes = [vp, C.c_char_p, sz, C.POINTER(i)]
         L.hvc_encode_frames_recon.argtypes = [vp, vp, sz, vp, i, C.POINTER(Component), i, i, vp, sz, vp, vp, i]
         L.hvc_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
         L.hvc_device_free.argtypes = [vp, vp]
@@ -284,6 +286,15 @@ class Context:
 
     def synchronize(self):
         _chk(lib().hvc_synchronize(self._h))
+
+    def set_host_cpus(self, cpulist):
+        """which CPUs the batch pipelines' host threads may run on: "0-15,32-47", "auto" (the GPU's NUMA node), None"""
+        _chk(lib().hvc_set_host_cpus(self._h, cpulist.encode() if cpulist else None), "hvc_set_host_cpus(%r)" % (cpulist,))
+
+    def get_host_cpus(self):
+        buf, n = C.create_string_buffer(256), C.c_int()
+        _chk(lib().hvc_get_host_cpus(self._h, buf, 256, C.byref(n)))
+        return buf.value.decode(), n.value
 
     def timer_begin(self):
         _chk(lib().hvc_timer_begin(self._h))
