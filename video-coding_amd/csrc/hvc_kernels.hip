@@ -905,8 +905,13 @@ __device__ __forceinline__ void emit_rows444(uint8_t *row_even, size_t W, int x0
                      __builtin_amdgcn_perm(q1, v1, LO), __builtin_amdgcn_perm(q1, v1, HI));
 }
 
+#ifdef HVC_444_WAVES /* experiments: -DHVC_444_WAVES=4 */
+#define HVC_444_ATTR __attribute__((amdgpu_waves_per_eu(HVC_444_WAVES, HVC_444_WAVES)))
+#else
+#define HVC_444_ATTR
+#endif
 template <bool ALIGNED, bool DCP>
-__global__ __launch_bounds__(HVC_PACKED_LB) void k_decode_444(Decode444Params P) {
+__global__ __launch_bounds__(HVC_PACKED_LB) HVC_444_ATTR void k_decode_444(Decode444Params P) {
     __shared__ uint4 edge[HVC_TILE]; // per lane: first row (x, y) and first column (z, w) of its chroma block
     const int lane = threadIdx.x;
     const bool chroma = (int)blockIdx.x >= P.y_tiles; // workgroup-uniform
@@ -1227,7 +1232,15 @@ __device__ __forceinline__ int quant1(int f, float r) {
 #ifndef HVC_ENCODE_LB
 #define HVC_ENCODE_LB HVC_TILE
 #endif
-__global__ __launch_bounds__(HVC_ENCODE_LB) void k_encode(EncodeParams P) {
+#ifdef HVC_ENCODE_WAVES /* experiments: -DHVC_ENCODE_WAVES=4 */
+#define HVC_ENCODE_ATTR __attribute__((amdgpu_waves_per_eu(HVC_ENCODE_WAVES, HVC_ENCODE_WAVES)))
+#else
+#define HVC_ENCODE_ATTR
+#endif
+#ifndef HVC_ENCODE_NT
+#define HVC_ENCODE_NT 0 /* experiments: non-temporal stores of the 1 KiB runs */
+#endif
+__global__ __launch_bounds__(HVC_ENCODE_LB) HVC_ENCODE_ATTR void k_encode(EncodeParams P) {
     BlockRef br;
     const int lane = threadIdx.x;
     const bool active = locate(P, blockIdx.y, blockIdx.x, lane, br);
@@ -1288,7 +1301,13 @@ __global__ __launch_bounds__(HVC_ENCODE_LB) void k_encode(EncodeParams P) {
     for (int j = 0; j < 8; j++) {
         const int blk = 8 * j + (l >> 3), ch = l & 7;
         const u4v t = lds[wv][blk * 8 + (ch ^ (blk & 7))];
-        if (wave_b0 + blk < br.nblk) dst[j * 64 + l] = t;
+        if (wave_b0 + blk < br.nblk) {
+#if HVC_ENCODE_NT
+            __builtin_nontemporal_store(t, dst + j * 64 + l);
+#else
+            dst[j * 64 + l] = t;
+#endif
+        }
     }
 }
 
@@ -1516,10 +1535,12 @@ hipError_t launch_decode_444(const Decode444Params &P, bool wide_only, hipStream
     const size_t W = (size_t)P.width;
     const bool aligned = (W % 16 == 0) && (P.out_fs % 16 == 0) && ((uintptr_t)P.out % 16 == 0);
     if (k0) (void)hipEventRecord(k0, s);
+    // HVC_444_LDS_PAD=bytes (experiments): dynamic LDS nobody uses, to hold the kernel to fewer workgroups per CU
+    static const unsigned pad = [] { const char *v = getenv("HVC_444_LDS_PAD"); return v ? (unsigned)atoi(v) : 0u; }();
     if (aligned && P.dc_plane)
-        hipLaunchKernelGGL((k_decode_444<true, true>), grid, dim3(HVC_TILE), 0, s, P);
+        hipLaunchKernelGGL((k_decode_444<true, true>), grid, dim3(HVC_TILE), pad, s, P);
     else if (aligned)
-        hipLaunchKernelGGL((k_decode_444<true, false>), grid, dim3(HVC_TILE), 0, s, P);
+        hipLaunchKernelGGL((k_decode_444<true, false>), grid, dim3(HVC_TILE), pad, s, P);
     else if (P.dc_plane)
         hipLaunchKernelGGL((k_decode_444<false, true>), grid, dim3(HVC_TILE), 0, s, P);
     else
@@ -1544,7 +1565,8 @@ hipError_t launch_encode(const EncodeParams &P, hipStream_t s, hipEvent_t k0, hi
     hipError_t e;
     dim3 grid((unsigned)P.tiles_per_frame, (unsigned)P.n_frames, 1);
     if (k0 && (e = hipEventRecord(k0, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_encode, grid, dim3(HVC_TILE), 0, s, P);
+    static const unsigned pad = [] { const char *v = getenv("HVC_ENC_LDS_PAD"); return v ? (unsigned)atoi(v) : 0u; }(); // experiments
+    hipLaunchKernelGGL(k_encode, grid, dim3(HVC_TILE), pad, s, P);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (k1 && (e = hipEventRecord(k1, s)) != hipSuccess) return e;
