@@ -401,3 +401,71 @@ def test_a_million_blocks_within_one_per_cent_of_each_guard_limit(ctx):
     # one already -- the coefficient energy binds first for most tables -- so the int64 side is the larger one: about
     # 9 in 10; the blocks aimed at a block's binding guard land on both sides of it.)
     assert took_wide > 50_000 and took_fast > 50_000, (took_wide, took_fast)
+
+
+def test_batches_cut_into_several_launches_give_the_same_bytes():
+    """Device-memory batches above HVC_LAUNCH_BYTES (default 10 GB of algorithmic bytes) are cut into equal launches
+    (hvc_capi.hip launch_bytes_limit: launches beyond ~3 ms run 2-3 % slower).  With the limit set to 1 MB a 23-frame
+    batch becomes a dozen launches: decode (with blocks for the fix-up list in several parts), fused 4:4:4 and encode
+    must give the bytes of the one-launch form.  The variable is read once per process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, "tests")
+import numpy as np, torch
+from helpers import synth_pixels
+from oracle import orc
+import video_coding_amd as hvc
+c = hvc.Context(0)
+c.set_stream(torch.cuda.current_stream().cuda_stream)
+planes = [(20, 12, 0), (10, 6, 1), (10, 6, 1)]
+specs, cfs, pfs = hvc.hvc.frame_layout(planes)
+qt = np.stack([orc.quant_scale(orc.quant_luma(), 75), orc.quant_scale(orc.quant_chroma(), 75)]).astype(np.uint16)
+n = 23
+rng = np.random.Generator(np.random.PCG64(3))
+pix = np.stack([np.concatenate([synth_pixels(100 * f + i, bh * 8, bw * 8).reshape(-1) for i, (bw, bh, _) in enumerate(planes)]) for f in range(n)])
+coefs = np.zeros((n, cfs), np.int16)
+want_pix = np.zeros((n, pfs), np.uint8)
+for f in range(n):
+    for s, (bw, bh, q) in zip(specs, planes):
+        p = pix[f, s["plane_offset"]:s["plane_offset"] + bw * bh * 64].reshape(bh * 8, bw * 8)
+        cf = orc.fdct_quant(p, qt[q], bw, bh).reshape(-1)
+        if f % 5 == 2:   # adversarial blocks: the fix-up list has entries in several of the launches
+            cf = rng.integers(-2047, 2048, size=cf.size).astype(np.int16)
+        coefs[f, s["coef_offset"]:s["coef_offset"] + cf.size] = cf
+        want_pix[f, s["plane_offset"]:s["plane_offset"] + bw * bh * 64] = orc.dequant_idct_recon(cf, qt[q], bw, bh)
+d_c = torch.from_numpy(coefs).cuda()
+d_p = torch.zeros((n, pfs), dtype=torch.uint8, device="cuda")
+c.decode_frames(d_c, cfs, qt, specs, n, d_p, pfs)
+c.synchronize()
+assert np.array_equal(d_p.cpu().numpy(), want_pix), "decode"
+assert c.last_wide_blocks() > 0
+# encode
+d_x = torch.from_numpy(pix).cuda()
+d_o = torch.zeros((n, cfs), dtype=torch.int16, device="cuda")
+c.encode_frames(d_x, pfs, qt, specs, n, d_o, cfs)
+c.synchronize()
+got = d_o.cpu().numpy()
+for f in range(n):
+    for s, (bw, bh, q) in zip(specs, planes):
+        p = pix[f, s["plane_offset"]:s["plane_offset"] + bw * bh * 64].reshape(bh * 8, bw * 8)
+        assert np.array_equal(got[f, s["coef_offset"]:s["coef_offset"] + bw * bh * 64], orc.fdct_quant(p, qt[q], bw, bh).reshape(-1)), ("encode", f)
+# fused 4:4:4 against the host-memory form (one part: below 64 MB it is a single launch... of the same entry point)
+W, H = 160, 96
+d_f = torch.zeros((n, 3 * W * H), dtype=torch.uint8, device="cuda")
+c.decode_frames_yuv444(d_c, cfs, qt, specs, n, W, H, d_f)
+c.synchronize()
+for f in range(n):
+    y = want_pix[f, :160 * 96].reshape(96, 160)
+    u = want_pix[f, 160 * 96:160 * 96 + 80 * 48].reshape(48, 80)
+    v = want_pix[f, 160 * 96 + 80 * 48:].reshape(48, 80)
+    want = np.concatenate([y.reshape(-1), orc.supersample_hv2(u).reshape(-1), orc.supersample_hv2(v).reshape(-1)])
+    assert np.array_equal(d_f[f].cpu().numpy(), want), ("444", f)
+print("split ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HVC_LAUNCH_BYTES="1000000")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "split ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -181,6 +181,29 @@ static void fix_reset(hvc_ctx *c) { // after a failed launch: both counters to z
     (void)hipMemsetAsync(c->d_fix_count, 0, 2 * sizeof(unsigned), c->stream);
 }
 
+// Launches longer than about 3 ms lose 2-3 % against back-to-back shorter ones (measured on MI355X: 1080p batches of
+// 2048 / 4096 frames per launch run at 71.9 / 71.6 % of the HBM peak, 1024-frame launches -- even 1900 of them back to
+// back over 3 s, or sixteen of them over a 154 GB resident set -- at 74.4 %; the counters show a lower clock and more
+// DRAM read-credit stalls late in a long launch, not TLB misses: DESIGN.md section 5).  So a device-memory batch is cut
+// into launches of at most this many algorithmic bytes (192 B per block); HVC_LAUNCH_BYTES overrides (experiments).
+static size_t launch_bytes_limit() {
+    static const size_t v = [] {
+        const char *e = std::getenv("HVC_LAUNCH_BYTES");
+        const double d = e ? std::atof(e) : 0.0;
+        return d >= 1e6 ? (size_t)d : (size_t)10000000000ull;
+    }();
+    return v;
+}
+// frames per launch for a batch of n_frames frames of blocks_per_frame blocks: equal parts, each within the limit
+static int frames_per_launch(int n_frames, unsigned long long blocks_per_frame) {
+    const unsigned long long fb = blocks_per_frame * 192ull;
+    unsigned long long per = fb ? launch_bytes_limit() / fb : (unsigned long long)n_frames;
+    if (per < 1) per = 1;
+    if (per >= (unsigned long long)n_frames) return n_frames;
+    const unsigned long long parts = ((unsigned long long)n_frames + per - 1) / per;
+    return (int)(((unsigned long long)n_frames + parts - 1) / parts);
+}
+
 // Geometry of one call -> CompK[]; shared by decode and encode.
 struct Layout {
     hvc::CompK comp[HVC_MAX_COMP];
@@ -681,7 +704,16 @@ static int decode_frames_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, 
         P.dc_fs = dc_fs;
         const bool prof = c->profiling && !wide_only;
         const int slot = (int)(c->k_calls % HVC_PROF_RING);
-        HIPCHK(c, launch(P, prof ? c->k0[slot] : nullptr, prof ? c->k1[slot] : nullptr));
+        const int per = frames_per_launch(n_frames, L.blocks_per_frame); // (see launch_bytes_limit)
+        for (int f0 = 0; f0 < n_frames; f0 += per) {
+            hvc::DecodeParams Pk = P;
+            Pk.n_frames = n_frames - f0 < per ? n_frames - f0 : per;
+            Pk.coefs = coefs + (size_t)f0 * coef_fs;
+            Pk.pixels = pixels + (size_t)f0 * pixel_fs;
+            if (dc_plane) Pk.dc_plane = dc_plane + (size_t)f0 * dc_fs;
+            // the event pair brackets the dominant kernel of all parts (and the few-microsecond fix-up kernels in between)
+            HIPCHK(c, launch(Pk, prof && f0 == 0 ? c->k0[slot] : nullptr, prof && f0 + per >= n_frames ? c->k1[slot] : nullptr));
+        }
         if (prof) c->k_calls++;
         return HVC_OK;
     }
@@ -853,7 +885,15 @@ static int decode_frames_yuv444_impl(hvc_ctx *c, const int16_t *coefs, size_t co
         P.dc_fs = dc_fs;
         const bool prof = c->profiling && !wide_only;
         const int slot = (int)(c->k_calls % HVC_PROF_RING);
-        HIPCHK(c, launch(P, prof ? c->k0[slot] : nullptr, prof ? c->k1[slot] : nullptr));
+        const int per = frames_per_launch(n_frames, L.blocks_per_frame); // (see launch_bytes_limit)
+        for (int f0 = 0; f0 < n_frames; f0 += per) {
+            hvc::Decode444Params Pk = P;
+            Pk.n_frames = n_frames - f0 < per ? n_frames - f0 : per;
+            Pk.coefs = coefs + (size_t)f0 * coef_fs;
+            Pk.out = frames + (size_t)f0 * frame_stride;
+            if (dc_plane) Pk.dc_plane = dc_plane + (size_t)f0 * dc_fs;
+            HIPCHK(c, launch(Pk, prof && f0 == 0 ? c->k0[slot] : nullptr, prof && f0 + per >= n_frames ? c->k1[slot] : nullptr));
+        }
         if (prof) c->k_calls++;
         return HVC_OK;
     }
@@ -961,11 +1001,17 @@ int hvc_encode_frames(hvc_ctx *c, const uint8_t *pixels, size_t pixel_fs, const 
 
     if (where == HVC_MEM_DEVICE) {
         if (((uintptr_t)coefs & 15) || ((uintptr_t)pixels & 7)) return HVC_E_ALIGNMENT;
-        P.coefs = coefs;
-        P.pixels = pixels;
         const bool prof = c->profiling;
         const int slot = (int)(c->k_calls % HVC_PROF_RING);
-        HIPCHK(c, hvc::launch_encode(P, c->stream, prof ? c->k0[slot] : nullptr, prof ? c->k1[slot] : nullptr));
+        const int per = frames_per_launch(n_frames, L.blocks_per_frame); // (see launch_bytes_limit)
+        for (int f0 = 0; f0 < n_frames; f0 += per) {
+            hvc::EncodeParams Pk = P;
+            Pk.n_frames = n_frames - f0 < per ? n_frames - f0 : per;
+            Pk.coefs = coefs + (size_t)f0 * coef_fs;
+            Pk.pixels = pixels + (size_t)f0 * pixel_fs;
+            HIPCHK(c, hvc::launch_encode(Pk, c->stream, prof && f0 == 0 ? c->k0[slot] : nullptr,
+                                         prof && f0 + per >= n_frames ? c->k1[slot] : nullptr));
+        }
         if (prof) c->k_calls++;
         return HVC_OK;
     }

@@ -469,6 +469,22 @@ __device__ __forceinline__ void ashr14_sat_pack2(unsigned &dst, int a, int b) {
 // A macro, not a function: spelled inline, hipcc 7.2 schedules the kernel for <= 4 waves/SIMD
 // (116 VGPRs, rows interleaved); through an (always-inlined) function it settles on 64 VGPRs /
 // 8 waves, measured 6 % slower on the same box (1.764 vs 1.660 ms per 1024-frame launch).
+// -DHVC_TRAFFIC_ONLY=1 (measurement builds only, never the shipped library): the kernels keep their exact memory
+// traffic -- every load, every store, the LDS exchanges -- but skip the arithmetic, so that a run shows the memory
+// ceiling of each kernel's OWN access shape.  The outputs are then garbage by construction.
+#ifndef HVC_TRAFFIC_ONLY
+#define HVC_TRAFFIC_ONLY 0
+#endif
+#if HVC_TRAFFIC_ONLY
+#define HVC_TRAFFIC_ONLY_DECODE(OUT)                                                                    \
+    _Pragma("unroll") for (int j = 0; j < 8; j++) {                                                     \
+        (OUT)[j][0] = w[4 * j] ^ w[4 * j + 2];                                                          \
+        (OUT)[j][1] = w[4 * j + 1] ^ w[4 * j + 3];                                                      \
+    }                                                                                                   \
+    break;
+#else
+#define HVC_TRAFFIC_ONLY_DECODE(OUT)
+#endif
 // PRE: statements run on the loaded dwords w[] before anything reads them (the DC override of DecodeParams::dc_plane).
 #define HVC_DECODE_BLOCK_PACKED(SRC, QP, OUT, G, PRE)                                                   \
     do {                                                                                                \
@@ -481,6 +497,7 @@ __device__ __forceinline__ void ashr14_sat_pack2(unsigned &dst, int a, int b) {
             w[4 * j + 3] = t.w;                                                                         \
         }                                                                                               \
         PRE                                                                                             \
+        HVC_TRAFFIC_ONLY_DECODE(OUT)                                                                    \
         _Pragma("unroll") for (int d = 0; d < 32; d++) (G).energy = dot2_sat(w[d], w[d], (G).energy);   \
         /* rows in the order that completes one column operand pair per two rows */                    \
         unsigned cA[8], cB[8], cC[8], cZ[8];                                                            \
@@ -1238,7 +1255,9 @@ __device__ __forceinline__ int quant1(int f, float r) {
 #define HVC_ENCODE_ATTR
 #endif
 #ifndef HVC_ENCODE_NT
-#define HVC_ENCODE_NT 0 /* experiments: non-temporal stores of the 1 KiB runs */
+// the 1 KiB runs leave as non-temporal stores: +2.5 % (1.754 -> 1.712 ms per 256 4K frames, same box, alternating
+// runs; profiles/r02e_ab.txt).  (For the lane-strided 16-byte pieces of the first version nt stores were 5x worse.)
+#define HVC_ENCODE_NT 1
 #endif
 __global__ __launch_bounds__(HVC_ENCODE_LB) HVC_ENCODE_ATTR void k_encode(EncodeParams P) {
     BlockRef br;
@@ -1255,6 +1274,10 @@ __global__ __launch_bounds__(HVC_ENCODE_LB) HVC_ENCODE_ATTR void k_encode(Encode
     }
     // Dct.Chen.forward_8x8 (dct.ml:189-196): columns first, then rows
     int v[64];
+#if HVC_TRAFFIC_ONLY
+#pragma unroll
+    for (int k = 0; k < 64; k++) v[k] = (int)((px[k >> 3][(k >> 2) & 1] >> (8 * (k & 3))) & 0xffu);
+#else
     fdct_col_bytes<0>(px, v);
     fdct_col_bytes<1>(px, v);
     fdct_col_bytes<2>(px, v);
@@ -1269,6 +1292,7 @@ __global__ __launch_bounds__(HVC_ENCODE_LB) HVC_ENCODE_ATTR void k_encode(Encode
         fdct_tail<false>(p[0] + p[7], p[1] + p[6], p[2] + p[5], p[3] + p[4], p[3] - p[4], p[2] - p[5], p[1] - p[6],
                          p[0] - p[7], p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
     }
+#endif
     // Encoder.quant (encoder.ml:103-108): quant[zz] = quant_and_scale fdct[ZI[zz]] table[zz]
     const float *__restrict__ qr = P.qrcp + br.qtab * 64;
     // A lane holds its block's 128 output bytes; storing them as eight 16-byte pieces 128 bytes apart
@@ -1286,8 +1310,13 @@ __global__ __launch_bounds__(HVC_ENCODE_LB) HVC_ENCODE_ATTR void k_encode(Encode
 #pragma unroll
         for (int h = 0; h < 4; h++) {
             const int k = j * 8 + h * 2;
+#if HVC_TRAFFIC_ONLY
+            const int lo = v[ZI[k]], hi = v[ZI[k + 1]];
+            (void)qr;
+#else
             const int lo = quant1(v[ZI[k]], qr[k]);
             const int hi = quant1(v[ZI[k + 1]], qr[k + 1]);
+#endif
             w[h] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(lo, hi)); // |q| <= 2^13: no saturation
         }
         const u4v t = {w[0], w[1], w[2], w[3]};
