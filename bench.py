@@ -138,9 +138,10 @@ def measured_traffic(config, frames):
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
-        if t.get("frames_per_launch") == frames and t.get("config", 2) == config:
-            return round(t["hbm_bytes"]), "profiles/traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
-                                          "this command, not collected in this run" % t.get("session", "r01f")
+        for e in t.get("entries", [t]):
+            if e.get("frames_per_launch") == frames and e.get("config", 2) == config:
+                return round(e["hbm_bytes"]), "profiles/traffic.json (session %s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
+                                              "this command, not collected in this run" % (e.get("session") or "r01f")
         return None, "no committed PMC pass for config %d at %d frames per launch" % (config, frames)
     except (OSError, ValueError, KeyError):
         return None, "profiles/traffic.json absent"
@@ -168,7 +169,7 @@ def dist_init(world, backend, device=None):
     """Process group for timing closure only (barrier + MAX of the elapsed time): the data path
     has no collective.  backend: "nccl" (= RCCL, one rank per GPU) or "gloo" (CPU rehearsal)."""
     import torch.distributed as dist
-    if world > 1 and not dist.is_initialized():
+    if use_group(world) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
@@ -176,26 +177,32 @@ def dist_init(world, backend, device=None):
     return dist
 
 
+def use_group(world):
+    """a process group exists: more than one rank -- or one rank started by a launcher with HVC_BENCH_DIST_ALWAYS=1,
+    which lets a one-GPU box run the RCCL calls of the N > 1 path (init, barrier, all-reduce) for real"""
+    return world > 1 or (os.environ.get("HVC_BENCH_DIST_ALWAYS") == "1" and "WORLD_SIZE" in os.environ)
+
+
 def timed_steps(step, steps, warmup, sync, world, dist=None):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + sync on both sides."""
     for _ in range(warmup):
         step()
     sync()
-    if world > 1:
+    if use_group(world):
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     sync()
-    if world > 1:
+    if use_group(world):
         dist.barrier()
     sync()
     return time.perf_counter() - t0
 
 
 def max_over_ranks(dt, world, dist=None, device="cpu"):
-    if world == 1:
+    if not use_group(world):
         return dt
     import torch
     t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -268,7 +275,7 @@ def run_without_gpu(args, rank, world):
                           "vs_baseline": None, "dtype": "int32",
                           "data": "none: launch-path rehearsal without a GPU (HVC_BENCH_NO_GPU=1), nothing decoded, not a measurement",
                           "config": {"workload": wl["name"], "step_calls_rank0": len(calls)}}), flush=True)
-    if world > 1:
+    if use_group(world):
         dist.destroy_process_group()
 
 
@@ -340,7 +347,7 @@ def main():
     want = expected_checksums(args.config, len(sums), rank) if args.distinct <= 8 else None
     frames_host = d_distinct.cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     ok_local = want is not None and sums == want
-    if world > 1:  # every rank's output is verified; rank 0 reports how many were
+    if use_group(world):  # every rank's output is verified; rank 0 reports how many were
         t = torch.tensor([1.0 if ok_local else 0.0], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         ranks_ok = int(t.item())
@@ -390,7 +397,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(frames_host, qtabs, planes, PW * PH, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if use_group(world):
         dist.destroy_process_group()
 
 

@@ -128,3 +128,19 @@ def test_contexts_by_device_index():
         with pytest.raises(hvc.HvcError) as e:
             hvc.Context(bad)
         assert e.value.code == -2
+
+
+def test_bench_rccl_calls_on_one_gpu():
+    """The N > 1 path of bench.py closes its timing with RCCL (backend "nccl"): init_process_group with the rank's
+    device, barriers, a MAX all-reduce and the SUM all-reduce of the verification flags.  A one-GPU box cannot hold two
+    RCCL ranks, but it can run exactly those calls in a world of one: the driver's launcher around bench.py with
+    one process and HVC_BENCH_DIST_ALWAYS=1."""
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    e.update(HVC_BENCH_DIST_ALWAYS="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29551", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "1", "--steps", "3", "--warmup", "1", "--frames", "64", "--no-cpu-baseline"],
+                         capture_output=True, text=True, env=e, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 1 and rec["checksum"]["ranks_verified"] == 1 and "REHEARSAL" not in rec["data"]

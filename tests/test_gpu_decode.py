@@ -405,7 +405,7 @@ def test_a_million_blocks_within_one_per_cent_of_each_guard_limit(ctx):
 
 def test_batches_cut_into_several_launches_give_the_same_bytes():
     """Device-memory batches above HVC_LAUNCH_BYTES (default 10 GB of algorithmic bytes) are cut into equal launches
-    (hvc_capi.hip launch_bytes_limit: launches beyond ~3 ms run 2-3 % slower).  With the limit set to 1 MB a 23-frame
+    (hvc_capi.hip launch_bytes_limit: launches beyond ~3 ms run 2-3 % slower).  With the limit set to 150 kB a 23-frame
     batch becomes a dozen launches: decode (with blocks for the fix-up list in several parts), fused 4:4:4 and encode
     must give the bytes of the one-launch form.  The variable is read once per process, hence the child process."""
     import os
@@ -466,6 +466,6 @@ for f in range(n):
 print("split ok")
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HVC_LAUNCH_BYTES="1000000")
+    env = dict(os.environ, HVC_LAUNCH_BYTES="150000")  # 69 KB a frame: two frames per launch
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "split ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

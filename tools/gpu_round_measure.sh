@@ -1,13 +1,17 @@
 #!/bin/bash
 # One GPU session that produces every number DESIGN.md quotes (run via gpurun from the repo root):
-#   gpurun_out/m_*.json  bench lines, gpurun_out/prof_<tag>/ rocprofv3 databases
+#   gpurun_out/m_*.json  bench lines, gpurun_out/prof_<tag>_*/ rocprofv3 databases -> gpurun_out/<tag>_*_rocprofv3.txt
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out
 python bench.py > gpurun_out/m_bench.json 2> gpurun_out/m_bench.err
+python bench.py --config 4 --no-cpu-baseline > gpurun_out/m_bench_c4.json 2> gpurun_out/m_bench_c4.err
+HVC_BENCH_REHEARSAL=1 python bench.py --gpus 2 --steps 20 --no-cpu-baseline > gpurun_out/m_bench_rehearsal2.json 2> gpurun_out/m_bench_rehearsal2.err
+python bench.py --frames 4096 --steps 20 --no-cpu-baseline > gpurun_out/m_bench_f4096.json 2> /dev/null
+python tools/bench_sustained.py > gpurun_out/m_sustained.json 2> /dev/null
 echo "bench done"
 python tools/bench_configs.py --config 3 --frames 1024 --threads 16 > gpurun_out/m_c3.json 2> gpurun_out/m_c3.err
-echo "c3 done"
 python tools/bench_configs.py --config 4 > gpurun_out/m_c4.json 2> gpurun_out/m_c4.err
 python tools/bench_configs.py --config 5 > gpurun_out/m_c5.json 2> gpurun_out/m_c5.err
 python tools/bench_configs.py --config 6 > gpurun_out/m_c6.json 2> gpurun_out/m_c6.err
@@ -18,18 +22,42 @@ HVC_DECODE_KERNEL=q16 python bench.py --no-cpu-baseline > gpurun_out/m_bench_q16
 # the file-level pipelines with the entropy stages on the GPU, the GPU Huffman coder alone, one file at a time
 python tools/bench_configs.py --config 3 --frames 1024 --threads 16 --gpu-entropy --chunk 64 > gpurun_out/m_c3_gpu_entropy.json 2> gpurun_out/m_c3g.err
 python tools/bench_configs.py --config 3 --frames 4096 --threads 16 --gpu-entropy --chunk 256 > gpurun_out/m_c3_gpu_entropy_4096.json 2>> gpurun_out/m_c3g.err
+python tools/bench_configs.py --config 3 --frames 4096 --threads 16 --gpu-entropy --chunk 256 --own-tables > gpurun_out/m_c3_gpu_entropy_4096_own_tables.json 2>> gpurun_out/m_c3g.err
+python tools/bench_configs.py --config 3 --frames 4096 --threads 16 --gpu-entropy --chunk 256 --host-out > gpurun_out/m_c3_gpu_entropy_host_out.json 2>> gpurun_out/m_c3g.err
 python tools/bench_configs.py --config 8 --gpu-entropy > gpurun_out/m_c5_files_gpu_entropy.json 2> gpurun_out/m_c5g.err
 python tools/bench_configs.py --config 9 > gpurun_out/m_huffman_gpu.json 2> gpurun_out/m_huffman_gpu.err
 python tools/bench_single.py > gpurun_out/m_single_file.jsonl 2> gpurun_out/m_single_file.err
 echo "configs done"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mem_ubench3 tools/ubench/mem_ubench3.hip 2> /dev/null
+/tmp/mem_ubench3 > gpurun_out/m_mem_ubench3.txt 2>&1 || true
+# every kernel against the memory ceiling of its own access shape (traffic-only measurement build)
+if [ -f build/variants/libhvc_traffic.so ]; then
+  T=$ROOT/build/variants/libhvc_traffic.so
+  { echo "# shipped library, then the traffic-only build (same loads / stores / LDS exchanges, no arithmetic), same box, same session"
+    for rep in 1 2; do
+      echo -n "K1 shipped      "; python bench.py --steps 40 --no-cpu-baseline | grep -o '"frac": [0-9.]*\|"kernel_ms": [0-9.]*' | paste - -
+      echo -n "K1 traffic-only "; HVC_JPEG_LIB=$T python bench.py --steps 40 --no-cpu-baseline | grep -o '"frac": [0-9.]*\|"kernel_ms": [0-9.]*' | paste - -
+      echo -n "K3 shipped      "; python tools/bench_configs.py --config 5 | grep -o '"kernel_ms": [0-9.]*\|"frac_of_8TBps": [0-9.]*' | paste - -
+      echo -n "K3 traffic-only "; HVC_JPEG_LIB=$T python tools/bench_configs.py --config 5 | grep -o '"kernel_ms": [0-9.]*\|"frac_of_8TBps": [0-9.]*' | paste - -
+      echo -n "444 shipped      "; python tools/bench_configs.py --config 7 | grep -o '"fused_ms": [0-9.]*\|"frac_of_8TBps": [0-9.]*' | paste - -
+      echo -n "444 traffic-only "; HVC_JPEG_LIB=$T python tools/bench_configs.py --config 7 | grep -o '"fused_ms": [0-9.]*\|"frac_of_8TBps": [0-9.]*' | paste - -
+    done; } > gpurun_out/m_shape_ceilings.txt 2> /dev/null
+fi
+echo "ceilings done"
 bash tools/gpu_profile.sh ${TAG}_decode
 echo "decode profile done"
+bash tools/gpu_profile.sh ${TAG}_decode_c4 --config 4 --steps 2 --warmup 1
+echo "config-4 profile done"
 bash tools/gpu_profile_cmd.sh ${TAG}_444 tools/bench_configs.py --config 7 --steps 10
 echo "444 profile done"
 bash tools/gpu_profile_cmd.sh ${TAG}_encode tools/bench_configs.py --config 5 --steps 10
 echo "encode profile done"
 bash tools/gpu_profile_cmd.sh ${TAG}_c3g tools/bench_configs.py --config 3 --frames 512 --threads 16 --gpu-entropy --chunk 256 --steps 2
 echo "reader profile done"
+bash tools/gpu_profile_cmd.sh ${TAG}_c3g_own tools/bench_configs.py --config 3 --frames 512 --threads 16 --gpu-entropy --chunk 256 --steps 2 --own-tables
+echo "reader (own tables) profile done"
+python tools/rocpd_summary.py gpurun_out/prof_${TAG}_decode --traffic k_decode_packed 1024 2 ${TAG} > gpurun_out/traffic_${TAG}.json 2> /dev/null || true
+python tools/rocpd_summary.py gpurun_out/prof_${TAG}_decode_c4 --traffic k_decode_packed 128 4 ${TAG} > gpurun_out/traffic_${TAG}_c4.json 2> /dev/null || true
 # summaries here, databases deleted: gpurun only brings back 64 MiB
 for d in gpurun_out/prof_${TAG}_*; do
     python tools/rocpd_summary.py $d > gpurun_out/$(basename $d | sed 's/^prof_//')_rocprofv3.txt 2>&1 || true

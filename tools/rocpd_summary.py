@@ -62,13 +62,7 @@ def main(d):
             print("  %-40s %-22s %16.1f  (n=%d)%s" % (kn[:40], cn, avg, n, extra))
 
 
-if __name__ == "__main__":
-    if len(sys.argv) > 2:
-        WARMUP = int(sys.argv[2])
-    main(sys.argv[1])
-
-
-def traffic_json(d, kernel_substr, frames):
+def traffic_json(d, kernel_substr, frames, config=2, session=""):
     """HBM bytes per launch of one kernel from the FETCH_SIZE / WRITE_SIZE passes, corrected as
     MI355X_MICROARCH.md prescribes (KB units; FETCH_SIZE x2 for 16 B/lane streaming reads on gfx950)."""
     out = {}
@@ -79,11 +73,17 @@ def traffic_json(d, kernel_substr, frames):
         out[name] = rows[0][0]
     fetch = out["FETCH_SIZE"] * 1024 * 2
     write = out["WRITE_SIZE"] * 1024
-    return {"kernel": kernel_substr, "frames_per_launch": frames, "fetch_bytes": fetch, "write_bytes": write,
-            "hbm_bytes": fetch + write, "source": d,
+    return {"kernel": kernel_substr, "config": config, "session": session, "frames_per_launch": frames, "fetch_bytes": fetch,
+            "write_bytes": write, "hbm_bytes": fetch + write, "source": os.path.basename(os.path.normpath(d)),
             "corrections": "FETCH_SIZE KB x1024 x2 (gfx950 16 B/lane read undercount), WRITE_SIZE KB x1024"}
 
 
-if __name__ == "__main__" and len(sys.argv) > 3 and sys.argv[2] == "--traffic":
-    import json
-    print(json.dumps(traffic_json(sys.argv[1], sys.argv[3], int(sys.argv[4])), indent=1), file=sys.stderr)
+if __name__ == "__main__":
+    if len(sys.argv) > 4 and sys.argv[2] == "--traffic":  # <dir> --traffic <kernel> <frames> [config] [session]
+        import json
+        print(json.dumps(traffic_json(sys.argv[1], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]) if len(sys.argv) > 5 else 2,
+                                      sys.argv[6] if len(sys.argv) > 6 else ""), indent=1))
+    else:
+        if len(sys.argv) > 2:
+            WARMUP = int(sys.argv[2])
+        main(sys.argv[1])

@@ -190,7 +190,7 @@ static size_t launch_bytes_limit() {
     static const size_t v = [] {
         const char *e = std::getenv("HVC_LAUNCH_BYTES");
         const double d = e ? std::atof(e) : 0.0;
-        return d >= 1e6 ? (size_t)d : (size_t)10000000000ull;
+        return d >= 1.0 ? (size_t)d : (size_t)10000000000ull;
     }();
     return v;
 }
