@@ -60,7 +60,8 @@ python tools/rocpd_summary.py gpurun_out/prof_${TAG}_decode --traffic k_decode_p
 python tools/rocpd_summary.py gpurun_out/prof_${TAG}_decode_c4 --traffic k_decode_packed 128 4 ${TAG} > gpurun_out/traffic_${TAG}_c4.json 2> /dev/null || true
 # summaries here, databases deleted: gpurun only brings back 64 MiB
 for d in gpurun_out/prof_${TAG}_*; do
-    python tools/rocpd_summary.py $d > gpurun_out/$(basename $d | sed 's/^prof_//')_rocprofv3.txt 2>&1 || true
+    case $d in *_decode) W=18;; *_decode_c4) W=32;; *) W=10;; esac   # untimed launches of the profiled command (bench.py: 8 setup + 10 warm-up)
+    python tools/rocpd_summary.py $d $W > gpurun_out/$(basename $d | sed 's/^prof_//')_rocprofv3.txt 2>&1 || true
     find $d -name '*.db' -delete
 done
 echo "summaries done"
