@@ -844,13 +844,11 @@ static int decode_frames_yuv444_impl(hvc_ctx *c, const int16_t *coefs, size_t co
     }
     // umulhi(b, ceil(2^32 / d)) == b / d needs b * d < 2^32
     if ((unsigned long long)P.pl[0].cbw * P.pl[0].cbw * P.pl[0].cbh >= (1ull << 32)) return HVC_E_TOO_LARGE;
-    P.y_tiles = (P.pl[0].cbw * P.pl[0].cbh + HVC_TILE - 1) / HVC_TILE;
-    P.y_magic = (unsigned)(((1ull << 32) + P.pl[0].cbw - 1) / P.pl[0].cbw);
-    P.c_tiles_x = P.pl[1].cbw <= HVC_444_TILE_BW ? 1 : (P.pl[1].cbw - 1 + HVC_444_TILE_STEP - 1) / HVC_444_TILE_STEP;
-    P.c_tiles_y = (P.pl[1].cbh + HVC_444_TILE_BH - 1) / HVC_444_TILE_BH;
-    P.c_magic = (unsigned)(((1ull << 32) + P.c_tiles_x - 1) / P.c_tiles_x);
-    P.tiles_per_frame = P.y_tiles + 2 * P.c_tiles_x * P.c_tiles_y;
-    const unsigned long long ids = (unsigned long long)n_frames * P.tiles_per_frame * HVC_TILE;
+    // the 16-byte store form (and with it the wide chroma tiles) needs aligned rows: device output as the caller gave it,
+    // host output through the library's own (256-byte aligned) scratch
+    const bool aligned = width % 16 == 0 && frame_stride % 16 == 0 && (where == HVC_MEM_HOST || (uintptr_t)frames % 16 == 0);
+    hvc::plan_decode_444(P, aligned);
+    const unsigned long long ids = (unsigned long long)n_frames * P.tiles_per_frame * HVC_TILE * P.nw;
     if (ids >= (1ull << 32)) return HVC_E_TOO_LARGE;
     DeviceGuard g(c->device);
     if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);

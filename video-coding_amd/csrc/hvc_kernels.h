@@ -87,9 +87,10 @@ struct Plane444K {
     size_t out_off;   // bytes from the frame's output record (plane p sits at p * W * H)
 };
 
-#define HVC_444_TILE_BW 64 /* chroma workgroup tile: 64 x 4 blocks (one block row per wave) */
+/* chroma workgroup tile of the fused kernel: (64 * nw) x 4 blocks, nw = 1, 2 or 4 waves side by side per block row
+ * (workgroup = 256 * nw lanes); horizontally consecutive tiles overlap by one block column */
+#define HVC_444_TILE_BW 64
 #define HVC_444_TILE_BH 4
-#define HVC_444_TILE_STEP 63 /* consecutive tiles overlap by one block column */
 
 struct Decode444Params {
     const int16_t *coefs;
@@ -102,7 +103,11 @@ struct Decode444Params {
     unsigned y_magic;      // ceil(2^32 / cbw)
     int c_tiles_x, c_tiles_y; // chroma: tiles of 64 x 4 blocks (x step 63) over cbw x cbh, per plane
     unsigned c_magic;      // ceil(2^32 / c_tiles_x)
-    int pad;
+    int skip;              // measurements only (HVC_444_ONLY): 1 = luma tiles return at once, 2 = chroma tiles do; 0 = the kernel
+    int nw;                // workgroup = 256 * nw lanes: luma tiles of that many blocks, chroma tiles (64 * nw) x 4 blocks.
+                           // Chosen so that ONE chroma tile spans the output row where it can (1080p: nw = 2, 4K: nw = 4):
+                           // a workgroup then writes whole rows, measured 58 -> 66 % of the HBM peak for the chroma half
+    int pad2;
     Plane444K pl[3];
     int qt[HVC_MAX_QTABS * 64];
     unsigned qpair[HVC_MAX_QTABS * 32];
@@ -116,6 +121,9 @@ struct Decode444Params {
 // wide_only: every block through the int64 kernel (tables with entries > 255).
 hipError_t launch_decode_444(const Decode444Params &P, bool wide_only, hipStream_t s, hipEvent_t k0 = nullptr,
                              hipEvent_t k1 = nullptr);
+// nw, y_tiles, c_tiles_*, magics, tiles_per_frame from the planes' crop geometry (P.pl[], P.width set); aligned = the
+// 16-byte store form can be used (width % 16 == 0, frame stride % 16 == 0, 16-byte aligned output)
+void plan_decode_444(Decode444Params &P, bool aligned);
 hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr);
 hipError_t launch_decode_wide_only(const DecodeParams &P, hipStream_t s);
 hipError_t launch_encode(const EncodeParams &P, hipStream_t s, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr);

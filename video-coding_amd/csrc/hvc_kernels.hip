@@ -825,12 +825,13 @@ struct Ref444 {
     bool store;  // ... and this lane owns its output (false for a chroma tile's overlap column)
 };
 
-__device__ __forceinline__ Ref444 locate444(const Decode444Params &P, int tile, int lane) {
+// wgs = lanes per workgroup (256 * P.nw), tw = chroma tile width in blocks (64 * P.nw)
+__device__ __forceinline__ Ref444 locate444(const Decode444Params &P, int tile, int lane, int wgs, int tw) {
     Ref444 r;
     if (tile < P.y_tiles) {
         const Plane444K &K = P.pl[0];
         const int n = K.cbw * K.cbh;
-        int b = tile * HVC_TILE + lane;
+        int b = tile * wgs + lane;
         r.active = b < n;
         b = r.active ? b : n - 1;
         const unsigned by = K.cbw == 1 ? (unsigned)b : __umulhi((unsigned)b, P.y_magic);
@@ -849,12 +850,13 @@ __device__ __forceinline__ Ref444 locate444(const Decode444Params &P, int tile, 
         const unsigned ty = P.c_tiles_x == 1 ? (unsigned)t : __umulhi((unsigned)t, P.c_magic);
         const unsigned tx = (unsigned)t - ty * (unsigned)P.c_tiles_x;
         const Plane444K &K = P.pl[r.p];
-        // consecutive tiles share one block column: lane 63 only feeds lane 62's right-neighbour
-        // samples, its own output belongs to lane 0 of the next tile (unless it is the last column)
-        const int lx = lane & 63;
-        const int bx = (int)tx * HVC_444_TILE_STEP + lx, by = (int)ty * HVC_444_TILE_BH + (lane >> 6);
+        // lanes run along the tile's block row first (tw = a power of two): lane = y_in_tile * tw + x_in_tile.
+        // Consecutive tiles share one block column: the last lane of a tile row only feeds its left neighbour's
+        // right-neighbour samples, its own output belongs to lane 0 of the next tile (unless it is the last column)
+        const int lx = lane & (tw - 1), ly = lane / tw;
+        const int bx = (int)tx * (tw - 1) + lx, by = (int)ty * HVC_444_TILE_BH + ly;
         r.active = bx < K.cbw && by < K.cbh;
-        r.store = r.active && (lx < HVC_444_TILE_STEP || bx == K.cbw - 1);
+        r.store = r.active && (lx < tw - 1 || bx == K.cbw - 1);
         r.bx = min(bx, K.cbw - 1);
         r.by = min(by, K.cbh - 1);
     }
@@ -927,12 +929,15 @@ __device__ __forceinline__ void emit_rows444(uint8_t *row_even, size_t W, int x0
 #else
 #define HVC_444_ATTR
 #endif
-template <bool ALIGNED, bool DCP>
-__global__ __launch_bounds__(HVC_PACKED_LB) HVC_444_ATTR void k_decode_444(Decode444Params P) {
-    __shared__ uint4 edge[HVC_TILE]; // per lane: first row (x, y) and first column (z, w) of its chroma block
+// NW = P.nw: 256 * NW lanes per workgroup (16 waves per CU asked for in every form: NW = 1 -> 4 workgroups, ...)
+template <bool ALIGNED, bool DCP, int NW>
+__global__ __launch_bounds__(HVC_TILE * NW, 4 / NW) HVC_444_ATTR void k_decode_444(Decode444Params P) {
+    constexpr int WGS = HVC_TILE * NW, TW = HVC_444_TILE_BW * NW;
+    __shared__ uint4 edge[WGS]; // per lane: first row (x, y) and first column (z, w) of its chroma block
     const int lane = threadIdx.x;
     const bool chroma = (int)blockIdx.x >= P.y_tiles; // workgroup-uniform
-    const Ref444 r = locate444(P, blockIdx.x, lane);
+    if (P.skip && P.skip == (chroma ? 2 : 1)) return;  // (measurements: one half of the kernel alone)
+    const Ref444 r = locate444(P, blockIdx.x, lane, WGS, TW);
     const Plane444K &K = P.pl[r.p];
     const size_t in_frame = K.coef_off + ((size_t)r.by * K.bw + r.bx) * 64; // the block's place in the frame record
     const uint4 *src = reinterpret_cast<const uint4 *>(P.coefs + (size_t)blockIdx.y * P.coef_fs + in_frame);
@@ -972,9 +977,9 @@ __global__ __launch_bounds__(HVC_PACKED_LB) HVC_444_ATTR void k_decode_444(Decod
         edge[lane] = make_uint4(out[0][0], out[0][1], c0, c1);
         __syncthreads();
         // right / lower / lower-right neighbours; past the tile the values are placeholders (seam pass)
-        const uint4 rt = edge[min(lane + 1, HVC_TILE - 1)];
-        const uint4 dn = edge[min(lane + 64, HVC_TILE - 1)];
-        const unsigned dg = edge[min(lane + 65, HVC_TILE - 1)].x;
+        const uint4 rt = edge[min(lane + 1, WGS - 1)];
+        const uint4 dn = edge[min(lane + TW, WGS - 1)];
+        const unsigned dg = edge[min(lane + TW + 1, WGS - 1)].x;
         const int lastx = K.aw - 1 - r.bx * 8; // samples at or beyond it take b = a
         const unsigned long long mm = lastx >= 8 ? 0ull : (~0ull << (8 * max(lastx, 0)));
         const unsigned m0 = (unsigned)mm, m1 = (unsigned)(mm >> 32);
@@ -1009,7 +1014,7 @@ __global__ __launch_bounds__(HVC_PACKED_LB) HVC_444_ATTR void k_decode_444(Decod
         base = __shfl(base, 0);
         if (flag) {
             unsigned idx = base + (unsigned)__popcll(m & ((1ull << wl) - 1ull));
-            P.fix_list[idx] = ((unsigned)blockIdx.y * (unsigned)P.tiles_per_frame + blockIdx.x) * HVC_TILE + lane;
+            P.fix_list[idx] = ((unsigned)blockIdx.y * (unsigned)P.tiles_per_frame + blockIdx.x) * WGS + lane;
         }
     }
 }
@@ -1024,12 +1029,13 @@ __global__ __launch_bounds__(64) void k_decode_wide_444(Decode444Params P, const
     for (unsigned long long i = (unsigned long long)blockIdx.x * 64 + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * 64) {
         const unsigned long long id = list ? list[i] : i;
-        const int lane = (int)(id % HVC_TILE);
-        const unsigned long long t = id / HVC_TILE;
+        const unsigned wgs = (unsigned)(HVC_TILE * P.nw);
+        const int lane = (int)(id % wgs);
+        const unsigned long long t = id / wgs;
         const int tile = (int)(t % (unsigned)P.tiles_per_frame);
         const size_t frame = (size_t)(t / (unsigned)P.tiles_per_frame);
         if (frame >= (size_t)P.n_frames) continue; // an id from another geometry must never turn into an address
-        const Ref444 r = locate444(P, tile, lane);
+        const Ref444 r = locate444(P, tile, lane, (int)wgs, HVC_444_TILE_BW * P.nw);
         if (!r.store) continue;
         const Plane444K &K = P.pl[r.p];
         const int *q = P.qt + K.qtab * 64;
@@ -1130,12 +1136,13 @@ __global__ __launch_bounds__(256) void k_reinterp_444(Decode444Params P, const u
          i += nthreads) {
         const unsigned long long id = list[i / 81];
         const int k = (int)(i % 81);
-        const int lane = (int)(id % HVC_TILE);
-        const unsigned long long t = id / HVC_TILE;
+        const unsigned wgs = (unsigned)(HVC_TILE * P.nw);
+        const int lane = (int)(id % wgs);
+        const unsigned long long t = id / wgs;
         const int tile = (int)(t % (unsigned)P.tiles_per_frame);
         const size_t f = (size_t)(t / (unsigned)P.tiles_per_frame);
         if (f >= (size_t)P.n_frames) continue;
-        const Ref444 rr = locate444(P, tile, lane);
+        const Ref444 rr = locate444(P, tile, lane, (int)wgs, HVC_444_TILE_BW * P.nw);
         if (!rr.store || rr.p == 0) continue;
         const int c = rr.bx * 8 - 1 + k % 9, r = rr.by * 8 - 1 + k / 9;
         if (c < 0 || r < 0 || c >= aw || r >= ah) continue;
@@ -1547,12 +1554,34 @@ hipError_t launch_decode_wide_only(const DecodeParams &P, hipStream_t s) {
     return hipGetLastError();
 }
 
+void plan_decode_444(Decode444Params &P, bool aligned) {
+    const int cbw = P.pl[1].cbw;
+    // one chroma tile across the whole row where 256 blocks reach (the byte-store form for odd sizes keeps the small tile)
+    P.nw = !aligned || cbw <= HVC_444_TILE_BW ? 1 : cbw <= 2 * HVC_444_TILE_BW ? 2 : 4;
+    const int wgs = HVC_TILE * P.nw, tw = HVC_444_TILE_BW * P.nw;
+    P.y_tiles = (P.pl[0].cbw * P.pl[0].cbh + wgs - 1) / wgs;
+    P.y_magic = (unsigned)(((1ull << 32) + P.pl[0].cbw - 1) / P.pl[0].cbw);
+    P.c_tiles_x = cbw <= tw ? 1 : (cbw - 1 + (tw - 1) - 1) / (tw - 1);
+    P.c_tiles_y = (P.pl[1].cbh + HVC_444_TILE_BH - 1) / HVC_444_TILE_BH;
+    P.c_magic = (unsigned)(((1ull << 32) + P.c_tiles_x - 1) / P.c_tiles_x);
+    P.tiles_per_frame = P.y_tiles + 2 * P.c_tiles_x * P.c_tiles_y;
+}
+
+template <bool ALIGNED, int NW>
+static void launch_444_kernel(const Decode444Params &Q, dim3 grid, unsigned pad, hipStream_t s) {
+    if (Q.dc_plane)
+        hipLaunchKernelGGL((k_decode_444<ALIGNED, true, NW>), grid, dim3(HVC_TILE * NW), pad, s, Q);
+    else
+        hipLaunchKernelGGL((k_decode_444<ALIGNED, false, NW>), grid, dim3(HVC_TILE * NW), pad, s, Q);
+}
+
 hipError_t launch_decode_444(const Decode444Params &P, bool wide_only, hipStream_t s, hipEvent_t k0, hipEvent_t k1) {
     if (P.n_frames <= 0 || P.tiles_per_frame <= 0) return hipSuccess;
+    if (P.nw != 1 && P.nw != 2 && P.nw != 4) return hipErrorInvalidValue;
     const dim3 grid((unsigned)P.tiles_per_frame, (unsigned)P.n_frames, 1);
     const long long per_plane = (long long)P.pl[1].aw * P.pl[1].ah;
     if (wide_only) {
-        const unsigned long long total = (unsigned long long)P.n_frames * P.tiles_per_frame * HVC_TILE;
+        const unsigned long long total = (unsigned long long)P.n_frames * P.tiles_per_frame * HVC_TILE * P.nw;
         if (k0) (void)hipEventRecord(k0, s);
         hipLaunchKernelGGL(k_decode_wide_444, dim3(4096), dim3(64), 0, s, P, (const unsigned *)nullptr,
                            (const unsigned *)nullptr, total);
@@ -1564,16 +1593,21 @@ hipError_t launch_decode_444(const Decode444Params &P, bool wide_only, hipStream
     const size_t W = (size_t)P.width;
     const bool aligned = (W % 16 == 0) && (P.out_fs % 16 == 0) && ((uintptr_t)P.out % 16 == 0);
     if (k0) (void)hipEventRecord(k0, s);
+    // HVC_444_ONLY=luma|chroma (measurements): the other half of the tiles returns at once
+    static const int only = [] { const char *v = getenv("HVC_444_ONLY"); return !v ? 0 : v[0] == 'l' ? 2 : v[0] == 'c' ? 1 : 0; }();
+    Decode444Params Q = P;
+    Q.skip = only;
     // HVC_444_LDS_PAD=bytes (experiments): dynamic LDS nobody uses, to hold the kernel to fewer workgroups per CU
     static const unsigned pad = [] { const char *v = getenv("HVC_444_LDS_PAD"); return v ? (unsigned)atoi(v) : 0u; }();
-    if (aligned && P.dc_plane)
-        hipLaunchKernelGGL((k_decode_444<true, true>), grid, dim3(HVC_TILE), pad, s, P);
-    else if (aligned)
-        hipLaunchKernelGGL((k_decode_444<true, false>), grid, dim3(HVC_TILE), pad, s, P);
-    else if (P.dc_plane)
-        hipLaunchKernelGGL((k_decode_444<false, true>), grid, dim3(HVC_TILE), 0, s, P);
+    if (!aligned && P.nw != 1) return hipErrorInvalidValue; // (plan_decode_444 was told otherwise)
+    if (!aligned)
+        launch_444_kernel<false, 1>(Q, grid, 0, s);
+    else if (P.nw == 1)
+        launch_444_kernel<true, 1>(Q, grid, pad, s);
+    else if (P.nw == 2)
+        launch_444_kernel<true, 2>(Q, grid, pad, s);
     else
-        hipLaunchKernelGGL((k_decode_444<false, false>), grid, dim3(HVC_TILE), 0, s, P);
+        launch_444_kernel<true, 4>(Q, grid, pad, s);
     if (k1) (void)hipEventRecord(k1, s);
     hipLaunchKernelGGL(k_decode_wide_444, dim3(256), dim3(64), 0, s, P, (const unsigned *)P.fix_count,
                        (const unsigned *)P.fix_list, 0ull);
