@@ -13,7 +13,9 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import video_coding_amd as hvc  # noqa: E402
+from jpeg_opt_writer import jpeg_optimised_tables  # noqa: E402
 
 
 def content(rng, h, w, kind):
@@ -60,6 +62,10 @@ def main():
         except hvc.HvcError:   # a geometry the model's encoder raises on (hvc_jpeg_encoder_check)
             refused += 1
             continue
+        if case % 3 == 2:   # a third of the cases: files with their own optimised Huffman tables, 1 to 3 table sets each
+            qt = np.stack([hvc.hvc.quant_table(0, q), hvc.hvc.quant_table(1, q)])
+            files = [jpeg_optimised_tables(w, h, chroma, qt, hvc.hvc.jpeg_entropy_decode(j)[1], int(rng.integers(1, 4)))
+                     if rng.integers(0, 5) else j for j in files]
         _, got, used = ctx.jpeg_entropy_decode_gpu(files, device=bool(case & 1))
         used_gpu += used == 1
         fell_back += used != 1

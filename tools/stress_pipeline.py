@@ -13,8 +13,10 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import video_coding_amd as hvc  # noqa: E402
 from video_coding_amd.synth import synth_pixels  # noqa: E402
+from jpeg_opt_writer import jpeg_optimised_tables  # noqa: E402
 
 
 def main():
@@ -25,7 +27,7 @@ def main():
     import torch
     rng = np.random.Generator(np.random.PCG64(args.seed))
     ctx = hvc.Context(0)
-    bad = odd = 0
+    bad = odd = own_batches = 0
     for case in range(args.cases):
         w = int(rng.integers(1, 30)) * 16
         h = int(rng.integers(1, 20)) * 16
@@ -36,6 +38,13 @@ def main():
             s = int(rng.integers(0, 1 << 30))
             files.append(ctx.jpeg_encode(synth_pixels(s, h, w), synth_pixels(s + 1, h // 2, w // 2), synth_pixels(s + 2, h // 2, w // 2),
                                          w, h, 420, q))
+        own = int(rng.integers(0, 3))   # a third of the batches: some or all files re-written with their own optimised Huffman
+        if own == 1:                    # tables (1, 2 or 3 table sets): the GPU pipeline's per-frame-table mode
+            qt = np.stack([hvc.hvc.quant_table(0, q), hvc.hvc.quant_table(1, q)])
+            for d in range(n_distinct):
+                if n_distinct == 1 or rng.integers(0, 4) != 0:
+                    files[d] = jpeg_optimised_tables(w, h, 420, qt, hvc.hvc.jpeg_entropy_decode(files[d])[1], int(rng.integers(1, 4)))
+            own_batches += 1
         n = int(rng.integers(1, 41))
         batch = [files[int(rng.integers(0, n_distinct))] for _ in range(n)]
         info = hvc.hvc.jpeg_read_header(batch[0])
@@ -76,7 +85,7 @@ def main():
         if not same:
             bad += 1
             print("MISMATCH", case, (w, h, q, n, chunk, threads, host_out, yuv444), file=sys.stderr)
-    print({"cases": args.cases, "batches_with_truncated_files": odd, "mismatches": bad})
+    print({"cases": args.cases, "batches_with_truncated_files": odd, "batches_with_per_file_tables": own_batches, "mismatches": bad})
     ctx.close()
     sys.exit(1 if bad else 0)
 
