@@ -20,17 +20,16 @@
  *  - an hvc_ctx is bound to ONE GPU and is NOT thread-safe: one per host
  *    thread / GPU.  There is no CPU backend: hvc_create fails with
  *    HVC_E_NO_DEVICE when no gfx950 device is usable.
- *  - all results are bit-exact to the OCaml model for every input that fits the
- *    coefficient record: int16 coefficients (DC absolute), 8- or 16-bit quantiser
- *    entries.  ONE class of streams the model decodes is outside that: the model's
- *    ints are 63-bit (decoder.ml:143 `dc = coefs.(0) + dc_pred` never wraps), so a
- *    malformed-but-decodable stream whose DC differences pile up to an absolute DC
- *    beyond +-32767 (17 blocks of +2047 in a row do it; no encoder writes that: a
- *    baseline DC is within +-2047 after an 8-bit forward DCT) still decodes there --
- *    to saturated blocks.  The entropy front end refuses such a stream with
- *    HVC_E_RANGE instead of wrapping; the int16 record cannot carry it.
- *    tests/test_host_entropy.py::test_dc_beyond_int16_is_refused_not_wrapped pins
- *    the model's output next to the refusal.
+ *  - all results are bit-exact to the OCaml model: for every coefficient record (int16 coefficients, DC absolute;
+ *    8- or 16-bit quantiser entries) and for every file the model decodes.  One thing the int16 RECORD cannot
+ *    carry: the model's ints are 63-bit (decoder.ml:143 `dc = coefs.(0) + dc_pred` never wraps), so a malformed-
+ *    but-decodable stream whose DC differences pile up to an absolute DC beyond +-32767 (17 blocks of +2047 in a
+ *    row do it; no encoder writes that) still decodes there, to saturated blocks.  The entry points that RETURN
+ *    records (hvc_jpeg_entropy_decode, hvc_jpeg_entropy_decode_gpu) refuse such a stream with HVC_E_RANGE instead
+ *    of wrapping; the entry points that decode FILES TO PIXELS (hvc_jpeg_decode, hvc_jpeg_decode_yuv444, the
+ *    hvc_jpeg_decode_batch family) carry those blocks' true DCs on a side list through an int64 fix-up and give the
+ *    model's pixels (tests/test_host_entropy.py::test_dc_beyond_int16_is_refused_not_wrapped,
+ *    tests/test_gpu_jpeg_api.py::test_dc_beyond_int16_decodes_like_the_model).
  *
  * Data layouts
  *  - coefficients: int16, [plane][blocks_h][blocks_w][64], each block in
@@ -63,7 +62,8 @@ typedef enum hvc_status {
     HVC_E_NO_DEVICE = -2,    /* no usable gfx950 GPU / HIP runtime error at create */
     HVC_E_HIP = -3,          /* a HIP call failed; hvc_last_hip_error() has the code */
     HVC_E_ALIGNMENT = -4,    /* plane pointer/stride not 8-byte aligned, coefs not 16-byte aligned */
-    HVC_E_RANGE = -5,        /* quantiser entry 0, encoder output outside int16, or a decoded absolute DC outside int16 */
+    HVC_E_RANGE = -5,        /* quantiser entry 0, encoder output outside int16, or (record-returning entry points) a
+                                decoded absolute DC outside int16 */
     HVC_E_OUT_OF_MEMORY = -6,
     HVC_E_TOO_LARGE = -7,    /* plane geometry beyond the kernel's index range */
     HVC_E_BAD_JPEG = -8,     /* the model would raise: missing frame/scan/table, invalid Huffman code,

@@ -219,15 +219,15 @@ def test_files_with_their_own_optimised_tables(ctx, w, h, chroma, q, table_sets)
 
 def test_dc_beyond_int16_reaches_the_caller_as_range_error(ctx):
     """the contract edge of include/hvc_jpeg.h on the GPU side: k_hd_dc's prefix sum sees the DC leave int16, raises
-    its status bit, the call falls to the host reader, which refuses with HVC_E_RANGE (the model would decode)"""
+    its status bit, the call falls to the host reader, which -- for an entry point that returns records -- refuses
+    with HVC_E_RANGE (the file-to-pixels entry points decode it: tests/test_gpu_jpeg_api.py)"""
     import video_coding_amd as hvc
     qt = np.stack([orc.quant_scale(orc.quant_luma(), 75), orc.quant_scale(orc.quant_chroma(), 75)])
     rec = np.zeros((3, 64, 64), dtype=np.int64)
     rec[0, :, 0] = 2047 * (np.arange(64) + 1)
     jpg = jpeg_optimised_tables(64, 64, 444, qt, rec.reshape(-1))
     assert orc.Decoder(jpg).coef_record().max() == 2047 * 64
-    for call in (lambda: ctx.jpeg_entropy_decode_gpu([jpg]), lambda: ctx.jpeg_entropy_decode_gpu([jpg, jpg], device=True),
-                 lambda: ctx.jpeg_decode(jpg)):
-        with pytest.raises(hvc.HvcError) as e:
+    for call in (lambda: ctx.jpeg_entropy_decode_gpu([jpg]), lambda: ctx.jpeg_entropy_decode_gpu([jpg, jpg], device=True)):
+        with pytest.raises(hvc.HvcError) as e:   # the entry points that RETURN int16 records cannot carry it
             call()
         assert e.value.code == -5

@@ -418,3 +418,87 @@ def test_gpu_batch_whose_first_file_has_three_table_sets(ctx):
         d.decode()
         for i, plane in enumerate(info.planes(out[f * fs:(f + 1) * fs])):
             assert np.array_equal(plane, d.plane(i)), (f, i)
+
+
+@pytest.mark.parametrize("chroma,w,h", [(444, 64, 64), (420, 96, 64), (420, 640, 352)])
+def test_dc_beyond_int16_decodes_like_the_model(ctx, chroma, w, h):
+    """A malformed-but-decodable stream: DC differences of +-2047 pile up far beyond int16 (the model's ints are
+    63-bit, decoder.ml:143).  The int16 record cannot hold those DCs, so the file-to-pixels entry points carry them
+    on a side list through an int64 fix-up: hvc_jpeg_decode, hvc_jpeg_decode_yuv444 and both batch pipelines
+    (device and host output, fused 4:4:4 output) must give the model's planes, in every component."""
+    import torch
+    import video_coding_amd as hvc
+    from helpers import jpeg_optimised_tables
+    q = 60
+    qt = np.stack([orc.quant_scale(orc.quant_luma(), q), orc.quant_scale(orc.quant_chroma(), q)])
+    info0 = hvc.hvc.jpeg_encoder_layout(w, h, chroma, q)
+    rng = np.random.Generator(np.random.PCG64(w + h + chroma))
+    files = []
+    for variant in range(3):
+        rec = np.zeros(info0.coef_count, dtype=np.int64).reshape(-1, 64)
+        rec[:, 1:6] = rng.integers(-3, 4, size=(rec.shape[0], 5))
+        for i in range(3):   # per component (the writer codes differences in scan order): a walk of +-2047 steps
+            L = info0.layout[i]
+            nb = L.blocks_w * L.blocks_h
+            steps = rng.choice([-2047, 2047, 2047, 900, 0], size=nb) if variant else np.full(nb, 2047)
+            if variant == 2 and i == 1:
+                steps = -np.abs(steps)
+            plane = rec[L.coef_offset // 64:L.coef_offset // 64 + nb]
+            # differences accumulate in SCAN order; any assignment of absolute values is a valid record, the writer
+            # derives the differences -- keep each step within what the baseline categories can code (|d| <= 2047
+            # between blocks that follow each other in scan order is not guaranteed by a raster walk, so clamp the
+            # walk itself mildly and let the writer's category reach 12-16 bits where the scan order jumps)
+            plane[:, 0] = np.cumsum(steps)
+        files.append(jpeg_optimised_tables(w, h, chroma, qt, rec.reshape(-1)))
+    wants = []
+    for j in files:
+        d = orc.Decoder(j)
+        assert np.abs(d.coef_record()).max() > 40000      # far beyond int16: the record-level reader refuses
+        with pytest.raises(hvc.HvcError) as e:
+            hvc.hvc.jpeg_entropy_decode(j)
+        assert e.value.code == -5
+        d2 = orc.Decoder(j)
+        d2.decode()
+        wants.append(d2)
+    info = hvc.hvc.jpeg_read_header(files[0])
+    for j, d in zip(files, wants):                        # one file at a time
+        _, pixels = ctx.jpeg_decode(j)
+        for i, plane in enumerate(info.planes(pixels)):
+            assert np.array_equal(plane, d.plane(i)), i
+        if chroma == 420:
+            _, frame = ctx.jpeg_decode_yuv444(j)
+            y, u, v = d.get_yuv_frame()
+            assert np.array_equal(frame[0], y) and np.array_equal(frame[1], orc.supersample_hv2(u)) and \
+                np.array_equal(frame[2], orc.supersample_hv2(v))
+    batch = [files[i % 3] for i in range(7)] + _plain_same_geometry(ctx, w, h, chroma, q, 2)
+    order = [0, 1, 2, 0, 1, 2, 0, None, None]
+    for gpu in (False, True):
+        for device in (False, True):
+            fs = info.pixel_bytes
+            out = torch.zeros(len(batch) * fs, dtype=torch.uint8, device="cuda") if device else np.zeros(len(batch) * fs, np.uint8)
+            ctx.jpeg_decode_batch(batch, out, fs, threads=3, frames_per_chunk=4, gpu_entropy=gpu)
+            got = out.cpu().numpy() if device else out
+            for f, j in enumerate(batch):
+                d = wants[order[f]] if order[f] is not None else None
+                if d is None:
+                    d = orc.Decoder(j)
+                    d.decode()
+                for i, plane in enumerate(info.planes(got[f * fs:(f + 1) * fs])):
+                    assert np.array_equal(plane, d.plane(i)), (gpu, device, f, i)
+        if chroma == 420:
+            fs = 3 * w * h
+            out = np.zeros(len(batch) * fs, np.uint8)
+            ctx.jpeg_decode_batch(batch, out, fs, threads=2, frames_per_chunk=3, yuv444=True, gpu_entropy=gpu)
+            for f in range(7):
+                y, u, v = wants[order[f]].get_yuv_frame()
+                want = np.concatenate([y.reshape(-1), orc.supersample_hv2(u).reshape(-1), orc.supersample_hv2(v).reshape(-1)])
+                assert np.array_equal(out[f * fs:(f + 1) * fs], want), (gpu, f)
+
+
+def _plain_same_geometry(ctx, w, h, chroma, q, n):
+    """ordinary files of the same geometry and quantiser tables (the model's encoder), to sit in the same batch"""
+    cw, ch = orc.chroma_dims(chroma, w, h)
+    out = []
+    for f in range(n):
+        out.append(orc.encode_yuv(synth_pixels(900 + f, h, w), synth_pixels(910 + f, ch, cw), synth_pixels(920 + f, ch, cw), w, h, chroma, q))
+    return out

@@ -66,6 +66,8 @@ struct hvc_ctx {
     size_t gd_ftabs_cap = 0;
     void *gd_dcv = nullptr;   // batch pipeline: the blocks' DC values as a compact array (hvc::DecodeParams::dc_plane)
     size_t gd_dcv_cap = 0;
+    void *d_dcfix = nullptr;  // blocks with a DC beyond int16 (hvc::WideDc): ids, true DCs, count
+    size_t dcfix_cap = 0;
     // hvc_set_host_cpus: the CPUs the batch pipelines' host threads may run on (empty = no restriction)
     bool have_cpus = false;
     cpu_set_t cpus;
@@ -409,6 +411,7 @@ void hvc_destroy(hvc_ctx *c) {
     if (c->gd_dcd) (void)hipFree(c->gd_dcd);
     if (c->gd_ftabs) (void)hipFree(c->gd_ftabs);
     if (c->gd_dcv) (void)hipFree(c->gd_dcv);
+    if (c->d_dcfix) (void)hipFree(c->d_dcfix);
     delete c->gd_tables_host;
     if (c->hd_tables) (void)hipFree(c->hd_tables);
     if (c->hd_lens) (void)hipFree(c->hd_lens);
@@ -637,10 +640,104 @@ static void prepare_tables(const uint16_t *qtabs, int n_qtabs, int *qt, int *eth
 }
 
 // ---------------------------------------------------------------------------
+// A block of a batch whose true DC does not fit the int16 record (hvc::WideDc of frame `frame` of the batch): after
+// the batch's launches it is recomputed in int64 with that DC -- what the model's 63-bit arithmetic gives.
+struct WideFix {
+    int frame;
+    uint32_t block;
+    long long dc;
+};
+
+// ids (fix-list encoding of the launch geometry) + DCs -> device scratch; returns pointers into it
+static int upload_dcfix(hvc_ctx *c, const std::vector<unsigned> &ids, const std::vector<long long> &dcs, const unsigned **d_count,
+                        const unsigned **d_ids, const long long **d_dcs) {
+    const size_t n = ids.size();
+    const size_t off_ids = 16, off_dcs = (off_ids + n * sizeof(unsigned) + 15) & ~(size_t)15;
+    int r = grow(c, &c->d_dcfix, &c->dcfix_cap, off_dcs + n * sizeof(long long));
+    if (r) return r;
+    const unsigned cnt = (unsigned)n;
+    char *base = (char *)c->d_dcfix;
+    HIPCHK(c, hipMemcpyAsync(base, &cnt, sizeof cnt, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(base + off_ids, ids.data(), n * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(base + off_dcs, dcs.data(), n * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // (the sources are the caller's vectors; a rare path)
+    *d_count = (const unsigned *)base;
+    *d_ids = (const unsigned *)(base + off_ids);
+    *d_dcs = (const long long *)(base + off_dcs);
+    return HVC_OK;
+}
+
+static int apply_wide_dc(hvc_ctx *c, const hvc::DecodeParams &P, const std::vector<WideFix> &wide) {
+    std::vector<unsigned> ids;
+    std::vector<long long> dcs;
+    for (const WideFix &w : wide) {
+        for (int i = 0; i < P.n_comp; i++) {
+            const hvc::CompK &K = P.comp[i];
+            const size_t b0 = K.coef_off / 64;
+            if (w.block < b0 || w.block >= b0 + (size_t)K.nblk) continue;
+            const unsigned b = (unsigned)(w.block - b0);
+            ids.push_back(((unsigned)w.frame * (unsigned)P.tiles_per_frame + (unsigned)K.tile0 + b / HVC_TILE) * HVC_TILE + b % HVC_TILE);
+            dcs.push_back(w.dc);
+            break;
+        }
+    }
+    if (ids.empty()) return HVC_OK;
+    const unsigned *d_count, *d_ids;
+    const long long *d_dcs;
+    int r = upload_dcfix(c, ids, dcs, &d_count, &d_ids, &d_dcs);
+    if (r) return r;
+    hvc::DecodeParams Q = P;
+    Q.dc_plane = nullptr; // (the list carries the DC)
+    HIPCHK(c, hvc::launch_decode_dcfix(Q, d_count, d_ids, d_dcs, c->stream));
+    return HVC_OK;
+}
+
+static int apply_wide_dc_444(hvc_ctx *c, const hvc::Decode444Params &P, const std::vector<WideFix> &wide) {
+    std::vector<unsigned> ids;
+    std::vector<long long> dcs;
+    const unsigned wgs = (unsigned)(HVC_TILE * P.nw), tw = (unsigned)(HVC_444_TILE_BW * P.nw);
+    for (const WideFix &w : wide) {
+        int p = -1; // the plane whose coefficient offset is the largest one not beyond the block
+        for (int i = 0; i < 3; i++)
+            if (P.pl[i].coef_off / 64 <= w.block && (p < 0 || P.pl[i].coef_off > P.pl[p].coef_off)) p = i;
+        if (p < 0) continue;
+        {
+            const hvc::Plane444K &K = P.pl[p];
+            const size_t rel = w.block - K.coef_off / 64;
+            const unsigned by = (unsigned)(rel / (unsigned)K.bw), bx = (unsigned)(rel % (unsigned)K.bw);
+            if (bx >= (unsigned)K.cbw || by >= (unsigned)K.cbh) continue; // outside the crop: never decoded
+            unsigned tile, lane;
+            if (p == 0) {
+                const unsigned b = by * (unsigned)K.cbw + bx;
+                tile = b / wgs;
+                lane = b % wgs;
+            } else { // locate444's chroma mapping, inverted
+                unsigned tx = P.c_tiles_x == 1 ? 0u : bx / (tw - 1);
+                if (tx >= (unsigned)P.c_tiles_x) tx = (unsigned)P.c_tiles_x - 1;
+                const unsigned lx = bx - tx * (tw - 1), ty = by / HVC_444_TILE_BH, ly = by % HVC_444_TILE_BH;
+                tile = (unsigned)P.y_tiles + (unsigned)(p - 1) * (unsigned)(P.c_tiles_x * P.c_tiles_y) + ty * (unsigned)P.c_tiles_x + tx;
+                lane = ly * tw + lx;
+            }
+            ids.push_back(((unsigned)w.frame * (unsigned)P.tiles_per_frame + tile) * wgs + lane);
+            dcs.push_back(w.dc);
+        }
+    }
+    if (ids.empty()) return HVC_OK;
+    const unsigned *d_count, *d_ids;
+    const long long *d_dcs;
+    int r = upload_dcfix(c, ids, dcs, &d_count, &d_ids, &d_dcs);
+    if (r) return r;
+    hvc::Decode444Params Q = P;
+    Q.dc_plane = nullptr;
+    HIPCHK(c, hvc::launch_decode_444_dcfix(Q, d_count, d_ids, d_dcs, (unsigned)ids.size(), c->stream));
+    return HVC_OK;
+}
+
 // dc_plane (device memory calls only, default kernels only): see hvc::DecodeParams::dc_plane
+// wide (device memory calls only): blocks to recompute with their true DC once the launches are enqueued
 static int decode_frames_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const uint16_t *qtabs, int n_qtabs,
                               const hvc_component *comps, int n_comp, int n_frames, uint8_t *pixels, size_t pixel_fs,
-                              int where, const int16_t *dc_plane, size_t dc_fs) {
+                              int where, const int16_t *dc_plane, size_t dc_fs, const std::vector<WideFix> *wide = nullptr) {
     if (!c || !coefs || !pixels || n_frames < 0) return HVC_E_INVALID_ARG;
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
     int r = check_qtabs(qtabs, n_qtabs);
@@ -715,9 +812,10 @@ static int decode_frames_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, 
             HIPCHK(c, launch(Pk, prof && f0 == 0 ? c->k0[slot] : nullptr, prof && f0 + per >= n_frames ? c->k1[slot] : nullptr));
         }
         if (prof) c->k_calls++;
+        if (wide && !wide->empty()) return apply_wide_dc(c, P, *wide);
         return HVC_OK;
     }
-    if (dc_plane) return HVC_E_INVALID_ARG;
+    if (dc_plane || (wide && !wide->empty())) return HVC_E_INVALID_ARG;
 
     // host memory: mirror the caller's record layout on the device
     size_t cbytes = ((size_t)(n_frames - 1) * coef_fs + L.coef_span) * sizeof(int16_t);
@@ -798,7 +896,8 @@ int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const ui
 // 4:2:0 coefficient records -> tight 4:4:4 frames (block stage + crop + chroma upsample fused)
 static int decode_frames_yuv444_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const uint16_t *qtabs, int n_qtabs,
                                      const hvc_component *comps, int n_comp, int n_frames, int width, int height,
-                                     uint8_t *frames, size_t frame_stride, int where, const int16_t *dc_plane, size_t dc_fs) {
+                                     uint8_t *frames, size_t frame_stride, int where, const int16_t *dc_plane, size_t dc_fs,
+                                     const std::vector<WideFix> *wide = nullptr) {
     if (!c || !coefs || !frames || !comps || n_frames < 0) return HVC_E_INVALID_ARG;
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
     int r = check_qtabs(qtabs, n_qtabs);
@@ -874,7 +973,7 @@ static int decode_frames_yuv444_impl(hvc_ctx *c, const int16_t *coefs, size_t co
         return e;
     };
 
-    if (where == HVC_MEM_HOST && dc_plane) return HVC_E_INVALID_ARG;
+    if (where == HVC_MEM_HOST && (dc_plane || (wide && !wide->empty()))) return HVC_E_INVALID_ARG;
     if (where == HVC_MEM_DEVICE) {
         if ((uintptr_t)coefs & 15) return HVC_E_ALIGNMENT;
         P.coefs = coefs;
@@ -893,6 +992,7 @@ static int decode_frames_yuv444_impl(hvc_ctx *c, const int16_t *coefs, size_t co
             HIPCHK(c, launch(Pk, prof && f0 == 0 ? c->k0[slot] : nullptr, prof && f0 + per >= n_frames ? c->k1[slot] : nullptr));
         }
         if (prof) c->k_calls++;
+        if (wide && !wide->empty()) return apply_wide_dc_444(c, P, *wide);
         return HVC_OK;
     }
     const size_t cbytes = ((size_t)(n_frames - 1) * coef_fs + L.coef_span) * sizeof(int16_t);
@@ -1233,6 +1333,38 @@ static int single_frame_coefs_on_device(hvc_ctx *c, const uint8_t *jpeg, size_t 
     return gpu_entropy_decode(c, &jpeg, &n, 1, *info, (int16_t *)c->gd_coefs, info->coef_count, used);
 }
 
+// One frame whose record came from the host reader with blocks on the wide-DC list: upload, block stage, the int64
+// fix-up with the true DCs, download -- the model's output for a stream whose DC leaves int16 (decoder.ml:143).
+static int decode_one_with_wide_dc(hvc_ctx *c, const hvc_jpeg_info *info, const int16_t *coefs, const std::vector<hvc::WideDc> &wide,
+                                   bool yuv444, uint8_t *out) {
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
+    const size_t cb = info->coef_count * sizeof(int16_t);
+    const size_t ob = yuv444 ? (size_t)3 * info->width * info->height : info->pixel_bytes;
+    int r;
+    if ((r = grow(c, &c->d_in, &c->in_cap, cb))) return r;
+    if ((r = grow(c, &c->d_out, &c->out_cap, ob))) return r;
+    std::vector<WideFix> fix;
+    try {
+        for (const hvc::WideDc &w : wide) fix.push_back(WideFix{0, w.block, w.dc});
+    } catch (const std::bad_alloc &) {
+        return HVC_E_OUT_OF_MEMORY;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_in, coefs, cb, hipMemcpyHostToDevice, c->stream));
+    const bool prof_saved = c->profiling;
+    c->profiling = false;
+    r = yuv444 ? decode_frames_yuv444_impl(c, (const int16_t *)c->d_in, info->coef_count, &info->qtabs[0][0], info->n_qtabs,
+                                           info->layout, info->n_comp, 1, info->width, info->height, (uint8_t *)c->d_out, ob,
+                                           HVC_MEM_DEVICE, nullptr, 0, &fix)
+               : decode_frames_impl(c, (const int16_t *)c->d_in, info->coef_count, &info->qtabs[0][0], info->n_qtabs, info->layout,
+                                    info->n_comp, 1, (uint8_t *)c->d_out, info->pixel_bytes, HVC_MEM_DEVICE, nullptr, 0, &fix);
+    c->profiling = prof_saved;
+    if (r) return r;
+    HIPCHK(c, hipMemcpyAsync(out, c->d_out, ob, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HVC_OK;
+}
+
 // Decoder.decode_a_frame minus the crop (decoder.ml:422-427)
 int hvc_jpeg_decode_yuv444(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_info *info, uint8_t *frame,
                            size_t frame_cap) {
@@ -1264,8 +1396,10 @@ int hvc_jpeg_decode_yuv444(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_i
     } catch (const std::bad_alloc &) {
         return HVC_E_OUT_OF_MEMORY;
     }
-    r = hvc_jpeg_entropy_decode(jpeg, n, info, coefs.data());
+    std::vector<hvc::WideDc> wide;
+    r = hvc::entropy_decode_wide(jpeg, n, info, coefs.data(), wide);
     if (r) return r;
+    if (!wide.empty()) return decode_one_with_wide_dc(c, info, coefs.data(), wide, true, frame);
     return hvc_decode_frames_yuv444(c, coefs.data(), info->coef_count, &info->qtabs[0][0], info->n_qtabs, info->layout,
                                     info->n_comp, 1, info->width, info->height, frame,
                                     (size_t)3 * info->width * info->height, HVC_MEM_HOST);
@@ -1294,8 +1428,10 @@ int hvc_jpeg_decode(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_info *in
     } catch (const std::bad_alloc &) {
         return HVC_E_OUT_OF_MEMORY;
     }
-    r = hvc_jpeg_entropy_decode(jpeg, n, info, coefs.data());
+    std::vector<hvc::WideDc> wide;
+    r = hvc::entropy_decode_wide(jpeg, n, info, coefs.data(), wide);
     if (r) return r;
+    if (!wide.empty()) return decode_one_with_wide_dc(c, info, coefs.data(), wide, false, pixels);
     return hvc_decode_frames(c, coefs.data(), info->coef_count, &info->qtabs[0][0], info->n_qtabs, info->layout,
                              info->n_comp, 1, pixels, info->pixel_bytes, HVC_MEM_HOST);
 }
@@ -1440,10 +1576,12 @@ static int decode_batch_impl(hvc_ctx *c, const uint8_t *const *jpegs, const size
     std::atomic<int> next_frame{0};
     std::atomic<int> error{0};
     std::vector<int> done_in_chunk((size_t)n_chunks, 0);
+    std::vector<std::vector<WideFix>> chunk_wide((size_t)n_chunks); // blocks whose DC left int16 (frame = index in the chunk)
     int released_upto = NB - 1; // chunks 0..NB-1 may be written at once
     std::atomic<long long> entropy_ns{0};
     auto worker = [&]() {
         if (!pin_to_ctx_cpus(c)) error.store(HVC_E_INVALID_ARG); // hvc_set_host_cpus
+        std::vector<hvc::WideDc> wide;
         for (;;) {
             const int f = next_frame.fetch_add(1);
             if (f >= n_frames || error.load()) return;
@@ -1461,10 +1599,17 @@ static int decode_batch_impl(hvc_ctx *c, const uint8_t *const *jpegs, const size
                        std::memcmp(fi.qtabs, info0.qtabs, sizeof fi.qtabs)))
                 e = HVC_E_INVALID_ARG; // a batch shares one geometry and one set of tables
             if (!e)
-                e = hvc_jpeg_entropy_decode(jpegs[f], sizes[f], &fi,
-                                            (int16_t *)c->h_ring[slot] + (size_t)(f - k * C) * info0.coef_count);
+                e = hvc::entropy_decode_wide(jpegs[f], sizes[f], &fi,
+                                             (int16_t *)c->h_ring[slot] + (size_t)(f - k * C) * info0.coef_count, wide);
             entropy_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
             std::lock_guard<std::mutex> lk(mu);
+            if (!e && !wide.empty()) {
+                try {
+                    for (const hvc::WideDc &w : wide) chunk_wide[(size_t)k].push_back(WideFix{f - k * C, w.block, w.dc});
+                } catch (const std::bad_alloc &) {
+                    e = HVC_E_OUT_OF_MEMORY;
+                }
+            }
             if (e) error.store(e);
             done_in_chunk[(size_t)k]++;
             cv.notify_all();
@@ -1499,11 +1644,12 @@ static int decode_batch_impl(hvc_ctx *c, const uint8_t *const *jpegs, const size
         const bool prof_saved = c->profiling;
         c->profiling = false;
         he = hipEventRecord(c->ev_t[1], compute);
-        rc = yuv444 ? hvc_decode_frames_yuv444(c, (const int16_t *)c->d_ring[slot], info0.coef_count, &info0.qtabs[0][0],
-                                               info0.n_qtabs, info0.layout, info0.n_comp, cnt, info0.width, info0.height,
-                                               dst, dst_fs, HVC_MEM_DEVICE)
-                    : hvc_decode_frames(c, (const int16_t *)c->d_ring[slot], info0.coef_count, &info0.qtabs[0][0],
-                                        info0.n_qtabs, info0.layout, info0.n_comp, cnt, dst, dst_fs, HVC_MEM_DEVICE);
+        const std::vector<WideFix> *wf = &chunk_wide[(size_t)k]; // (complete: the chunk's workers are done)
+        rc = yuv444 ? decode_frames_yuv444_impl(c, (const int16_t *)c->d_ring[slot], info0.coef_count, &info0.qtabs[0][0],
+                                                info0.n_qtabs, info0.layout, info0.n_comp, cnt, info0.width, info0.height,
+                                                dst, dst_fs, HVC_MEM_DEVICE, nullptr, 0, wf)
+                    : decode_frames_impl(c, (const int16_t *)c->d_ring[slot], info0.coef_count, &info0.qtabs[0][0],
+                                         info0.n_qtabs, info0.layout, info0.n_comp, cnt, dst, dst_fs, HVC_MEM_DEVICE, nullptr, 0, wf);
         c->profiling = prof_saved;
         if (rc) break;
         if (he == hipSuccess) he = hipEventRecord(c->ev_t[2], compute);

@@ -297,7 +297,16 @@ int hvc_jpeg_read_header(const uint8_t *data, size_t n, hvc_jpeg_info *info) {
 // The Huffman half of Decoder.decode (decode_seq order, decoder.ml:362-395; huffman_decode :118-140;
 // the DC predictor add of :143) into one frame's coefficient record: int16, zig-zag order, DC absolute,
 // block (bx,by) of component i at coefs + layout[i].coef_offset + (by*blocks_w + bx)*64.
+static int entropy_decode_impl(const uint8_t *data, size_t n, const hvc_jpeg_info *info, int16_t *coefs,
+                               std::vector<hvc::WideDc> *wide);
 int hvc_jpeg_entropy_decode(const uint8_t *data, size_t n, const hvc_jpeg_info *info, int16_t *coefs) {
+    return entropy_decode_impl(data, n, info, coefs, nullptr);
+}
+
+// wide == nullptr: an absolute DC outside int16 is HVC_E_RANGE (the int16 record cannot carry it).  Otherwise the
+// record gets the saturated value and the block goes on the list with its true DC (hvc_huff.h WideDc).
+static int entropy_decode_impl(const uint8_t *data, size_t n, const hvc_jpeg_info *info, int16_t *coefs,
+                               std::vector<hvc::WideDc> *wide) {
     if (!data || !info || !coefs) return HVC_E_INVALID_ARG;
     Header h;
     int r = parse_header(data, n, h);
@@ -334,7 +343,7 @@ int hvc_jpeg_entropy_decode(const uint8_t *data, size_t n, const hvc_jpeg_info *
     // clear_block (decoder.ml:109-116) happens per block below, right before the block is written: one
     // pass over the record instead of a 6 MB memset that has left the cache by the time the block comes up
     BitReader br{ecs.data(), ecs_len};
-    int dc_pred[4] = {0, 0, 0, 0};
+    long long dc_pred[4] = {0, 0, 0, 0}; // (the model's 63-bit ints: 67 M blocks of +-65535 stay far inside)
     const hvc_jpeg_component &c0 = info->comp[0];
     const int mbs_wide = c0.decoded_width / (8 * c0.hscale), mbs_high = c0.decoded_height / (8 * c0.vscale);
     for (int my = 0; my < mbs_high; my++)
@@ -364,10 +373,19 @@ int hvc_jpeg_entropy_decode(const uint8_t *data, size_t n, const hvc_jpeg_info *
                             diff = extend(cat, br.peek(cat));
                             br.skip(cat);
                         }
-                        const int dcv = diff + dc_pred[i];
+                        const long long dcv = diff + dc_pred[i];
                         dc_pred[i] = dcv;
-                        if (dcv < -32768 || dcv > 32767) return HVC_E_RANGE;
-                        blk[0] = (int16_t)dcv;
+                        if (dcv < -32768 || dcv > 32767) {
+                            if (!wide) return HVC_E_RANGE;
+                            try {
+                                wide->push_back(hvc::WideDc{(uint32_t)((size_t)(blk - coefs) >> 6), dcv});
+                            } catch (const std::bad_alloc &) {
+                                return HVC_E_OUT_OF_MEMORY;
+                            }
+                            blk[0] = (int16_t)(dcv < 0 ? -32767 : 32767);
+                        } else {
+                            blk[0] = (int16_t)dcv;
+                        }
                         int k = 1;
                         while (k < 64) {
                             br.refill();
@@ -642,6 +660,11 @@ int hvc_jpeg_encoder_check(const hvc_jpeg_info *info) {
 } // extern "C"
 
 namespace hvc {
+int entropy_decode_wide(const uint8_t *data, size_t n, const ::hvc_jpeg_info *info, int16_t *coefs, std::vector<WideDc> &wide) {
+    wide.clear();
+    return entropy_decode_impl(data, n, info, coefs, &wide);
+}
+
 // Encoder.write_headers (encoder.ml:371-418) for `info`: SOI .. SOS, appended to o
 void jpeg_header_bytes(const hvc_jpeg_info *info, std::vector<uint8_t> &o) {
     put_marker(o, 0xd8);

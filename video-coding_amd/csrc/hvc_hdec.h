@@ -113,5 +113,17 @@ int prepare_gpu_decode(const uint8_t *jpeg, size_t n, const ::hvc_jpeg_info *inf
 int prepare_gpu_decode_to(const uint8_t *jpeg, size_t n, const ::hvc_jpeg_info *info, HdTables &t, uint8_t *dst, size_t cap,
                           size_t *ecs_size, bool &gpu_ok);
 
+
+// A block whose absolute DC (decoder.ml:143, a 63-bit sum in the model) does not fit the int16 coefficient record:
+// the record holds the value saturated to +-32767, this entry the true one.  block = the block's coefficient offset
+// inside the frame record / 64.
+struct WideDc {
+    uint32_t block;
+    long long dc;
+};
+// hvc_jpeg_entropy_decode that goes on where that one answers HVC_E_RANGE: such blocks are listed in `wide` (the
+// file-level decode entry points then recompute them in int64 with their true DC, as the model does)
+int entropy_decode_wide(const uint8_t *data, size_t n, const ::hvc_jpeg_info *info, int16_t *coefs, std::vector<WideDc> &wide);
+
 } // namespace hvc
 #endif

@@ -49,5 +49,6 @@ void default_enc_tables(uint32_t (*out)[16 + 256]);
 struct hvc_jpeg_info;
 namespace hvc {
 void jpeg_header_bytes(const ::hvc_jpeg_info *info, std::vector<uint8_t> &o);
+
 }
 #endif

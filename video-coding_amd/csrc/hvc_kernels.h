@@ -126,6 +126,11 @@ hipError_t launch_decode_444(const Decode444Params &P, bool wide_only, hipStream
 void plan_decode_444(Decode444Params &P, bool aligned);
 hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr);
 hipError_t launch_decode_wide_only(const DecodeParams &P, hipStream_t s);
+// after a batch's launches: the listed blocks (fix-list ids of P's geometry) recomputed in int64 with the DC of dcs[]
+hipError_t launch_decode_dcfix(const DecodeParams &P, const unsigned *count, const unsigned *ids, const long long *dcs,
+                               hipStream_t s);
+hipError_t launch_decode_444_dcfix(const Decode444Params &P, const unsigned *count, const unsigned *ids, const long long *dcs,
+                                   unsigned n_host, hipStream_t s);
 hipError_t launch_encode(const EncodeParams &P, hipStream_t s, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr);
 hipError_t launch_upsample420(const UpsampleParams &P, hipStream_t s);
 // error = |recon - P.pixels| per sample of the component planes (Encoder.recon, encoder.ml:119-125); P.coefs unused

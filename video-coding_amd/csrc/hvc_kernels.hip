@@ -766,8 +766,10 @@ __global__ __launch_bounds__(HVC_TILE) void k_decode_q16(DecodeParams P) {
 
 // K1 wide: int64, one flagged block per thread; also usable on its own for a
 // whole batch (list == nullptr: every block).
+// dc_list (optional, parallel to list): the listed block's true absolute DC where it does not fit the int16 record
+// (hvc_hdec.h WideDc: the model's 63-bit dc of decoder.ml:143)
 __global__ __launch_bounds__(64) void k_decode_wide(DecodeParams P, const unsigned *count, const unsigned *list,
-                                                    unsigned long long total) {
+                                                    unsigned long long total, const long long *dc_list) {
     unsigned long long n = list ? (unsigned long long)*count : total;
     // The two fix-up counters alternate between calls: this launch reads the
     // current one and clears the other for the next call (no memset node).
@@ -788,6 +790,7 @@ __global__ __launch_bounds__(64) void k_decode_wide(DecodeParams P, const unsign
         for (int k = 0; k < 64; k++) v[ZI[k]] = (int64_t)cf[k] * (int64_t)q[k];
         if (P.dc_plane) // the DC lives in the compact array (DecodeParams::dc_plane)
             v[0] = (int64_t)P.dc_plane[(size_t)frame * P.dc_fs + ((br.coef_idx - (size_t)frame * P.coef_fs) >> 6)] * (int64_t)q[0];
+        if (dc_list) v[0] = (int64_t)dc_list[i] * (int64_t)q[0];
         for (int r = 0; r < 8; r++) idct_1d_wide<false>(v + r * 8, 1);
         for (int c = 0; c < 8; c++) idct_1d_wide<true>(v + c, 8);
         for (int j = 0; j < 8; j++)
@@ -1023,7 +1026,7 @@ __global__ __launch_bounds__(HVC_TILE * NW, 4 / NW) HVC_444_ATTR void k_decode_4
 // as they are; a chroma block's 64 samples go to the EVEN output coordinates, where supersample_hv2
 // puts the source sample; k_reinterp_444 then rebuilds the interpolated ones around it.
 __global__ __launch_bounds__(64) void k_decode_wide_444(Decode444Params P, const unsigned *count, const unsigned *list,
-                                                        unsigned long long total) {
+                                                        unsigned long long total, const long long *dc_list) {
     const unsigned long long n = list ? (unsigned long long)*count : total;
     if (blockIdx.x == 0 && threadIdx.x == 0 && P.fix_count_next) *P.fix_count_next = 0;
     for (unsigned long long i = (unsigned long long)blockIdx.x * 64 + threadIdx.x; i < n;
@@ -1044,6 +1047,7 @@ __global__ __launch_bounds__(64) void k_decode_wide_444(Decode444Params P, const
         const int16_t *cf = P.coefs + frame * P.coef_fs + in_frame;
         for (int k = 0; k < 64; k++) v[ZI[k]] = (int64_t)cf[k] * (int64_t)q[k];
         if (P.dc_plane) v[0] = (int64_t)P.dc_plane[frame * P.dc_fs + (in_frame >> 6)] * (int64_t)q[0];
+        if (dc_list) v[0] = (int64_t)dc_list[i] * (int64_t)q[0];
         for (int rr = 0; rr < 8; rr++) idct_1d_wide<false>(v + rr * 8, 1);
         for (int c = 0; c < 8; c++) idct_1d_wide<true>(v + c, 8);
         uint8_t *plane = P.out + frame * P.out_fs + K.out_off;
@@ -1542,7 +1546,37 @@ hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0, hi
     if (k1 && (e = hipEventRecord(k1, s)) != hipSuccess) return e;
     // Fixed small grid; every thread strides over the (normally empty) list and
     // exits as soon as its index passes *fix_count.
-    hipLaunchKernelGGL(k_decode_wide, dim3(256), dim3(64), 0, s, P, P.fix_count, P.fix_list, 0ull);
+    hipLaunchKernelGGL(k_decode_wide, dim3(256), dim3(64), 0, s, P, P.fix_count, P.fix_list, 0ull, (const long long *)nullptr);
+    return hipGetLastError();
+}
+
+// Blocks whose true DC does not fit the record (hvc_hdec.h WideDc), after the batch's normal launches: recomputed in
+// int64 with that DC.  ids = fix-list ids of P's geometry, dcs parallel, *count entries (all device memory).
+hipError_t launch_decode_dcfix(const DecodeParams &P, const unsigned *count, const unsigned *ids, const long long *dcs,
+                               hipStream_t s) {
+    DecodeParams Q = P;
+    Q.fix_count_next = nullptr; // (not part of the launches' counter ping-pong)
+    hipLaunchKernelGGL(k_decode_wide, dim3(64), dim3(64), 0, s, Q, count, ids, 0ull, dcs);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_444_dcfix(const Decode444Params &P, const unsigned *count, const unsigned *ids, const long long *dcs,
+                                   unsigned n_host, hipStream_t s) {
+    Decode444Params Q = P;
+    Q.fix_count_next = nullptr;
+    hipLaunchKernelGGL(k_decode_wide_444, dim3(64), dim3(64), 0, s, Q, count, ids, 0ull, dcs);
+    // the interpolated samples around the rewritten chroma blocks (9 x 9 source samples each); the seam rows are
+    // rebuilt once more on the way, from the same source samples
+    const size_t W = (size_t)P.width;
+    const bool aligned = (W % 16 == 0) && (P.out_fs % 16 == 0) && ((uintptr_t)P.out % 16 == 0);
+    const long long hw = aligned ? P.pl[1].aw / 8 : P.pl[1].aw;
+    const long long seams = 2 * (long long)(P.c_tiles_y - 1) * hw;
+    const long long want = seams > (long long)n_host * 81 ? seams : (long long)n_host * 81;
+    const dim3 rgrid((unsigned)((want + 255) / 256) ? (unsigned)((want + 255) / 256) : 1u, (unsigned)P.n_frames, 1);
+    if (aligned)
+        hipLaunchKernelGGL(k_reinterp_444<true>, rgrid, dim3(256), 0, s, Q, count, ids, 0);
+    else
+        hipLaunchKernelGGL(k_reinterp_444<false>, rgrid, dim3(256), 0, s, Q, count, ids, 0);
     return hipGetLastError();
 }
 
@@ -1550,7 +1584,7 @@ hipError_t launch_decode_wide_only(const DecodeParams &P, hipStream_t s) {
     if (P.n_frames <= 0 || P.tiles_per_frame <= 0) return hipSuccess;
     unsigned long long total = (unsigned long long)P.n_frames * P.tiles_per_frame * HVC_TILE;
     hipLaunchKernelGGL(k_decode_wide, dim3(4096), dim3(64), 0, s, P, (const unsigned *)nullptr,
-                       (const unsigned *)nullptr, total);
+                       (const unsigned *)nullptr, total, (const long long *)nullptr);
     return hipGetLastError();
 }
 
@@ -1584,7 +1618,7 @@ hipError_t launch_decode_444(const Decode444Params &P, bool wide_only, hipStream
         const unsigned long long total = (unsigned long long)P.n_frames * P.tiles_per_frame * HVC_TILE * P.nw;
         if (k0) (void)hipEventRecord(k0, s);
         hipLaunchKernelGGL(k_decode_wide_444, dim3(4096), dim3(64), 0, s, P, (const unsigned *)nullptr,
-                           (const unsigned *)nullptr, total);
+                           (const unsigned *)nullptr, total, (const long long *)nullptr);
         if (k1) (void)hipEventRecord(k1, s);
         hipLaunchKernelGGL(k_reinterp_444<false>, dim3((unsigned)((2 * per_plane + 255) / 256), (unsigned)P.n_frames, 1),
                            dim3(256), 0, s, P, (const unsigned *)P.fix_count, (const unsigned *)P.fix_list, 1);
@@ -1610,7 +1644,7 @@ hipError_t launch_decode_444(const Decode444Params &P, bool wide_only, hipStream
         launch_444_kernel<true, 4>(Q, grid, pad, s);
     if (k1) (void)hipEventRecord(k1, s);
     hipLaunchKernelGGL(k_decode_wide_444, dim3(256), dim3(64), 0, s, P, (const unsigned *)P.fix_count,
-                       (const unsigned *)P.fix_list, 0ull);
+                       (const unsigned *)P.fix_list, 0ull, (const long long *)nullptr);
     const long long hw = aligned ? P.pl[1].aw / 8 : P.pl[1].aw;
     const long long seams = 2 * (long long)(P.c_tiles_y - 1) * hw;
     const dim3 rgrid((unsigned)((seams + 255) / 256) ? (unsigned)((seams + 255) / 256) : 1u, (unsigned)P.n_frames, 1);
