@@ -29,7 +29,9 @@
  *    of wrapping; the entry points that decode FILES TO PIXELS (hvc_jpeg_decode, hvc_jpeg_decode_yuv444, the
  *    hvc_jpeg_decode_batch family) carry those blocks' true DCs on a side list through an int64 fix-up and give the
  *    model's pixels (tests/test_host_entropy.py::test_dc_beyond_int16_is_refused_not_wrapped,
- *    tests/test_gpu_jpeg_api.py::test_dc_beyond_int16_decodes_like_the_model).
+ *    tests/test_gpu_jpeg_api.py::test_dc_beyond_int16_decodes_like_the_model).  That includes DC categories of 17 to
+ *    32 bits, which the model reads without complaint; a Huffman table announcing MORE than 32 magnitude bits for a
+ *    DC symbol (the model would shift them through its 63-bit int) is refused as HVC_E_BAD_JPEG.
  *
  * Data layouts
  *  - coefficients: int16, [plane][blocks_h][blocks_w][64], each block in

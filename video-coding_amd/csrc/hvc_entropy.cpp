@@ -366,9 +366,20 @@ static int entropy_decode_impl(const uint8_t *data, size_t n, const hvc_jpeg_inf
                         if (!e) e = dct[br.peek(dmax)];
                         if (!e) return HVC_E_BAD_JPEG; // "Can't find dc code"
                         br.skip(e >> 8);
-                        int cat = e & 0xff, diff = 0;
-                        if (cat) {
-                            if (cat > 16) return HVC_E_BAD_JPEG;
+                        const int cat = e & 0xff;
+                        long long diff = 0;
+                        if (cat > 16) {
+                            // No JPEG has DC categories above 11 (baseline) / 16; the model, though, reads `cat`
+                            // magnitude bits for whatever the table says (decoder.ml:81-96: no check).  Up to 32 bits
+                            // this reader follows it -- such a difference never fits the int16 record (|d| >= 65536),
+                            // so only the wide-DC mode goes on -- beyond that the stream is refused.
+                            if (cat > 32) return HVC_E_BAD_JPEG;
+                            if (!wide) return HVC_E_RANGE;
+                            br.refill();
+                            const unsigned code = br.peek(cat);
+                            diff = ((code >> (cat - 1)) & 1u) ? (long long)code : (long long)code - ((1ll << cat) - 1);
+                            br.skip(cat);
+                        } else if (cat) {
                             br.refill();
                             diff = extend(cat, br.peek(cat));
                             br.skip(cat);
