@@ -1951,6 +1951,15 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
     unsigned flags[2] = {0, 0};
     HIPCHK(c, hipMemcpyAsync(flags, P.changed, sizeof flags, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+#ifdef HVC_HD_STATS // experiments: entries of k_hd_sync's work lists per round; walks / inner rounds of k_hd_round's launches
+    {
+        unsigned ln[HVC_HD_LIST_N];
+        HIPCHK(c, hipMemcpy(ln, P.list_n, sizeof ln, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "hd stats: %u subsequences; lists", P.total_sub);
+        for (int q = 2; q < HVC_HD_LIST_N - 2; q++) std::fprintf(stderr, " %u", ln[q]);
+        std::fprintf(stderr, "; k_hd_round walks %u, inner rounds %u; changed %u status %u\n", ln[HVC_HD_LIST_N - 2], ln[HVC_HD_LIST_N - 1], flags[0], flags[1]);
+    }
+#endif
     if (flags[0]) { // (the finish passes have turned the block counts into block indices: the rounds start over)
         const int max_rounds = 48;
         int round = 0;
@@ -2295,6 +2304,15 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     hipStream_t compute = c->stream;
     const bool prof_saved = c->profiling;
     c->profiling = false;
+    int pending_release = -1; // the chunk whose pinned segment slot is handed on once its upload has finished
+    auto release_after_upload = [&](int k) -> hipError_t {
+        const hipError_t he = hipEventSynchronize(c->ev_h2d[k % NB]);
+        if (he != hipSuccess) return he;
+        std::lock_guard<std::mutex> lk(mu);
+        released_upto = k + NB;
+        cv.notify_all();
+        return hipSuccess;
+    };
     for (int it = 0; it < n_chunks + NB && rc == HVC_OK; it++) {
         // verdict on chunk it - NB's slot before it is overwritten (and on the last chunks at the end)
         const int v = it - NB;
@@ -2326,17 +2344,23 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         {
             std::lock_guard<std::mutex> lk(mu);
             skip = chunk_host[(size_t)k] != 0;
-            if (skip) { // no GPU work for this chunk; its pinned slot goes to chunk k + NB, the downloader moves on
-                skipped[(size_t)k] = 1;
-                released_upto = k + NB;
-                stage_done.store(k + 1);
-                cv.notify_all();
-            }
         }
-        if (skip) continue;
+        if (skip) { // no GPU work for this chunk; its pinned slot goes to chunk k + NB, the downloader moves on
+            if (pending_release >= 0) { // (slots are released in order: the previous chunk's upload first)
+                const hipError_t he = release_after_upload(pending_release);
+                pending_release = -1;
+                if (he != hipSuccess) { rc = fail_hip(c, he); break; }
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            skipped[(size_t)k] = 1;
+            released_upto = k + NB;
+            stage_done.store(k + 1);
+            cv.notify_all();
+            continue;
+        }
         // the chunk's index arrays
         unsigned *hm = (unsigned *)c->gp_h_meta[slot];
-        unsigned *h_ecs_off = hm, *h_sub_off = hm + C, *h_tabset_of = h_sub_off + C + 1, *h_frame_of = h_tabset_of + C;
+        unsigned *h_ecs_off = hm, *h_sub_off = hm + C, *h_tabset_of = h_sub_off + C + 1; // (frame_of: filled on the GPU)
         unsigned subs = 0;
         bool pf = !uniform_ok;
         for (int f = 0; f < cnt; f++) {
@@ -2345,7 +2369,6 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
             pf |= frame_pf[(size_t)(first + f)] != 0;
             h_ecs_off[f] = (unsigned)((size_t)f * R);
             h_sub_off[f] = subs;
-            for (unsigned q = 0; q < nsub; q++) h_frame_of[subs + q] = (unsigned)f;
             subs += nsub;
             ecs_total += ecs_size[(size_t)(first + f)];
         }
@@ -2379,7 +2402,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         if (he == hipSuccess)
             he = hipMemcpyAsync(c->gp_d_ecs[slot], c->gp_h_ecs[slot], (size_t)cnt * R, hipMemcpyHostToDevice, c->copy_stream);
         if (he == hipSuccess)
-            he = hipMemcpyAsync(dm, hm, ((size_t)3 * C + 1 + subs) * sizeof(unsigned), hipMemcpyHostToDevice, c->copy_stream);
+            he = hipMemcpyAsync(dm, hm, ((size_t)3 * C + 1) * sizeof(unsigned), hipMemcpyHostToDevice, c->copy_stream);
         if (he == hipSuccess && pf) // the tables of the chunk's frames (36 KB a frame against ~1 MB of segment)
             he = hipMemcpyAsync(c->gp_d_ftabs[slot], c->gp_h_ftabs[slot], ((size_t)cnt + 1) * sizeof(hvc::HdFrameTabs),
                                 hipMemcpyHostToDevice, c->copy_stream);
@@ -2387,6 +2410,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         // (the slot's records and index arrays are free: the verdict above waited for chunk k - NB's block stage)
         if (he == hipSuccess) he = hipStreamWaitEvent(rs, c->ev_h2d[slot], 0);
         if (he == hipSuccess) he = hipEventRecord(c->ev_et[slot][1], rs);
+        if (he == hipSuccess) he = hvc::launch_hd_frame_of(P, rs);
         if (he == hipSuccess) he = gd_enqueue(P, 4, rs);
         if (he == hipSuccess) // changed + status -> the pinned copy of the index arrays
             he = hipMemcpyAsync(hm + (meta_words - 2), P.changed, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, rs);
@@ -2408,14 +2432,17 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
             cv.notify_all();
         }
         if (he == hipSuccess && where != HVC_MEM_HOST) he = hipEventRecord(c->ev_kern[slot], compute);
-        // hand the pinned segment slot to chunk k + NB once this chunk's upload is through
-        if (he == hipSuccess) he = hipEventSynchronize(c->ev_h2d[slot]);
+        // Hand the PREVIOUS chunk's pinned segment slot to chunk k - 1 + NB now that its upload is through -- this
+        // chunk's upload is queued behind it, so the copy engine goes from one to the next while this thread waits
+        // here, prepares the next chunk's index arrays and enqueues its launches (waiting for a chunk's own upload
+        // at this point left the engine idle for as long as that took: 0.5 - 2 ms in every 4.8).
+        if (he == hipSuccess && pending_release >= 0) he = release_after_upload(pending_release);
         if (he != hipSuccess) { rc = fail_hip(c, he); break; }
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            released_upto = k + NB;
-            cv.notify_all();
-        }
+        pending_release = k;
+    }
+    if (rc == HVC_OK && pending_release >= 0) {
+        const hipError_t he = release_after_upload(pending_release);
+        if (he != hipSuccess) rc = fail_hip(c, he);
     }
     c->profiling = prof_saved;
     {

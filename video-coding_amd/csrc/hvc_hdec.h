@@ -28,8 +28,9 @@ struct HdTables {
 
 // The same tables as the synchronisation walk wants them: it needs no values, only how far a symbol moves the
 // bit position and the zig-zag index.  Entry: bits 0-5 bits consumed (code + magnitude; 1 for "no code": the
-// walk steps one bit), bits 6-10 index advance (run + 1; 1 for a DC symbol; 0 where the index stays), bit 11
-// end of block (EOB); 0x8000 | n in the first level = continue in sub-table n, as in HdTable.
+// walk steps one bit), bits 6-12 index advance (run + 1; 1 for a DC symbol; 0 where the index stays; 64 for
+// EOB, so that "index >= 64" is the one end-of-block test); 0x8000 | n in the first level = continue in sub-table n,
+// as in HdTable.
 // Components that share their tables share a slot; frames with three different table sets keep to k_hd_round.
 struct HdSpec {
     uint16_t t[2][2][1024 + HVC_HD_SUBTABLES * 64]; // [slot][0 = DC, 1 = AC]
@@ -101,6 +102,7 @@ struct HdParams {
 };
 
 hipError_t launch_hd_round(const HdParams &P, int round, hipStream_t s);
+hipError_t launch_hd_frame_of(const HdParams &P, hipStream_t s); // fills P.frame_of from P.sub_off (callers that do not upload it)
 hipError_t launch_hd_finish(const HdParams &P, int rounds_done, hipStream_t s); // count scan, write pass, DC pass
 bool hd_write2_fits(const HdParams &P); // the fast write pass can address these records (PF mode needs it)
 

@@ -223,31 +223,53 @@ __device__ __forceinline__ void walk(const HdParams &P, const HdGeo &G, const Hd
 
 } // namespace
 
+// A staged subsequence: its S / 32 dwords and one more.  A symbol starts before bit S and is at most 32 bits long
+// (code <= 16, magnitude <= 16), so bit S + 31 is the last one any walk looks at.  S / 32 + 1 is odd: lanes reading
+// the same dword index of their rows hit different LDS banks.
+constexpr int SROW = S / 32 + 1;
+static_assert((SROW & 1) == 1, "odd row stride");
+__device__ __forceinline__ void stage_row(unsigned *row, const uint8_t *seg) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(seg);
+#pragma unroll
+    for (int q = 0; q < S / 128; q++) {
+        const uint4 v = src[q];
+        row[4 * q + 0] = __builtin_bswap32(v.x);
+        row[4 * q + 1] = __builtin_bswap32(v.y);
+        row[4 * q + 2] = __builtin_bswap32(v.z);
+        row[4 * q + 3] = __builtin_bswap32(v.w);
+    }
+    row[S / 32] = __builtin_bswap32(reinterpret_cast<const unsigned *>(seg)[S / 32]); // the segment buffer has 16 bytes past every frame
+}
+constexpr int SPEC_T = HVC_HD_SPEC_T;
+
+template <bool RD_FREE, class RD> // the lean walk of the synchronisation rounds, defined with k_hd_sync below
+__device__ __forceinline__ void spec_walk(RD rd, const uint16_t *sp, unsigned sel, int B, unsigned base, unsigned &p, int &k, int &b, unsigned &nb);
+
 // One synchronisation launch (see the header comment).  Even launches write exit_a, odd ones exit_b.
 // Inside the launch the 256 subsequences of a workgroup run up to INNER rounds among themselves through
 // LDS (exit of lane t - 1 -> start of lane t), so a launch settles whole workgroups and the launches only
 // have to carry states across workgroup boundaries.
 constexpr int INNER = 24;
-// PF (per-frame tables): the walk is spec_walk on the frame's own record in device memory, the bits come straight
-// from global memory as well (byte order restored on the way); no tables in LDS.
-template <bool PF>
+// MODE 0: the general walk, HdTables in LDS, bits straight from global memory.
+// MODE 1 (HdParams::spec set): behind k_hd_sync this kernel follows the few chains of hand-overs that are still moving,
+//   one step per inner round with one lane of a workgroup busy -- the latency of a single walk is all that counts, so
+//   it is the lean one: spec_walk on the HdSpec tables, the lane's subsequence staged in LDS.
+// MODE 2 (PF, per-frame tables): spec_walk on the frame's own record in device memory, the bits from global memory as
+//   well (byte order restored on the way); no tables in LDS.
+template <int MODE>
 __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
-    __shared__ __attribute__((aligned(16))) unsigned char Traw[PF ? 16 : sizeof(HdTables)];
+    constexpr bool PF = MODE == 2;
+    __shared__ __attribute__((aligned(16))) unsigned char Traw[MODE == 0 ? sizeof(HdTables) : MODE == 1 ? sizeof(HdSpec) : 16];
+    __shared__ unsigned rows[MODE == 1 ? 256 * SROW : 1];
     HdTables &T = *reinterpret_cast<HdTables *>(Traw);
     __shared__ HdGeo G;
     __shared__ unsigned long long exits[256];
     load_geo(P, G);
-    if (!PF) {
-        const unsigned *src = reinterpret_cast<const unsigned *>(P.tables);
-        unsigned *dst = reinterpret_cast<unsigned *>(&T);
-        for (unsigned i = threadIdx.x; i < sizeof(HdTables) / 4; i += 256) dst[i] = src[i];
-    }
     const int tid = threadIdx.x;
     const unsigned i = blockIdx.x * 256u + (unsigned)tid;
     const bool valid = i < P.total_sub;
     const unsigned f = valid ? P.frame_of[i] : 0u, j = valid ? i - P.sub_off[f] : 0u;
     const unsigned *slot = reinterpret_cast<const unsigned *>(P.ecs + P.ecs_off[f] + (size_t)j * (S / 8));
-    __syncthreads();
     const unsigned long long *prev = (round & 1) ? P.exit_a : P.exit_b;
     unsigned long long *cur = (round & 1) ? P.exit_b : P.exit_a;
     const unsigned base = j * (unsigned)S;
@@ -261,21 +283,42 @@ __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
         have = true;
         if (j > 0) st = prev[i - 1];
     }
+    // Behind k_hd_sync almost every workgroup only finds its hand-overs in order: the 18 KB of tables are loaded when
+    // a lane has to walk -- an inner round starts walks only where a neighbour's exit moved, i.e. after a walk --
+    // and a launch that verifies costs the three arrays it reads, not the tables 7 000 workgroups would fetch.
+    if (__syncthreads_or(valid && (!have || st != used)) && !PF) { // (the barrier also publishes G)
+        const unsigned *src = MODE == 1 ? reinterpret_cast<const unsigned *>(P.spec) : reinterpret_cast<const unsigned *>(P.tables);
+        unsigned *dst = reinterpret_cast<unsigned *>(Traw);
+        for (unsigned q = threadIdx.x; q < sizeof(Traw) / 4; q += 256) dst[q] = src[q];
+        __syncthreads();
+    }
     bool changed = false;
     for (int inner = 0; inner < INNER; inner++) {
         if (valid && (!have || st != used)) {
             unsigned p = (unsigned)st, err = 0;
             int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
             nb = 0;
-            if (PF)
-                spec_walk([slot](unsigned q) { return __builtin_bswap32(slot[q]); }, &P.ftabs[P.tabset_of[f]].spec[0][0][0],
-                          P.selmask, P.blocks_per_mcu, base, p, k, b, nb);
-            else
+            if (PF) {
+                spec_walk<false>([slot](unsigned q) { return __builtin_bswap32(slot[q]); }, &P.ftabs[P.tabset_of[f]].spec[0][0][0],
+                                 P.selmask, P.blocks_per_mcu, base, p, k, b, nb);
+            } else if (MODE == 1) {
+                unsigned *row = rows + tid * SROW; // (staged once per launch would do; a walk is 200 symbols, this is 40 instructions)
+                stage_row(row, reinterpret_cast<const uint8_t *>(slot));
+                spec_walk<true>([row](unsigned q) { return row[q]; }, reinterpret_cast<const uint16_t *>(Traw), P.selmask, P.blocks_per_mcu,
+                                base, p, k, b, nb);
+            } else {
                 walk<false>(P, G, T, slot, base, base + (unsigned)S, p, k, b, nb, 0, nullptr, err);
+            }
             ex = pack_state(p, k, b);
             used = st;
             have = true;
             changed = true;
+#ifdef HVC_HD_STATS // experiments: walks of the verifying launches, inner rounds they needed
+            if (round > 0) {
+                atomicAdd(&P.list_n[HVC_HD_LIST_N - 2], 1u);
+                atomicMax(&P.list_n[HVC_HD_LIST_N - 1], (unsigned)inner + 1u);
+            }
+#endif
         }
         exits[tid] = ex;
         __syncthreads();
@@ -320,29 +363,16 @@ __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
 constexpr int SYNC_ROUNDS = 12;
 constexpr unsigned SYNC_TAIL_MAX_SUB = 32768; // up to four 1080p files of 1 MB: k_hd_sync_tail
 constexpr int SYNC_TAIL_FROM = 5;
-// A staged subsequence: its S / 32 dwords and one more.  A symbol starts before bit S and is at most 32 bits long
-// (code <= 16, magnitude <= 16), so bit S + 31 is the last one any walk looks at.  S / 32 + 1 is odd: lanes reading
-// the same dword index of their rows hit different LDS banks.
-constexpr int SROW = S / 32 + 1;
-static_assert((SROW & 1) == 1, "odd row stride");
-__device__ __forceinline__ void stage_row(unsigned *row, const uint8_t *seg) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(seg);
-#pragma unroll
-    for (int q = 0; q < S / 128; q++) {
-        const uint4 v = src[q];
-        row[4 * q + 0] = __builtin_bswap32(v.x);
-        row[4 * q + 1] = __builtin_bswap32(v.y);
-        row[4 * q + 2] = __builtin_bswap32(v.z);
-        row[4 * q + 3] = __builtin_bswap32(v.w);
-    }
-    row[S / 32] = __builtin_bswap32(reinterpret_cast<const unsigned *>(seg)[S / 32]); // the segment buffer has 16 bytes past every frame
-}
-constexpr int SPEC_T = HVC_HD_SPEC_T;
 
 // rd(i) = dword i of the subsequence, big-endian order restored (i <= S / 32: one dword past it).  sp = the tables of
 // the frame: [slot or component][DC, AC][SPEC_T] -- in LDS (one set for the whole batch) or, in PF mode, in device
 // memory (this frame's record); sel = HdParams::selmask.
-template <class RD>
+// The loop body is straight-line code but for the second-level look-up: in a wavefront of 64 walks SOME lane refills
+// its window or ends a block in nine iterations out of ten, so a branch around either is paid every time, plus its
+// mask bookkeeping -- and a refill inside a branch made the wavefront wait for its LDS read on the spot.  Selects
+// instead; with RD_FREE (rows in LDS) the dword after the window is simply read again in every iteration (rd(ni) is a
+// function of ni), and nothing waits for it before the next table look-up has come back anyway.
+template <bool RD_FREE, class RD>
 __device__ __forceinline__ void spec_walk(RD rd, const uint16_t *sp, unsigned sel, int B, unsigned base, unsigned &p, int &k,
                                           int &b, unsigned &nb) {
     const unsigned limit = base + (unsigned)S;
@@ -360,22 +390,30 @@ __device__ __forceinline__ void spec_walk(RD rd, const uint16_t *sp, unsigned se
         unsigned e = t[w >> 22];
         if (e & 0x8000u) e = t[1024u + (e & 0x7fffu) * 64u + ((w >> 16) & 63u)];
         const int used = (int)(e & 63u);
-        k += (int)((e >> 6) & 31u);
+        k += (int)((e >> 6) & 127u); // an EOB advances by 64
         p += (unsigned)used;
         s -= used;
-        if (s < 0) { // `hi` is used up (used <= 32: one step is enough)
+        const bool refill = s < 0; // `hi` is used up (used <= 32: one step is enough)
+        if (RD_FREE) {
+            hi = refill ? lo : hi;
+            lo = refill ? nx : lo;
+            s += refill ? 32 : 0;
+            ni += refill ? 1u : 0u;
+            nx = rd(min(ni, (unsigned)(SROW - 1)));
+        } else if (refill) {
             hi = lo;
             lo = nx;
             s += 32;
             ni++;
             nx = rd(min(ni, (unsigned)(SROW - 1)));
         }
-        if ((e & 0x800u) || k >= 64) { // EOB, index 63 written, or past it (the model raises: the true parse never gets here)
-            k = 0;
-            b = b + 1 == B ? 0 : b + 1;
-            nb++;
-            bt = sp + ((sel >> (2 * b)) & 3u) * (2 * SPEC_T);
-        }
+        // EOB, index 63 written, or past it (the model raises: the true parse never gets here)
+        const bool end = k >= 64;
+        const int b1 = b + 1 == B ? 0 : b + 1;
+        k = end ? 0 : k;
+        b = end ? b1 : b;
+        nb += end ? 1u : 0u;
+        bt = sp + ((sel >> (2 * b)) & 3u) * (2 * SPEC_T);
     }
 }
 
@@ -397,7 +435,7 @@ __device__ __forceinline__ bool sync_one(const HdParams &P, int round, bool vali
     unsigned p = (unsigned)st, nb = 0;
     int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
     const uint16_t *sp = PF ? &P.ftabs[P.tabset_of[f]].spec[0][0][0] : sp_lds;
-    spec_walk([row](unsigned q) { return row[q]; }, sp, P.selmask, P.blocks_per_mcu, base, p, k, b, nb);
+    spec_walk<true>([row](unsigned q) { return row[q]; }, sp, P.selmask, P.blocks_per_mcu, base, p, k, b, nb);
     const unsigned long long ex = pack_state(p, k, b);
     const bool differs = round == 0 || ex != P.exit_a[i];
     P.exit_a[i] = ex;
@@ -412,6 +450,10 @@ template <bool PF>
 __global__ __launch_bounds__(SYNC_WG) void k_hd_sync(HdParams P, int round) {
     __shared__ uint16_t sp[PF ? 2 : 2 * 2 * SPEC_T];
     __shared__ unsigned rows[SYNC_WG / 64][64 * SROW];
+    const unsigned count = round < 2 ? P.total_sub : P.list_n[round];
+    // the late rounds are launched over lists that hold a few hundred entries or none: a workgroup without work
+    // leaves before it fetches 12 KB of tables (55 us a round for the 512 workgroups of such a launch, 10 without)
+    if (blockIdx.x * (unsigned)SYNC_WG >= count) return;
     if (!PF) {
         const unsigned *src = reinterpret_cast<const unsigned *>(P.spec);
         unsigned *dst = reinterpret_cast<unsigned *>(sp);
@@ -422,7 +464,6 @@ __global__ __launch_bounds__(SYNC_WG) void k_hd_sync(HdParams P, int round) {
     unsigned *row = rows[wave] + lane * SROW;
     const unsigned *list = (round & 1) ? P.list1 : P.list0; // rounds 0 and 1: every subsequence, no list
     unsigned *next = (round & 1) ? P.list0 : P.list1;
-    const unsigned count = round < 2 ? P.total_sub : P.list_n[round];
     const unsigned long long *pe = (round & 1) ? P.exit_b : P.exit_c; // exits of round - 1
     unsigned long long *ce = (round & 1) ? P.exit_c : P.exit_b;       // exits of this round
     for (unsigned t0 = (blockIdx.x * (unsigned)(SYNC_WG / 64) + (unsigned)wave) * 64u; t0 < count; t0 += gridDim.x * (unsigned)SYNC_WG) {
@@ -581,6 +622,20 @@ constexpr int WR_EXTRA = 3; // rows staged past the workgroup's own, for the las
 #endif
 constexpr int WR_BATCH = HVC_WR_BATCH; // block ends handled together
 
+// One entry of a value table (k_hd_write2; HdFrameTabs::val): from HdTable's (length << 8) | value.
+//   bits 0-4 code length, 5-9 magnitude bits, 10-13 run of zeros, bit 14 EOB; 0x8000 | n (first level only) = continue
+//   in sub-table n.  Magnitude bits = 31 marks what the model raises on -- no code with this prefix (length 1: the walk
+//   steps one bit) or a DC category the magnitude of which decoder.ml:73-79 cannot hold; for the DC that is category 16
+//   as well: its differences (|d| >= 32768, or -32768) leave int16 or the range a JPEG DC can have, so the stream goes
+//   to the host reader either way and the loop needs no range check.
+__host__ __device__ inline unsigned val_entry(unsigned e, bool dc) {
+    if (e & 0x8000u) return e;
+    if (!e) return 1u | (31u << 5);
+    const unsigned len = e >> 8, v = e & 0xffu;
+    if (dc) return len | ((v >= 16u ? 31u : v) << 5);
+    return len | ((v & 15u) << 5) | ((v >> 4) << 10) | (v ? 0u : 0x4000u);
+}
+
 template <bool PF>
 __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) {
     __shared__ uint16_t tv[PF ? 2 : 2 * 2 * SPEC_T]; // value tables of the two slots: [slot][DC, AC] (PF: the frame's record in device memory instead)
@@ -590,25 +645,11 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
     __shared__ uint2 flist[4][64];  // per wavefront: blocks to store (offset in the batch's records in 16-byte units, lane)
     load_geo(P, G);
     {
-        // value tables in the form the loop below wants: bits 0-4 code length (0: no code), 5-9 magnitude bits,
-        // 10-13 run of zeros, bit 14 EOB; 0x8000 | n (first level only) = continue in sub-table n
-        // (make_frame_tabs on the host writes the same form for PF mode)
         for (int sl = 0; sl < (PF ? 0 : 2); sl++)
             for (int cls = 0; cls < 2; cls++) {
                 const HdTable *src_t = cls ? &P.tables->ac[P.slot_rep[sl]] : &P.tables->dc[P.slot_rep[sl]];
                 const uint16_t *src = reinterpret_cast<const uint16_t *>(src_t);
-                for (unsigned i = threadIdx.x; i < sizeof(HdTable) / 2; i += 256) {
-                    const unsigned e = src[i];
-                    unsigned o = e;
-                    if (!(e & 0x8000u) && e) {
-                        const unsigned len = e >> 8, val = e & 0xffu;
-                        // DC: categories above 16 are errors (decoder.ml:73-79 has no such magnitude) and so, here, is 16
-                        // itself: its differences (|d| >= 32768, or -32768) leave int16 or the range a JPEG DC can have,
-                        // so the stream goes to the host decoder either way and the loop needs no range check
-                        o = cls ? (len | ((val & 15u) << 5) | ((val >> 4) << 10) | (val ? 0u : 0x4000u)) : (len | ((val >= 16u ? 31u : val) << 5));
-                    }
-                    tv[(sl * 2 + cls) * SPEC_T + i] = (uint16_t)o;
-                }
+                for (unsigned i = threadIdx.x; i < sizeof(HdTable) / 2; i += 256) tv[(sl * 2 + cls) * SPEC_T + i] = (uint16_t)val_entry(src[i], cls == 0);
             }
 #pragma unroll
         for (int q = 0; q < 8; q++) lbuf[threadIdx.x * 8 + q] = make_uint4(0, 0, 0, 0);
@@ -631,6 +672,9 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
     // dword ni of the stream from this lane's subsequence on: rows are consecutive subsequences, SROW = S / 32 + 1
     auto rd = [&](unsigned ni) -> unsigned { ni = min(ni, (unsigned)((WR_EXTRA + 1) * (S / 32) - 1)); return row[ni + ni / (unsigned)(S / 32)]; };
     int16_t *lb = reinterpret_cast<int16_t *>(lbuf + tid * 8);
+    // where the coefficients of a block that is not this lane's go: the lane's own entry of the wavefront's store list
+    // (written before it is read in every flush, and LDS operations of a wavefront keep their order)
+    int16_t *const nowhere = reinterpret_cast<int16_t *>(&flist[wave][lane]);
     const int B = P.blocks_per_mcu;
     const unsigned base = j * (unsigned)S, limit = base + (unsigned)S, hard = limit + (unsigned)(WR_EXTRA * S);
     unsigned bi = valid ? P.nblk[i] : 0xffffffffu; // the block this subsequence starts in
@@ -664,7 +708,13 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
     unsigned nx = rd(ni);
     const uint16_t *const tvb = PF ? &P.ftabs[P.tabset_of[f]].val[0][0][0] : tv;
     const uint16_t *bt = tvb + ((P.selmask >> (2 * b)) & 3u) * (2 * SPEC_T);
-    unsigned exit_p = 0, exit_kb = 0; // exit_p stays 0 for a lane that never gets that far
+    const uint16_t *bt_ac = bt + SPEC_T;
+    // the exit the synchronisation launches recorded for this subsequence must be the one this walk arrives at
+    const unsigned long long fin_i = valid ? ((final_round & 1) ? P.exit_a : P.exit_b)[i] : 0ull; // launch final_round - 1 wrote it
+    // the next bit position that needs a look: the end of the lane's own subsequence, then the end of what is staged
+    unsigned watch = limit;
+    // (Errors -- anything the model raises on in a lane's own block, a hand-over that does not match -- go straight to
+    // P.status from the rare branches that find them: carried in registers they cost every iteration a few copies.)
     // What happens at the end of a block -- store it, find the next one's place -- costs more than a symbol, and in
     // a wavefront some lane ends a block in almost every iteration.  A lane that ends a block therefore WAITS
     // (pending) until WR_BATCH lanes do, or nobody else can go on; then the wavefront does all of them at once.
@@ -672,51 +722,49 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
     unsigned cur_block = live ? block_no(b) : 0u; // where the block in progress goes
     while (__any(act)) {
         if (act && !pending) {
+            // One symbol.  Straight-line code but for the second-level look-up and the (once per lane) crossing of the
+            // subsequence's end: whatever a branch here guards, some lane of the 64 takes it nearly every time, and
+            // the branch, its masks and -- for a refill -- the wait for an LDS read inside it came on top.
             const unsigned w = __builtin_amdgcn_alignbit(hi, lo, (unsigned)s); // the next 32 bits: a whole symbol
-            const uint16_t *t = bt + (k ? SPEC_T : 0);
+            const uint16_t *t = k ? bt_ac : bt;
             unsigned e = t[w >> 22];
             if (e & 0x8000u) e = t[1024u + (e & 0x7fffu) * 64u + ((w >> 16) & 63u)];
-            // One path for DC and AC symbols (a DC symbol is "run 0" at index 0), no branches but the store:
-            const unsigned len = e & 31u, size = (e >> 5) & 31u, run = (e >> 10) & 15u;
-            const bool bad = !e || size > 16u; // "Can't find dc / ac code" (one bit further) / DC category 16 and above (the code is skipped)
-            const unsigned used = bad ? max(len, 1u) : len + size;
+            // One path for DC and AC symbols (a DC symbol is "run 0" at index 0)
+            const unsigned len = e & 31u, size_f = (e >> 5) & 31u, run = (e >> 10) & 15u;
+            const bool bad = size_f > 16u; // "Can't find dc / ac code" (one bit further) / DC category 16 and above (the code is skipped)
+            const bool eob = (e & 0x4000u) != 0u;
+            const unsigned size = bad ? 0u : size_f;
+            const unsigned used = len + size;
             // decoder.ml:73-79 mag': `size` bits after the code; a leading 0 bit means negative
-            const unsigned mbits = __builtin_amdgcn_ubfe(w, 32u - len - size, size);
+            const unsigned mbits = __builtin_amdgcn_ubfe(w, 32u - used, size);
             const unsigned full = (1u << size) - 1u;
             const int mag = (int)mbits - (mbits <= (full >> 1) ? (int)full : 0);
-            const int kk = k + (int)run; // the index this symbol's coefficient has
-            const bool eob = (e & 0x4000u) != 0u;
-            if (live) {
-                if (bad || (kk >= 64 && !eob)) err |= 1u; // ... / "coefficient index out of range"
-                else if (size) lb[kk] = (int16_t)mag; // |mag| < 2^15: size <= 15
-            }
+            const int kk = k + (int)run;                 // the index this symbol's coefficient has
+            const bool wrong = bad || (kk >= 64 && !eob); // ... / "coefficient index out of range"
+            // (a zero written at kk -- EOB, a run of 16 -- changes nothing: the indices of a block only grow)
+            *((live && !wrong) ? lb + kk : nowhere) = (int16_t)mag; // |mag| < 2^15: size <= 15 wherever it counts
+            if (live && wrong) atomicOr(P.status, 1u);
             const bool end_block = !bad && (eob || kk >= 63);
-            if (!bad) k = kk + 1;
-            p += (unsigned)used;
-            s -= used;
-            if (s < 0) {
-                hi = lo;
-                lo = nx;
-                s += 32;
-                ni++;
-                nx = rd(ni);
-            }
-            if (end_block) {
-                pending = true;
-                k = 0;
-            }
-            // where k_hd_sync's walk of this subsequence stopped: the one symbol that takes p across the limit
-            // (selects, no flag to carry: as a branch with a 64-bit state this check cost 13 % of the pass)
-            const bool cross = p - (unsigned)used < limit && p >= limit;
-            const int b_after = end_block ? (b + 1 == B ? 0 : b + 1) : b;
-            exit_p = cross ? p : exit_p;
-            exit_kb = cross ? (unsigned)k | ((unsigned)b_after << 8) : exit_kb;
-            if (p >= limit && !end_block) {
-                // a block in progress is finished here unless it is not this lane's (or nobody's: past the frame)
-                const bool mine = k > 0 && live;
-                if (!mine) act = false;
-                else if (p >= hard) { // cannot happen: 64 symbols of <= 32 bits end a block
-                    err |= 1u;
+            k = end_block ? 0 : bad ? k : kk + 1;
+            p += used;
+            s -= (int)used;
+            const bool refill = s < 0;
+            hi = refill ? lo : hi;
+            lo = refill ? nx : lo;
+            s += refill ? 32 : 0;
+            ni += refill ? 1u : 0u;
+            nx = rd(ni); // (a function of ni: read again rather than branched around)
+            pending = end_block;
+            if (p >= watch) {
+                if (watch == limit) {
+                    // where k_hd_sync's walk of this subsequence stopped: the one symbol that takes p across the limit
+                    if (pack_state(p, k, end_block ? (b + 1 == B ? 0 : b + 1) : b) != fin_i) atomicOr(P.status, 8u);
+                    watch = hard;
+                    // a block in progress is finished here unless it is not this lane's (or nobody's: past the frame);
+                    // a block that ends here: see below
+                    if (!end_block && !live) act = false;
+                } else { // cannot happen: 64 symbols of <= 32 bits end a block
+                    atomicOr(P.status, 1u);
                     act = false;
                 }
             }
@@ -747,6 +795,7 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
                 bi++;
                 live = bi < P.blocks_per_frame;
                 bt = tvb + ((P.selmask >> (2 * b)) & 3u) * (2 * SPEC_T);
+                bt_ac = bt + SPEC_T;
                 if (b == 0) { // next MCU
                     mx++;
                     if (mx == (unsigned)P.mbs_wide) {
@@ -758,10 +807,6 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
                 else cur_block = block_no(b);
             }
         }
-    }
-    if (valid && exit_p) {
-        const unsigned long long *fin = (final_round & 1) ? P.exit_a : P.exit_b; // launch final_round - 1 wrote it
-        if (pack_state(exit_p, (int)(exit_kb & 0xffu), (int)(exit_kb >> 8)) != fin[i]) err |= 8u;
     }
     if (err) atomicOr(P.status, err);
 }
@@ -830,7 +875,7 @@ static void convert_table(const HdTable &src, bool dc, uint16_t *spec, uint16_t 
         const unsigned len = e >> 8, v = e & 0xffu;
         if (dc) return (uint16_t)(v > 16 ? len : (len + v) | (1u << 6)); // category > 16: the index stays 0
         const unsigned size = v & 15u, run = v >> 4;
-        if (!size && !run) return (uint16_t)(len | 0x800u);
+        if (!size && !run) return (uint16_t)(len | (64u << 6)); // EOB: the index leaves the block
         return (uint16_t)((len + size) | ((run + 1u) << 6));
     };
     const uint16_t *all = reinterpret_cast<const uint16_t *>(&src); // fast[1024] then sub[HVC_HD_SUBTABLES * 64]
@@ -838,17 +883,7 @@ static void convert_table(const HdTable &src, bool dc, uint16_t *spec, uint16_t 
     for (int q = 0; q < SPEC_T; q++) {
         const uint16_t e = all[q];
         if (spec) spec[q] = (q >= 1024 && (e & 0x8000u)) ? (uint16_t)1 : conv(e);
-        if (val) {
-            unsigned o = e;
-            if (!(e & 0x8000u) && e) {
-                const unsigned len = e >> 8, v = e & 0xffu;
-                // DC: categories above 16 are errors (decoder.ml:73-79 has no such magnitude) and so, here, is 16
-                // itself: its differences (|d| >= 32768, or -32768) leave int16 or the range a JPEG DC can have,
-                // so the stream goes to the host decoder either way and the loop needs no range check
-                o = dc ? (len | ((v >= 16u ? 31u : v) << 5)) : (len | ((v & 15u) << 5) | ((v >> 4) << 10) | (v ? 0u : 0x4000u));
-            }
-            val[q] = (uint16_t)o;
-        }
+        if (val) val[q] = (uint16_t)val_entry(e, dc);
     }
 }
 
@@ -882,10 +917,23 @@ void make_frame_tabs(const HdTables &t, int n_comp, HdFrameTabs &out) {
     }
 }
 
+// frame_of[i] = the frame subsequence i belongs to, from sub_off (one workgroup per frame).  The batch pipeline used to
+// fill and upload this array per chunk: two million words written by the one thread that also feeds the copy engine.
+__global__ __launch_bounds__(256) void k_hd_frame_of(const unsigned *sub_off, unsigned *frame_of) {
+    const unsigned f = blockIdx.x, end = sub_off[f + 1];
+    for (unsigned q = sub_off[f] + threadIdx.x; q < end; q += 256u) frame_of[q] = f;
+}
+
+hipError_t launch_hd_frame_of(const HdParams &P, hipStream_t s) {
+    if (P.total_sub == 0 || P.n_frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_hd_frame_of, dim3((unsigned)P.n_frames), dim3(256), 0, s, P.sub_off, const_cast<unsigned *>(P.frame_of));
+    return hipGetLastError();
+}
+
 template <bool PF>
 static hipError_t launch_hd_round_t(const HdParams &P, int round, hipStream_t s) {
     if (round == 0 && (PF || P.spec)) { // all the fast rounds; launches 1.. of k_hd_round verify and, if need be, continue
-        hipError_t e = hipMemsetAsync(P.list_n, 0, (SYNC_ROUNDS + 2) * sizeof(unsigned), s);
+        hipError_t e = hipMemsetAsync(P.list_n, 0, HVC_HD_LIST_N * sizeof(unsigned), s);
         if (e != hipSuccess) return e;
         const unsigned all = (P.total_sub + (unsigned)SYNC_WG - 1u) / (unsigned)SYNC_WG;
         if (P.total_sub <= SYNC_TAIL_MAX_SUB) { // a few files: five rounds as launches, the rest inside one workgroup
@@ -908,7 +956,9 @@ static hipError_t launch_hd_round_t(const HdParams &P, int round, hipStream_t s)
         }
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_hd_round<PF>, dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, round);
+    if (PF) hipLaunchKernelGGL(k_hd_round<2>, dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, round);
+    else if (P.spec) hipLaunchKernelGGL(k_hd_round<1>, dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, round);
+    else hipLaunchKernelGGL(k_hd_round<0>, dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, round);
     return hipGetLastError();
 }
 
