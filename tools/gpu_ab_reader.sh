@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of library variants on the file-level pipeline (config 3, GPU Huffman reader): throughput at 4096 files and the GPU
-# work per 256-file chunk from a kernel trace.   usage: tools/gpu_ab_reader.sh <tag> <name>=<library> ...
+# work per 256-file chunk from a kernel trace.   usage: tools/gpu_ab_reader.sh <tag> <name>=<library>[@VAR=value] ...
 set -e
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -9,6 +9,8 @@ OUTF=$ROOT/gpurun_out/${TAG}_ab.txt
 : > $OUTF
 for spec in "$@"; do
     name=${spec%%=*}; lib=${spec#*=}
+    unset HVC_WR_MODE
+    case $lib in *@*) export "${lib#*@}"; lib=${lib%%@*};; esac
     export HVC_JPEG_LIB=$ROOT/$lib
     echo "== $name ($lib)" | tee -a $OUTF
     timeout -k 10 300 python -m pytest tests/test_gpu_hdec.py -m gpu -q -x 2>&1 | tail -1 | tee -a $OUTF

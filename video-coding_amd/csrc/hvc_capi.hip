@@ -1896,7 +1896,7 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
     }
     h_meta[(size_t)2 * n_frames] = sub_off[(size_t)n_frames];
     int r;
-    if ((r = grow(c, &c->gd_ecs, &c->gd_ecs_cap, bytes))) return r;
+    if ((r = grow(c, &c->gd_ecs, &c->gd_ecs_cap, bytes + HVC_HD_ECS_SLACK))) return r;
     if ((r = grow(c, &c->gd_meta, &c->gd_meta_cap, meta_words * sizeof(unsigned) + 64))) return r;
     if ((r = grow(c, &c->gd_state, &c->gd_state_cap, HVC_HD_STATE_BYTES(subs)))) return r;
     if ((r = grow(c, &c->gd_dcd, &c->gd_dcd_cap, (size_t)n_frames * P.blocks_per_frame * sizeof(int16_t)))) return r;
@@ -1958,6 +1958,10 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
         std::fprintf(stderr, "hd stats: %u subsequences; lists", P.total_sub);
         for (int q = 2; q < HVC_HD_LIST_N - 2; q++) std::fprintf(stderr, " %u", ln[q]);
         std::fprintf(stderr, "; k_hd_round walks %u, inner rounds %u; changed %u status %u\n", ln[HVC_HD_LIST_N - 2], ln[HVC_HD_LIST_N - 1], flags[0], flags[1]);
+        unsigned long long hs[4];
+        hvc::hd_stats_read(hs);
+        std::fprintf(stderr, "hd stats: round 0 walked %llu symbols (%.1f a subsequence); 64 x the longest walk of every wavefront: %llu (lanes busy %.1f %%)\n",
+                     hs[0], (double)hs[0] / P.total_sub, hs[1], 100.0 * (double)hs[0] / (double)(hs[1] ? hs[1] : 1));
     }
 #endif
     if (flags[0]) { // (the finish passes have turned the block counts into block indices: the rounds start over)
@@ -2118,7 +2122,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         c->gp_ecs_bytes = c->gp_meta_bytes = c->gp_ftabs_bytes = 0;
         for (int i = 0; i < NB; i++)
             if (hipHostMalloc(&c->gp_h_ecs[i], ecs_bytes, HVC_UPLOAD_RING_FLAGS) != hipSuccess ||
-                hipMalloc(&c->gp_d_ecs[i], ecs_bytes) != hipSuccess ||
+                hipMalloc(&c->gp_d_ecs[i], ecs_bytes + HVC_HD_ECS_SLACK) != hipSuccess ||
                 hipHostMalloc(&c->gp_h_meta[i], meta_bytes, hipHostMallocDefault) != hipSuccess ||
                 hipMalloc(&c->gp_d_meta[i], meta_bytes) != hipSuccess ||
                 hipHostMalloc(&c->gp_h_ftabs[i], ftabs_bytes, HVC_UPLOAD_RING_FLAGS) != hipSuccess ||

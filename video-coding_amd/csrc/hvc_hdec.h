@@ -54,6 +54,9 @@ void make_frame_tabs(const HdTables &t, int n_comp, HdFrameTabs &out);
 #define HVC_HD_SUBSEQ_BITS 1024 /* bits per lane in the synchronisation rounds (a multiple of 128) */
 #endif
 #define HVC_HD_MAX_MCU_BLOCKS 16
+// bytes that must be readable behind the segment buffer (HdParams::ecs): a lane of the write pass that reads its bits
+// from global memory looks up to four subsequences past the start of the last one
+#define HVC_HD_ECS_SLACK 1024
 #define HVC_HD_LIST_N 16 /* >= rounds of k_hd_sync + 2 */
 // device bytes of the per-subsequence state for n subsequences (hvc_capi.hip carves HdParams' arrays out of it)
 #define HVC_HD_STATE_BYTES(n) ((size_t)(n) * (4 * sizeof(unsigned long long) + 3 * sizeof(unsigned)) + HVC_HD_LIST_N * sizeof(unsigned) + 64)
@@ -102,6 +105,9 @@ struct HdParams {
 };
 
 hipError_t launch_hd_round(const HdParams &P, int round, hipStream_t s);
+#ifdef HVC_HD_STATS
+void hd_stats_read(unsigned long long out[4]); // experiments (tools/exp_hd_stats.py)
+#endif
 hipError_t launch_hd_frame_of(const HdParams &P, hipStream_t s); // fills P.frame_of from P.sub_off (callers that do not upload it)
 hipError_t launch_hd_finish(const HdParams &P, int rounds_done, hipStream_t s); // count scan, write pass, DC pass
 bool hd_write2_fits(const HdParams &P); // the fast write pass can address these records (PF mode needs it)

@@ -31,6 +31,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace hvc {
 
@@ -242,6 +243,15 @@ __device__ __forceinline__ void stage_row(unsigned *row, const uint8_t *seg) {
 }
 constexpr int SPEC_T = HVC_HD_SPEC_T;
 
+#ifdef HVC_HD_STATS
+__device__ unsigned long long g_hd_stats[4];
+void hd_stats_read(unsigned long long out[4]) { // experiments: read and clear
+    unsigned long long z[4] = {0, 0, 0, 0};
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hd_stats), sizeof z);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hd_stats), z, sizeof z);
+}
+#endif
+
 template <bool RD_FREE, class RD> // the lean walk of the synchronisation rounds, defined with k_hd_sync below
 __device__ __forceinline__ void spec_walk(RD rd, const uint16_t *sp, unsigned sel, int B, unsigned base, unsigned &p, int &k, int &b, unsigned &nb);
 
@@ -375,37 +385,39 @@ constexpr int SYNC_TAIL_FROM = 5;
 template <bool RD_FREE, class RD>
 __device__ __forceinline__ void spec_walk(RD rd, const uint16_t *sp, unsigned sel, int B, unsigned base, unsigned &p, int &k,
                                           int &b, unsigned &nb) {
-    const unsigned limit = base + (unsigned)S;
-    const unsigned off = p - base;      // < 32 + S
-    unsigned ni = off >> 5;             // next dword of the row
-    int s = (32 - (int)(off & 31u)) & 31; // bits of `hi` not yet consumed, 0..31; the window is {hi, lo} >> s
-    unsigned hi = 0;
-    if (s) hi = rd(min(ni++, (unsigned)(SROW - 1)));
-    unsigned lo = rd(min(ni++, (unsigned)(SROW - 1)));
-    unsigned nx = rd(min(ni, (unsigned)(SROW - 1)));
+    // The bit position is kept as mm = ~(P + 31), P = bits consumed since the start of the row (P < 32 + S at the
+    // start): its low five bits are what v_alignbit has to shift {hi, lo} by, (31 - mm) >> 5 is the dword after the
+    // window, the window moves on by a dword when mm changes above bit 4, and "p < limit" is "mm > ~(S + 31)" -- one
+    // subtraction per symbol keeps all of that current.  lo = dword (P + 31) >> 5 of the row, hi the one before (not
+    // looked at when P is a multiple of 32), nx the one after.
+    const unsigned P0 = p - base;
+    unsigned mm = ~(P0 + 31u);
+    const unsigned mm_limit = ~((unsigned)S + 31u);
+    const unsigned l0 = (P0 + 31u) >> 5;
+    unsigned hi = l0 ? rd(l0 - 1u) : 0u;
+    unsigned lo = rd(min(l0, (unsigned)(SROW - 1)));
+    unsigned nx = rd(min(l0 + 1u, (unsigned)(SROW - 1)));
     const uint16_t *bt = sp + ((sel >> (2 * b)) & 3u) * (2 * SPEC_T);
-    while (p < limit) {
-        const unsigned w = __builtin_amdgcn_alignbit(hi, lo, (unsigned)s); // the next 32 bits
+    while (mm > mm_limit) {
+        const unsigned w = __builtin_amdgcn_alignbit(hi, lo, mm); // the next 32 bits
         const uint16_t *t = bt + (k ? SPEC_T : 0);
         unsigned e = t[w >> 22];
         if (e & 0x8000u) e = t[1024u + (e & 0x7fffu) * 64u + ((w >> 16) & 63u)];
-        const int used = (int)(e & 63u);
         k += (int)((e >> 6) & 127u); // an EOB advances by 64
-        p += (unsigned)used;
-        s -= used;
-        const bool refill = s < 0; // `hi` is used up (used <= 32: one step is enough)
+#ifdef HVC_HD_STATS
+        nb += 1u << 16; // experiments: symbols of this walk in the upper half (the caller takes it out again)
+#endif
+        const unsigned mn = mm - (e & 63u);
+        const bool refill = ((mn ^ mm) >> 5) != 0u; // the window's first dword is used up (<= 32 bits a symbol: one step is enough)
+        mm = mn;
         if (RD_FREE) {
             hi = refill ? lo : hi;
             lo = refill ? nx : lo;
-            s += refill ? 32 : 0;
-            ni += refill ? 1u : 0u;
-            nx = rd(min(ni, (unsigned)(SROW - 1)));
+            nx = rd(min((31u - mn) >> 5, (unsigned)(SROW - 1)));
         } else if (refill) {
             hi = lo;
             lo = nx;
-            s += 32;
-            ni++;
-            nx = rd(min(ni, (unsigned)(SROW - 1)));
+            nx = rd(min((31u - mn) >> 5, (unsigned)(SROW - 1)));
         }
         // EOB, index 63 written, or past it (the model raises: the true parse never gets here)
         const bool end = k >= 64;
@@ -415,6 +427,7 @@ __device__ __forceinline__ void spec_walk(RD rd, const uint16_t *sp, unsigned se
         nb += end ? 1u : 0u;
         bt = sp + ((sel >> (2 * b)) & 3u) * (2 * SPEC_T);
     }
+    p = base + ~mm - 31u;
 }
 
 // 512 lanes per workgroup: 12 KB of tables + 66 KB of rows = 78 KB, two workgroups = 16 wavefronts per CU.  (With
@@ -436,6 +449,18 @@ __device__ __forceinline__ bool sync_one(const HdParams &P, int round, bool vali
     int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
     const uint16_t *sp = PF ? &P.ftabs[P.tabset_of[f]].spec[0][0][0] : sp_lds;
     spec_walk<true>([row](unsigned q) { return row[q]; }, sp, P.selmask, P.blocks_per_mcu, base, p, k, b, nb);
+#ifdef HVC_HD_STATS // experiments, round 0: symbols walked / 64 x the longest walk of each wavefront (what it costs)
+    {
+        const unsigned nsym = nb >> 16;
+        nb &= 0xffffu;
+        if (round == 0) {
+            unsigned mx = nsym;
+            for (int o = 32; o; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+            atomicAdd(&g_hd_stats[0], (unsigned long long)nsym);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&g_hd_stats[1], 64ull * mx);
+        }
+    }
+#endif
     const unsigned long long ex = pack_state(p, k, b);
     const bool differs = round == 0 || ex != P.exit_a[i];
     P.exit_a[i] = ex;
@@ -622,65 +647,78 @@ constexpr int WR_EXTRA = 3; // rows staged past the workgroup's own, for the las
 #endif
 constexpr int WR_BATCH = HVC_WR_BATCH; // block ends handled together
 
-// One entry of a value table (k_hd_write2; HdFrameTabs::val): from HdTable's (length << 8) | value.
-//   bits 0-4 code length, 5-9 magnitude bits, 10-13 run of zeros, bit 14 EOB; 0x8000 | n (first level only) = continue
-//   in sub-table n.  Magnitude bits = 31 marks what the model raises on -- no code with this prefix (length 1: the walk
-//   steps one bit) or a DC category the magnitude of which decoder.ml:73-79 cannot hold; for the DC that is category 16
-//   as well: its differences (|d| >= 32768, or -32768) leave int16 or the range a JPEG DC can have, so the stream goes
-//   to the host reader either way and the loop needs no range check.
-__host__ __device__ inline unsigned val_entry(unsigned e, bool dc) {
-    if (e & 0x8000u) return e;
-    if (!e) return 1u | (31u << 5);
+// One entry of a value table (k_hd_write2; HdFrameTabs::val), from HdTable's (length << 8) | value:
+//   bits 0-4   bits the symbol takes: code + magnitude, 1..31;  0 = (first level only) the code is longer: bits 5-15
+//              hold the number of the sub-table that has it
+//   bits 5-8   magnitude bits (0..15)
+//   bits 9-13  index advance: run of zeros + 1 (1 for a DC symbol; an EOB's does not matter);  0 marks what the model
+//              raises on -- no code with this prefix (the walk steps one bit) or a DC category whose magnitude
+//              decoder.ml:73-79 cannot hold; for the DC that is category 16 as well: its differences (|d| >= 32768, or
+//              -32768) leave int16 or the range a JPEG DC can have, so the stream goes to the host reader either way
+//              and the loop needs no range check
+//   bit 15     EOB
+__host__ __device__ inline unsigned val_entry(unsigned e, bool dc, bool second_level) {
+    if (e & 0x8000u) return second_level ? 1u : (e & 0x7fffu) << 5; // (a pointer inside a sub-table: no such code)
+    if (!e) return 1u;
     const unsigned len = e >> 8, v = e & 0xffu;
-    if (dc) return len | ((v >= 16u ? 31u : v) << 5);
-    return len | ((v & 15u) << 5) | ((v >> 4) << 10) | (v ? 0u : 0x4000u);
+    if (dc) return v >= 16u ? len : (len + v) | (v << 5) | (1u << 9);
+    const unsigned size = v & 15u, run = v >> 4;
+    return (len + size) | (size << 5) | ((run + 1u) << 9) | (v ? 0u : 0x8000u);
 }
 
-template <bool PF>
-__global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) {
+// GBITS: the bits come straight from global memory (a dword per refill, requested one refill ahead) instead of rows
+// staged in LDS -- 34 KB less of it per 256 lanes, which is what holds the staged form at two wavefronts per SIMD.
+template <bool PF, bool GBITS, int WG>
+__global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
     __shared__ uint16_t tv[PF ? 2 : 2 * 2 * SPEC_T]; // value tables of the two slots: [slot][DC, AC] (PF: the frame's record in device memory instead)
     __shared__ HdGeo G;
-    __shared__ unsigned rows[(256 + WR_EXTRA) * SROW];
-    __shared__ uint4 lbuf[256 * 8]; // 64 int16 per lane
-    __shared__ uint2 flist[4][64];  // per wavefront: blocks to store (offset in the batch's records in 16-byte units, lane)
+    __shared__ unsigned rows[GBITS ? 1 : (WG + WR_EXTRA + 2) * SROW]; // (+ 2: what a lane about to give up at `hard` may still read, unstaged)
+    __shared__ uint4 lbuf[WG * 8]; // 64 int16 per lane
+    __shared__ uint2 flist[WG / 64][64];  // per wavefront: blocks to store (offset in the batch's records in 16-byte units, lane)
     load_geo(P, G);
     {
         for (int sl = 0; sl < (PF ? 0 : 2); sl++)
             for (int cls = 0; cls < 2; cls++) {
                 const HdTable *src_t = cls ? &P.tables->ac[P.slot_rep[sl]] : &P.tables->dc[P.slot_rep[sl]];
                 const uint16_t *src = reinterpret_cast<const uint16_t *>(src_t);
-                for (unsigned i = threadIdx.x; i < sizeof(HdTable) / 2; i += 256) tv[(sl * 2 + cls) * SPEC_T + i] = (uint16_t)val_entry(src[i], cls == 0);
+                for (unsigned i = threadIdx.x; i < sizeof(HdTable) / 2; i += WG) tv[(sl * 2 + cls) * SPEC_T + i] = (uint16_t)val_entry(src[i], cls == 0, i >= 1024u);
             }
 #pragma unroll
         for (int q = 0; q < 8; q++) lbuf[threadIdx.x * 8 + q] = make_uint4(0, 0, 0, 0);
     }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const unsigned i = blockIdx.x * 256u + (unsigned)tid;
+    const unsigned i = blockIdx.x * (unsigned)WG + (unsigned)tid;
     const bool valid = i < P.total_sub;
     const unsigned f = valid ? P.frame_of[i] : 0u, j = valid ? i - P.sub_off[f] : 0u;
     if (*P.changed) return; // not settled: nothing is stored (see k_hd_write); uniform, before any barrier
-    if (valid) stage_row(rows + tid * SROW, P.ecs + P.ecs_off[f] + (size_t)j * (S / 8));
-    if (tid < WR_EXTRA) {
-        const unsigned i2 = blockIdx.x * 256u + 256u + (unsigned)tid;
-        if (i2 < P.total_sub) {
-            const unsigned f2 = P.frame_of[i2];
-            stage_row(rows + (256 + tid) * SROW, P.ecs + P.ecs_off[f2] + (size_t)(i2 - P.sub_off[f2]) * (S / 8));
+    if (!GBITS) {
+        if (valid) stage_row(rows + tid * SROW, P.ecs + P.ecs_off[f] + (size_t)j * (S / 8));
+        if (tid < WR_EXTRA) {
+            const unsigned i2 = blockIdx.x * (unsigned)WG + (unsigned)WG + (unsigned)tid;
+            if (i2 < P.total_sub) {
+                const unsigned f2 = P.frame_of[i2];
+                stage_row(rows + (WG + tid) * SROW, P.ecs + P.ecs_off[f2] + (size_t)(i2 - P.sub_off[f2]) * (S / 8));
+            }
         }
     }
     __syncthreads();
-    const unsigned *row = rows + tid * SROW;
-    // dword ni of the stream from this lane's subsequence on: rows are consecutive subsequences, SROW = S / 32 + 1
-    auto rd = [&](unsigned ni) -> unsigned { ni = min(ni, (unsigned)((WR_EXTRA + 1) * (S / 32) - 1)); return row[ni + ni / (unsigned)(S / 32)]; };
-    int16_t *lb = reinterpret_cast<int16_t *>(lbuf + tid * 8);
+    const unsigned *row = rows + (GBITS ? 0 : tid * SROW);
+    // the lane's subsequence in the segment buffer (the following ones come behind it; past the frame's last one
+    // there is padding, another frame or the slack behind the buffer: nothing a block of this frame can reach)
+    const unsigned *gbits = reinterpret_cast<const unsigned *>(P.ecs + P.ecs_off[f] + (size_t)j * (S / 8));
+    // dword q of the stream from this lane's subsequence on.  LDS: rows are consecutive subsequences, SROW = S / 32 + 1
+    auto rd = [&](unsigned q) -> unsigned { return GBITS ? __builtin_bswap32(gbits[q]) : row[q + (q >> 5)]; };
+    static_assert(S == 1024, "rd(): S / 32 dwords per row");
     // where the coefficients of a block that is not this lane's go: the lane's own entry of the wavefront's store list
     // (written before it is read in every flush, and LDS operations of a wavefront keep their order)
     int16_t *const nowhere = reinterpret_cast<int16_t *>(&flist[wave][lane]);
+    int16_t *const lb = reinterpret_cast<int16_t *>(lbuf + tid * 8);
     const int B = P.blocks_per_mcu;
     const unsigned base = j * (unsigned)S, limit = base + (unsigned)S, hard = limit + (unsigned)(WR_EXTRA * S);
     unsigned bi = valid ? P.nblk[i] : 0xffffffffu; // the block this subsequence starts in
     bool act = valid && bi < P.blocks_per_frame;   // past the last coded block: the model never reads this far
     const unsigned long long st = act ? P.start_used[i] : 0ull;
-    unsigned p = act ? (unsigned)st : 0u;
+    const unsigned p0 = act ? (unsigned)st : base;
     int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
     // live: the block in progress is this lane's (it started here) and inside the frame -- its coefficients are stored,
     // its errors count.  A lane that starts in the middle of a block (k > 0) only walks that one to its end.
@@ -699,67 +737,79 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
         return frame_unit0 + (G.coef_off[comp] >> 3) +
                ((my * (unsigned)G.v[comp] + G.b2sy[bb]) * (unsigned)G.bw[comp] + (mx * (unsigned)G.h[comp] + G.b2sx[bb])) * 8u;
     };
-    const unsigned off = p - base;
-    unsigned ni = off >> 5;
-    int s = (32 - (int)(off & 31u)) & 31;
-    unsigned hi = 0;
-    if (s) hi = rd(ni++);
-    unsigned lo = rd(ni++);
-    unsigned nx = rd(ni);
+    // The bit position is kept as mm = ~(P + 31), P = bits consumed since the start of the lane's row: its low five
+    // bits are what v_alignbit has to shift {hi, lo} by, (31 - mm) >> 5 is the dword after the window, the window moves
+    // on by a dword when mm changes above bit 4, and positions compare as mm's do, the other way round -- one
+    // subtraction per symbol keeps all of that current.  lo = dword (P + 31) >> 5 of the stream, hi the one before
+    // (not looked at when P is a multiple of 32), nx the one after.
+    unsigned mm = ~(p0 - base + 31u);
+    const unsigned l0 = (p0 - base + 31u) >> 5;
+    unsigned hi = l0 ? rd(l0 - 1u) : 0u, lo = rd(l0), nx = rd(l0 + 1u);
+    auto pos = [&]() -> unsigned { return base + ~mm - 31u; };                  // the bit position itself (rare branches)
+    auto mm_of = [&](unsigned p) -> unsigned { return ~(p - base + 31u); };
     const uint16_t *const tvb = PF ? &P.ftabs[P.tabset_of[f]].val[0][0][0] : tv;
     const uint16_t *bt = tvb + ((P.selmask >> (2 * b)) & 3u) * (2 * SPEC_T);
     const uint16_t *bt_ac = bt + SPEC_T;
     // the exit the synchronisation launches recorded for this subsequence must be the one this walk arrives at
     const unsigned long long fin_i = valid ? ((final_round & 1) ? P.exit_a : P.exit_b)[i] : 0ull; // launch final_round - 1 wrote it
     // the next bit position that needs a look: the end of the lane's own subsequence, then the end of what is staged
-    unsigned watch = limit;
+    const unsigned mm_limit = mm_of(limit), mm_hard = mm_of(hard);
+    unsigned watch = mm_limit;
     // (Errors -- anything the model raises on in a lane's own block, a hand-over that does not match -- go straight to
     // P.status from the rare branches that find them: carried in registers they cost every iteration a few copies.)
-    // What happens at the end of a block -- store it, find the next one's place -- costs more than a symbol, and in
-    // a wavefront some lane ends a block in almost every iteration.  A lane that ends a block therefore WAITS
+    // In a wavefront some lane ends a block in almost every iteration.  A lane that ends a block therefore WAITS
     // (pending) until WR_BATCH lanes do, or nobody else can go on; then the wavefront does all of them at once.
-    bool pending = false;
     unsigned cur_block = live ? block_no(b) : 0u; // where the block in progress goes
     while (__any(act)) {
-        if (act && !pending) {
+        // Symbols: every lane that has something to go on with decodes until it ends a block, and the wavefront goes on
+        // until WR_BATCH lanes have ended one (or nobody is left).  An inner loop that lanes LEAVE, not an `if` around
+        // the body in one loop: with three lane flags changing inside such an `if` the mask bookkeeping at its joins
+        // was 48 scalar instructions per symbol -- 40 % of all the kernel issued.
+        bool pending = false;
+        unsigned npend = 0; // (the same in every lane)
+        bool run = act;
+        while (run) {
             // One symbol.  Straight-line code but for the second-level look-up and the (once per lane) crossing of the
             // subsequence's end: whatever a branch here guards, some lane of the 64 takes it nearly every time, and
             // the branch, its masks and -- for a refill -- the wait for an LDS read inside it came on top.
-            const unsigned w = __builtin_amdgcn_alignbit(hi, lo, (unsigned)s); // the next 32 bits: a whole symbol
+            const unsigned w = __builtin_amdgcn_alignbit(hi, lo, mm); // the next 32 bits: a whole symbol
             const uint16_t *t = k ? bt_ac : bt;
-            unsigned e = t[w >> 22];
-            if (e & 0x8000u) e = t[1024u + (e & 0x7fffu) * 64u + ((w >> 16) & 63u)];
-            // One path for DC and AC symbols (a DC symbol is "run 0" at index 0)
-            const unsigned len = e & 31u, size_f = (e >> 5) & 31u, run = (e >> 10) & 15u;
-            const bool bad = size_f > 16u; // "Can't find dc / ac code" (one bit further) / DC category 16 and above (the code is skipped)
-            const bool eob = (e & 0x4000u) != 0u;
-            const unsigned size = bad ? 0u : size_f;
-            const unsigned used = len + size;
-            // decoder.ml:73-79 mag': `size` bits after the code; a leading 0 bit means negative
-            const unsigned mbits = __builtin_amdgcn_ubfe(w, 32u - used, size);
-            const unsigned full = (1u << size) - 1u;
-            const int mag = (int)mbits - (mbits <= (full >> 1) ? (int)full : 0);
-            const int kk = k + (int)run;                 // the index this symbol's coefficient has
-            const bool wrong = bad || (kk >= 64 && !eob); // ... / "coefficient index out of range"
-            // (a zero written at kk -- EOB, a run of 16 -- changes nothing: the indices of a block only grow)
-            *((live && !wrong) ? lb + kk : nowhere) = (int16_t)mag; // |mag| < 2^15: size <= 15 wherever it counts
+            unsigned e = t[__builtin_amdgcn_ubfe(w, 22u, 10u)];
+            if ((e & 31u) == 0u) e = t[1024u + (e >> 5) * 64u + __builtin_amdgcn_ubfe(w, 16u, 6u)];
+            // One path for DC and AC symbols (a DC symbol advances the index from 0 to 1): see val_entry
+            const unsigned used = e & 31u, size = __builtin_amdgcn_ubfe(e, 5u, 4u), adv = __builtin_amdgcn_ubfe(e, 9u, 5u);
+            const bool eob = (int16_t)e < 0;
+            const bool bad = adv == 0u; // "Can't find dc / ac code" (one bit further) / DC category 16 and above (the code is skipped)
+            // decoder.ml:73-79 mag': `size` bits after the code; a leading 0 bit means negative, i.e. the field minus
+            // (2^size - 1).  As a signed field x that is x - full where the leading bit is 0, x - ~full where it is 1.
+            const int x = __builtin_amdgcn_sbfe((int)w, 32u - used, size);
+            const int full = (int)__builtin_amdgcn_ubfe(0xffffffffu, 0u, size);
+            const int mag = x - (full ^ (x >> 31));
+            const int kn = k + (int)adv;                // one past the index this symbol's coefficient has
+            const bool wrong = bad || (kn > 64 && !eob); // ... / "coefficient index out of range"
+            // (a zero written at kn - 1 -- EOB, a run of 16 -- changes nothing: the indices of a block only grow)
+            *((live && !wrong) ? lb + kn - 1 : nowhere) = (int16_t)mag; // |mag| < 2^15: size <= 15
             if (live && wrong) atomicOr(P.status, 1u);
-            const bool end_block = !bad && (eob || kk >= 63);
-            k = end_block ? 0 : bad ? k : kk + 1;
-            p += used;
-            s -= (int)used;
-            const bool refill = s < 0;
-            hi = refill ? lo : hi;
-            lo = refill ? nx : lo;
-            s += refill ? 32 : 0;
-            ni += refill ? 1u : 0u;
-            nx = rd(ni); // (a function of ni: read again rather than branched around)
+            const bool end_block = eob || kn > 63; // (what is `bad` advances by 0 and is no EOB)
+            k = end_block ? 0 : kn;
+            const unsigned mn = mm - used;
+            const bool refill = ((mn ^ mm) >> 5) != 0u;
+            mm = mn;
+            if (!GBITS) {
+                hi = refill ? lo : hi;
+                lo = refill ? nx : lo;
+                nx = rd((31u - mn) >> 5); // (a function of the position: read again rather than branched around)
+            } else if (refill) {
+                hi = lo;
+                lo = nx;
+                nx = rd((31u - mn) >> 5);
+            }
             pending = end_block;
-            if (p >= watch) {
-                if (watch == limit) {
+            if (mm <= watch) { // p >= the position watched
+                if (watch == mm_limit) {
                     // where k_hd_sync's walk of this subsequence stopped: the one symbol that takes p across the limit
-                    if (pack_state(p, k, end_block ? (b + 1 == B ? 0 : b + 1) : b) != fin_i) atomicOr(P.status, 8u);
-                    watch = hard;
+                    if (pack_state(pos(), k, end_block ? (b + 1 == B ? 0 : b + 1) : b) != fin_i) atomicOr(P.status, 8u);
+                    watch = mm_hard;
                     // a block in progress is finished here unless it is not this lane's (or nobody's: past the frame);
                     // a block that ends here: see below
                     if (!end_block && !live) act = false;
@@ -768,9 +818,12 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
                     act = false;
                 }
             }
+            npend += (unsigned)__popcll(__ballot(end_block)); // (of the lanes still in the loop)
+            run = act && !end_block && npend < (unsigned)WR_BATCH;
         }
-        const unsigned long long mp = __ballot(pending);
-        if (mp && ((int)__popcll(mp) >= WR_BATCH || !__any(act && !pending))) { // wavefront-uniform: every lane is here
+        // What happens at the end of a block -- store it, find the next one's place -- costs more than a symbol: the
+        // wavefront does it for all the lanes that wait at one (every lane is here again).
+        if (__any(pending)) {
             const bool flush = pending && live;
             const unsigned long long m = __ballot(flush);
             asm volatile("" ::: "memory"); // the int16 stores above and the 16-byte reads below meet in LDS, not in the type system
@@ -790,7 +843,6 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
             }
             asm volatile("" ::: "memory");
             if (pending) { // on to the next block
-                pending = false;
                 b = b + 1 == B ? 0 : b + 1;
                 bi++;
                 live = bi < P.blocks_per_frame;
@@ -803,7 +855,7 @@ __global__ __launch_bounds__(256) void k_hd_write2(HdParams P, int final_round) 
                         my++;
                     }
                 }
-                if (p >= limit) act = false; // the next block starts in another lane's subsequence
+                if (mm <= mm_limit) act = false; // the next block starts in another lane's subsequence
                 else cur_block = block_no(b);
             }
         }
@@ -883,7 +935,7 @@ static void convert_table(const HdTable &src, bool dc, uint16_t *spec, uint16_t 
     for (int q = 0; q < SPEC_T; q++) {
         const uint16_t e = all[q];
         if (spec) spec[q] = (q >= 1024 && (e & 0x8000u)) ? (uint16_t)1 : conv(e);
-        if (val) val[q] = (uint16_t)val_entry(e, dc);
+        if (val) val[q] = (uint16_t)val_entry(e, dc, q >= 1024);
     }
 }
 
@@ -974,11 +1026,20 @@ hipError_t launch_hd_finish(const HdParams &P, int rounds_done, hipStream_t s) {
     if (P.total_sub == 0) return hipSuccess;
     hipLaunchKernelGGL(k_hd_scan, dim3((unsigned)P.n_frames), dim3(1024), 0, s, P);
     HdParams Q = P;
+    // HVC_WR_MODE (experiments): 0 = subsequences staged in LDS, 256 lanes; 1 = bits from global memory, 512 lanes;
+    // 2 = bits from global memory, 256 lanes
+    static const int wr_mode = [] { const char *v = getenv("HVC_WR_MODE"); return v ? atoi(v) : 0; }();
+    auto write2 = [&](auto pf) {
+        constexpr bool PFv = decltype(pf)::value;
+        if (wr_mode == 1) hipLaunchKernelGGL((k_hd_write2<PFv, true, 512>), dim3((P.total_sub + 511u) / 512u), dim3(512), 0, s, P, rounds_done);
+        else if (wr_mode == 2) hipLaunchKernelGGL((k_hd_write2<PFv, true, 256>), dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, rounds_done);
+        else hipLaunchKernelGGL((k_hd_write2<PFv, false, 256>), dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, rounds_done);
+    };
     if (P.ftabs) { // PF mode has no general write pass: the host side asks hd_write2_fits() before it chooses the mode
         if (!P.dcd || !hd_write2_fits(P)) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(k_hd_write2<true>, dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, rounds_done);
+        write2(std::true_type{});
     } else if (P.spec && P.dcd && hd_write2_fits(P)) {
-        hipLaunchKernelGGL(k_hd_write2<false>, dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, rounds_done);
+        write2(std::false_type{});
     } else {
         Q.dcd = nullptr; // k_hd_write leaves the differences in the records only
         hipLaunchKernelGGL(k_hd_write, dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, rounds_done);
