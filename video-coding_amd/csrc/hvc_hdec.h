@@ -29,8 +29,8 @@ struct HdTables {
 // The same tables as the synchronisation walk wants them: it needs no values, only how far a symbol moves the
 // bit position and the zig-zag index.  Entry: bits 0-5 bits consumed (code + magnitude; 1 for "no code": the
 // walk steps one bit), bits 6-12 index advance (run + 1; 1 for a DC symbol; 0 where the index stays; 64 for
-// EOB, so that "index >= 64" is the one end-of-block test); 0x8000 | n in the first level = continue in sub-table n,
-// as in HdTable.
+// EOB, so that "index >= 64" is the one end-of-block test); in the first level "0 bits consumed" = the code is
+// longer than 10 bits, and bits 6-15 then hold the number of the sub-table that has it.
 // Components that share their tables share a slot; frames with three different table sets keep to k_hd_round.
 struct HdSpec {
     uint16_t t[2][2][1024 + HVC_HD_SUBTABLES * 64]; // [slot][0 = DC, 1 = AC]

@@ -252,8 +252,9 @@ void hd_stats_read(unsigned long long out[4]) { // experiments: read and clear
 }
 #endif
 
-template <bool RD_FREE, class RD> // the lean walk of the synchronisation rounds, defined with k_hd_sync below
-__device__ __forceinline__ void spec_walk(RD rd, const uint16_t *sp, unsigned sel, int B, unsigned base, unsigned &p, int &k, int &b, unsigned &nb);
+template <bool RD_FREE, bool SEL1, class RD> // the lean walk of the synchronisation rounds, defined with k_hd_sync below
+__device__ __forceinline__ void spec_walk(RD rd, const unsigned *row, const uint16_t *sp, unsigned sel, int B, unsigned base, unsigned &p,
+                                          int &k, int &b, unsigned &nb);
 
 // One synchronisation launch (see the header comment).  Even launches write exit_a, odd ones exit_b.
 // Inside the launch the 256 subsequences of a workgroup run up to INNER rounds among themselves through
@@ -270,7 +271,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
     constexpr bool PF = MODE == 2;
     __shared__ __attribute__((aligned(16))) unsigned char Traw[MODE == 0 ? sizeof(HdTables) : MODE == 1 ? sizeof(HdSpec) : 16];
-    __shared__ unsigned rows[MODE == 1 ? 256 * SROW : 1];
+    __shared__ unsigned rows[MODE == 1 ? 256 * SROW + 2 : 1];
     HdTables &T = *reinterpret_cast<HdTables *>(Traw);
     __shared__ HdGeo G;
     __shared__ unsigned long long exits[256];
@@ -309,13 +310,13 @@ __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
             int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
             nb = 0;
             if (PF) {
-                spec_walk<false>([slot](unsigned q) { return __builtin_bswap32(slot[q]); }, &P.ftabs[P.tabset_of[f]].spec[0][0][0],
-                                 P.selmask, P.blocks_per_mcu, base, p, k, b, nb);
+                spec_walk<false, false>([slot](unsigned q) { return __builtin_bswap32(slot[q]); }, nullptr, &P.ftabs[P.tabset_of[f]].spec[0][0][0],
+                                        P.selmask, P.blocks_per_mcu, base, p, k, b, nb);
             } else if (MODE == 1) {
                 unsigned *row = rows + tid * SROW; // (staged once per launch would do; a walk is 200 symbols, this is 40 instructions)
                 stage_row(row, reinterpret_cast<const uint8_t *>(slot));
-                spec_walk<true>([row](unsigned q) { return row[q]; }, reinterpret_cast<const uint16_t *>(Traw), P.selmask, P.blocks_per_mcu,
-                                base, p, k, b, nb);
+                spec_walk<true, true>([row](unsigned q) { return row[q]; }, row, reinterpret_cast<const uint16_t *>(Traw), P.slotmask,
+                                      P.blocks_per_mcu, base, p, k, b, nb);
             } else {
                 walk<false>(P, G, T, slot, base, base + (unsigned)S, p, k, b, nb, 0, nullptr, err);
             }
@@ -382,14 +383,16 @@ constexpr int SYNC_TAIL_FROM = 5;
 // mask bookkeeping -- and a refill inside a branch made the wavefront wait for its LDS read on the spot.  Selects
 // instead; with RD_FREE (rows in LDS) the dword after the window is simply read again in every iteration (rd(ni) is a
 // function of ni), and nothing waits for it before the next table look-up has come back anyway.
-template <bool RD_FREE, class RD>
-__device__ __forceinline__ void spec_walk(RD rd, const uint16_t *sp, unsigned sel, int B, unsigned base, unsigned &p, int &k,
-                                          int &b, unsigned &nb) {
+// RD_FREE: the row sits in LDS at `row` (SROW dwords and two more that may be read, whatever they hold).
+// SEL1: sel has one bit per block of an MCU (HdParams::slotmask: the two slots of HdSpec); otherwise two (selmask).
+template <bool RD_FREE, bool SEL1, class RD>
+__device__ __forceinline__ void spec_walk(RD rd, const unsigned *row, const uint16_t *sp, unsigned sel, int B, unsigned base, unsigned &p,
+                                          int &k, int &b, unsigned &nb) {
     // The bit position is kept as mm = ~(P + 31), P = bits consumed since the start of the row (P < 32 + S at the
-    // start): its low five bits are what v_alignbit has to shift {hi, lo} by, (31 - mm) >> 5 is the dword after the
-    // window, the window moves on by a dword when mm changes above bit 4, and "p < limit" is "mm > ~(S + 31)" -- one
-    // subtraction per symbol keeps all of that current.  lo = dword (P + 31) >> 5 of the row, hi the one before (not
-    // looked at when P is a multiple of 32), nx the one after.
+    // start): its low five bits are what v_alignbit has to shift {hi, lo} by, the window moves on by a dword when mm
+    // changes above bit 4, and "p < limit" is "mm > ~(S + 31)" -- one subtraction per symbol keeps all of that current.
+    // lo = dword (P + 31) >> 5 of the row, hi the one before (not looked at when P is a multiple of 32), nx the one
+    // after -- read from *np, which moves with the window (up to two dwords past the row: nothing looks at those).
     const unsigned P0 = p - base;
     unsigned mm = ~(P0 + 31u);
     const unsigned mm_limit = ~((unsigned)S + 31u);
@@ -397,23 +400,32 @@ __device__ __forceinline__ void spec_walk(RD rd, const uint16_t *sp, unsigned se
     unsigned hi = l0 ? rd(l0 - 1u) : 0u;
     unsigned lo = rd(min(l0, (unsigned)(SROW - 1)));
     unsigned nx = rd(min(l0 + 1u, (unsigned)(SROW - 1)));
-    const uint16_t *bt = sp + ((sel >> (2 * b)) & 3u) * (2 * SPEC_T);
+    const unsigned *np = row + l0 + 1u;
+    auto tables_of = [&](int bb) -> const uint16_t * {
+        return sp + __umul24(SEL1 ? __builtin_amdgcn_ubfe(sel, (unsigned)bb, 1u) : (sel >> (2 * bb)) & 3u, 2u * SPEC_T); // (a 32-bit multiply runs at a quarter of the rate)
+    };
+    const uint16_t *bt = tables_of(b);
     while (mm > mm_limit) {
         const unsigned w = __builtin_amdgcn_alignbit(hi, lo, mm); // the next 32 bits
         const uint16_t *t = bt + (k ? SPEC_T : 0);
         unsigned e = t[w >> 22];
-        if (e & 0x8000u) e = t[1024u + (e & 0x7fffu) * 64u + ((w >> 16) & 63u)];
+        unsigned used = e & 63u;
+        if (used == 0u) { // the code is longer than the first level's 10 bits
+            e = t[1024u + (e >> 6) * 64u + ((w >> 16) & 63u)];
+            used = e & 63u;
+        }
         k += (int)((e >> 6) & 127u); // an EOB advances by 64
 #ifdef HVC_HD_STATS
         nb += 1u << 16; // experiments: symbols of this walk in the upper half (the caller takes it out again)
 #endif
-        const unsigned mn = mm - (e & 63u);
+        const unsigned mn = mm - used;
         const bool refill = ((mn ^ mm) >> 5) != 0u; // the window's first dword is used up (<= 32 bits a symbol: one step is enough)
         mm = mn;
         if (RD_FREE) {
             hi = refill ? lo : hi;
             lo = refill ? nx : lo;
-            nx = rd(min((31u - mn) >> 5, (unsigned)(SROW - 1)));
+            np += refill ? 1 : 0;
+            nx = *np;
         } else if (refill) {
             hi = lo;
             lo = nx;
@@ -425,7 +437,7 @@ __device__ __forceinline__ void spec_walk(RD rd, const uint16_t *sp, unsigned se
         k = end ? 0 : k;
         b = end ? b1 : b;
         nb += end ? 1u : 0u;
-        bt = sp + ((sel >> (2 * b)) & 3u) * (2 * SPEC_T);
+        bt = tables_of(b);
     }
     p = base + ~mm - 31u;
 }
@@ -448,7 +460,8 @@ __device__ __forceinline__ bool sync_one(const HdParams &P, int round, bool vali
     unsigned p = (unsigned)st, nb = 0;
     int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
     const uint16_t *sp = PF ? &P.ftabs[P.tabset_of[f]].spec[0][0][0] : sp_lds;
-    spec_walk<true>([row](unsigned q) { return row[q]; }, sp, P.selmask, P.blocks_per_mcu, base, p, k, b, nb);
+    if (PF) spec_walk<true, false>([row](unsigned q) { return row[q]; }, row, sp, P.selmask, P.blocks_per_mcu, base, p, k, b, nb);
+    else spec_walk<true, true>([row](unsigned q) { return row[q]; }, row, sp, P.slotmask, P.blocks_per_mcu, base, p, k, b, nb);
 #ifdef HVC_HD_STATS // experiments, round 0: symbols walked / 64 x the longest walk of each wavefront (what it costs)
     {
         const unsigned nsym = nb >> 16;
@@ -474,7 +487,7 @@ __device__ __forceinline__ bool sync_one(const HdParams &P, int round, bool vali
 template <bool PF>
 __global__ __launch_bounds__(SYNC_WG) void k_hd_sync(HdParams P, int round) {
     __shared__ uint16_t sp[PF ? 2 : 2 * 2 * SPEC_T];
-    __shared__ unsigned rows[SYNC_WG / 64][64 * SROW];
+    __shared__ unsigned rows[SYNC_WG / 64][64 * SROW + 2]; // (+ 2: see spec_walk)
     const unsigned count = round < 2 ? P.total_sub : P.list_n[round];
     // the late rounds are launched over lists that hold a few hundred entries or none: a workgroup without work
     // leaves before it fetches 12 KB of tables (55 us a round for the 512 workgroups of such a launch, 10 without)
@@ -514,7 +527,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_hd_sync(HdParams P, int round) {
 template <bool PF>
 __global__ __launch_bounds__(SYNC_WG) void k_hd_sync_tail(HdParams P, int first_round, int last_round) {
     __shared__ uint16_t sp[PF ? 2 : 2 * 2 * SPEC_T];
-    __shared__ unsigned rows[SYNC_WG / 64][64 * SROW];
+    __shared__ unsigned rows[SYNC_WG / 64][64 * SROW + 2]; // (+ 2: see spec_walk)
     __shared__ unsigned cnt_s[2];
     if (!PF) {
         const unsigned *src = reinterpret_cast<const unsigned *>(P.spec);
@@ -765,7 +778,6 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
         // until WR_BATCH lanes have ended one (or nobody is left).  An inner loop that lanes LEAVE, not an `if` around
         // the body in one loop: with three lane flags changing inside such an `if` the mask bookkeeping at its joins
         // was 48 scalar instructions per symbol -- 40 % of all the kernel issued.
-        bool pending = false;
         unsigned npend = 0; // (the same in every lane)
         bool run = act;
         while (run) {
@@ -789,9 +801,8 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
             const bool wrong = bad || (kn > 64 && !eob); // ... / "coefficient index out of range"
             // (a zero written at kn - 1 -- EOB, a run of 16 -- changes nothing: the indices of a block only grow)
             *((live && !wrong) ? lb + kn - 1 : nowhere) = (int16_t)mag; // |mag| < 2^15: size <= 15
-            if (live && wrong) atomicOr(P.status, 1u);
             const bool end_block = eob || kn > 63; // (what is `bad` advances by 0 and is no EOB)
-            k = end_block ? 0 : kn;
+            k = end_block ? 64 : kn; // (64: "waits at the end of a block"; the index itself stays below)
             const unsigned mn = mm - used;
             const bool refill = ((mn ^ mm) >> 5) != 0u;
             mm = mn;
@@ -804,23 +815,26 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
                 lo = nx;
                 nx = rd((31u - mn) >> 5);
             }
-            pending = end_block;
-            if (mm <= watch) { // p >= the position watched
-                if (watch == mm_limit) {
-                    // where k_hd_sync's walk of this subsequence stopped: the one symbol that takes p across the limit
-                    if (pack_state(pos(), k, end_block ? (b + 1 == B ? 0 : b + 1) : b) != fin_i) atomicOr(P.status, 8u);
-                    watch = mm_hard;
-                    // a block in progress is finished here unless it is not this lane's (or nobody's: past the frame);
-                    // a block that ends here: see below
-                    if (!end_block && !live) act = false;
-                } else { // cannot happen: 64 symbols of <= 32 bits end a block
-                    atomicOr(P.status, 1u);
-                    act = false;
+            if ((live && wrong) || mm <= watch) { // the rare things behind one branch
+                if (live && wrong) atomicOr(P.status, 1u);
+                if (mm <= watch) { // p >= the position watched
+                    if (watch == mm_limit) {
+                        // where k_hd_sync's walk of this subsequence stopped: the one symbol that takes p across the limit
+                        if (pack_state(pos(), end_block ? 0 : k, end_block ? (b + 1 == B ? 0 : b + 1) : b) != fin_i) atomicOr(P.status, 8u);
+                        watch = mm_hard;
+                        // a block in progress is finished here unless it is not this lane's (or nobody's: past the
+                        // frame); a block that ends here: see below
+                        if (!end_block && !live) act = false;
+                    } else { // cannot happen: 64 symbols of <= 32 bits end a block
+                        atomicOr(P.status, 1u);
+                        act = false;
+                    }
                 }
             }
-            npend += (unsigned)__popcll(__ballot(end_block)); // (of the lanes still in the loop)
-            run = act && !end_block && npend < (unsigned)WR_BATCH;
+            npend += (unsigned)__popcll(__ballot(k == 64)); // (of the lanes still in the loop)
+            run = act && k != 64 && npend < (unsigned)WR_BATCH;
         }
+        const bool pending = act && k == 64; // the lanes that wait at the end of a block
         // What happens at the end of a block -- store it, find the next one's place -- costs more than a symbol: the
         // wavefront does it for all the lanes that wait at one (every lane is here again).
         if (__any(pending)) {
@@ -843,6 +857,7 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
             }
             asm volatile("" ::: "memory");
             if (pending) { // on to the next block
+                k = 0;
                 b = b + 1 == B ? 0 : b + 1;
                 bi++;
                 live = bi < P.blocks_per_frame;
@@ -922,7 +937,7 @@ __global__ __launch_bounds__(1024) void k_hd_dc(HdParams P) {
 //                       0x8000 | n (first level only) = continue in sub-table n
 static void convert_table(const HdTable &src, bool dc, uint16_t *spec, uint16_t *val) {
     auto conv = [dc](uint16_t e) -> uint16_t {
-        if (e & 0x8000u) return e;             // continues in a sub-table
+        if (e & 0x8000u) return (uint16_t)((e & 0x7fffu) << 6); // continues in a sub-table: "0 bits" and its number
         if (!e) return 1;                      // no code: one bit further, same state
         const unsigned len = e >> 8, v = e & 0xffu;
         if (dc) return (uint16_t)(v > 16 ? len : (len + v) | (1u << 6)); // category > 16: the index stays 0
