@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
 // time).  What they leave -- start_used / exit_a / nblk -- is what k_hd_round leaves; k_hd_round(1..) then
 // verifies every hand-over and keeps going where a stream needs more rounds (smooth content with its periodic
 // bit patterns can take hundreds), and the write pass compares the exit of its own walk with the recorded one.
-constexpr int SYNC_ROUNDS = 12;
+constexpr int SYNC_ROUNDS = 12, SYNC_ROUNDS_PF = 22;
 constexpr unsigned SYNC_TAIL_MAX_SUB = 32768; // up to four 1080p files of 1 MB: k_hd_sync_tail
 constexpr int SYNC_TAIL_FROM = 5;
 
@@ -1021,10 +1021,13 @@ static hipError_t launch_hd_round_t(const HdParams &P, int round, hipStream_t s)
         // (fewer list rounds for a single file's few thousand subsequences -- leaving the slow stretches to
         // k_hd_round's inner rounds earlier -- was tried: 10-25 % slower)
         // HVC_HD_SYNC_ROUNDS=n (experiments): fewer list rounds, leaving more to k_hd_round's inner rounds
+        // Per-file tables are mostly optimised ones: codes without unused space fall into step more slowly (the lists
+        // shrink to 0.72 of their length a round, not to 0.53), and what the list rounds leave is walked by the
+        // verifying launches at the price of look-ups in device memory -- ten more rounds at 70 us each are cheaper.
         static const int rounds = [] {
-            const char *v = getenv("HVC_HD_SYNC_ROUNDS");
-            const int n = v ? atoi(v) : SYNC_ROUNDS;
-            return n < 2 ? 2 : n > SYNC_ROUNDS ? SYNC_ROUNDS : n;
+            const char *v = getenv(PF ? "HVC_HD_SYNC_ROUNDS_PF" : "HVC_HD_SYNC_ROUNDS");
+            const int most = PF ? SYNC_ROUNDS_PF : SYNC_ROUNDS, n = v ? atoi(v) : most;
+            return n < 2 ? 2 : n > HVC_HD_LIST_N - 4 ? HVC_HD_LIST_N - 4 : n;
         }();
         for (int r = 0; r < rounds; r++) {
             // the lists shrink by about half a round; a grid-stride loop takes whatever is there
