@@ -788,9 +788,10 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
         // until WR_BATCH lanes have ended one (or nobody is left).  An inner loop that lanes LEAVE, not an `if` around
         // the body in one loop: with three lane flags changing inside such an `if` the mask bookkeeping at its joins
         // was 48 scalar instructions per symbol -- 40 % of all the kernel issued.
+        // The lane's state is in the index: below 64 it decodes; 64 = it waits at the end of a block; 65 = it has
+        // stopped for good -- one comparison decides who stays in the loop, and no lane flag changes inside it.
         unsigned npend = 0; // (the same in every lane)
-        bool run = act;
-        while (run) {
+        if (act) for (;;) {
             // One symbol.  Straight-line code but for the second-level look-up and the (once per lane) crossing of the
             // subsequence's end: whatever a branch here guards, some lane of the 64 takes it nearly every time, and
             // the branch, its masks and -- for a refill -- the wait for an LDS read inside it came on top.
@@ -834,16 +835,17 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
                         watch = mm_hard;
                         // a block in progress is finished here unless it is not this lane's (or nobody's: past the
                         // frame); a block that ends here: see below
-                        if (!end_block && !live) act = false;
+                        if (!end_block && !live) k = 65;
                     } else { // cannot happen: 64 symbols of <= 32 bits end a block
                         atomicOr(P.status, 1u);
-                        act = false;
+                        k = 65;
                     }
                 }
             }
             npend += (unsigned)__popcll(__ballot(k == 64)); // (of the lanes still in the loop)
-            run = act && k != 64 && npend < (unsigned)WR_BATCH;
+            if (k >= 64 || npend >= (unsigned)WR_BATCH) break;
         }
+        if (k == 65) act = false;
         const bool pending = act && k == 64; // the lanes that wait at the end of a block
         // What happens at the end of a block -- store it, find the next one's place -- costs more than a symbol: the
         // wavefront does it for all the lanes that wait at one (every lane is here again).
