@@ -162,6 +162,41 @@ print("classic ok")
     assert r.returncode == 0 and "classic ok" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_write_pass_variants_that_read_their_bits_from_global_memory(mode):
+    """HVC_WR_MODE=1 / 2: k_hd_write2 without staged rows (512 / 256 lanes per workgroup) -- the variants DESIGN.md
+    quotes measurements of.  Same records as the oracle and the host reader, with the model's tables and with
+    per-file optimised ones (PF mode), and the last subsequences of the last frame read into the slack behind the
+    segment buffer.  The variable is read once per process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, "tests")
+import numpy as np
+from test_gpu_hdec import make_jpeg, check_records
+from helpers import jpeg_optimised_tables
+from conftest import golden_bytes
+from oracle import orc
+import video_coding_amd as hvc
+c = hvc.Context(0)
+qt = np.stack([orc.quant_scale(orc.quant_luma(), 75), orc.quant_scale(orc.quant_chroma(), 75)])
+own = [jpeg_optimised_tables(640, 352, 420, qt, orc.Decoder(make_jpeg(700 + 11 * f, 640, 352, 420, 75)).coef_record(), 2) for f in range(4)]
+jobs = [[golden_bytes("mini.jpg")], [golden_bytes("Mouse480.jpg")], [make_jpeg(900 + f, 480, 320, 420, 60) for f in range(5)],
+        [make_jpeg(950 + f, 200, 120, 444, 95) for f in range(2)], [make_jpeg(970 + f, 1920, 1088, 420, 75) for f in range(2)], own]
+for files in jobs:
+    _, got, used = c.jpeg_entropy_decode_gpu(files, device=True)
+    assert used == 1
+    check_records(files, got)
+print("variants ok")
+'''
+    env = dict(os.environ, HVC_WR_MODE=mode)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "variants ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("w,h,chroma", [(64, 48, 420), (48, 32, 444), (64, 32, 422)])
 def test_constructed_records_blocks_longer_than_a_subsequence(ctx, w, h, chroma):
     """Every AC at +-1023 (26 bits a symbol, 1.6 kbit a block: each block runs through two or three 1024-bit

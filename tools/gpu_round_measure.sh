@@ -28,6 +28,16 @@ python tools/bench_configs.py --config 8 --gpu-entropy > gpurun_out/m_c5_files_g
 python tools/bench_configs.py --config 9 > gpurun_out/m_huffman_gpu.json 2> gpurun_out/m_huffman_gpu.err
 python tools/bench_single.py > gpurun_out/m_single_file.jsonl 2> gpurun_out/m_single_file.err
 echo "configs done"
+# the GPU Huffman reader alone on one 256-file chunk, one stream: per-kernel durations that do not depend on what the
+# other reader stream of the pipeline is doing (model's tables; every file with its own optimised tables)
+for v in "" "--own-tables"; do
+  n=reader_chunk$(echo "$v" | sed 's/--own-tables/_own_tables/')
+  D=$ROOT/gpurun_out/prof_${TAG}_$n; mkdir -p $D
+  (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d $D/trace -o trace -- python3 $ROOT/tools/bench_reader_chunk.py --files 256 --reps 4 $v > $D/trace.log 2>&1) || true
+  { grep records_equal $D/trace.log; python tools/reader_chunk_ms.py $D/trace; } > gpurun_out/m_$n.txt 2>&1 || true
+  rm -rf $D
+done
+echo "reader chunk done"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mem_ubench3 tools/ubench/mem_ubench3.hip 2> /dev/null
 /tmp/mem_ubench3 > gpurun_out/m_mem_ubench3.txt 2>&1 || true
 # every kernel against the memory ceiling of its own access shape (traffic-only measurement build)
