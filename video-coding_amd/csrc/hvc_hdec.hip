@@ -24,8 +24,9 @@
 // across workgroups through launches) and k_hd_write -- takes any frame the host side lets through.
 // The fast one -- k_hd_sync (level-synchronous rounds over work lists, skip-only tables, subsequences
 // staged in LDS; k_hd_sync_tail: the late rounds of a few files inside one workgroup) and k_hd_write2
-// (blocks owned by the lane they start in, wavefront-wide batched stores) -- needs the components to share at most two (DC, AC) table pairs, as every baseline file's do;
-// launch_hd_round / launch_hd_finish pick it whenever HdParams::spec is set, and k_hd_round then only
+// (blocks owned by the lane they start in, wavefront-wide batched stores) -- needs the components to share at most
+// two (DC, AC) table pairs, as every baseline file's do, or runs with per-frame tables from device memory (PF);
+// launch_hd_round / launch_hd_finish pick it whenever HdParams::spec or ::ftabs is set, and k_hd_round then only
 // verifies the hand-overs and finishes what takes more rounds than k_hd_sync is given.
 #include "hvc_hdec.h"
 
@@ -660,10 +661,10 @@ __global__ __launch_bounds__(256) void k_hd_write(HdParams P, int final_round) {
 //     that starts in the middle of a block walks to its end without storing.  Every block leaves whole.
 //   * Coefficients are assembled in a 128-byte LDS buffer per lane; finished blocks are stored by the WAVEFRONT:
 //     the lanes concerned put (place in the records, lane) on a small list, then eight lanes per block move one
-//     16-byte piece each from LDS to the record and clear it.  (The loop is therefore wavefront-uniform: no lane
-//     leaves before the last one is done.)
-//   * Block ends are batched: see WR_BATCH below.
-// 81.4 KB of LDS per workgroup: two workgroups per CU.
+//     16-byte piece each from LDS to the record and clear it.
+//   * Block ends are batched (WR_BATCH below): the symbols run in an inner loop that a lane leaves when it ends a
+//     block, and the wavefront when WR_BATCH lanes have.
+// 81.7 KB of LDS per workgroup: two workgroups per CU.
 constexpr int WR_EXTRA = 3; // rows staged past the workgroup's own, for the last lanes' overrun
 #ifndef HVC_WR_BATCH
 #define HVC_WR_BATCH 12
@@ -945,8 +946,7 @@ __global__ __launch_bounds__(1024) void k_hd_dc(HdParams P) {
 
 // One Huffman table in the two forms the fast kernels read (SPEC_T entries each: first level, then the sub-tables).
 //   spec (synchronisation walk): see HdSpec
-//   val  (k_hd_write2): bits 0-4 code length (0: no code), 5-9 magnitude bits, 10-13 run of zeros, bit 14 EOB;
-//                       0x8000 | n (first level only) = continue in sub-table n
+//   val  (k_hd_write2): see val_entry
 static void convert_table(const HdTable &src, bool dc, uint16_t *spec, uint16_t *val) {
     auto conv = [dc](uint16_t e) -> uint16_t {
         if (e & 0x8000u) return (uint16_t)((e & 0x7fffu) << 6); // continues in a sub-table: "0 bits" and its number
