@@ -2175,7 +2175,10 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     }
     for (int i = 0; i < NB; i++)
         if (!c->ev_rd[i]) HIPCHK(c, hipEventCreate(&c->ev_rd[i]));
-    constexpr int NRD = 2; // reader streams in use (1: 71 Gpixel/s on config 3, 2: 77, 3: 79 with half as much scratch again)
+#ifndef HVC_NRD
+#define HVC_NRD 2
+#endif
+    constexpr int NRD = HVC_NRD; // reader streams in use (round 1: 1: 71 Gpixel/s on config 3, 2: 77, 3: 79 with half as much scratch again)
     const size_t state_bytes = (HVC_HD_STATE_BYTES((size_t)C * nsub_max) + 255) & ~(size_t)255;
     if ((r = grow(c, &c->gd_state, &c->gd_state_cap, NRD * state_bytes))) return r;
     const size_t dcd_elems = ((size_t)C * G.blocks_per_frame + 127) & ~(size_t)127;
