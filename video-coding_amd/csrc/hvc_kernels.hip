@@ -486,11 +486,18 @@ __device__ __forceinline__ void ashr14_sat_pack2(unsigned &dst, int a, int b) {
 #define HVC_TRAFFIC_ONLY_DECODE(OUT)
 #endif
 // PRE: statements run on the loaded dwords w[] before anything reads them (the DC override of DecodeParams::dc_plane).
+// -DHVC_TRAFFIC_ONLY=2: additionally, the loads of a wavefront cover whole lines (lane l takes piece l of 1 KB per
+// instruction instead of 16 bytes at a stride of 128): what a load shape with a transpose behind it could reach.
+#if HVC_TRAFFIC_ONLY == 2
+#define HVC_PACKED_SRC(SRC, j) (SRC)[hvc_src_stride * (j)]
+#else
+#define HVC_PACKED_SRC(SRC, j) (SRC)[j]
+#endif
 #define HVC_DECODE_BLOCK_PACKED(SRC, QP, OUT, G, PRE)                                                   \
     do {                                                                                                \
         unsigned w[32];                                                                                 \
         _Pragma("unroll") for (int j = 0; j < 8; j++) {                                                 \
-            const uint4 t = (SRC)[j];                                                                   \
+            const uint4 t = HVC_PACKED_SRC(SRC, j);                                                     \
             w[4 * j + 0] = t.x;                                                                         \
             w[4 * j + 1] = t.y;                                                                         \
             w[4 * j + 2] = t.z;                                                                         \
@@ -550,6 +557,11 @@ __global__ __launch_bounds__(HVC_PACKED_LB) void k_decode_packed(DecodeParams P)
     unsigned out[8][2];
     int16_t dcv = 0;
     if (DCP) dcv = P.dc_plane[(size_t)blockIdx.y * P.dc_fs + ((br.coef_idx - (size_t)blockIdx.y * P.coef_fs) >> 6)];
+#if HVC_TRAFFIC_ONLY == 2 // whole-line loads where all 64 blocks of the wavefront exist (they are contiguous then)
+    const bool hvc_full = __ballot(active) == ~0ull;
+    const int hvc_src_stride = hvc_full ? 64 : 1;
+    if (hvc_full) src = src - 8 * (lane & 63) + (lane & 63);
+#endif
     HVC_DECODE_BLOCK_PACKED(src, qp, out, g, if (DCP) w[0] = with_dc(w[0], dcv););
 
     const bool bad = packed_guard_failed(g, P.ethr_packed[br.qtab]);
@@ -949,6 +961,9 @@ __global__ __launch_bounds__(HVC_TILE * NW, 4 / NW) HVC_444_ATTR void k_decode_4
     unsigned out[8][2];
     int16_t dcv = 0;
     if (DCP) dcv = P.dc_plane[(size_t)blockIdx.y * P.dc_fs + (in_frame >> 6)];
+#if HVC_TRAFFIC_ONLY == 2
+    const int hvc_src_stride = 1; // (the fused kernel keeps its load shape)
+#endif
     HVC_DECODE_BLOCK_PACKED(src, qp, out, g, if (DCP) w[0] = with_dc(w[0], dcv););
     const bool bad = packed_guard_failed(g, P.ethr_packed[K.qtab]);
 
