@@ -62,6 +62,8 @@ struct hvc_ctx {
     size_t gp_ecs_bytes = 0, gp_meta_bytes = 0, gp_ftabs_bytes = 0;
     // GPU Huffman decoder (hvc_jpeg_entropy_decode_gpu): device scratch, grown on demand
     void *gd_ecs = nullptr, *gd_meta = nullptr, *gd_state = nullptr, *gd_tables = nullptr, *gd_coefs = nullptr, *gd_dcd = nullptr;
+    void *gd_h_ecs = nullptr; // pinned: the batch's unstuffed segments on their way to gd_ecs
+    size_t gd_h_ecs_cap = 0;
     void *gd_ftabs = nullptr; // per-frame tables of hvc_jpeg_entropy_decode_gpu (PF mode)
     size_t gd_ftabs_cap = 0;
     void *gd_dcv = nullptr;   // batch pipeline: the blocks' DC values as a compact array (hvc::DecodeParams::dc_plane)
@@ -404,6 +406,7 @@ void hvc_destroy(hvc_ctx *c) {
     for (int i = 0; i < 4; i++)
         if (c->ev_t[i]) (void)hipEventDestroy(c->ev_t[i]);
     if (c->gd_ecs) (void)hipFree(c->gd_ecs);
+    if (c->gd_h_ecs) (void)hipHostFree(c->gd_h_ecs);
     if (c->gd_meta) (void)hipFree(c->gd_meta);
     if (c->gd_state) (void)hipFree(c->gd_state);
     if (c->gd_tables) (void)hipFree(c->gd_tables);
@@ -1843,7 +1846,36 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
     // else = per-frame tables in device memory (PF mode, hvc_hdec.h).
     std::vector<hvc::HdTables> sets;
     std::vector<unsigned> tabset_of((size_t)n_frames, 0u);
-    std::vector<std::vector<uint8_t>> ecs((size_t)n_frames);
+    // The segments go straight from the files into ONE pinned buffer (unstuffed on the way) and from there to the
+    // device: laid out by an upper bound of every segment's length -- its file's -- so that the places are known before
+    // the files are read.  (Through per-file vectors, a pageable batch buffer and the runtime's own staging the bytes of
+    // a 1 MB file were copied three times before the copy engine saw them: 0.15 of the call's 1.0 ms.)
+    const unsigned SB = HVC_HD_SUBSEQ_BITS / 8;
+    std::vector<unsigned> ecs_off((size_t)n_frames), sub_off((size_t)n_frames + 1);
+    size_t bytes = 0, subs = 0;
+    try {
+        for (int f = 0; f < n_frames; f++) {
+            const size_t nsub_most = (sizes[f] + SB - 1) / SB + 1; // an entropy-coded segment is shorter than its file
+            ecs_off[(size_t)f] = (unsigned)bytes;
+            bytes += nsub_most * SB + 16; // SB = 128: every frame starts on a 16-byte boundary, 16 zero bytes of overshoot
+            if (bytes >= (1ull << 31)) return HVC_OK;
+        }
+    } catch (const std::bad_alloc &) {
+        return HVC_E_OUT_OF_MEMORY;
+    }
+    if (bytes > c->gd_h_ecs_cap) {
+        if (c->gd_h_ecs) (void)hipHostFree(c->gd_h_ecs);
+        c->gd_h_ecs = nullptr;
+        c->gd_h_ecs_cap = 0;
+        const size_t want = bytes + bytes / 2;
+        if (hipHostMalloc(&c->gd_h_ecs, want, HVC_UPLOAD_RING_FLAGS) != hipSuccess) {
+            (void)hipGetLastError();
+            c->gd_h_ecs = nullptr;
+            return HVC_E_OUT_OF_MEMORY;
+        }
+        c->gd_h_ecs_cap = want;
+    }
+    uint8_t *const h_ecs = (uint8_t *)c->gd_h_ecs;
     try {
         hvc::HdTables t;
         for (int f = 0; f < n_frames; f++) {
@@ -1852,9 +1884,16 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
             if (r) return r;
             if (!same_geometry(fi, info0)) return HVC_E_INVALID_ARG; // a batch shares one geometry
             bool ok = false;
-            r = hvc::prepare_gpu_decode(jpegs[f], sizes[f], &fi, t, ecs[(size_t)f], ok);
+            const size_t room = (sizes[f] + SB - 1) / SB * SB; // (the frame's slot without its extra subsequence and overshoot)
+            size_t got = 0;
+            r = hvc::prepare_gpu_decode_to(jpegs[f], sizes[f], &fi, t, h_ecs + ecs_off[(size_t)f], room, &got, ok);
             if (r) return r;
             if (!ok) return HVC_OK;
+            const size_t nsub = (got + SB - 1) / SB + 1; // one extra: the reader sees zeros past the end
+            std::memset(h_ecs + ecs_off[(size_t)f] + got, 0, nsub * SB + 16 - got); // (the buffer is reused from call to call)
+            sub_off[(size_t)f] = (unsigned)subs;
+            subs += nsub;
+            if (subs >= (1ull << 31)) return HVC_OK;
             size_t k = sets.size(); // newest first: files of one source tend to come in runs
             while (k > 0 && std::memcmp(&sets[k - 1], &t, sizeof t)) k--;
             if (k == 0) {
@@ -1870,29 +1909,15 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
     hvc::HdParams P;
     if (!gd_geometry(info0, P)) return HVC_OK;
     P.n_frames = n_frames;
-    // layout of the segment buffer and the per-subsequence arrays
-    const unsigned SB = HVC_HD_SUBSEQ_BITS / 8;
-    std::vector<unsigned> ecs_off((size_t)n_frames), sub_off((size_t)n_frames + 1);
-    size_t bytes = 0, subs = 0;
-    for (int f = 0; f < n_frames; f++) {
-        const size_t nsub = (ecs[(size_t)f].size() + SB - 1) / SB + 1; // one extra: the reader sees zeros past the end
-        ecs_off[(size_t)f] = (unsigned)bytes;
-        sub_off[(size_t)f] = (unsigned)subs;
-        bytes += nsub * SB + 16; // SB = 128: every frame starts on a 16-byte boundary, 16 zero bytes of overshoot
-        subs += nsub;
-        if (bytes >= (1ull << 31) || subs >= (1ull << 31)) return HVC_OK;
-    }
     sub_off[(size_t)n_frames] = (unsigned)subs;
     P.total_sub = (unsigned)subs;
-    std::vector<uint8_t> h_ecs(bytes, 0);
-    // the index arrays (and the two flags behind them, as zeros) travel as one block
+    // the index arrays: [ecs_off n][sub_off n + 1] travel; [frame_of subs] is filled on the device from sub_off,
+    // [frame_blocks n][changed, status] are written there
     const size_t meta_words = (size_t)n_frames + ((size_t)n_frames + 1) + subs + (size_t)n_frames + 2;
-    std::vector<unsigned> h_meta(meta_words, 0u);
+    std::vector<unsigned> h_meta((size_t)2 * n_frames + 1);
     for (int f = 0; f < n_frames; f++) {
-        std::memcpy(h_ecs.data() + ecs_off[(size_t)f], ecs[(size_t)f].data(), ecs[(size_t)f].size());
         h_meta[(size_t)f] = ecs_off[(size_t)f];
         h_meta[(size_t)n_frames + (size_t)f] = sub_off[(size_t)f];
-        for (unsigned k = sub_off[(size_t)f]; k < sub_off[(size_t)f + 1]; k++) h_meta[(size_t)2 * n_frames + 1 + k] = (unsigned)f;
     }
     h_meta[(size_t)2 * n_frames] = sub_off[(size_t)n_frames];
     int r;
@@ -1905,8 +1930,8 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
     unsigned *d_ecs_off = m, *d_sub_off = m + n_frames, *d_frame_of = d_sub_off + n_frames + 1;
     unsigned *d_frame_blocks = d_frame_of + subs, *d_flags = d_frame_blocks + n_frames;
     hipStream_t st = c->stream;
-    HIPCHK(c, hipMemcpyAsync(c->gd_ecs, h_ecs.data(), bytes, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(m, h_meta.data(), meta_words * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->gd_ecs, h_ecs, bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(m, h_meta.data(), h_meta.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
     std::vector<hvc::HdFrameTabs> ftabs; // (lives until the synchronisation below: the upload reads it)
     bool pf = sets.size() > 1;
     if (!pf) {
@@ -1947,6 +1972,7 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
     // Everything in one go, as the batch pipeline does: four synchronisation launches (all of k_hd_sync's rounds count
     // as the first), the finish passes, one look at the two flags.  Only a stream that has not settled by then -- smooth
     // content can take hundreds of rounds -- is done again round by round.
+    HIPCHK(c, hvc::launch_hd_frame_of(P, st));
     HIPCHK(c, gd_enqueue(P, 4, st)); // clears the flags first
     unsigned flags[2] = {0, 0};
     HIPCHK(c, hipMemcpyAsync(flags, P.changed, sizeof flags, hipMemcpyDeviceToHost, st));
