@@ -46,7 +46,10 @@ bool make_spec(const HdTables &t, int n_comp, HdSpec &out, unsigned char slot_of
 #define HVC_HD_SPEC_T (1024 + HVC_HD_SUBTABLES * 64)
 struct HdFrameTabs {
     uint16_t spec[3][2][HVC_HD_SPEC_T]; // [component][0 = DC, 1 = AC] in HdSpec's entry format (synchronisation walk)
-    uint16_t val[3][2][HVC_HD_SPEC_T];  // the same tables in the write pass's format (k_hd_write2: length, size, run, EOB)
+    uint16_t val[3][2][HVC_HD_SPEC_T];  // the same tables in the write pass's format (k_hd_write2: see val_entry)
+    // bit 0: the third component reads the second one's tables (or there is none): the frame's tables are the first
+    // 12 KB of each form, and a workgroup whose subsequences all belong to this frame keeps them in LDS
+    unsigned flags, pad[3];
 };
 void make_frame_tabs(const HdTables &t, int n_comp, HdFrameTabs &out);
 

@@ -447,11 +447,18 @@ __device__ __forceinline__ void spec_walk(RD rd, const unsigned *row, const uint
 // 256 lanes the tables weigh twice as much per lane and 12 wavefronts fit; the loop is latency-bound enough --
 // 8 wavefronts per CU were 1.4x slower -- for the 16 to show.)
 constexpr int SYNC_WG = 512;
+// 2-bit fields of a PF selmask with component 2 renamed 1 (its tables are component 1's: HdFrameTabs::flags)
+__device__ __forceinline__ unsigned selmask_c2_as_c1(unsigned sel) {
+    const unsigned hi = sel & 0xaaaaaaaau;
+    return (sel & ~hi) | (hi >> 1);
+}
+
 // One subsequence of one round: true when its successor has to start again.  PF: the frame's own tables, in device
-// memory (sp_lds unused); otherwise the batch's one set in LDS.
+// memory -- or, with pf_lds (the same in every lane), in sp_lds: the tables of the one frame all of the workgroup's
+// lanes are in; otherwise the batch's one set in LDS.
 template <bool PF>
 __device__ __forceinline__ bool sync_one(const HdParams &P, int round, bool valid, unsigned i, unsigned *row, const uint16_t *sp_lds,
-                                         const unsigned long long *pe, unsigned long long *ce) {
+                                         const unsigned long long *pe, unsigned long long *ce, bool pf_lds = false) {
     const unsigned f = P.frame_of[i], j = i - P.sub_off[f];
     const unsigned base = j * (unsigned)S;
     unsigned long long st = pack_state(base, 0, 0); // the guess; the truth for j == 0
@@ -460,9 +467,10 @@ __device__ __forceinline__ bool sync_one(const HdParams &P, int round, bool vali
     stage_row(row, P.ecs + P.ecs_off[f] + (size_t)j * (S / 8));
     unsigned p = (unsigned)st, nb = 0;
     int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
-    const uint16_t *sp = PF ? &P.ftabs[P.tabset_of[f]].spec[0][0][0] : sp_lds;
-    if (PF) spec_walk<true, false>([row](unsigned q) { return row[q]; }, row, sp, P.selmask, P.blocks_per_mcu, base, p, k, b, nb);
-    else spec_walk<true, true>([row](unsigned q) { return row[q]; }, row, sp, P.slotmask, P.blocks_per_mcu, base, p, k, b, nb);
+    auto rd = [row](unsigned q) { return row[q]; };
+    if (!PF) spec_walk<true, true>(rd, row, sp_lds, P.slotmask, P.blocks_per_mcu, base, p, k, b, nb);
+    else if (pf_lds) spec_walk<true, false>(rd, row, sp_lds, selmask_c2_as_c1(P.selmask), P.blocks_per_mcu, base, p, k, b, nb);
+    else spec_walk<true, false>(rd, row, &P.ftabs[P.tabset_of[f]].spec[0][0][0], P.selmask, P.blocks_per_mcu, base, p, k, b, nb);
 #ifdef HVC_HD_STATS // experiments, round 0: symbols walked / 64 x the longest walk of each wavefront (what it costs)
     {
         const unsigned nsym = nb >> 16;
@@ -487,14 +495,27 @@ __device__ __forceinline__ bool sync_one(const HdParams &P, int round, bool vali
 
 template <bool PF>
 __global__ __launch_bounds__(SYNC_WG) void k_hd_sync(HdParams P, int round) {
-    __shared__ uint16_t sp[PF ? 2 : 2 * 2 * SPEC_T];
+    __shared__ uint16_t sp[2 * 2 * SPEC_T];
     __shared__ unsigned rows[SYNC_WG / 64][64 * SROW + 2]; // (+ 2: see spec_walk)
     const unsigned count = round < 2 ? P.total_sub : P.list_n[round];
     // the late rounds are launched over lists that hold a few hundred entries or none: a workgroup without work
     // leaves before it fetches 12 KB of tables (55 us a round for the 512 workgroups of such a launch, 10 without)
     if (blockIdx.x * (unsigned)SYNC_WG >= count) return;
-    if (!PF) {
-        const unsigned *src = reinterpret_cast<const unsigned *>(P.spec);
+    // PF: in rounds 0 and 1 a workgroup takes 512 consecutive subsequences -- nearly always of ONE frame, whose tables
+    // (two components' worth: see HdFrameTabs::flags) then go to LDS like the batch-wide ones; the list rounds mix
+    // frames within a wavefront and keep reading the frames' records in device memory.
+    bool pf_lds = false;
+    const unsigned *src = reinterpret_cast<const unsigned *>(P.spec);
+    if (PF && round < 2) {
+        const unsigned i0 = blockIdx.x * (unsigned)SYNC_WG, i1 = min(i0 + (unsigned)SYNC_WG, count) - 1u;
+        const unsigned f0 = P.frame_of[i0];
+        if (f0 == P.frame_of[i1]) {
+            const HdFrameTabs &ft = P.ftabs[P.tabset_of[f0]];
+            pf_lds = (ft.flags & 1u) != 0u;
+            src = reinterpret_cast<const unsigned *>(&ft.spec[0][0][0]);
+        }
+    }
+    if (!PF || pf_lds) {
         unsigned *dst = reinterpret_cast<unsigned *>(sp);
         for (unsigned i = threadIdx.x; i < sizeof(HdSpec) / 4; i += SYNC_WG) dst[i] = src[i];
         __syncthreads(); // the tables; from here on the wavefronts have nothing to do with one another
@@ -513,7 +534,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_hd_sync(HdParams P, int round) {
         const unsigned t = tb + (unsigned)threadIdx.x;
         const bool valid = t < count;
         const unsigned i = !valid ? 0u : round < 2 ? t : list[t];
-        const bool push = sync_one<PF>(P, round, valid, i, row, sp, pe, ce);
+        const bool push = sync_one<PF>(P, round, valid, i, row, sp, pe, ce, pf_lds);
         const unsigned long long m = __ballot(push);
         if (round == 0) continue; // (nothing is pushed: round 1 takes every subsequence)
         if (lane == 0) wcount[trip][wave] = (unsigned)__popcll(m);
@@ -694,7 +715,7 @@ __host__ __device__ inline unsigned val_entry(unsigned e, bool dc, bool second_l
 // staged in LDS -- 34 KB less of it per 256 lanes, which is what holds the staged form at two wavefronts per SIMD.
 template <bool PF, bool GBITS, int WG>
 __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
-    __shared__ uint16_t tv[PF ? 2 : 2 * 2 * SPEC_T]; // value tables of the two slots: [slot][DC, AC] (PF: the frame's record in device memory instead)
+    __shared__ uint16_t tv[2 * 2 * SPEC_T]; // value tables: [slot][DC, AC] -- PF: of the workgroup's one frame, if it is one (else they stay in device memory)
     __shared__ HdGeo G;
     __shared__ unsigned rows[GBITS ? 1 : (WG + WR_EXTRA + 2) * SROW]; // (+ 2: what a lane about to give up at `hard` may still read, unstaged)
     __shared__ uint4 lbuf[WG * 8]; // 64 int16 per lane
@@ -715,6 +736,22 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
     const bool valid = i < P.total_sub;
     const unsigned f = valid ? P.frame_of[i] : 0u, j = valid ? i - P.sub_off[f] : 0u;
     if (*P.changed) return; // not settled: nothing is stored (see k_hd_write); uniform, before any barrier
+    // PF: the workgroup's subsequences are consecutive -- nearly always of ONE frame, whose tables (two components'
+    // worth: HdFrameTabs::flags) then go to LDS like the batch-wide ones
+    bool pf_lds = false;
+    if (PF) {
+        const unsigned i0 = blockIdx.x * (unsigned)WG, i1 = min(i0 + (unsigned)WG, P.total_sub) - 1u;
+        const unsigned f0 = P.frame_of[i0];
+        if (f0 == P.frame_of[i1]) {
+            const HdFrameTabs &ft = P.ftabs[P.tabset_of[f0]];
+            if (ft.flags & 1u) {
+                pf_lds = true;
+                const unsigned *src = reinterpret_cast<const unsigned *>(&ft.val[0][0][0]);
+                unsigned *dst = reinterpret_cast<unsigned *>(tv);
+                for (unsigned q = threadIdx.x; q < sizeof(tv) / 4; q += WG) dst[q] = src[q];
+            }
+        }
+    }
     if (!GBITS) {
         if (valid) stage_row(rows + tid * SROW, P.ecs + P.ecs_off[f] + (size_t)j * (S / 8));
         if (tid < WR_EXTRA) {
@@ -771,8 +808,10 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
     unsigned hi = l0 ? rd(l0 - 1u) : 0u, lo = rd(l0), nx = rd(l0 + 1u);
     auto pos = [&]() -> unsigned { return base + ~mm - 31u; };                  // the bit position itself (rare branches)
     auto mm_of = [&](unsigned p) -> unsigned { return ~(p - base + 31u); };
-    const uint16_t *const tvb = PF ? &P.ftabs[P.tabset_of[f]].val[0][0][0] : tv;
-    const uint16_t *bt = tvb + ((P.selmask >> (2 * b)) & 3u) * (2 * SPEC_T);
+    // The tables are in LDS or in device memory: the walk is written once and instantiated per address space (a
+    // pointer that could be either would make every look-up a flat load).
+    auto decode_and_store = [&](const uint16_t *const tvb, const unsigned selmask) {
+    const uint16_t *bt = tvb + ((selmask >> (2 * b)) & 3u) * (2 * SPEC_T);
     const uint16_t *bt_ac = bt + SPEC_T;
     // the exit the synchronisation launches recorded for this subsequence must be the one this walk arrives at
     const unsigned long long fin_i = valid ? ((final_round & 1) ? P.exit_a : P.exit_b)[i] : 0ull; // launch final_round - 1 wrote it
@@ -874,7 +913,7 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
                 b = b + 1 == B ? 0 : b + 1;
                 bi++;
                 live = bi < P.blocks_per_frame;
-                bt = tvb + ((P.selmask >> (2 * b)) & 3u) * (2 * SPEC_T);
+                bt = tvb + ((selmask >> (2 * b)) & 3u) * (2 * SPEC_T);
                 bt_ac = bt + SPEC_T;
                 if (b == 0) { // next MCU
                     mx++;
@@ -888,6 +927,10 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
             }
         }
     }
+    };
+    if (!PF) decode_and_store(tv, P.selmask);
+    else if (pf_lds) decode_and_store(tv, selmask_c2_as_c1(P.selmask));
+    else decode_and_store(&P.ftabs[P.tabset_of[f]].val[0][0][0], P.selmask);
     if (err) atomicOr(P.status, err);
 }
 
@@ -989,6 +1032,8 @@ bool make_spec(const HdTables &t, int n_comp, HdSpec &out, unsigned char slot_of
 }
 
 void make_frame_tabs(const HdTables &t, int n_comp, HdFrameTabs &out) {
+    out.flags = (n_comp < 3 || (!std::memcmp(&t.dc[2], &t.dc[1], sizeof(HdTable)) && !std::memcmp(&t.ac[2], &t.ac[1], sizeof(HdTable)))) ? 1u : 0u;
+    out.pad[0] = out.pad[1] = out.pad[2] = 0;
     for (int c = 0; c < 3; c++) {
         const int s = c < n_comp ? c : 0; // components the frame does not have: a copy, never read
         convert_table(t.dc[s], true, out.spec[c][0], out.val[c][0]);
