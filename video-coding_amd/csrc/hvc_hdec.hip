@@ -253,6 +253,12 @@ void hd_stats_read(unsigned long long out[4]) { // experiments: read and clear
 }
 #endif
 
+// 2-bit fields of a PF selmask with component 2 renamed 1 (its tables are component 1's: HdFrameTabs::flags)
+__device__ __forceinline__ unsigned selmask_c2_as_c1(unsigned sel) {
+    const unsigned hi = sel & 0xaaaaaaaau;
+    return (sel & ~hi) | (hi >> 1);
+}
+
 template <bool RD_FREE, bool SEL1, class RD> // the lean walk of the synchronisation rounds, defined with k_hd_sync below
 __device__ __forceinline__ void spec_walk(RD rd, const unsigned *row, const uint16_t *sp, unsigned sel, int B, unsigned base, unsigned &p,
                                           int &k, int &b, unsigned &nb);
@@ -266,13 +272,15 @@ constexpr int INNER = 24;
 // MODE 1 (HdParams::spec set): behind k_hd_sync this kernel follows the few chains of hand-overs that are still moving,
 //   one step per inner round with one lane of a workgroup busy -- the latency of a single walk is all that counts, so
 //   it is the lean one: spec_walk on the HdSpec tables, the lane's subsequence staged in LDS.
-// MODE 2 (PF, per-frame tables): spec_walk on the frame's own record in device memory, the bits from global memory as
-//   well (byte order restored on the way); no tables in LDS.
+// MODE 2 (PF, per-frame tables): the same lean walk on a row staged in LDS; the tables are the frame's own record --
+//   copied to LDS when every subsequence of the workgroup belongs to one frame whose tables fit two components'
+//   worth (HdFrameTabs::flags), read from device memory otherwise.  (With 12 list rounds before it this kernel had
+//   walks in most workgroups and the copies cost more than they saved; with 22 it has them in a few.)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
     constexpr bool PF = MODE == 2;
-    __shared__ __attribute__((aligned(16))) unsigned char Traw[MODE == 0 ? sizeof(HdTables) : MODE == 1 ? sizeof(HdSpec) : 16];
-    __shared__ unsigned rows[MODE == 1 ? 256 * SROW + 2 : 1];
+    __shared__ __attribute__((aligned(16))) unsigned char Traw[MODE == 0 ? sizeof(HdTables) : sizeof(HdSpec)];
+    __shared__ unsigned rows[MODE != 0 ? 256 * SROW + 2 : 1];
     HdTables &T = *reinterpret_cast<HdTables *>(Traw);
     __shared__ HdGeo G;
     __shared__ unsigned long long exits[256];
@@ -298,10 +306,22 @@ __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
     // Behind k_hd_sync almost every workgroup only finds its hand-overs in order: the 18 KB of tables are loaded when
     // a lane has to walk -- an inner round starts walks only where a neighbour's exit moved, i.e. after a walk --
     // and a launch that verifies costs the three arrays it reads, not the tables 7 000 workgroups would fetch.
-    if (__syncthreads_or(valid && (!have || st != used)) && !PF) { // (the barrier also publishes G)
+    bool pf_lds = false; // MODE 2: the workgroup's one frame's tables are in LDS
+    if (__syncthreads_or(valid && (!have || st != used))) { // (the barrier also publishes G)
         const unsigned *src = MODE == 1 ? reinterpret_cast<const unsigned *>(P.spec) : reinterpret_cast<const unsigned *>(P.tables);
-        unsigned *dst = reinterpret_cast<unsigned *>(Traw);
-        for (unsigned q = threadIdx.x; q < sizeof(Traw) / 4; q += 256) dst[q] = src[q];
+        if (PF) {
+            const unsigned i0 = blockIdx.x * 256u, i1 = min(i0 + 256u, P.total_sub) - 1u;
+            const unsigned f0 = P.frame_of[i0];
+            if (f0 == P.frame_of[i1]) {
+                const HdFrameTabs &ft = P.ftabs[P.tabset_of[f0]];
+                pf_lds = (ft.flags & 1u) != 0u;
+                src = reinterpret_cast<const unsigned *>(&ft.spec[0][0][0]);
+            }
+        }
+        if (!PF || pf_lds) {
+            unsigned *dst = reinterpret_cast<unsigned *>(Traw);
+            for (unsigned q = threadIdx.x; q < sizeof(Traw) / 4; q += 256) dst[q] = src[q];
+        }
         __syncthreads();
     }
     bool changed = false;
@@ -310,14 +330,14 @@ __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
             unsigned p = (unsigned)st, err = 0;
             int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
             nb = 0;
-            if (PF) {
-                spec_walk<false, false>([slot](unsigned q) { return __builtin_bswap32(slot[q]); }, nullptr, &P.ftabs[P.tabset_of[f]].spec[0][0][0],
-                                        P.selmask, P.blocks_per_mcu, base, p, k, b, nb);
-            } else if (MODE == 1) {
+            if (MODE != 0) {
                 unsigned *row = rows + tid * SROW; // (staged once per launch would do; a walk is 200 symbols, this is 40 instructions)
                 stage_row(row, reinterpret_cast<const uint8_t *>(slot));
-                spec_walk<true, true>([row](unsigned q) { return row[q]; }, row, reinterpret_cast<const uint16_t *>(Traw), P.slotmask,
-                                      P.blocks_per_mcu, base, p, k, b, nb);
+                auto rd = [row](unsigned q) { return row[q]; };
+                const uint16_t *lt = reinterpret_cast<const uint16_t *>(Traw);
+                if (MODE == 1) spec_walk<true, true>(rd, row, lt, P.slotmask, P.blocks_per_mcu, base, p, k, b, nb);
+                else if (pf_lds) spec_walk<true, false>(rd, row, lt, selmask_c2_as_c1(P.selmask), P.blocks_per_mcu, base, p, k, b, nb);
+                else spec_walk<true, false>(rd, row, &P.ftabs[P.tabset_of[f]].spec[0][0][0], P.selmask, P.blocks_per_mcu, base, p, k, b, nb);
             } else {
                 walk<false>(P, G, T, slot, base, base + (unsigned)S, p, k, b, nb, 0, nullptr, err);
             }
@@ -447,12 +467,6 @@ __device__ __forceinline__ void spec_walk(RD rd, const unsigned *row, const uint
 // 256 lanes the tables weigh twice as much per lane and 12 wavefronts fit; the loop is latency-bound enough --
 // 8 wavefronts per CU were 1.4x slower -- for the 16 to show.)
 constexpr int SYNC_WG = 512;
-// 2-bit fields of a PF selmask with component 2 renamed 1 (its tables are component 1's: HdFrameTabs::flags)
-__device__ __forceinline__ unsigned selmask_c2_as_c1(unsigned sel) {
-    const unsigned hi = sel & 0xaaaaaaaau;
-    return (sel & ~hi) | (hi >> 1);
-}
-
 // One subsequence of one round: true when its successor has to start again.  PF: the frame's own tables, in device
 // memory -- or, with pf_lds (the same in every lane), in sp_lds: the tables of the one frame all of the workgroup's
 // lanes are in; otherwise the batch's one set in LDS.
