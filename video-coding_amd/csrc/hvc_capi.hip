@@ -5,6 +5,7 @@
 #include <pthread.h>
 #include <sched.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -64,6 +65,8 @@ struct hvc_ctx {
     void *gd_ecs = nullptr, *gd_meta = nullptr, *gd_state = nullptr, *gd_tables = nullptr, *gd_coefs = nullptr, *gd_dcd = nullptr;
     void *gd_h_ecs = nullptr; // pinned: the batch's unstuffed segments on their way to gd_ecs
     size_t gd_h_ecs_cap = 0;
+    void *gd_fcnt = nullptr;  // PF mode: per-frame list lengths per round (hvc::HdParams::list_fn)
+    size_t gd_fcnt_cap = 0;
     void *gd_ftabs = nullptr; // per-frame tables of hvc_jpeg_entropy_decode_gpu (PF mode)
     size_t gd_ftabs_cap = 0;
     void *gd_dcv = nullptr;   // batch pipeline: the blocks' DC values as a compact array (hvc::DecodeParams::dc_plane)
@@ -407,6 +410,7 @@ void hvc_destroy(hvc_ctx *c) {
         if (c->ev_t[i]) (void)hipEventDestroy(c->ev_t[i]);
     if (c->gd_ecs) (void)hipFree(c->gd_ecs);
     if (c->gd_h_ecs) (void)hipHostFree(c->gd_h_ecs);
+    if (c->gd_fcnt) (void)hipFree(c->gd_fcnt);
     if (c->gd_meta) (void)hipFree(c->gd_meta);
     if (c->gd_state) (void)hipFree(c->gd_state);
     if (c->gd_tables) (void)hipFree(c->gd_tables);
@@ -1815,6 +1819,13 @@ static int gd_upload_tables(hvc_ctx *c, const hvc::HdTables &t, hvc::HdParams &P
     return HVC_OK;
 }
 
+// PF mode: one work list per frame (hvc::HdParams::list_fn) pays where a frame fills workgroups of 512 subsequences by
+// itself -- 1080p files have 7 000 -- and the frames fit the launch grid's second dimension; batches of small files
+// keep the batch-wide lists, which pack the subsequences of many frames into one workgroup.
+static bool gd_lists_per_frame(size_t total_sub, int n_frames) {
+    return n_frames >= 1 && n_frames <= 65535 && total_sub / (size_t)n_frames >= 1024;
+}
+
 // PF mode (per-frame Huffman tables, hvc_hdec.h): which tables block b of an MCU reads = its component
 static unsigned gd_component_selmask(const hvc::HdParams &P) {
     unsigned m = 0;
@@ -1957,6 +1968,11 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
         P.ftabs = (const hvc::HdFrameTabs *)c->gd_ftabs;
         P.tabset_of = (const unsigned *)((char *)c->gd_ftabs + tb);
         P.selmask = gd_component_selmask(P);
+        if (gd_lists_per_frame(P.total_sub, n_frames)) {
+            if ((r = grow(c, &c->gd_fcnt, &c->gd_fcnt_cap, (size_t)HVC_HD_LIST_N * (size_t)n_frames * sizeof(unsigned)))) return r;
+            P.list_fn = (unsigned *)c->gd_fcnt; // work lists per frame (k_hd_sync_pf)
+            for (int f = 0; f < n_frames; f++) P.max_frame_sub = std::max(P.max_frame_sub, sub_off[(size_t)f + 1] - sub_off[(size_t)f]);
+        }
     }
     P.ecs = (const uint8_t *)c->gd_ecs;
     P.ecs_off = d_ecs_off;
@@ -2207,6 +2223,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     constexpr int NRD = HVC_NRD; // reader streams in use (round 1: 1: 71 Gpixel/s on config 3, 2: 77, 3: 79 with half as much scratch again)
     const size_t state_bytes = (HVC_HD_STATE_BYTES((size_t)C * nsub_max) + 255) & ~(size_t)255;
     if ((r = grow(c, &c->gd_state, &c->gd_state_cap, NRD * state_bytes))) return r;
+    if ((r = grow(c, &c->gd_fcnt, &c->gd_fcnt_cap, (size_t)NRD * HVC_HD_LIST_N * (size_t)C * sizeof(unsigned)))) return r;
     const size_t dcd_elems = ((size_t)C * G.blocks_per_frame + 127) & ~(size_t)127;
     if ((r = grow(c, &c->gd_dcd, &c->gd_dcd_cap, NRD * dcd_elems * sizeof(int16_t)))) return r;
     // The DC values go from the reader's DC pass to the block stage through a compact array, one per ring slot (a
@@ -2420,6 +2437,10 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
             P.ftabs = (const hvc::HdFrameTabs *)c->gp_d_ftabs[slot];
             P.tabset_of = dm + C + C + 1;
             P.selmask = comp_selmask;
+            if (gd_lists_per_frame(subs, cnt)) {
+                P.list_fn = (unsigned *)c->gd_fcnt + (size_t)(k % NRD) * HVC_HD_LIST_N * (size_t)C; // work lists per frame (k_hd_sync_pf)
+                P.max_frame_sub = (unsigned)nsub_max;
+            }
         }
         P.frame_blocks = dm + (meta_words - 2 - C);
         P.changed = dm + (meta_words - 2);

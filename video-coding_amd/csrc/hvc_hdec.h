@@ -96,6 +96,11 @@ struct HdParams {
     // k_hd_sync only: second per-round exit buffer (exit_b is the first), the two work lists, list lengths per round
     unsigned long long *exit_c;
     unsigned *list0, *list1, *list_n; // [total_sub], [total_sub], [HVC_HD_LIST_N]
+    // PF mode with more than a handful of files: one work list per FRAME (frame f's entries sit at list0/1 + sub_off[f],
+    // their number per round in list_fn[round * n_frames + f]), so that a workgroup's entries are all of one frame and
+    // its tables can go to LDS.  list_fn: [HVC_HD_LIST_N * n_frames], or null (then the batch-wide lists are used).
+    unsigned *list_fn;
+    unsigned max_frame_sub;    // the largest number of subsequences any frame has (the launches' grid)
     int16_t *dcd;              // [n_frames * blocks_per_frame] DC differences in scan order (k_hd_write2 -> k_hd_dc), or null
     int16_t *dc_plane;         // null: k_hd_dc puts the DC values into the records.  Otherwise into this compact array,
     size_t dc_fs;              //   dc_plane[frame * dc_fs + (block's coefficient offset in the frame record) / 64] -- what

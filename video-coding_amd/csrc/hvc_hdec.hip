@@ -565,6 +565,55 @@ __global__ __launch_bounds__(SYNC_WG) void k_hd_sync(HdParams P, int round) {
     }
 }
 
+// PF mode, the rounds per FRAME: workgroup (x, f) takes 512 entries of frame f -- its subsequences themselves in
+// rounds 0 and 1, its own work list afterwards (HdParams::list_fn) -- so that every lane of a workgroup reads the same
+// tables and they can sit in LDS (where the frame's third component shares the second's: HdFrameTabs::flags; otherwise
+// the lanes read the frame's record in device memory as before).  With batch-wide lists the list rounds mixed frames
+// within a wavefront and paid a look-up in device memory per symbol: 20 rounds of 22.
+__global__ __launch_bounds__(SYNC_WG) void k_hd_sync_pf(HdParams P, int round) {
+    __shared__ uint16_t sp[2 * 2 * SPEC_T];
+    __shared__ unsigned rows[SYNC_WG / 64][64 * SROW + 2]; // (+ 2: see spec_walk)
+    __shared__ unsigned wcount[2][SYNC_WG / 64], wbase[2];
+    const unsigned f = blockIdx.y, s0 = P.sub_off[f];
+    const unsigned count = round < 2 ? P.sub_off[f + 1] - s0 : P.list_fn[(unsigned)round * (unsigned)P.n_frames + f];
+    if (blockIdx.x * (unsigned)SYNC_WG >= count) return;
+    const HdFrameTabs &ft = P.ftabs[P.tabset_of[f]];
+    const bool pf_lds = (ft.flags & 1u) != 0u;
+    if (pf_lds) {
+        const unsigned *src = reinterpret_cast<const unsigned *>(&ft.spec[0][0][0]);
+        unsigned *dst = reinterpret_cast<unsigned *>(sp);
+        for (unsigned i = threadIdx.x; i < sizeof(sp) / 4; i += SYNC_WG) dst[i] = src[i];
+        __syncthreads();
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned *row = rows[wave] + lane * SROW;
+    const unsigned *list = ((round & 1) ? P.list1 : P.list0) + s0;
+    unsigned *next = ((round & 1) ? P.list0 : P.list1) + s0;
+    unsigned *next_n = P.list_fn + (unsigned)(round + 1) * (unsigned)P.n_frames + f;
+    const unsigned long long *pe = (round & 1) ? P.exit_b : P.exit_c; // exits of round - 1
+    unsigned long long *ce = (round & 1) ? P.exit_c : P.exit_b;       // exits of this round
+    int trip = 0;
+    for (unsigned tb = blockIdx.x * (unsigned)SYNC_WG; tb < count; tb += gridDim.x * (unsigned)SYNC_WG, trip ^= 1) {
+        const unsigned t = tb + (unsigned)threadIdx.x;
+        const bool valid = t < count;
+        const unsigned i = !valid ? s0 : round < 2 ? s0 + t : list[t];
+        const bool push = sync_one<true>(P, round, valid, i, row, sp, pe, ce, pf_lds);
+        const unsigned long long m = __ballot(push);
+        if (round == 0) continue; // (nothing is pushed: round 1 takes every subsequence)
+        if (lane == 0) wcount[trip][wave] = (unsigned)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned total = 0;
+            for (int q = 0; q < SYNC_WG / 64; q++) total += wcount[trip][q];
+            wbase[trip] = total ? atomicAdd(next_n, total) : 0u;
+        }
+        __syncthreads();
+        unsigned at = wbase[trip];
+        for (int q = 0; q < wave; q++) at += wcount[trip][q];
+        if (push) next[at + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = i + 1;
+    }
+}
+
 // The same rounds for a handful of files (one at a time is how the model's decode_a_frame is called): from round 5
 // on the lists hold a few hundred subsequences, and what a round costs is a launch and the latency of one walk.  One
 // workgroup keeps the tables and goes from round to round by itself -- a barrier instead of a launch, the list lengths
@@ -1090,6 +1139,13 @@ static hipError_t launch_hd_round_t(const HdParams &P, int round, hipStream_t s)
             const int most = PF ? SYNC_ROUNDS_PF : SYNC_ROUNDS, n = v ? atoi(v) : most;
             return n < 2 ? 2 : n > HVC_HD_LIST_N - 4 ? HVC_HD_LIST_N - 4 : n;
         }();
+        if (PF && P.list_fn && P.max_frame_sub) { // per-frame lists (k_hd_sync_pf)
+            e = hipMemsetAsync(P.list_fn, 0, (size_t)HVC_HD_LIST_N * (size_t)P.n_frames * sizeof(unsigned), s);
+            if (e != hipSuccess) return e;
+            const unsigned per_frame = (P.max_frame_sub + (unsigned)SYNC_WG - 1u) / (unsigned)SYNC_WG;
+            for (int r = 0; r < rounds; r++) hipLaunchKernelGGL(k_hd_sync_pf, dim3(per_frame, (unsigned)P.n_frames), dim3(SYNC_WG), 0, s, P, r);
+            return hipGetLastError();
+        }
         for (int r = 0; r < rounds; r++) {
             // the lists shrink by about half a round; a grid-stride loop takes whatever is there
             const unsigned grid = r < 2 ? all : min(all, r < 4 ? 2048u : 512u);
