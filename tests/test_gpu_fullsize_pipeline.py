@@ -100,3 +100,36 @@ def test_config3_shape_fused_444_output(ctx, files):
     got = out.cpu().numpy().reshape(N_FILES, fs)
     for f in range(0, N_FILES, 7):
         assert np.array_equal(got[f], fused[order[f]]), f
+
+
+def test_config3_shape_with_per_file_tables(ctx, files):
+    """The same shape with the files' Huffman tables re-written: every file its own optimised tables, two or three
+    different sets per file, and files with the model's tables in between -- chunks in PF mode with one work list per
+    frame (k_hd_sync_pf), tables in LDS for some frames and in device memory for others, next to chunks that happen to
+    be uniform.  Same coefficients, so the model's frames are the reference as before."""
+    import torch
+    import video_coding_amd as hvc
+    from helpers import jpeg_optimised_tables
+    batch, order, padded, _ = files
+    qt = np.stack([orc.quant_scale(orc.quant_luma(), 75), orc.quant_scale(orc.quant_chroma(), 75)])
+    variants = {}
+    for k in range(N_DISTINCT):
+        rec = orc.Decoder(batch[k]).coef_record()   # batch[:N_DISTINCT] are the distinct files in order
+        variants[k] = [batch[k], jpeg_optimised_tables(W, H, 420, qt, rec, 2), jpeg_optimised_tables(W, H, 420, qt, rec, 3)]
+    rng = np.random.Generator(np.random.PCG64(77))
+    n = 96
+    pick = rng.integers(0, 3, size=n)
+    pick[70:] = 0                                   # the last chunk(s): the model's tables throughout
+    mixed = [variants[order[f]][pick[f]] for f in range(n)]
+    info = hvc.hvc.jpeg_read_header(mixed[0])
+    fs = info.pixel_bytes
+    out = torch.zeros(n * fs, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    st = ctx.jpeg_decode_batch(mixed, out, fs, threads=8, frames_per_chunk=16, gpu_entropy=True)
+    assert st.chunks == 6 and st.entropy_ms_sum == 0, "a chunk fell to the host reader"
+    sums = ctx.checksum_records(out, fs, n)
+    want_sums = checksum_records(np.stack(padded))
+    got = out.cpu().numpy().reshape(n, fs)
+    for f in range(n):
+        assert sums[f] == want_sums[order[f]], f
+        assert np.array_equal(got[f], padded[order[f]]), f

@@ -252,6 +252,23 @@ def test_files_with_their_own_optimised_tables(ctx, w, h, chroma, q, table_sets)
     assert used == 1
 
 
+def test_large_files_with_their_own_tables_take_the_per_frame_work_lists(ctx):
+    """Per-file tables on files large enough for one work list per frame (k_hd_sync_pf: a frame fills workgroups of 512
+    subsequences by itself, and the batch is past the single-workgroup tail of the rounds): frames whose chroma
+    components share their tables keep them in LDS, frames with three different table sets read them from device
+    memory -- both kinds in one batch, and next to a file with the model's own tables."""
+    w, h, q = 1920, 1088, 80
+    qt = np.stack([orc.quant_scale(orc.quant_luma(), q), orc.quant_scale(orc.quant_chroma(), q)])
+    files = []
+    for f in range(6):
+        j = make_jpeg(1300 + 7 * f, w, h, 420, q)
+        files.append(j if f == 4 else jpeg_optimised_tables(w, h, 420, qt, orc.Decoder(j).coef_record(), 3 if f % 2 else 2))
+    assert sum(len(j) for j in files) > 6 * 700_000  # ~ 6 000 subsequences a file: well over 1024 a frame, 32 768 a batch
+    _, got, used = ctx.jpeg_entropy_decode_gpu(files, device=True)
+    assert used == 1
+    check_records(files, got)
+
+
 def test_dc_beyond_int16_reaches_the_caller_as_range_error(ctx):
     """the contract edge of include/hvc_jpeg.h on the GPU side: k_hd_dc's prefix sum sees the DC leave int16, raises
     its status bit, the call falls to the host reader, which -- for an entry point that returns records -- refuses
