@@ -269,6 +269,23 @@ def test_large_files_with_their_own_tables_take_the_per_frame_work_lists(ctx):
     check_records(files, got)
 
 
+@pytest.mark.parametrize("table_sets", [0, 2, 3])
+def test_one_large_file(ctx, table_sets):
+    """A single 6-megapixel 4:4:4 file: 36 000 subsequences in ONE frame -- past the single-workgroup tail of the rounds,
+    so the work lists of a batch (model's tables) and the per-frame lists with one frame (own tables, two and three
+    sets) run with nothing but this file in them."""
+    w, h = 3072, 2048
+    q = 60
+    j = make_jpeg(1700, w, h, 444, q)
+    if table_sets:
+        qt = np.stack([orc.quant_scale(orc.quant_luma(), q), orc.quant_scale(orc.quant_chroma(), q)])
+        j = jpeg_optimised_tables(w, h, 444, qt, orc.Decoder(j).coef_record(), table_sets)
+    assert len(j) > 33_000 * 128  # more subsequences than the tail path takes
+    _, got, used = ctx.jpeg_entropy_decode_gpu([j], device=True)
+    assert used == 1
+    check_records([j], got)
+
+
 def test_dc_beyond_int16_reaches_the_caller_as_range_error(ctx):
     """the contract edge of include/hvc_jpeg.h on the GPU side: k_hd_dc's prefix sum sees the DC leave int16, raises
     its status bit, the call falls to the host reader, which -- for an entry point that returns records -- refuses
