@@ -2004,6 +2004,9 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
         hvc::hd_stats_read(hs);
         std::fprintf(stderr, "hd stats: round 0 walked %llu symbols (%.1f a subsequence); 64 x the longest walk of every wavefront: %llu (lanes busy %.1f %%)\n",
                      hs[0], (double)hs[0] / P.total_sub, hs[1], 100.0 * (double)hs[0] / (double)(hs[1] ? hs[1] : 1));
+        const unsigned long long own = hs[2] & 0xffffffffull, over = hs[2] >> 32;
+        std::fprintf(stderr, "hd stats: write pass %llu symbols inside the lanes' own subsequences + %llu beyond them (%.1f %%); 64 x trips of every wavefront: %llu (lanes busy %.1f %%)\n",
+                     own, over, 100.0 * (double)over / (double)(own ? own : 1), hs[3], 100.0 * (double)(own + over) / (double)(hs[3] ? hs[3] : 1));
     }
 #endif
     if (flags[0]) { // (the finish passes have turned the block counts into block indices: the rounds start over)

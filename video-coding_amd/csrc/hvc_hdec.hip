@@ -886,6 +886,9 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
     // In a wavefront some lane ends a block in almost every iteration.  A lane that ends a block therefore WAITS
     // (pending) until WR_BATCH lanes do, or nobody else can go on; then the wavefront does all of them at once.
     unsigned cur_block = live ? block_no(b) : 0u; // where the block in progress goes
+#ifdef HVC_HD_STATS
+    unsigned st_sym = 0, st_trips = 0;
+#endif
     while (__any(act)) {
         // Symbols: every lane that has something to go on with decodes until it ends a block, and the wavefront goes on
         // until WR_BATCH lanes have ended one (or nobody is left).  An inner loop that lanes LEAVE, not an `if` around
@@ -946,6 +949,10 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
                 }
             }
             npend += (unsigned)__popcll(__ballot(k == 64)); // (of the lanes still in the loop)
+#ifdef HVC_HD_STATS // experiments: symbols this lane decoded (split at the end of its own subsequence) / trips of the wavefront
+            st_sym += mm > mm_limit ? 1u : 0x10000u;
+            st_trips += (unsigned)__popcll(__ballot(true)) ? 1u : 0u;
+#endif
             if (k >= 64 || npend >= (unsigned)WR_BATCH) break;
         }
         if (k == 65) act = false;
@@ -990,6 +997,14 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
             }
         }
     }
+#ifdef HVC_HD_STATS // [2] symbols inside the lanes' own subsequences, [3] beyond them (finishing a block), and per
+    {                   // wavefront 64 x the trips of its symbol loop -- counted by the lane that made the most
+        unsigned mx = st_trips;
+        for (int o = 32; o; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+        atomicAdd(&g_hd_stats[2], (unsigned long long)(st_sym & 0xffffu) | ((unsigned long long)(st_sym >> 16) << 32));
+        if (lane == 0) atomicAdd(&g_hd_stats[3], 64ull * mx);
+    }
+#endif
     };
     if (!PF) decode_and_store(tv, P.selmask);
     else if (pf_lds) decode_and_store(tv, selmask_c2_as_c1(P.selmask));
