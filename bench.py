@@ -25,6 +25,8 @@ itself (page touch + clock ramp).  Inputs: seeded synthetic pixel frames (video-
 through this library's OWN forward path (k_encode, quality 75) on the GPU, outside the timed region -- so the
 coefficients are encoder-producible.
 
+The command exits non-zero when the decoded frames' checksums differ from the golden ones on any rank.
+
 The JSON line also carries
   roofline      achieved algorithmic GB/s of the dominant kernel (k_decode_packed: 192 B per 8x8 block =
                 128 B int16 coefficients read + 64 B pixels written) over its HIP-event-timed duration (events
@@ -34,6 +36,9 @@ The JSON line also carries
                 values tests/golden/bench_checksums.json holds for these seeds -- which the CPU suite
                 reproduces from the model restatement (tests/test_bench_checksums.py): the timed output is
                 the model's output, not just fast;
+  sustained     >= --sustain-seconds (2 s) of the same step repeated AFTER the K timed steps, one event pair per step:
+                first / last decile of the step time (clock or thermal drift would show), the GPU-busy fraction; never
+                part of `value` / `ms_per_step`, which come from the K timed steps alone;
   cpu_baseline  the CPU restatement of the model path (oracle/hvc_oracle.c, scalar, 1 thread) timed on this
                 host on a bounded sample of the same workload.  The oracle is the checker, timed as a
                 baseline only: this leg is its only use here (parity is the job of tests/).
@@ -151,7 +156,8 @@ def expected_checksums(config, n_distinct, rank):
     """tests/golden/bench_checksums.json: the K5 checksums of the decoded distinct frames as the model
     restatement gives them (made by tests/golden/make_bench_checksums.py, re-derived by the CPU suite)."""
     try:
-        with open(os.path.join(ROOT, "tests", "golden", "bench_checksums.json")) as f:
+        # (HVC_BENCH_GOLDEN: another file -- how the suite checks that a mismatch fails the command)
+        with open(os.environ.get("HVC_BENCH_GOLDEN") or os.path.join(ROOT, "tests", "golden", "bench_checksums.json")) as f:
             g = json.load(f)
         vals = g["bench_config%d" % config]["rank%d" % rank]
         return [int(v, 16) for v in vals[:n_distinct]] if len(vals) >= n_distinct else None
@@ -201,6 +207,35 @@ def timed_steps(step, steps, warmup, sync, world, dist=None):
     return time.perf_counter() - t0
 
 
+def sustained_run(step, seconds, launches_per_step):
+    """>= `seconds` of the same step back to back AFTER the timed region (so `value` / `ms_per_step` are untouched):
+    every step bracketed by its own pair of events on the stream the library launches on (the context was put on
+    torch's current stream), enqueued in batches so the host stays ahead of the GPU without an unbounded queue.
+    Returns the `sustained` object of the JSON line: a drifting clock shows as first != last decile."""
+    import torch
+    if seconds <= 0:
+        return None
+    events, t0 = [], time.perf_counter()
+    batch = max(1, 64 // launches_per_step)
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(batch):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            step()
+            e1.record()
+            events.append((e0, e1))
+        events[-1][1].synchronize()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms = np.array([a.elapsed_time(b) for a, b in events])
+    dec = max(1, len(ms) // 10)
+    return {"steps": len(ms), "launches": len(ms) * launches_per_step, "wall_s": round(wall, 3),
+            "first_decile_ms": round(float(ms[:dec].mean()), 4), "last_decile_ms": round(float(ms[-dec:].mean()), 4),
+            "median_ms": round(float(np.median(ms)), 4), "min_ms": round(float(ms.min()), 4), "max_ms": round(float(ms.max()), 4),
+            "gpu_busy_fraction": round(float(ms.sum()) * 1e-3 / wall, 3),
+            "what": "the same step repeated after the timed region, one event pair per step; not part of value"}
+
+
 def max_over_ranks(dt, world, dist=None, device="cpu"):
     if not use_group(world):
         return dt
@@ -244,6 +279,9 @@ def parse_args(argv=None):
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames (replicated)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--sustain-seconds", type=float, default=2.0,
+                    help="after the K timed steps: this many seconds of the same step back to back, reported as "
+                         "`sustained` (never part of `value`); 0 = skip")
     args = ap.parse_args(argv)
     wl = WORKLOADS[args.config]
     args.frames = args.frames or wl["frames"]
@@ -345,6 +383,10 @@ def main():
     # K5: what was decoded -- the distinct frames' pixel records, checksummed where they are
     sums = [int(x) for x in ctx.checksum_records(d_pix, pfs, min(args.distinct, held))]
     want = expected_checksums(args.config, len(sums), rank) if args.distinct <= 8 else None
+    sustained = sustained_run(step, args.sustain_seconds, launches)  # (after everything `value` is made of)
+    if sustained is not None:  # ... and what the sustained run left behind is still the model's output
+        again = [int(x) for x in ctx.checksum_records(d_pix, pfs, min(args.distinct, held))]
+        sustained["output_unchanged"] = again == sums
     frames_host = d_distinct.cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     ok_local = want is not None and sums == want
     if use_group(world):  # every rank's output is verified; rank 0 reports how many were
@@ -391,14 +433,22 @@ def main():
                          "rank0": ["%016x" % s for s in sums],
                          "expected": "tests/golden/bench_checksums.json" if want is not None else None,
                          "verified": bool(ok_local) if want is not None else None,
-                         "ranks_verified": ranks_ok if want is not None else None},
+                         "ranks_verified": ranks_ok if want is not None else None,
+                         "verification": "compared on every rank" if want is not None else
+                                         "SKIPPED: no golden checksums for this run (--distinct > 8 or no entry for this rank)"},
         }
+        if sustained is not None:
+            out["sustained"] = sustained
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames_host, qtabs, planes, PW * PH, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     ctx.close()
     if use_group(world):
         dist.destroy_process_group()
+    # a run whose output is not the model's is not a measurement: the line above says so ("verified": false) and the
+    # command fails (every rank knows ranks_ok: it came out of an all-reduce)
+    if want is not None and ranks_ok != world:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

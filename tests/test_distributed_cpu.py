@@ -108,3 +108,28 @@ def test_bench_under_the_drivers_launcher_and_alone():
                           "--master-addr", "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "bench.py"),
                           "--gpus", "4"], capture_output=True, text=True, env=_clean_env(HVC_BENCH_NO_GPU="1"), timeout=300, cwd=ROOT)
     assert out.returncode != 0
+
+
+def test_eight_ranks_as_the_driver_will_start_them():
+    """The scaling run is N = 1, 2, 4, 8 on an 8-GPU node nobody here can reach: the 8-rank launch itself -- self-launch
+    as typed and the driver's torch.distributed.run form, configs 2 and 4 -- is rehearsed under gloo (a GPU box admits
+    at most 6 processes on its card, so eight ranks can only be rehearsed on the CPU)."""
+    for config, extra in ((2, []), (4, ["--shard", "256"])):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                              "--config", str(config)] + extra,
+                             capture_output=True, text=True, env=_clean_env(HVC_BENCH_NO_GPU="1", OMP_NUM_THREADS="1"),
+                             timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-3000:]
+        rec = _json_line(out.stdout)
+        assert rec["n_gpus"] == 8 and rec["steps"] == 3 and rec["scaling"] == "weak"
+        assert rec["ms_per_step"] >= 8.0  # rank 7 sleeps 8 ms a step and bounds the job
+        frames = 1024 if config == 2 else 256
+        px = 1920 * 1080 if config == 2 else 3840 * 2160
+        assert abs(rec["value"] - 8 * frames * px / (rec["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * rec["value"]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                          "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, env=_clean_env(HVC_BENCH_NO_GPU="1", OMP_NUM_THREADS="1"),
+                         timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert _json_line(out.stdout)["n_gpus"] == 8

@@ -74,7 +74,7 @@ def _run_bench(args, **env):
 def test_bench_line_is_verified_against_the_golden_checksums():
     """python bench.py (config 2, small batch): the line carries roofline + cpu_baseline + a checksum that equals
     tests/golden/bench_checksums.json -- entries the CPU suite derives from the model restatement."""
-    rec = _run_bench(["--steps", "3", "--warmup", "1", "--frames", "64", "--cpu-seconds", "1"])
+    rec = _run_bench(["--steps", "3", "--warmup", "1", "--frames", "64", "--cpu-seconds", "1", "--sustain-seconds", "0.5"])
     with open(os.path.join(GOLDEN, "bench_checksums.json")) as f:
         g = json.load(f)
     assert rec["checksum"]["verified"] is True and rec["checksum"]["rank0"] == g["bench_config2"]["rank0"]
@@ -82,6 +82,8 @@ def test_bench_line_is_verified_against_the_golden_checksums():
     assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["cores"] == 1
     assert rec["timed_region_s"] > 0 and rec["roofline"]["traffic_source"]
     assert rec["config"]["wide_path_blocks"] == 0
+    su = rec["sustained"]  # the same step repeated after the timed region, never part of value
+    assert su["wall_s"] >= 0.5 and su["steps"] >= 64 and su["output_unchanged"] is True and 0 < su["first_decile_ms"] < 50
 
 
 def test_bench_n_rank_path_on_one_gpu():
@@ -94,6 +96,40 @@ def test_bench_n_rank_path_on_one_gpu():
                      HVC_BENCH_REHEARSAL="1")
     assert rec["n_gpus"] == 2 and rec["config"]["baseline_config"] == 4 and rec["checksum"]["ranks_verified"] == 2
     assert rec["config"]["frames_per_gpu_per_step"] == 16 and rec["config"]["frames_per_launch"] == 8
+
+
+def test_bench_four_ranks_on_one_gpu():
+    """The widest rehearsal a one-GPU box allows (at most 6 processes may use its card; eight ranks are rehearsed on
+    the CPU, tests/test_distributed_cpu.py): four ranks of both configurations, every rank's shard verified against
+    the golden checksums of ITS rank (distinct seeds per rank)."""
+    rec = _run_bench(["--gpus", "4", "--steps", "2", "--warmup", "1", "--frames", "32", "--sustain-seconds", "0.2"],
+                     HVC_BENCH_REHEARSAL="1")
+    assert rec["n_gpus"] == 4 and rec["checksum"]["ranks_verified"] == 4 and "REHEARSAL" in rec["data"]
+    assert rec["sustained"]["output_unchanged"] is True
+    rec = _run_bench(["--gpus", "4", "--config", "4", "--steps", "1", "--warmup", "0", "--frames", "8", "--shard", "16",
+                      "--sustain-seconds", "0"], HVC_BENCH_REHEARSAL="1")
+    assert rec["n_gpus"] == 4 and rec["config"]["baseline_config"] == 4 and rec["checksum"]["ranks_verified"] == 4
+    assert "sustained" not in rec
+
+
+def test_bench_fails_when_the_output_is_not_the_models(tmp_path):
+    """A run whose checksums differ from the golden ones exits non-zero and says "verified": false: here
+    the golden file is swapped for one with another rank's values."""
+    with open(os.path.join(GOLDEN, "bench_checksums.json")) as f:
+        g = json.load(f)
+    g["bench_config2"]["rank0"] = g["bench_config2"]["rank1"]
+    alt = tmp_path / "bench_checksums.json"
+    alt.write_text(json.dumps(g))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    e["HVC_BENCH_GOLDEN"] = str(alt)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "32",
+                          "--no-cpu-baseline", "--sustain-seconds", "0"], capture_output=True, text=True, env=e, timeout=900, cwd=ROOT)
+    assert out.returncode == 3, out.stdout[-2000:] + out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["checksum"]["verified"] is False and rec["checksum"]["ranks_verified"] == 0
+    # more distinct frames than the golden file holds: the line says the comparison was skipped, exit 0
+    rec = _run_bench(["--steps", "2", "--warmup", "1", "--frames", "32", "--distinct", "9", "--no-cpu-baseline", "--sustain-seconds", "0"])
+    assert rec["checksum"]["verified"] is None and rec["checksum"]["verification"].startswith("SKIPPED")
 
 
 def test_contexts_by_device_index():

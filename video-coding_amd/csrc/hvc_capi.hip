@@ -35,7 +35,10 @@ struct hvc_ctx {
     unsigned long long k_calls = 0;
     bool profiling = false;
     int decode_kernel = 0; // hvc_set_decode_kernel: 0 packed (default), 1 unpacked int32, 2 int64 for every block, 3 q16
-    unsigned *d_fix_count = nullptr; // two counters, used alternately (see k_decode_wide)
+    unsigned *d_fix_count = nullptr; // two counters, used alternately (see k_decode_wide); behind them (+ 8 bytes) the 64-bit
+                                     // total of the last call's fix-up blocks over all its launches (hvc_last_wide_blocks)
+    bool wide_total_started = false; // the current call has enqueued a launch that stores (rather than adds to) that total
+    long long wide_host = -1;        // >= 0: the last call sent every block through the int64 kernel (no list): this many
     int fix_phase = 0;               // index of the counter the NEXT decode call appends to
     int fix_last = 0;                // index of the counter the last decode call used
     unsigned *d_fix_list = nullptr;
@@ -179,13 +182,21 @@ static void fix_assign(const hvc_ctx *c, Params &P) {
     P.fix_count = c->d_fix_count + c->fix_phase;
     P.fix_count_next = c->d_fix_count + (c->fix_phase ^ 1);
     P.fix_list = c->d_fix_list;
+    P.wide_total = reinterpret_cast<unsigned long long *>(c->d_fix_count + 2);
+    P.wide_first = c->wide_total_started ? 0 : 1;
 }
 static void fix_commit(hvc_ctx *c) {
     c->fix_last = c->fix_phase;
     c->fix_phase ^= 1;
+    c->wide_total_started = true; // the call's next launches add to the total
+}
+// at the start of every decode call: its first launch starts the total over
+static void wide_total_begin(hvc_ctx *c) {
+    c->wide_total_started = false;
+    c->wide_host = -1;
 }
 static void fix_reset(hvc_ctx *c) { // after a failed launch: both counters to zero, in stream order
-    (void)hipMemsetAsync(c->d_fix_count, 0, 2 * sizeof(unsigned), c->stream);
+    (void)hipMemsetAsync(c->d_fix_count, 0, 4 * sizeof(unsigned), c->stream); // (and the total behind them)
 }
 
 // Launches longer than about 3 ms lose 2-3 % against back-to-back shorter ones (measured on MI355X: 1080p batches of
@@ -345,8 +356,8 @@ int hvc_create(hvc_ctx **out, int device) {
                       if (hipEventCreate(&c->k0[i]) != hipSuccess || hipEventCreate(&c->k1[i]) != hipSuccess) return false;
                   return true;
               }() &&
-              hipMalloc((void **)&c->d_fix_count, 2 * sizeof(unsigned)) == hipSuccess &&
-              hipMemset(c->d_fix_count, 0, 2 * sizeof(unsigned)) == hipSuccess;
+              hipMalloc((void **)&c->d_fix_count, 4 * sizeof(unsigned)) == hipSuccess &&
+              hipMemset(c->d_fix_count, 0, 4 * sizeof(unsigned)) == hipSuccess;
     if (!ok) {
         hvc_destroy(c);
         return HVC_E_NO_DEVICE;
@@ -614,10 +625,10 @@ int hvc_checksum_records(hvc_ctx *c, const void *data, size_t record_bytes, size
 int hvc_last_wide_blocks(hvc_ctx *c, uint64_t *count) {
     if (!c || !count) return HVC_E_INVALID_ARG;
     DeviceGuard g(c->device);
-    unsigned v = 0;
-    HIPCHK(c, hipMemcpyAsync(&v, c->d_fix_count + c->fix_last, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long v = 0; // the total over ALL launches of the last call (a large batch is cut into several)
+    HIPCHK(c, hipMemcpyAsync(&v, c->d_fix_count + 2, sizeof v, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    *count = v;
+    *count = c->wide_host >= 0 ? (uint64_t)c->wide_host : (uint64_t)v;
     return HVC_OK;
 }
 
@@ -781,6 +792,7 @@ static int decode_frames_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, 
     P.tiles_per_frame = L.tiles_per_frame;
     for (int i = 0; i < L.n_comp; i++) P.comp[i] = L.comp[i];
     prepare_tables(qtabs, n_qtabs, P.qt, P.ethr, P.ethr_packed, P.qpair);
+    wide_total_begin(c);
     fix_assign(c, P);
 
     // 16-bit quantiser entries above 255 leave the fast kernel's proven range
@@ -791,7 +803,10 @@ static int decode_frames_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, 
     P.kernel_sel = (c->decode_kernel == 1 || c->decode_kernel == 3) ? c->decode_kernel : 0;
     // one launch: consumes counter fix_phase, its wide kernel clears the other one (fix_assign / fix_commit above)
     auto launch = [&](hvc::DecodeParams &Q, hipEvent_t k0, hipEvent_t k1) -> hipError_t {
-        if (wide_only) return hvc::launch_decode_wide_only(Q, c->stream);
+        if (wide_only) {
+            c->wide_host = (long long)((unsigned long long)n_frames * L.blocks_per_frame);
+            return hvc::launch_decode_wide_only(Q, c->stream);
+        }
         fix_assign(c, Q);
         const hipError_t e = hvc::launch_decode(Q, c->stream, k0, k1);
         if (e == hipSuccess) fix_commit(c);
@@ -971,8 +986,12 @@ static int decode_frames_yuv444_impl(hvc_ctx *c, const int16_t *coefs, size_t co
     bool wide_only = c->decode_kernel == 2;
     for (int i = 0; i < n_qtabs * 64; i++) wide_only |= qtabs[i] > 255;
     P.fix_list = c->d_fix_list;
+    wide_total_begin(c);
     auto launch = [&](hvc::Decode444Params &Q, hipEvent_t k0, hipEvent_t k1) -> hipError_t {
-        if (wide_only) return hvc::launch_decode_444(Q, true, c->stream, k0, k1); // no list, no counters
+        if (wide_only) { // no list, no counters: every block inside the crop
+            c->wide_host = (long long)n_frames * ((long long)P.pl[0].cbw * P.pl[0].cbh + 2ll * P.pl[1].cbw * P.pl[1].cbh);
+            return hvc::launch_decode_444(Q, true, c->stream, k0, k1);
+        }
         fix_assign(c, Q);
         const hipError_t e = hvc::launch_decode_444(Q, false, c->stream, k0, k1);
         if (e == hipSuccess) fix_commit(c);
@@ -1941,9 +1960,15 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
     unsigned *d_ecs_off = m, *d_sub_off = m + n_frames, *d_frame_of = d_sub_off + n_frames + 1;
     unsigned *d_frame_blocks = d_frame_of + subs, *d_flags = d_frame_blocks + n_frames;
     hipStream_t st = c->stream;
+    // From here on copies out of this function's own vectors (h_meta, ftabs, tabset_of) and out of the reused pinned
+    // buffer are in flight: EVERY way out of the function waits for the stream first (the early returns included).
+    std::vector<hvc::HdFrameTabs> ftabs; // (declared BEFORE the guard: destroyed after the guard has waited)
+    struct SyncOnExit {
+        hipStream_t s;
+        ~SyncOnExit() { (void)hipStreamSynchronize(s); }
+    } sync_on_exit{st};
     HIPCHK(c, hipMemcpyAsync(c->gd_ecs, h_ecs, bytes, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(m, h_meta.data(), h_meta.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
-    std::vector<hvc::HdFrameTabs> ftabs; // (lives until the synchronisation below: the upload reads it)
     bool pf = sets.size() > 1;
     if (!pf) {
         if ((r = gd_upload_tables(c, tables0, P, st))) return r;

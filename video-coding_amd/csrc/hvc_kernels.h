@@ -57,6 +57,10 @@ struct DecodeParams {
     // writes 2 bytes per block into a compact array instead of 2 bytes into every 128-byte record.
     const int16_t *dc_plane;
     size_t dc_fs;
+    // hvc_last_wide_blocks: the fix-up kernels of ONE call add their list lengths up here (a call may be cut into several
+    // launches, each with its own counter): the first launch of a call stores, the others add (stream order, no memset)
+    unsigned long long *wide_total;
+    int wide_first;
 };
 
 struct EncodeParams {
@@ -115,6 +119,8 @@ struct Decode444Params {
     unsigned *fix_count, *fix_count_next, *fix_list;
     const int16_t *dc_plane; // as in DecodeParams
     size_t dc_fs;
+    unsigned long long *wide_total; // as in DecodeParams
+    int wide_first;
 };
 
 // k0/k1 (optional): events recorded right before / after the dominant kernel.

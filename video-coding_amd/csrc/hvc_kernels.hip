@@ -785,7 +785,10 @@ __global__ __launch_bounds__(64) void k_decode_wide(DecodeParams P, const unsign
     unsigned long long n = list ? (unsigned long long)*count : total;
     // The two fix-up counters alternate between calls: this launch reads the
     // current one and clears the other for the next call (no memset node).
-    if (blockIdx.x == 0 && threadIdx.x == 0 && P.fix_count_next) *P.fix_count_next = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (P.fix_count_next) *P.fix_count_next = 0;
+        if (P.wide_total && list) *P.wide_total = P.wide_first ? n : *P.wide_total + n; // hvc_last_wide_blocks: the call's total
+    }
     for (unsigned long long i = (unsigned long long)blockIdx.x * 64 + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * 64) {
         unsigned long long id = list ? list[i] : i;
@@ -1043,7 +1046,10 @@ __global__ __launch_bounds__(HVC_TILE * NW, 4 / NW) HVC_444_ATTR void k_decode_4
 __global__ __launch_bounds__(64) void k_decode_wide_444(Decode444Params P, const unsigned *count, const unsigned *list,
                                                         unsigned long long total, const long long *dc_list) {
     const unsigned long long n = list ? (unsigned long long)*count : total;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && P.fix_count_next) *P.fix_count_next = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (P.fix_count_next) *P.fix_count_next = 0;
+        if (P.wide_total && list) *P.wide_total = P.wide_first ? n : *P.wide_total + n;
+    }
     for (unsigned long long i = (unsigned long long)blockIdx.x * 64 + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * 64) {
         const unsigned long long id = list ? list[i] : i;
@@ -1546,8 +1552,10 @@ hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0, hi
         const char *v = getenv("HVC_DECODE_KERNEL");
         return !v ? 0 : (v[0] == 'v' && v[1] == '2') ? 1 : (v[0] == 'q') ? 3 : 0;
     }();
-    const int sel = P.kernel_sel ? P.kernel_sel : env_sel;
-    if (P.dc_plane && sel != 0) return hipErrorInvalidValue; // (the A/B alternates read the DC from the record: hvc_capi.hip never combines them)
+    // (the A/B alternates read the DC from the record: with a compact DC array the environment's choice does not apply,
+    // and hvc_capi.hip never combines an explicit selection with one)
+    const int sel = P.kernel_sel ? P.kernel_sel : P.dc_plane ? 0 : env_sel;
+    if (P.dc_plane && sel != 0) return hipErrorInvalidValue;
     if (sel == 3)
         hipLaunchKernelGGL(k_decode_q16, grid, dim3(HVC_TILE), 0, s, P);
     else if (sel == 1)
@@ -1571,6 +1579,7 @@ hipError_t launch_decode_dcfix(const DecodeParams &P, const unsigned *count, con
                                hipStream_t s) {
     DecodeParams Q = P;
     Q.fix_count_next = nullptr; // (not part of the launches' counter ping-pong)
+    Q.wide_total = nullptr;
     hipLaunchKernelGGL(k_decode_wide, dim3(64), dim3(64), 0, s, Q, count, ids, 0ull, dcs);
     return hipGetLastError();
 }
@@ -1579,6 +1588,7 @@ hipError_t launch_decode_444_dcfix(const Decode444Params &P, const unsigned *cou
                                    unsigned n_host, hipStream_t s) {
     Decode444Params Q = P;
     Q.fix_count_next = nullptr;
+    Q.wide_total = nullptr;
     hipLaunchKernelGGL(k_decode_wide_444, dim3(64), dim3(64), 0, s, Q, count, ids, 0ull, dcs);
     // the interpolated samples around the rewritten chroma blocks (9 x 9 source samples each); the seam rows are
     // rebuilt once more on the way, from the same source samples
