@@ -10,7 +10,8 @@
  * reference root).  INTEGRATION.md shows the OCaml ctypes binding.
  *
  * Conventions
- *  - plain C, no exceptions cross the boundary; every function returns
+ *  - plain C, no exceptions cross the boundary (every entry point is a function-try-block: std::bad_alloc comes
+ *    back as HVC_E_OUT_OF_MEMORY, std::system_error as HVC_E_SYSTEM); every function returns
  *    HVC_OK (0) or a negative hvc_status; hvc_strerror() gives a static string.
  *    The OCaml wrapper maps a non-zero code to `raise_s [%message "hvc" ...]`,
  *    the model's own error style (decoder.ml:67, 92, 101, 136).
@@ -70,7 +71,10 @@ typedef enum hvc_status {
     HVC_E_TOO_LARGE = -7,    /* plane geometry beyond the kernel's index range */
     HVC_E_BAD_JPEG = -8,     /* the model would raise: missing frame/scan/table, invalid Huffman code,
                                 coefficient index out of range (decoder.ml:92, 101, 136, 228-243, 291) */
-    HVC_E_UNSUPPORTED_MARKER = -9 /* "unsupported marker code" (decoder.ml:67) */
+    HVC_E_UNSUPPORTED_MARKER = -9, /* "unsupported marker code" (decoder.ml:67) */
+    HVC_E_SYSTEM = -10,      /* the system refused a resource the call needs: a host thread of the batch pipelines
+                                could not be started (pids limit, RLIMIT_NPROC); the context stays usable */
+    HVC_E_INTERNAL = -11     /* an unexpected C++ exception was stopped at the boundary (never seen; reported, not thrown) */
 } hvc_status;
 
 /* where the data pointers of a call live */
@@ -86,7 +90,16 @@ HVC_API int hvc_last_hip_error(const hvc_ctx *ctx);
 HVC_API const char *hvc_version(void);
 
 /* The host threads of the batch pipelines (hvc_jpeg_decode_batch*, hvc_jpeg_encode_batch*, the download threads of
- * the host-buffer entry points): which CPUs they may run on.  No counterpart in the reference (the model is one
+ * the host-buffer entry points) live in the context: started by the first call that needs them (more when a later
+ * call asks for more `threads`), reused by every call after that, joined by hvc_destroy.  A thread the system refuses
+ * to start makes the call return HVC_E_SYSTEM; nothing is left running and the context stays usable.
+ * hvc_host_threads reports how many the context holds and how many it has ever started (diagnostic).
+ * hvc_host_threads_probe (no context, no GPU): starts `threads` pool threads the way a batch call would, runs an empty
+ * task on each and joins them -- HVC_OK or HVC_E_SYSTEM; what tests/test_host_threads.py runs under RLIMIT_NPROC. */
+HVC_API int hvc_host_threads(const hvc_ctx *ctx, int *alive, uint64_t *ever_started);
+HVC_API int hvc_host_threads_probe(int threads);
+
+/* Which CPUs those threads may run on.  No counterpart in the reference (the model is one
  * thread); it matters on a node with eight GPUs, where eight contexts each start `threads` workers: left alone they
  * wander over both sockets, away from the pinned rings they fill and from their GPU's PCIe root.
  *   cpulist  Linux list format, "0-15,32-47"; "auto" = the CPUs local to the context's GPU (the local_cpulist of its

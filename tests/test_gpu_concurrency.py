@@ -136,3 +136,82 @@ def test_host_threads_stay_on_the_cpus_they_are_given():
         assert c.get_host_cpus() == ("", 0)
     finally:
         c.close()
+
+
+def test_batch_calls_reuse_the_contexts_threads():
+    """The workers live in the context (csrc/hvc_pool.h): a loop of small batch calls starts them once.  Every kind of
+    batch call, host and device side of the pool (the downloader of host output is one more thread)."""
+    import video_coding_amd as hvc
+    w, h, n = 320, 176, 12
+    frames = _frames(n, w, h, 11000)
+    jpegs = [orc.encode_yuv(y, u, v, w, h, 420, 75) for y, u, v in frames]
+    raw = [np.concatenate([p.reshape(-1) for p in f]) for f in frames]
+    want = []
+    for j in jpegs:
+        d = orc.Decoder(j)
+        d.decode()
+        want.append(np.concatenate([d.plane(i).reshape(-1) for i in range(3)]))
+    c = hvc.Context(0)
+    try:
+        assert c.host_threads() == (0, 0)  # nothing until a batch call needs them
+        fs = hvc.hvc.jpeg_read_header(jpegs[0]).pixel_bytes
+        for rep in range(6):
+            out = np.zeros(n * fs, np.uint8)
+            c.jpeg_decode_batch(jpegs, out, fs, threads=5, frames_per_chunk=4, gpu_entropy=rep % 2 == 1)
+            for f in range(n):
+                assert np.array_equal(out[f * fs:(f + 1) * fs], want[f]), (rep, f)
+            got, _ = c.jpeg_encode_batch(raw, w, h, 420, 75, threads=3, frames_per_chunk=4, gpu_entropy=rep % 2 == 0)
+            assert got == jpegs, rep
+        alive, ever = c.host_threads()
+        assert alive == ever == 6, (alive, ever)  # 5 workers + the host-output downloader, started once in 12 calls
+        c.jpeg_decode_batch(jpegs, out, fs, threads=9, frames_per_chunk=4, gpu_entropy=True)  # a wider call adds threads
+        assert c.host_threads() == (10, 10)
+        c.jpeg_decode_batch(jpegs, out, fs, threads=2, frames_per_chunk=4, gpu_entropy=False)  # a narrower one none
+        assert c.host_threads() == (10, 10)
+    finally:
+        c.close()
+
+
+def test_a_refused_host_thread_fails_the_call_not_the_process():
+    """EAGAIN from thread creation (a pids limit: 8 ranks x 16 workers per node) inside a real batch call, with some
+    workers already running: HVC_E_SYSTEM, and the same context then serves a call that fits the threads it has."""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, "tests")
+import numpy as np
+from helpers import synth_pixels
+from oracle import orc
+import video_coding_amd as hvc
+w, h, n = 320, 176, 8
+fr = [(synth_pixels(1 + f, h, w), synth_pixels(50 + f, h // 2, w // 2), synth_pixels(90 + f, h // 2, w // 2)) for f in range(n)]
+jpegs = [orc.encode_yuv(y, u, v, w, h, 420, 75) for y, u, v in fr]
+raw = [np.concatenate([p.reshape(-1) for p in f]) for f in fr]
+c = hvc.Context(0)
+fs = hvc.hvc.jpeg_read_header(jpegs[0]).pixel_bytes
+out = np.zeros(n * fs, np.uint8)
+for gpu in (False, True):
+    try:
+        c.jpeg_decode_batch(jpegs, out, fs, threads=8, frames_per_chunk=3, gpu_entropy=gpu)
+        raise SystemExit("the call should have failed")
+    except hvc.HvcError as e:
+        assert e.code == -10, e
+try:
+    c.jpeg_encode_batch(raw, w, h, 420, 75, threads=8, frames_per_chunk=3)
+    raise SystemExit("the call should have failed")
+except hvc.HvcError as e:
+    assert e.code == -10, e
+assert c.host_threads() == (3, 3)          # the three that did start stay in the pool
+c.jpeg_decode_batch(jpegs, out, fs, threads=2, frames_per_chunk=3, gpu_entropy=True)   # 2 workers + the downloader
+d = orc.Decoder(jpegs[5]); d.decode()
+assert np.array_equal(out[5 * fs:6 * fs], np.concatenate([d.plane(i).reshape(-1) for i in range(3)]))
+got, _ = c.jpeg_encode_batch(raw, w, h, 420, 75, threads=3, frames_per_chunk=3, gpu_entropy=True)
+assert got == jpegs
+c.close()
+print("refusal ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HVC_POOL_FAIL_AFTER="3")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "refusal ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -441,7 +441,16 @@ d_p = torch.zeros((n, pfs), dtype=torch.uint8, device="cuda")
 c.decode_frames(d_c, cfs, qt, specs, n, d_p, pfs)
 c.synchronize()
 assert np.array_equal(d_p.cpu().numpy(), want_pix), "decode"
-assert c.last_wide_blocks() > 0
+# hvc_last_wide_blocks covers the whole call, not its last launch (ADVICE r2): the total over the split launches equals
+# the count of the frame-by-frame form, and the fused entry point agrees with itself the same way
+wide_call = c.last_wide_blocks()
+wide_sum = 0
+for f in range(n):
+    c.decode_frames(d_c[f:f + 1], cfs, qt, specs, 1, d_p[f:f + 1], pfs)
+    wide_sum += c.last_wide_blocks()
+assert wide_call == wide_sum > 0, (wide_call, wide_sum)
+assert wide_call > c.last_wide_blocks()  # (the last frame alone has fewer: a per-launch count would have said that)
+print("wide blocks of the split call", wide_call)
 # encode
 d_x = torch.from_numpy(pix).cuda()
 d_o = torch.zeros((n, cfs), dtype=torch.int16, device="cuda")
@@ -463,6 +472,12 @@ for f in range(n):
     v = want_pix[f, 160 * 96 + 80 * 48:].reshape(48, 80)
     want = np.concatenate([y.reshape(-1), orc.supersample_hv2(u).reshape(-1), orc.supersample_hv2(v).reshape(-1)])
     assert np.array_equal(d_f[f].cpu().numpy(), want), ("444", f)
+wide_call = c.last_wide_blocks()
+wide_sum = 0
+for f in range(n):
+    c.decode_frames_yuv444(d_c[f:f + 1], cfs, qt, specs, 1, W, H, d_f[f:f + 1])
+    wide_sum += c.last_wide_blocks()
+assert wide_call == wide_sum > 0, ("444", wide_call, wide_sum)
 print("split ok")
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -22,6 +22,7 @@
 #include "hvc_hdec.h"
 #include "hvc_huff.h"
 #include "hvc_kernels.h"
+#include "hvc_pool.h"
 
 #define HVC_PROF_RING 64
 
@@ -80,6 +81,9 @@ struct hvc_ctx {
     bool have_cpus = false;
     cpu_set_t cpus;
     char cpulist[256] = "";
+    bool have_default_cpus = false; // the process's own mask when the context was created: what the pool's threads go
+    cpu_set_t default_cpus;         // back to when a restriction is lifted (they outlive the call that pinned them)
+    hvc::WorkerPool pool;           // the batch pipelines' host threads (hvc_pool.h): persistent, joined in hvc_destroy
     hvc::HdTables *gd_tables_host = nullptr; // what gd_tables holds (value tables; the HdSpec behind them follows from these)
     bool gd_tables_valid = false;
     int gd_tables_ncomp = 0;
@@ -123,9 +127,15 @@ int fail_hip(hvc_ctx *c, hipError_t e) {
 // Every host thread a batch pipeline starts calls this first (hvc_set_host_cpus); false = the restriction could not
 // be applied (the batch call then fails rather than run somewhere it was told not to).
 bool pin_to_ctx_cpus(const hvc_ctx *c) {
-    if (!c->have_cpus) return true;
+    if (!c->have_cpus) { // a pool thread may still carry an earlier call's restriction
+        if (c->have_default_cpus) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &c->default_cpus);
+        return true;
+    }
     return pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &c->cpus) == 0;
 }
+
+// `n` pool threads for a pipeline call (+ `extra` for its downloader): HVC_OK, or HVC_E_SYSTEM when the system refuses one
+int pool_ready(hvc_ctx *c, int n, int extra = 0) { return c->pool.ensure(n + extra); }
 
 // Linux cpulist format ("0-15,32-47") -> cpu_set_t; false on a syntax error, an empty set or a CPU beyond CPU_SETSIZE
 bool parse_cpulist(const char *s, cpu_set_t &set) {
@@ -285,7 +295,10 @@ static int overlapped_parts(hvc_ctx *c, int n_frames, Up up, Run run, Down down)
         f0 = (int)((long long)n_frames * k / K);
         cnt = (int)((long long)n_frames * (k + 1) / K) - f0;
     };
-    std::thread downloader([&] {
+    int pr = pool_ready(c, 1);
+    if (pr) return pr;
+    hvc::PoolScope scope(c->pool, [&] { if (launched.load() < K) herr.store(herr.load() ? herr.load() : (int)hipErrorUnknown); });
+    pr = c->pool.submit([&] {
         (void)pin_to_ctx_cpus(c);
         if (hipSetDevice(c->device) != hipSuccess) { herr.store((int)hipErrorInvalidDevice); return; }
         for (int k = 0; k < K; k++) {
@@ -298,7 +311,8 @@ static int overlapped_parts(hvc_ctx *c, int n_frames, Up up, Run run, Down down)
             if (e == hipSuccess) e = hipStreamSynchronize(c->down_stream);
             if (e != hipSuccess) { herr.store((int)e); return; }
         }
-    });
+    }, 1);
+    if (pr) return pr;
     hipError_t e = hipSuccess;
     for (int k = 0; k < K && e == hipSuccess && !herr.load(); k++) {
         int f0, cnt;
@@ -309,8 +323,9 @@ static int overlapped_parts(hvc_ctx *c, int n_frames, Up up, Run run, Down down)
         if (e == hipSuccess) launched.store(k + 1, std::memory_order_release);
     }
     if (e != hipSuccess) herr.store((int)e);
-    downloader.join();
+    pr = scope.finish();
     (void)hipStreamSynchronize(c->stream);
+    if (pr) return pr;
     if (herr.load()) return fail_hip(c, (hipError_t)herr.load());
     return HVC_OK;
 }
@@ -333,11 +348,13 @@ const char *hvc_strerror(int code) {
     case HVC_E_TOO_LARGE: return "plane geometry too large";
     case HVC_E_BAD_JPEG: return "malformed or unsupported JPEG stream";
     case HVC_E_UNSUPPORTED_MARKER: return "unsupported marker code";
+    case HVC_E_SYSTEM: return "the system refused a host thread";
+    case HVC_E_INTERNAL: return "internal error (C++ exception stopped at the boundary)";
     default: return "unknown hvc error";
     }
 }
 
-int hvc_create(hvc_ctx **out, int device) {
+int hvc_create(hvc_ctx **out, int device) try {
     if (!out) return HVC_E_INVALID_ARG;
     *out = nullptr;
     int n = 0;
@@ -363,13 +380,15 @@ int hvc_create(hvc_ctx **out, int device) {
         return HVC_E_NO_DEVICE;
     }
     c->stream = c->own_stream;
+    c->have_default_cpus = sched_getaffinity(0, sizeof c->default_cpus, &c->default_cpus) == 0;
     if (const char *env = std::getenv("HVC_HOST_CPUS")) (void)hvc_set_host_cpus(c, env); // an unusable list leaves the threads unrestricted
     *out = c;
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
 void hvc_destroy(hvc_ctx *c) {
     if (!c) return;
+    c->pool.shutdown(); // (idle: every call waits for its own tasks)
     DeviceGuard g(c->device);
     // everything this context may still have in flight: the caller's stream (NULL is HIP's default stream -- a
     // stream like any other), its own, and the pipelines' side streams
@@ -449,7 +468,7 @@ void hvc_destroy(hvc_ctx *c) {
 
 int hvc_last_hip_error(const hvc_ctx *c) { return c ? c->last_hip : 0; }
 
-int hvc_set_host_cpus(hvc_ctx *c, const char *cpulist) {
+int hvc_set_host_cpus(hvc_ctx *c, const char *cpulist) try {
     if (!c) return HVC_E_INVALID_ARG;
     if (!cpulist || !*cpulist) {
         c->have_cpus = false;
@@ -483,14 +502,35 @@ int hvc_set_host_cpus(hvc_ctx *c, const char *cpulist) {
     for (char *p = c->cpulist; *p; p++)
         if (*p == '\n') *p = 0;
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
-int hvc_get_host_cpus(const hvc_ctx *c, char *out, size_t cap, int *n_cpus) {
+int hvc_host_threads(const hvc_ctx *c, int *alive, uint64_t *ever_started) try {
+    if (!c) return HVC_E_INVALID_ARG;
+    if (alive) *alive = c->pool.size();
+    if (ever_started) *ever_started = c->pool.threads_created();
+    return HVC_OK;
+} HVC_ABI_CATCH
+
+int hvc_host_threads_probe(int threads) try {
+    if (threads < 1 || threads > 4096) return HVC_E_INVALID_ARG;
+    hvc::WorkerPool pool;
+    int r = pool.ensure(threads);
+    if (r) return r; // (the pool's destructor joins whatever did start)
+    std::atomic<int> ran{0};
+    if ((r = pool.submit([&] { ran++; }, threads))) {
+        (void)pool.wait();
+        return r;
+    }
+    r = pool.wait();
+    return r ? r : ran.load() == threads ? HVC_OK : HVC_E_INTERNAL;
+} HVC_ABI_CATCH
+
+int hvc_get_host_cpus(const hvc_ctx *c, char *out, size_t cap, int *n_cpus) try {
     if (!c || (!out && cap)) return HVC_E_INVALID_ARG;
     if (out && cap) std::snprintf(out, cap, "%s", c->have_cpus ? c->cpulist : "");
     if (n_cpus) *n_cpus = c->have_cpus ? CPU_COUNT(&c->cpus) : 0;
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
 // Work enqueued on the stream the context leaves is drained first: device-memory calls return while their kernels
 // run, the scratch they use (fix-up list and counters, staging buffers) is re-grown and re-used in the order of ONE
@@ -503,53 +543,53 @@ static int switch_stream(hvc_ctx *c, hipStream_t s) {
     return HVC_OK;
 }
 
-int hvc_set_stream(hvc_ctx *c, void *s) {
+int hvc_set_stream(hvc_ctx *c, void *s) try {
     if (!c) return HVC_E_INVALID_ARG;
     return switch_stream(c, (hipStream_t)s); // NULL is a stream too: HIP's default (null) stream
-}
+} HVC_ABI_CATCH
 
-int hvc_reset_stream(hvc_ctx *c) {
+int hvc_reset_stream(hvc_ctx *c) try {
     if (!c) return HVC_E_INVALID_ARG;
     return switch_stream(c, c->own_stream);
-}
+} HVC_ABI_CATCH
 
-int hvc_synchronize(hvc_ctx *c) {
+int hvc_synchronize(hvc_ctx *c) try {
     if (!c) return HVC_E_INVALID_ARG;
     DeviceGuard g(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
-int hvc_timer_begin(hvc_ctx *c) {
+int hvc_timer_begin(hvc_ctx *c) try {
     if (!c) return HVC_E_INVALID_ARG;
     DeviceGuard g(c->device);
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
-int hvc_timer_end(hvc_ctx *c, float *ms) {
+int hvc_timer_end(hvc_ctx *c, float *ms) try {
     if (!c || !ms) return HVC_E_INVALID_ARG;
     DeviceGuard g(c->device);
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev1));
     HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
-int hvc_set_decode_kernel(hvc_ctx *c, int which) {
+int hvc_set_decode_kernel(hvc_ctx *c, int which) try {
     if (!c || which < 0 || which > 3) return HVC_E_INVALID_ARG;
     c->decode_kernel = which;
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
-int hvc_set_profiling(hvc_ctx *c, int enabled) {
+int hvc_set_profiling(hvc_ctx *c, int enabled) try {
     if (!c) return HVC_E_INVALID_ARG;
     c->profiling = enabled != 0;
     c->k_calls = 0;
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
-int hvc_kernel_ms_history(hvc_ctx *c, float *ms, int n) {
+int hvc_kernel_ms_history(hvc_ctx *c, float *ms, int n) try {
     if (!c || !ms || n < 1 || n > HVC_PROF_RING || (unsigned long long)n > c->k_calls) return HVC_E_INVALID_ARG;
     DeviceGuard g(c->device);
     for (int i = 0; i < n; i++) { // ms[0] = oldest of the last n profiled calls
@@ -558,11 +598,11 @@ int hvc_kernel_ms_history(hvc_ctx *c, float *ms, int n) {
         HIPCHK(c, hipEventElapsedTime(&ms[i], c->k0[slot], c->k1[slot]));
     }
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
 int hvc_last_kernel_ms(hvc_ctx *c, float *ms) { return hvc_kernel_ms_history(c, ms, 1); }
 
-int hvc_device_alloc(hvc_ctx *c, size_t bytes, void **out) {
+int hvc_device_alloc(hvc_ctx *c, size_t bytes, void **out) try {
     if (!c || !out) return HVC_E_INVALID_ARG;
     DeviceGuard g(c->device);
     hipError_t e = hipMalloc(out, bytes ? bytes : 1);
@@ -572,33 +612,33 @@ int hvc_device_alloc(hvc_ctx *c, size_t bytes, void **out) {
         return HVC_E_OUT_OF_MEMORY;
     }
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
-int hvc_device_free(hvc_ctx *c, void *p) {
+int hvc_device_free(hvc_ctx *c, void *p) try {
     if (!c) return HVC_E_INVALID_ARG;
     DeviceGuard g(c->device);
     HIPCHK(c, hipFree(p));
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
-int hvc_memcpy_h2d(hvc_ctx *c, void *dst, const void *src, size_t bytes) {
+int hvc_memcpy_h2d(hvc_ctx *c, void *dst, const void *src, size_t bytes) try {
     if (!c || (!dst && bytes) || (!src && bytes)) return HVC_E_INVALID_ARG;
     DeviceGuard g(c->device);
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
-int hvc_memcpy_d2h(hvc_ctx *c, void *dst, const void *src, size_t bytes) {
+int hvc_memcpy_d2h(hvc_ctx *c, void *dst, const void *src, size_t bytes) try {
     if (!c || (!dst && bytes) || (!src && bytes)) return HVC_E_INVALID_ARG;
     DeviceGuard g(c->device);
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
 int hvc_checksum_records(hvc_ctx *c, const void *data, size_t record_bytes, size_t record_stride, int n_records,
-                         uint64_t *sums, int where) {
+                         uint64_t *sums, int where) try {
     if (!c || !sums || n_records < 0 || (!data && n_records && record_bytes)) return HVC_E_INVALID_ARG;
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
     if (n_records == 0) return HVC_OK;
@@ -620,9 +660,9 @@ int hvc_checksum_records(hvc_ctx *c, const void *data, size_t record_bytes, size
     HIPCHK(c, hipMemcpyAsync(sums, c->d_sums, sum_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
-int hvc_last_wide_blocks(hvc_ctx *c, uint64_t *count) {
+int hvc_last_wide_blocks(hvc_ctx *c, uint64_t *count) try {
     if (!c || !count) return HVC_E_INVALID_ARG;
     DeviceGuard g(c->device);
     unsigned long long v = 0; // the total over ALL launches of the last call (a large batch is cut into several)
@@ -630,7 +670,7 @@ int hvc_last_wide_blocks(hvc_ctx *c, uint64_t *count) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *count = c->wide_host >= 0 ? (uint64_t)c->wide_host : (uint64_t)v;
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
 // Kernel-side forms of the quantiser tables: plain ints, the energy thresholds of the two int32
 // kernels, and the packed kernel's per-row operand pairs.
@@ -910,9 +950,9 @@ static int decode_frames_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, 
 
 int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const uint16_t *qtabs, int n_qtabs,
                       const hvc_component *comps, int n_comp, int n_frames, uint8_t *pixels, size_t pixel_fs,
-                      int where) {
+                      int where) try {
     return decode_frames_impl(c, coefs, coef_fs, qtabs, n_qtabs, comps, n_comp, n_frames, pixels, pixel_fs, where, nullptr, 0);
-}
+} HVC_ABI_CATCH
 
 // ---------------------------------------------------------------------------
 // 4:2:0 coefficient records -> tight 4:4:4 frames (block stage + crop + chroma upsample fused)
@@ -1061,14 +1101,14 @@ static int decode_frames_yuv444_impl(hvc_ctx *c, const int16_t *coefs, size_t co
 
 int hvc_decode_frames_yuv444(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const uint16_t *qtabs, int n_qtabs,
                              const hvc_component *comps, int n_comp, int n_frames, int width, int height,
-                             uint8_t *frames, size_t frame_stride, int where) {
+                             uint8_t *frames, size_t frame_stride, int where) try {
     return decode_frames_yuv444_impl(c, coefs, coef_fs, qtabs, n_qtabs, comps, n_comp, n_frames, width, height, frames,
                                      frame_stride, where, nullptr, 0);
-}
+} HVC_ABI_CATCH
 
 int hvc_dequant_idct_recon(hvc_ctx *c, const int16_t *coefs, size_t coef_plane_stride, const uint16_t *qtab,
                            int blocks_w, int blocks_h, int n_planes, uint8_t *plane, size_t stride,
-                           size_t plane_stride, int where) {
+                           size_t plane_stride, int where) try {
     if (blocks_w < 1 || blocks_h < 1) return HVC_E_INVALID_ARG;
     hvc_component comp;
     std::memset(&comp, 0, sizeof comp);
@@ -1088,12 +1128,12 @@ int hvc_dequant_idct_recon(hvc_ctx *c, const int16_t *coefs, size_t coef_plane_s
         done += n;
     }
     return n_planes < 0 ? HVC_E_INVALID_ARG : HVC_OK;
-}
+} HVC_ABI_CATCH
 
 // ---------------------------------------------------------------------------
 int hvc_encode_frames(hvc_ctx *c, const uint8_t *pixels, size_t pixel_fs, const uint16_t *qtabs, int n_qtabs,
                       const hvc_component *comps, int n_comp, int n_frames, int16_t *coefs, size_t coef_fs,
-                      int where) {
+                      int where) try {
     if (!c || !coefs || !pixels || n_frames < 0) return HVC_E_INVALID_ARG;
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
     int r = check_qtabs(qtabs, n_qtabs);
@@ -1198,13 +1238,13 @@ int hvc_encode_frames(hvc_ctx *c, const uint8_t *pixels, size_t pixel_fs, const 
         }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
 // Encoder.encode_block with compute_reconstruction_error (encoder.ml:195-205): K3, then K1 on the coefficients it
 // wrote, then the error plane.  A debugging path in the model and here: three launches, nothing fused.
 int hvc_encode_frames_recon(hvc_ctx *c, const uint8_t *pixels, size_t pixel_fs, const uint16_t *qtabs, int n_qtabs,
                             const hvc_component *comps, int n_comp, int n_frames, int16_t *coefs, size_t coef_fs,
-                            uint8_t *recon, uint8_t *error, int where) {
+                            uint8_t *recon, uint8_t *error, int where) try {
     if (!c || !coefs || !pixels || n_frames < 0) return HVC_E_INVALID_ARG;
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
     Layout L;
@@ -1272,10 +1312,10 @@ int hvc_encode_frames_recon(hvc_ctx *c, const uint8_t *pixels, size_t pixel_fs, 
         }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
 int hvc_fdct_quant(hvc_ctx *c, const uint8_t *plane, size_t stride, size_t plane_stride, const uint16_t *qtab,
-                   int blocks_w, int blocks_h, int n_planes, int16_t *coefs, size_t coef_plane_stride, int where) {
+                   int blocks_w, int blocks_h, int n_planes, int16_t *coefs, size_t coef_plane_stride, int where) try {
     if (blocks_w < 1 || blocks_h < 1 || n_planes < 0) return HVC_E_INVALID_ARG;
     hvc_component comp;
     std::memset(&comp, 0, sizeof comp);
@@ -1294,10 +1334,10 @@ int hvc_fdct_quant(hvc_ctx *c, const uint8_t *plane, size_t stride, size_t plane
         done += n;
     }
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
 int hvc_upsample420(hvc_ctx *c, const uint8_t *src, int cw, int ch, size_t src_stride, uint8_t *dst,
-                    size_t dst_stride, int n_planes, size_t src_ps, size_t dst_ps, int where) {
+                    size_t dst_stride, int n_planes, size_t src_ps, size_t dst_ps, int where) try {
     if (!c || !src || !dst || cw < 1 || ch < 1 || n_planes < 0) return HVC_E_INVALID_ARG;
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
     if (src_stride < (size_t)cw || dst_stride < (size_t)cw * 2) return HVC_E_INVALID_ARG;
@@ -1337,7 +1377,7 @@ int hvc_upsample420(hvc_ctx *c, const uint8_t *src, int cw, int ch, size_t src_s
                                    dst_stride, (size_t)cw * 2, (size_t)ch * 2, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
 // ---------------------------------------------------------------------------
 // single-frame conveniences (host memory)
@@ -1393,7 +1433,7 @@ static int decode_one_with_wide_dc(hvc_ctx *c, const hvc_jpeg_info *info, const 
 
 // Decoder.decode_a_frame minus the crop (decoder.ml:422-427)
 int hvc_jpeg_decode_yuv444(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_info *info, uint8_t *frame,
-                           size_t frame_cap) {
+                           size_t frame_cap) try {
     if (!c || !jpeg || !info || !frame) return HVC_E_INVALID_ARG;
     int r = hvc_jpeg_read_header(jpeg, n, info);
     if (r) return r;
@@ -1429,9 +1469,9 @@ int hvc_jpeg_decode_yuv444(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_i
     return hvc_decode_frames_yuv444(c, coefs.data(), info->coef_count, &info->qtabs[0][0], info->n_qtabs, info->layout,
                                     info->n_comp, 1, info->width, info->height, frame,
                                     (size_t)3 * info->width * info->height, HVC_MEM_HOST);
-}
+} HVC_ABI_CATCH
 
-int hvc_jpeg_decode(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_info *info, uint8_t *pixels, size_t pixel_cap) {
+int hvc_jpeg_decode(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_info *info, uint8_t *pixels, size_t pixel_cap) try {
     if (!c || !jpeg || !info || !pixels) return HVC_E_INVALID_ARG;
     int r = hvc_jpeg_read_header(jpeg, n, info);
     if (r) return r;
@@ -1460,14 +1500,14 @@ int hvc_jpeg_decode(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_info *in
     if (!wide.empty()) return decode_one_with_wide_dc(c, info, coefs.data(), wide, false, pixels);
     return hvc_decode_frames(c, coefs.data(), info->coef_count, &info->qtabs[0][0], info->n_qtabs, info->layout,
                              info->n_comp, 1, pixels, info->pixel_bytes, HVC_MEM_HOST);
-}
+} HVC_ABI_CATCH
 
 // Encoder.encode_420/422/444 (encoder.ml:512-541)
 static int huffman_prepare(hvc_ctx *c, const hvc_jpeg_info *info, const int16_t *d_coefs, size_t coef_fs, int n_frames,
                            uint8_t *d_out, size_t out_cap, unsigned long long *d_offsets, hvc::HuffParams &P);
 
 int hvc_jpeg_encode(hvc_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v, int width, int height, int chroma,
-                    int quality, uint8_t *out, size_t cap, size_t *out_len) {
+                    int quality, uint8_t *out, size_t cap, size_t *out_len) try {
     if (!c || !y || !u || !v || !out_len) return HVC_E_INVALID_ARG;
     hvc_jpeg_info info;
     int r = hvc_jpeg_encoder_layout(width, height, chroma, quality, &info);
@@ -1524,7 +1564,7 @@ int hvc_jpeg_encode(hvc_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_
     out[header.size() + off[1]] = 0xff; // complete_and_write_eoi (encoder.ml:507-510)
     out[header.size() + off[1] + 1] = 0xd9;
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
 // ---------------------------------------------------------------------------
 // BASELINE config 3: host Huffman || hipMemcpyAsync (copy stream) || block-stage kernel (compute stream)
@@ -1605,7 +1645,7 @@ static int decode_batch_impl(hvc_ctx *c, const uint8_t *const *jpegs, const size
     std::vector<std::vector<WideFix>> chunk_wide((size_t)n_chunks); // blocks whose DC left int16 (frame = index in the chunk)
     int released_upto = NB - 1; // chunks 0..NB-1 may be written at once
     std::atomic<long long> entropy_ns{0};
-    auto worker = [&]() {
+    auto worker_body = [&]() {
         if (!pin_to_ctx_cpus(c)) error.store(HVC_E_INVALID_ARG); // hvc_set_host_cpus
         std::vector<hvc::WideDc> wide;
         for (;;) {
@@ -1641,13 +1681,34 @@ static int decode_batch_impl(hvc_ctx *c, const uint8_t *const *jpegs, const size
             cv.notify_all();
         }
     };
+    auto worker = [&]() { // (a pool thread: nothing may leave it but through the error flag the orchestrator watches)
+        try {
+            worker_body();
+        } catch (...) {
+            const int e = hvc::exception_code();
+            std::lock_guard<std::mutex> lk(mu);
+            error.store(e);
+            cv.notify_all();
+        }
+    };
     const auto wall0 = std::chrono::steady_clock::now();
-    std::vector<std::thread> pool;
-    for (int t = 0; t < threads; t++) pool.emplace_back(worker);
+    if ((r = pool_ready(c, threads))) return r;
+    bool completed = false; // (the workers have run out of frames by themselves)
+    hvc::PoolScope scope(c->pool, [&] {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!completed && !error.load()) error.store(HVC_E_INTERNAL);
+        cv.notify_all();
+    });
+    if ((r = c->pool.submit(worker, threads))) {
+        std::lock_guard<std::mutex> lk(mu);
+        error.store(r);
+        return r; // (the scope waits for the copies that were queued)
+    }
 
     int rc = HVC_OK;
     double h2d_ms = 0, k_ms = 0, d2h_ms = 0;
     hipStream_t compute = c->stream;
+    try {
     for (int k = 0; k < n_chunks && rc == HVC_OK; k++) {
         const int slot = k % NB, first = k * C, cnt = (first + C <= n_frames) ? C : n_frames - first;
         {
@@ -1704,12 +1765,20 @@ static int decode_batch_impl(hvc_ctx *c, const uint8_t *const *jpegs, const size
             if (hipEventElapsedTime(&ms, c->ev_t[2], c->ev_t[3]) == hipSuccess) d2h_ms += ms;
         }
     }
-    if (rc != HVC_OK) {
+    } catch (...) {
+        rc = hvc::exception_code();
+    }
+    {
         std::lock_guard<std::mutex> lk(mu);
-        error.store(rc);
+        if (rc != HVC_OK) error.store(rc);
+        else completed = true;
         cv.notify_all();
     }
-    for (auto &t : pool) t.join();
+    {
+        const int te = scope.finish();
+        if (rc == HVC_OK && te) rc = te;
+    }
+    if (rc == HVC_OK && error.load()) rc = error.load();
     if (rc == HVC_OK) {
         hipError_t he = hipStreamSynchronize(compute);
         if (he == hipSuccess) he = hipStreamSynchronize(c->copy_stream);
@@ -1733,16 +1802,16 @@ static int decode_batch_impl(hvc_ctx *c, const uint8_t *const *jpegs, const size
 }
 
 int hvc_jpeg_decode_batch(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *sizes, int n_frames, int threads,
-                          int frames_per_chunk, uint8_t *pixels, size_t pixel_fs, int where, hvc_batch_stats *stats) {
+                          int frames_per_chunk, uint8_t *pixels, size_t pixel_fs, int where, hvc_batch_stats *stats) try {
     return decode_batch_impl(c, jpegs, sizes, n_frames, threads, frames_per_chunk, pixels, pixel_fs, where, stats, false);
-}
+} HVC_ABI_CATCH
 
 int hvc_jpeg_decode_batch_yuv444(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *sizes, int n_frames,
                                  int threads, int frames_per_chunk, uint8_t *frames, size_t frame_stride, int where,
-                                 hvc_batch_stats *stats) {
+                                 hvc_batch_stats *stats) try {
     return decode_batch_impl(c, jpegs, sizes, n_frames, threads, frames_per_chunk, frames, frame_stride, where, stats,
                              true);
-}
+} HVC_ABI_CATCH
 
 // Two files of one batch: the same frame geometry (sizes, sampling, planes)?  The Huffman table selectors of the scan
 // may differ -- the GPU reader takes every file's tables from the file itself.
@@ -2060,7 +2129,7 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
 }
 
 int hvc_jpeg_entropy_decode_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *sizes, int n_frames, int16_t *coefs,
-                                size_t coef_fs, int where, hvc_jpeg_info *info, int *used_gpu) {
+                                size_t coef_fs, int where, hvc_jpeg_info *info, int *used_gpu) try {
     if (!c || !jpegs || !sizes || !coefs || !info || n_frames < 1) return HVC_E_INVALID_ARG;
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
     int r = hvc_jpeg_read_header(jpegs[0], sizes[0], info);
@@ -2106,7 +2175,7 @@ int hvc_jpeg_entropy_decode_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const s
         }
     }
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
 // ---------------------------------------------------------------------------
 // BASELINE config 3 with the Huffman reader on the GPU as well: host threads only parse headers and
@@ -2285,7 +2354,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     std::vector<unsigned> ecs_size((size_t)n_frames, 0);
     int released_upto = NB - 1;
     std::atomic<long long> prep_ns{0};
-    auto worker = [&]() {
+    auto worker_body = [&]() {
         hvc::HdTables t;
         if (!pin_to_ctx_cpus(c)) error.store(HVC_E_INVALID_ARG); // hvc_set_host_cpus
         for (;;) {
@@ -2325,18 +2394,38 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
             cv.notify_all();
         }
     };
+    auto worker = [&]() { // (a pool thread: nothing may leave it but through the error flag the orchestrator watches)
+        try {
+            worker_body();
+        } catch (...) {
+            const int e = hvc::exception_code();
+            std::lock_guard<std::mutex> lk(mu);
+            error.store(e);
+            cv.notify_all();
+        }
+    };
     const auto wall0 = std::chrono::steady_clock::now();
-    std::vector<std::thread> pool;
-    for (int t = 0; t < threads; t++) pool.emplace_back(worker);
+    if ((r = pool_ready(c, threads, where == HVC_MEM_HOST ? 1 : 0))) return r;
+    std::atomic<int> stage_done{0}, dl_abort{0}, dl_err{0}; // chunks whose block stage is enqueued
+    bool completed = false; // (the workers have run out of frames, the downloader out of chunks)
+    hvc::PoolScope scope(c->pool, [&] {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!completed && !error.load()) error.store(HVC_E_INTERNAL);
+        dl_abort.store(1);
+        cv.notify_all();
+    });
 
     // Host output: a thread of its own downloads chunk after chunk on c->down_stream (copies to pageable memory hold
     // their caller -- issued from the loop below they kept the next chunk's launches waiting, and on the block
     // stage's stream its kernels too: 18 Gpixel/s, 33 with this).
-    std::atomic<int> stage_done{0}, dl_abort{0}, dl_err{0}; // chunks whose block stage is enqueued
     std::vector<char> downloaded((size_t)n_chunks, 0);
-    std::thread downloader;
-    if (where == HVC_MEM_HOST) {
-        downloader = std::thread([&] {
+    auto submit_failed = [&](int e) {
+        std::lock_guard<std::mutex> lk(mu);
+        error.store(e);
+        return e; // (the scope wakes and waits for whatever was queued)
+    };
+    if (where == HVC_MEM_HOST) { // (first: it must run beside the workers, never queue behind them)
+        r = c->pool.submit([&] {
             (void)pin_to_ctx_cpus(c);
             if (hipSetDevice(c->device) != hipSuccess) { dl_err.store((int)hipErrorInvalidDevice); return; }
             for (int k = 0; k < n_chunks; k++) {
@@ -2365,16 +2454,10 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
                 cv.notify_all();
                 if (e != hipSuccess) return;
             }
-        });
+        }, 1);
+        if (r) return submit_failed(r);
     }
-    auto stop_downloader = [&] {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            dl_abort.store(1);
-            cv.notify_all();
-        }
-        if (downloader.joinable()) downloader.join();
-    };
+    if ((r = c->pool.submit(worker, threads))) return submit_failed(r);
 
     int rc = HVC_OK;
     double h2d_ms = 0, k_ms = 0;
@@ -2391,6 +2474,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         cv.notify_all();
         return hipSuccess;
     };
+    try {
     for (int it = 0; it < n_chunks + NB && rc == HVC_OK; it++) {
         // verdict on chunk it - NB's slot before it is overwritten (and on the last chunks at the end)
         const int v = it - NB;
@@ -2526,14 +2610,20 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         const hipError_t he = release_after_upload(pending_release);
         if (he != hipSuccess) rc = fail_hip(c, he);
     }
+    } catch (...) {
+        rc = hvc::exception_code();
+    }
     c->profiling = prof_saved;
     {
         std::lock_guard<std::mutex> lk(mu);
         if (rc != HVC_OK) error.store(rc);
+        else completed = true;
         cv.notify_all();
     }
-    stop_downloader(); // (after a complete run it has finished: the last verdicts waited for its last chunks)
-    for (auto &t : pool) t.join();
+    { // (after a complete run the downloader has finished: the last verdicts waited for its last chunks)
+        const int te = scope.finish();
+        if (rc == HVC_OK && te) rc = te;
+    }
     for (int i = 0; i < 3; i++) (void)hipStreamSynchronize(c->rd_stream[i]);
     (void)hipStreamSynchronize(compute);
     (void)hipStreamSynchronize(c->copy_stream);
@@ -2563,9 +2653,9 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
 
 int hvc_jpeg_decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *sizes, int n_frames, int threads,
                               int frames_per_chunk, uint8_t *pixels, size_t pixel_fs, int where, int yuv444,
-                              hvc_batch_stats *stats) {
+                              hvc_batch_stats *stats) try {
     return decode_batch_gpu(c, jpegs, sizes, n_frames, threads, frames_per_chunk, pixels, pixel_fs, where, stats, yuv444 != 0);
-}
+} HVC_ABI_CATCH
 
 // ---------------------------------------------------------------------------
 // Encoder back end on the GPU: RLE + Huffman + byte stuffing of coefficient records (hvc_huff.hip)
@@ -2635,7 +2725,7 @@ static int huffman_prepare(hvc_ctx *c, const hvc_jpeg_info *info, const int16_t 
     return HVC_OK;
 }
 
-int hvc_jpeg_header(const hvc_jpeg_info *info, uint8_t *out, size_t cap, size_t *len) {
+int hvc_jpeg_header(const hvc_jpeg_info *info, uint8_t *out, size_t cap, size_t *len) try {
     if (!info || !len || info->n_comp != 3) return HVC_E_INVALID_ARG;
     std::vector<uint8_t> o;
     hvc::jpeg_header_bytes(info, o);
@@ -2643,10 +2733,10 @@ int hvc_jpeg_header(const hvc_jpeg_info *info, uint8_t *out, size_t cap, size_t 
     if (!out || cap < o.size()) return HVC_E_INVALID_ARG;
     std::memcpy(out, o.data(), o.size());
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
 int hvc_huffman_encode_frames(hvc_ctx *c, const hvc_jpeg_info *info, const int16_t *coefs, size_t coef_fs, int n_frames,
-                              uint8_t *out, size_t out_cap, uint64_t *offsets, int where) {
+                              uint8_t *out, size_t out_cap, uint64_t *offsets, int where) try {
     if (!c || !info || !coefs || !out || !offsets || n_frames < 0 || info->n_comp != 3) return HVC_E_INVALID_ARG;
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
     if (n_frames == 0) {
@@ -2685,7 +2775,7 @@ int hvc_huffman_encode_frames(hvc_ctx *c, const hvc_jpeg_info *info, const int16
     if (status & 1u) return HVC_E_RANGE;       // a value the default tables have no code for
     if (status & 6u) return HVC_E_INVALID_ARG; // out_cap too small
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
 // ---------------------------------------------------------------------------
 // BASELINE config 5 end to end: raw frames in, JPEG files out.
@@ -2797,7 +2887,7 @@ static int encode_batch_impl(hvc_ctx *c, const uint8_t *const *frames, int n_fra
             const int f = t.frame, k = f / C, slot = k % NB;
             const auto t0 = std::chrono::steady_clock::now();
             int e = HVC_OK;
-            if (error.load() == 0) {
+            if (error.load() == 0) try {
                 if (t.kind == 0) {
                     uint8_t *rec = (uint8_t *)c->eh_in[slot] + (size_t)(f - k * C) * pix_bytes;
                     const uint8_t *src = frames[f];
@@ -2834,6 +2924,8 @@ static int encode_batch_impl(hvc_ctx *c, const uint8_t *const *frames, int n_fra
                         jpegs[f][header.size() + seg + 1] = 0xd9;
                     }
                 }
+            } catch (...) { // (the counters below must move whatever happened: the orchestrator waits for them)
+                e = hvc::exception_code();
             }
             const long long ns =
                 std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
@@ -2845,8 +2937,13 @@ static int encode_batch_impl(hvc_ctx *c, const uint8_t *const *frames, int n_fra
         }
     };
     const auto wall0 = std::chrono::steady_clock::now();
-    std::vector<std::thread> pool;
-    for (int t = 0; t < threads; t++) pool.emplace_back(worker);
+    if ((r = pool_ready(c, threads))) return r;
+    hvc::PoolScope scope(c->pool, [&] { // however this function is left: the workers drain the queue and return
+        std::lock_guard<std::mutex> lk(mu);
+        stop = true;
+        cv_task.notify_all();
+    });
+    if ((r = c->pool.submit(worker, threads))) return r;
     auto chunk_count = [&](int k) { return (k * C + C <= n_frames) ? C : n_frames - k * C; };
     auto submit = [&](int kind, int k) {
         std::lock_guard<std::mutex> lk(mu);
@@ -2864,6 +2961,7 @@ static int encode_batch_impl(hvc_ctx *c, const uint8_t *const *frames, int n_fra
     hipStream_t compute = c->stream;
     const bool prof_saved = c->profiling;
     c->profiling = false;
+    try {
     for (int it = 0; it < n_chunks + 3 && rc == HVC_OK; it++) {
         // stage 1: pad chunk `it` (its pinned slot was uploaded and synchronised two iterations ago)
         if (it < n_chunks) submit(0, it);
@@ -2956,9 +3054,12 @@ static int encode_batch_impl(hvc_ctx *c, const uint8_t *const *frames, int n_fra
         }
         if (error.load()) rc = error.load();
     }
-    c->profiling = prof_saved;
     if (rc == HVC_OK)
         for (int k = 0; k < n_chunks; k++) wait_for(ent_done, k);
+    } catch (...) {
+        rc = hvc::exception_code();
+    }
+    c->profiling = prof_saved;
     {
         std::lock_guard<std::mutex> lk(mu);
         if (rc != HVC_OK) {
@@ -2968,7 +3069,10 @@ static int encode_batch_impl(hvc_ctx *c, const uint8_t *const *frames, int n_fra
         stop = true;
         cv_task.notify_all();
     }
-    for (auto &t : pool) t.join();
+    {
+        const int te = scope.finish();
+        if (rc == HVC_OK && te) rc = te;
+    }
     (void)hipStreamSynchronize(compute);
     (void)hipStreamSynchronize(c->copy_stream);
     (void)hipStreamSynchronize(c->down_stream);
@@ -2990,16 +3094,16 @@ static int encode_batch_impl(hvc_ctx *c, const uint8_t *const *frames, int n_fra
 
 int hvc_jpeg_encode_batch(hvc_ctx *c, const uint8_t *const *frames, int n_frames, int width, int height, int chroma,
                           int quality, int threads, int frames_per_chunk, uint8_t *const *jpegs, const size_t *caps,
-                          size_t *sizes, hvc_batch_stats *stats) {
+                          size_t *sizes, hvc_batch_stats *stats) try {
     return encode_batch_impl(c, frames, n_frames, width, height, chroma, quality, threads, frames_per_chunk, jpegs, caps,
                              sizes, stats, false);
-}
+} HVC_ABI_CATCH
 
 int hvc_jpeg_encode_batch_gpu(hvc_ctx *c, const uint8_t *const *frames, int n_frames, int width, int height, int chroma,
                               int quality, int threads, int frames_per_chunk, uint8_t *const *jpegs, const size_t *caps,
-                              size_t *sizes, hvc_batch_stats *stats) {
+                              size_t *sizes, hvc_batch_stats *stats) try {
     return encode_batch_impl(c, frames, n_frames, width, height, chroma, quality, threads, frames_per_chunk, jpegs, caps,
                              sizes, stats, true);
-}
+} HVC_ABI_CATCH
 
 } // extern "C"

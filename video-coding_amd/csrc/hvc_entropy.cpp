@@ -21,6 +21,7 @@
 #include "../../include/hvc_jpeg.h"
 #include "hvc_hdec.h"
 #include "hvc_kernels.h"
+#include "hvc_pool.h"
 
 namespace {
 
@@ -229,7 +230,7 @@ inline int extend(int cat, unsigned code) {
 extern "C" {
 
 // Decoder.Header.decode + the geometry of Decoder.init (decoder.ml:294-345)
-int hvc_jpeg_read_header(const uint8_t *data, size_t n, hvc_jpeg_info *info) {
+int hvc_jpeg_read_header(const uint8_t *data, size_t n, hvc_jpeg_info *info) try {
     if (!data || !info) return HVC_E_INVALID_ARG;
     std::memset(info, 0, sizeof *info);
     Header h;
@@ -292,16 +293,16 @@ int hvc_jpeg_read_header(const uint8_t *data, size_t n, hvc_jpeg_info *info) {
     info->coef_count = coef_off;
     info->pixel_bytes = pix_off;
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
 // The Huffman half of Decoder.decode (decode_seq order, decoder.ml:362-395; huffman_decode :118-140;
 // the DC predictor add of :143) into one frame's coefficient record: int16, zig-zag order, DC absolute,
 // block (bx,by) of component i at coefs + layout[i].coef_offset + (by*blocks_w + bx)*64.
 static int entropy_decode_impl(const uint8_t *data, size_t n, const hvc_jpeg_info *info, int16_t *coefs,
                                std::vector<hvc::WideDc> *wide);
-int hvc_jpeg_entropy_decode(const uint8_t *data, size_t n, const hvc_jpeg_info *info, int16_t *coefs) {
+int hvc_jpeg_entropy_decode(const uint8_t *data, size_t n, const hvc_jpeg_info *info, int16_t *coefs) try {
     return entropy_decode_impl(data, n, info, coefs, nullptr);
-}
+} HVC_ABI_CATCH
 
 // wide == nullptr: an absolute DC outside int16 is HVC_E_RANGE (the int16 record cannot carry it).  Otherwise the
 // record gets the saturated value and the block goes on the list with its true DC (hvc_huff.h WideDc).
@@ -432,7 +433,7 @@ static int entropy_decode_impl(const uint8_t *data, size_t n, const hvc_jpeg_inf
 
 // Decoder.crop / get_yuv_frame (decoder.ml:403-420): the actual_w x actual_h top-left part of every
 // padded plane, planes back to back (the layout Frame.output writes, common/src/frame.ml:66-70).
-int hvc_jpeg_get_yuv_frame(const hvc_jpeg_info *info, const uint8_t *pixels, uint8_t *out, size_t cap, size_t *out_len) {
+int hvc_jpeg_get_yuv_frame(const hvc_jpeg_info *info, const uint8_t *pixels, uint8_t *out, size_t cap, size_t *out_len) try {
     if (!info || !pixels || !out) return HVC_E_INVALID_ARG;
     size_t need = 0;
     for (int i = 0; i < info->n_comp; i++) need += (size_t)info->comp[i].actual_width * info->comp[i].actual_height;
@@ -446,7 +447,7 @@ int hvc_jpeg_get_yuv_frame(const hvc_jpeg_info *info, const uint8_t *pixels, uin
             std::memcpy(o, p + (size_t)y * info->layout[i].stride, (size_t)c.actual_width);
     }
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
 } // extern "C"
 
@@ -591,7 +592,7 @@ void write_dht(std::vector<uint8_t> &o, int tclass, int id, const uint8_t *bits,
 extern "C" {
 
 // Quant_tables.scale (quant_tables.ml:139-147)
-int hvc_quant_table(int chroma_table, int quality, uint16_t *out) {
+int hvc_quant_table(int chroma_table, int quality, uint16_t *out) try {
     if (!out) return HVC_E_INVALID_ARG;
     int q = quality < 1 ? 1 : (quality > 100 ? 100 : quality);
     const int s = q < 50 ? 5000 / q : 200 - 2 * q;
@@ -601,11 +602,11 @@ int hvc_quant_table(int chroma_table, int quality, uint16_t *out) {
         out[i] = (uint16_t)(d < 1 ? 1 : (d > 255 ? 255 : d));
     }
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
 // Encoder.Parameters.c420/c422/c444 (encoder.ml:347-349) + Encoder.create plane geometry (:437-472):
 // the padded plane layout the encode kernel reads and the coefficient record it writes.
-int hvc_jpeg_encoder_layout(int width, int height, int chroma, int quality, hvc_jpeg_info *info) {
+int hvc_jpeg_encoder_layout(int width, int height, int chroma, int quality, hvc_jpeg_info *info) try {
     if (!info || width < 1 || height < 1 || width > 65535 || height > 65535) return HVC_E_INVALID_ARG;
     static const int S420[6] = {2, 2, 1, 1, 1, 1}, S422[6] = {2, 2, 1, 2, 1, 2}, S444[6] = {1, 1, 1, 1, 1, 1};
     const int *s = chroma == 420 ? S420 : chroma == 422 ? S422 : chroma == 444 ? S444 : nullptr;
@@ -642,14 +643,14 @@ int hvc_jpeg_encoder_layout(int width, int height, int chroma, int quality, hvc_
     info->coef_count = coef_off;
     info->pixel_bytes = pix_off;
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
 // Encoder.write_headers (encoder.ml:371-418) + encode_seq's rle / write_bits (:127-193, 476-505) +
 // complete_and_write_eoi (:507-510) over one frame's quantised coefficient record (zig-zag, DC absolute).
 // encode_seq (encoder.ml:476-505) walks the MCU grid of component 0 and reads h x v blocks of every
 // component per MCU; where that grid reaches past a component's plane the model raises
 // "[Plane.get] out of bounds" (plane.ml:43-50): 4:2:0 / 4:2:2 at width 16k + 1 (or height 16k + 1).
-int hvc_jpeg_encoder_check(const hvc_jpeg_info *info) {
+int hvc_jpeg_encoder_check(const hvc_jpeg_info *info) try {
     if (!info || info->n_comp != 3) return HVC_E_INVALID_ARG;
     const hvc_jpeg_component &c0 = info->comp[0];
     if (c0.hscale < 1 || c0.vscale < 1) return HVC_E_INVALID_ARG;
@@ -666,7 +667,7 @@ int hvc_jpeg_encoder_check(const hvc_jpeg_info *info) {
         if (dt < 0 || dt > 1 || at != dt || qt < 0 || qt > 1) return HVC_E_INVALID_ARG;
     }
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
 } // extern "C"
 
@@ -837,7 +838,7 @@ static int prepare_gpu_decode_impl(const uint8_t *jpeg, size_t n, const ::hvc_jp
 
 extern "C" {
 
-int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uint8_t *out, size_t cap, size_t *out_len) {
+int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uint8_t *out, size_t cap, size_t *out_len) try {
     if (!info || !coefs || !out_len || info->n_comp != 3) return HVC_E_INVALID_ARG;
     std::vector<uint8_t> o;
     o.reserve(info->coef_count / 4 + 1024);
@@ -895,13 +896,13 @@ int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uin
     if (!out || o.size() > cap) return HVC_E_INVALID_ARG;
     std::memcpy(out, o.data(), o.size());
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
 // Ocompare.max_difference / total_difference / square_error (tools/src/ocompare.ml:6-47) of two
 // equally sized planes given as n bytes each; the float metrics (mean_difference, mean_square_error,
 // psnr, :30-59) are one division / log10 on top and stay with the caller.
 int hvc_compare_planes(const uint8_t *a, const uint8_t *b, size_t n, int *max_difference, uint64_t *total_difference,
-                       uint64_t *square_error) {
+                       uint64_t *square_error) try {
     if ((!a || !b) && n) return HVC_E_INVALID_ARG;
     int mx = 0;
     uint64_t tot = 0, se = 0;
@@ -915,6 +916,6 @@ int hvc_compare_planes(const uint8_t *a, const uint8_t *b, size_t n, int *max_di
     if (total_difference) *total_difference = tot;
     if (square_error) *square_error = se;
     return HVC_OK;
-}
+} HVC_ABI_CATCH
 
 } // extern "C"

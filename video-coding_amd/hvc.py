@@ -22,6 +22,7 @@ SYMBOLS = [
     "hvc_jpeg_decode_batch", "hvc_quant_table", "hvc_jpeg_encoder_layout", "hvc_jpeg_entropy_encode",
     "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444", "hvc_jpeg_decode_yuv444", "hvc_compare_planes", "hvc_jpeg_encode_batch", "hvc_jpeg_decode_batch_yuv444", "hvc_jpeg_encoder_check", "hvc_huffman_encode_frames", "hvc_jpeg_header", "hvc_jpeg_encode_batch_gpu", "hvc_jpeg_entropy_decode_gpu", "hvc_jpeg_decode_batch_gpu",
     "hvc_checksum_records", "hvc_encode_frames_recon", "hvc_set_host_cpus", "hvc_get_host_cpus",
+    "hvc_host_threads", "hvc_host_threads_probe",
 ]
 
 
@@ -143,6 +144,8 @@ def lib():
         L.hvc_checksum_records.argtypes = [vp, vp, sz, sz, i, vp, i]
         L.hvc_set_host_cpus.argtypes = [vp, C.c_char_p]
         L.hvc_get_host_cpus.argtypes = [vp, C.c_char_p, sz, C.POINTER(i)]
+        L.hvc_host_threads.argtypes = [vp, C.POINTER(i), C.POINTER(C.c_uint64)]
+        L.hvc_host_threads_probe.argtypes = [i]
         L.hvc_encode_frames_recon.argtypes = [vp, vp, sz, vp, i, C.POINTER(Component), i, i, vp, sz, vp, vp, i]
         L.hvc_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
         L.hvc_device_free.argtypes = [vp, vp]
@@ -295,6 +298,12 @@ class Context:
         buf, n = C.create_string_buffer(256), C.c_int()
         _chk(lib().hvc_get_host_cpus(self._h, buf, 256, C.byref(n)))
         return buf.value.decode(), n.value
+
+    def host_threads(self):
+        """(threads the context's pool holds, threads it has ever started): the batch pipelines reuse them"""
+        alive, ever = C.c_int(), C.c_uint64()
+        _chk(lib().hvc_host_threads(self._h, C.byref(alive), C.byref(ever)))
+        return alive.value, ever.value
 
     def timer_begin(self):
         _chk(lib().hvc_timer_begin(self._h))
