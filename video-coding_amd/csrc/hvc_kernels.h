@@ -111,7 +111,7 @@ struct Decode444Params {
     int nw;                // workgroup = 256 * nw lanes: luma tiles of that many blocks, chroma tiles (64 * nw) x 4 blocks.
                            // Chosen so that ONE chroma tile spans the output row where it can (1080p: nw = 2, 4K: nw = 4):
                            // a workgroup then writes whole rows, measured 58 -> 66 % of the HBM peak for the chroma half
-    int pad2;
+    int tile0;             // added to blockIdx.x: 0, or y_tiles when the luma tiles run in a kernel of their own
     Plane444K pl[3];
     int qt[HVC_MAX_QTABS * 64];
     unsigned qpair[HVC_MAX_QTABS * 32];
