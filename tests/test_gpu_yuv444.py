@@ -239,3 +239,19 @@ def test_host_buffers_in_four_overlapped_parts_equal_the_device_path(ctx, pad):
     ctx.decode_frames_yuv444(batch, cfs, qt, specs, n, width, height, host, frame_stride=fs)
     assert np.array_equal(host[:, :3 * width * height], want)
     assert (host[:, 3 * width * height:] == 0x3C).all()
+
+
+def test_split_launch_modes_give_the_same_frames():
+    """HVC_444_MODE=1 / 2 (hvc_capi.hip fused444_mode: the luma planes through k_decode_packed itself, before or beside the
+    chroma tiles' kernel) are A/B alternates of the one-kernel form that ships (measured slower: profiles/r03b_ab.txt);
+    the variable is read once per process, so this module runs again in child processes under both."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("HVC_444_MODE"):
+        pytest.skip("already inside a child run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("1", "2"):
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu"], cwd=root,
+                           env=dict(os.environ, HVC_444_MODE=mode), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and " passed" in r.stdout, (mode, r.stdout[-2000:], r.stderr[-2000:])

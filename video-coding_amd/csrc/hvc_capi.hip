@@ -25,6 +25,7 @@
 #include "hvc_pool.h"
 
 #define HVC_PROF_RING 64
+#define HVC_FIX_WORDS 8 /* d_fix_count: [0] [1] counters, [2..3] the 64-bit total, [4] [5] the fused path's luma counters */
 
 struct hvc_ctx {
     int device = -1;
@@ -38,6 +39,11 @@ struct hvc_ctx {
     int decode_kernel = 0; // hvc_set_decode_kernel: 0 packed (default), 1 unpacked int32, 2 int64 for every block, 3 q16
     unsigned *d_fix_count = nullptr; // two counters, used alternately (see k_decode_wide); behind them (+ 8 bytes) the 64-bit
                                      // total of the last call's fix-up blocks over all its launches (hvc_last_wide_blocks)
+    // [4], [5]: a second pair of counters, for the luma planes of the fused 4:4:4 path when they run through
+    // k_decode_packed beside (or before) the chroma tiles' kernel, which uses the first pair
+    int fix_phase_l = 0;
+    hipStream_t side_stream = nullptr; // ... and the stream that kernel runs on in the side-by-side form, with its fork / join events
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool wide_total_started = false; // the current call has enqueued a launch that stores (rather than adds to) that total
     long long wide_host = -1;        // >= 0: the last call sent every block through the int64 kernel (no list): this many
     int fix_phase = 0;               // index of the counter the NEXT decode call appends to
@@ -205,8 +211,8 @@ static void wide_total_begin(hvc_ctx *c) {
     c->wide_total_started = false;
     c->wide_host = -1;
 }
-static void fix_reset(hvc_ctx *c) { // after a failed launch: both counters to zero, in stream order
-    (void)hipMemsetAsync(c->d_fix_count, 0, 4 * sizeof(unsigned), c->stream); // (and the total behind them)
+static void fix_reset(hvc_ctx *c) { // after a failed launch: all counters to zero, in stream order
+    (void)hipMemsetAsync(c->d_fix_count, 0, HVC_FIX_WORDS * sizeof(unsigned), c->stream); // (and the total behind the first pair)
 }
 
 // Launches longer than about 3 ms lose 2-3 % against back-to-back shorter ones (measured on MI355X: 1080p batches of
@@ -221,6 +227,20 @@ static size_t launch_bytes_limit() {
         return d >= 1.0 ? (size_t)d : (size_t)10000000000ull;
     }();
     return v;
+}
+// The fused 4:4:4 path's block stage (decode_frames_yuv444_impl): 0 = one kernel for luma and chroma tiles, 1 = the luma
+// planes through k_decode_packed, then the chroma tiles, 2 = the two side by side on two streams.  HVC_444_MODE
+// overrides the default (A/B measurements).
+#ifndef HVC_444_MODE_DEFAULT
+#define HVC_444_MODE_DEFAULT 0
+#endif
+static int fused444_mode() {
+    static const int m = [] {
+        const char *e = std::getenv("HVC_444_MODE");
+        const int v = e ? std::atoi(e) : HVC_444_MODE_DEFAULT;
+        return v < 0 || v > 2 ? 0 : v;
+    }();
+    return m;
 }
 // frames per launch for a batch of n_frames frames of blocks_per_frame blocks: equal parts, each within the limit
 static int frames_per_launch(int n_frames, unsigned long long blocks_per_frame) {
@@ -373,8 +393,8 @@ int hvc_create(hvc_ctx **out, int device) try {
                       if (hipEventCreate(&c->k0[i]) != hipSuccess || hipEventCreate(&c->k1[i]) != hipSuccess) return false;
                   return true;
               }() &&
-              hipMalloc((void **)&c->d_fix_count, 4 * sizeof(unsigned)) == hipSuccess &&
-              hipMemset(c->d_fix_count, 0, 4 * sizeof(unsigned)) == hipSuccess;
+              hipMalloc((void **)&c->d_fix_count, HVC_FIX_WORDS * sizeof(unsigned)) == hipSuccess &&
+              hipMemset(c->d_fix_count, 0, HVC_FIX_WORDS * sizeof(unsigned)) == hipSuccess;
     if (!ok) {
         hvc_destroy(c);
         return HVC_E_NO_DEVICE;
@@ -396,6 +416,7 @@ void hvc_destroy(hvc_ctx *c) {
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->down_stream) (void)hipStreamSynchronize(c->down_stream);
+    if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
     for (int i = 0; i < 3; i++)
         if (c->rd_stream[i]) (void)hipStreamSynchronize(c->rd_stream[i]);
     if (c->d_fix_count) (void)hipFree(c->d_fix_count);
@@ -462,6 +483,9 @@ void hvc_destroy(hvc_ctx *c) {
         if (c->ev_rd[i]) (void)hipEventDestroy(c->ev_rd[i]);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1027,11 +1051,94 @@ static int decode_frames_yuv444_impl(hvc_ctx *c, const int16_t *coefs, size_t co
     for (int i = 0; i < n_qtabs * 64; i++) wide_only |= qtabs[i] > 255;
     P.fix_list = c->d_fix_list;
     wide_total_begin(c);
+    // How the block stage is launched (fused444_mode): one kernel for luma and chroma tiles, or -- where the luma crop is
+    // whole blocks of the whole coefficient plane, which is every frame whose width and height are multiples of 16 and
+    // 8 -- the luma planes through k_decode_packed ITSELF (one component, stride = width: the kernel, the schedule and
+    // the fix-up kernel of hvc_decode_frames) and the chroma tiles alone in k_decode_444, one after the other or side
+    // by side on two streams.
+    const int split = (aligned && !wide_only && c->decode_kernel == 0 && height % 8 == 0 && P.pl[0].cbw == P.pl[0].bw) ? fused444_mode() : 0;
+    const size_t luma_ids = split ? (size_t)n_frames * (size_t)((P.pl[0].cbw * P.pl[0].cbh + HVC_TILE - 1) / HVC_TILE) * HVC_TILE : 0;
+    if (luma_ids + (size_t)ids > c->fix_cap) { // (the luma list sits behind the 4:4:4 kernels' list)
+        void *p = c->d_fix_list;
+        size_t cap = c->fix_cap * sizeof(unsigned);
+        r = grow(c, &p, &cap, (luma_ids + (size_t)ids) * sizeof(unsigned));
+        c->d_fix_list = (unsigned *)p;
+        c->fix_cap = cap / sizeof(unsigned);
+        if (r) return r;
+        P.fix_list = c->d_fix_list;
+    }
+    if (split == 2 && !c->side_stream) {
+        // (streams of one priority may share a hardware queue and then never overlap: HVC_444_SIDE_PRIO -1 / 0 / 1 =
+        // highest / the default / lowest priority for the side stream, experiments)
+        static const int prio_sel = [] { const char *v = std::getenv("HVC_444_SIDE_PRIO"); return v ? std::atoi(v) : 0; }();
+        int least = 0, greatest = 0;
+        HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(c, hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, prio_sel < 0 ? greatest : prio_sel > 0 ? least : 0));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    auto launch_split = [&](hvc::Decode444Params &Q, hipEvent_t k0, hipEvent_t k1) -> hipError_t {
+        const hvc::Plane444K &K = Q.pl[0];
+        hvc::DecodeParams Y;
+        std::memset(&Y, 0, sizeof Y);
+        Y.coefs = Q.coefs;
+        Y.pixels = Q.out;
+        Y.coef_fs = Q.coef_fs;
+        Y.pixel_fs = Q.out_fs;
+        Y.n_frames = Q.n_frames;
+        Y.n_comp = 1;
+        Y.comp[0].bw = K.cbw;
+        Y.comp[0].bh = K.cbh;
+        Y.comp[0].nblk = K.cbw * K.cbh;
+        Y.comp[0].magic = K.cbw == 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)K.cbw - 1) / (unsigned)K.cbw);
+        Y.comp[0].qtab = K.qtab;
+        Y.comp[0].coef_off = K.coef_off;
+        Y.comp[0].plane_off = K.out_off;
+        Y.comp[0].stride = (size_t)Q.width;
+        Y.tiles_per_frame = (Y.comp[0].nblk + HVC_TILE - 1) / HVC_TILE;
+        prepare_tables(qtabs, n_qtabs, Y.qt, Y.ethr, Y.ethr_packed, Y.qpair);
+        Y.dc_plane = Q.dc_plane;
+        Y.dc_fs = Q.dc_fs;
+        Y.fix_count = c->d_fix_count + 4 + c->fix_phase_l;
+        Y.fix_count_next = c->d_fix_count + 4 + (c->fix_phase_l ^ 1);
+        Y.fix_list = c->d_fix_list + (size_t)ids;
+        Y.wide_total = reinterpret_cast<unsigned long long *>(c->d_fix_count + 2);
+        fix_assign(c, Q);
+        Q.tile0 = Q.y_tiles; // the chroma tiles alone
+        hipStream_t ys = c->stream;
+        hipError_t e = hipSuccess;
+        if (k0) e = hipEventRecord(k0, c->stream);
+        if (split == 2) { // side by side: the total is cleared once per call, both fix-up kernels add atomically
+            if (e == hipSuccess && !c->wide_total_started) e = hipMemsetAsync(Y.wide_total, 0, sizeof(unsigned long long), c->stream);
+            Y.wide_first = Q.wide_first = 2;
+            if (e == hipSuccess) e = hipEventRecord(c->ev_fork, c->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->side_stream, c->ev_fork, 0);
+            ys = c->side_stream;
+        } else {
+            Y.wide_first = Q.wide_first; // luma first: it starts the call's total where this is the call's first launch
+            Q.wide_first = 0;
+        }
+        if (e == hipSuccess) e = hvc::launch_decode(Y, ys, nullptr, nullptr);
+        if (e == hipSuccess) c->fix_phase_l ^= 1;
+        if (e == hipSuccess) e = hvc::launch_decode_444(Q, false, c->stream, nullptr, nullptr);
+        if (e == hipSuccess && split == 2) {
+            e = hipEventRecord(c->ev_join, c->side_stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+        }
+        if (e == hipSuccess && k1) e = hipEventRecord(k1, c->stream);
+        if (e == hipSuccess) fix_commit(c);
+        else {
+            if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
+            fix_reset(c);
+        }
+        return e;
+    };
     auto launch = [&](hvc::Decode444Params &Q, hipEvent_t k0, hipEvent_t k1) -> hipError_t {
         if (wide_only) { // no list, no counters: every block inside the crop
             c->wide_host = (long long)n_frames * ((long long)P.pl[0].cbw * P.pl[0].cbh + 2ll * P.pl[1].cbw * P.pl[1].cbh);
             return hvc::launch_decode_444(Q, true, c->stream, k0, k1);
         }
+        if (split) return launch_split(Q, k0, k1);
         fix_assign(c, Q);
         const hipError_t e = hvc::launch_decode_444(Q, false, c->stream, k0, k1);
         if (e == hipSuccess) fix_commit(c);

@@ -787,7 +787,12 @@ __global__ __launch_bounds__(64) void k_decode_wide(DecodeParams P, const unsign
     // current one and clears the other for the next call (no memset node).
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (P.fix_count_next) *P.fix_count_next = 0;
-        if (P.wide_total && list) *P.wide_total = P.wide_first ? n : *P.wide_total + n; // hvc_last_wide_blocks: the call's total
+        // hvc_last_wide_blocks: the call's total (1 = this launch starts it, 0 = adds in stream order, 2 = adds beside
+        // another stream's launch)
+        if (P.wide_total && list) {
+            if (P.wide_first == 2) atomicAdd(P.wide_total, n);
+            else *P.wide_total = P.wide_first ? n : *P.wide_total + n;
+        }
     }
     for (unsigned long long i = (unsigned long long)blockIdx.x * 64 + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * 64) {
@@ -942,9 +947,6 @@ __device__ __forceinline__ void emit_rows444(uint8_t *row_even, size_t W, int x0
                      __builtin_amdgcn_perm(q1, v1, LO), __builtin_amdgcn_perm(q1, v1, HI));
 }
 
-#ifndef HVC_444_MODE_DEFAULT
-#define HVC_444_MODE_DEFAULT 0
-#endif
 #ifdef HVC_444_WAVES /* experiments: -DHVC_444_WAVES=4 */
 #define HVC_444_ATTR __attribute__((amdgpu_waves_per_eu(HVC_444_WAVES, HVC_444_WAVES)))
 #else
@@ -956,7 +958,7 @@ __global__ __launch_bounds__(HVC_TILE * NW, 4 / NW) HVC_444_ATTR void k_decode_4
     constexpr int WGS = HVC_TILE * NW, TW = HVC_444_TILE_BW * NW;
     __shared__ uint4 edge[WGS]; // per lane: first row (x, y) and first column (z, w) of its chroma block
     const int lane = threadIdx.x;
-    const int tile = (int)blockIdx.x + P.tile0;        // (tile0 = y_tiles when the luma tiles run in k_decode_444_luma)
+    const int tile = (int)blockIdx.x + P.tile0;        // (tile0 = y_tiles when the luma planes went through k_decode_packed)
     const bool chroma = tile >= P.y_tiles;             // workgroup-uniform
     if (P.skip && P.skip == (chroma ? 2 : 1)) return;  // (measurements: one half of the kernel alone)
     const Ref444 r = locate444(P, tile, lane, WGS, TW);
@@ -1044,69 +1046,6 @@ __global__ __launch_bounds__(HVC_TILE * NW, 4 / NW) HVC_444_ATTR void k_decode_4
     }
 }
 
-// The luma tiles of the fused path as a kernel of their own: k_decode_packed's workgroup (256 lanes) and launch bounds,
-// so that hipcc gives it k_decode_packed's schedule (<= 4 waves / SIMD, rows interleaved) -- inside k_decode_444 the
-// same macro body is scheduled for 75 VGPRs / 6 waves and the luma half alone ran at 67 % of the HBM peak where
-// k_decode_packed reaches 72-75 % on the same access shape.  Same linear block order over the cropped block
-// grid as k_decode_444's luma tiles (a tile of 256 * nw blocks = nw consecutive workgroups here), same fix-list ids.
-template <bool ALIGNED, bool DCP>
-__global__ __launch_bounds__(HVC_PACKED_LB) void k_decode_444_luma(Decode444Params P) {
-    const int lane = threadIdx.x;
-    const Plane444K &K = P.pl[0];
-    const int n = K.cbw * K.cbh;
-    int b = (int)blockIdx.x * HVC_TILE + lane;
-    const bool active = b < n;
-    b = active ? b : n - 1;
-    const unsigned by = K.cbw == 1 ? (unsigned)b : __umulhi((unsigned)b, P.y_magic);
-    const int bx = b - (int)by * K.cbw;
-    const size_t in_frame = K.coef_off + ((size_t)by * K.bw + bx) * 64;
-    const uint4 *src = reinterpret_cast<const uint4 *>(P.coefs + (size_t)blockIdx.y * P.coef_fs + in_frame);
-    const unsigned *__restrict__ qp = P.qpair + K.qtab * 32;
-    PackedGuard g;
-    unsigned out[8][2];
-    int16_t dcv = 0;
-    if (DCP) dcv = P.dc_plane[(size_t)blockIdx.y * P.dc_fs + (in_frame >> 6)];
-#if HVC_TRAFFIC_ONLY == 2
-    const int hvc_src_stride = 1;
-#endif
-    HVC_DECODE_BLOCK_PACKED(src, qp, out, g, if (DCP) w[0] = with_dc(w[0], dcv););
-    const bool bad = packed_guard_failed(g, P.ethr_packed[K.qtab]);
-    const size_t W = (size_t)P.width;
-    const int lasty = K.ah - 1 - (int)by * 8; // last block row that is inside the crop
-    if (active && !bad) {
-        uint8_t *p = P.out + (size_t)blockIdx.y * P.out_fs + K.out_off + (size_t)by * 8 * W + (size_t)bx * 8;
-        if (ALIGNED && lasty >= 7) { // (the usual block: all eight rows, k_decode_packed's store stage)
-#pragma unroll
-            for (int j = 0; j < 8; j++) store_row8(p + (size_t)j * W, out[j][0], out[j][1]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                if (j <= lasty) {
-                    if (ALIGNED) {
-                        store_row8(p + (size_t)j * W, out[j][0], out[j][1]);
-                    } else {
-                        for (int i = 0; i < 8; i++)
-                            if (bx * 8 + i < K.aw) p[(size_t)j * W + i] = (uint8_t)(out[j][i >> 2] >> (8 * (i & 3)));
-                    }
-                }
-            }
-        }
-    }
-    const bool flag = active && bad;
-    const unsigned long long m = __ballot(flag);
-    if (m) {
-        const int wl = lane & 63;
-        unsigned base = 0;
-        if (wl == 0) base = atomicAdd(P.fix_count, (unsigned)__popcll(m));
-        base = __shfl(base, 0);
-        if (flag) { // the id k_decode_444 would have given this block: tile of 256 * nw lanes, lane inside it
-            const unsigned idx = base + (unsigned)__popcll(m & ((1ull << wl) - 1ull));
-            const unsigned t444 = blockIdx.x / (unsigned)P.nw, l444 = (blockIdx.x % (unsigned)P.nw) * HVC_TILE + (unsigned)lane;
-            P.fix_list[idx] = ((unsigned)blockIdx.y * (unsigned)P.tiles_per_frame + t444) * (unsigned)(HVC_TILE * P.nw) + l444;
-        }
-    }
-}
-
 // int64 model arithmetic for listed blocks (list == nullptr: every block).  Luma blocks are written
 // as they are; a chroma block's 64 samples go to the EVEN output coordinates, where supersample_hv2
 // puts the source sample; k_reinterp_444 then rebuilds the interpolated ones around it.
@@ -1115,7 +1054,10 @@ __global__ __launch_bounds__(64) void k_decode_wide_444(Decode444Params P, const
     const unsigned long long n = list ? (unsigned long long)*count : total;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (P.fix_count_next) *P.fix_count_next = 0;
-        if (P.wide_total && list) *P.wide_total = P.wide_first ? n : *P.wide_total + n;
+        if (P.wide_total && list) {
+            if (P.wide_first == 2) atomicAdd(P.wide_total, n);
+            else *P.wide_total = P.wide_first ? n : *P.wide_total + n;
+        }
     }
     for (unsigned long long i = (unsigned long long)blockIdx.x * 64 + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * 64) {
@@ -1701,43 +1643,6 @@ static void launch_444_kernel(const Decode444Params &Q, dim3 grid, unsigned pad,
         hipLaunchKernelGGL((k_decode_444<ALIGNED, false, NW>), grid, dim3(HVC_TILE * NW), pad, s, Q);
 }
 
-template <bool ALIGNED>
-static void launch_444_luma(const Decode444Params &Q, hipStream_t s) {
-    const dim3 grid((unsigned)(Q.y_tiles * Q.nw), (unsigned)Q.n_frames, 1);
-    if (Q.dc_plane)
-        hipLaunchKernelGGL((k_decode_444_luma<ALIGNED, true>), grid, dim3(HVC_TILE), 0, s, Q);
-    else
-        hipLaunchKernelGGL((k_decode_444_luma<ALIGNED, false>), grid, dim3(HVC_TILE), 0, s, Q);
-}
-
-// How the fused path's block stage is launched (HVC_444_MODE, experiments; the default is what measured best):
-//   0  one kernel, luma and chroma tiles in one grid (k_decode_444)
-//   1  luma tiles in k_decode_444_luma, then the chroma tiles in k_decode_444, one after the other on the stream
-//   2  the same two kernels side by side: the chroma kernel on a side stream between a fork and a join event
-static int mode_444() {
-    static const int m = [] { const char *v = getenv("HVC_444_MODE"); return v ? atoi(v) : HVC_444_MODE_DEFAULT; }();
-    return m;
-}
-struct Side444 { // per device: the side stream and its fork / join events (created on first use, kept for the process)
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-};
-static Side444 *side_444() {
-    static Side444 side[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    Side444 &S = side[dev];
-    if (!S.stream) {
-        if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&S.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&S.join, hipEventDisableTiming) != hipSuccess) {
-            S.stream = nullptr;
-            return nullptr;
-        }
-    }
-    return &S;
-}
-
 hipError_t launch_decode_444(const Decode444Params &P, bool wide_only, hipStream_t s, hipEvent_t k0, hipEvent_t k1) {
     if (P.n_frames <= 0 || P.tiles_per_frame <= 0) return hipSuccess;
     if (P.nw != 1 && P.nw != 2 && P.nw != 4) return hipErrorInvalidValue;
@@ -1763,38 +1668,16 @@ hipError_t launch_decode_444(const Decode444Params &P, bool wide_only, hipStream
     // HVC_444_LDS_PAD=bytes (experiments): dynamic LDS nobody uses, to hold the kernel to fewer workgroups per CU
     static const unsigned pad = [] { const char *v = getenv("HVC_444_LDS_PAD"); return v ? (unsigned)atoi(v) : 0u; }();
     if (!aligned && P.nw != 1) return hipErrorInvalidValue; // (plan_decode_444 was told otherwise)
-    int mode = only ? 0 : mode_444();
-    Side444 *side = mode == 2 ? side_444() : nullptr;
-    if (mode == 2 && !side) mode = 1;
-    hipStream_t cs = s; // the stream of the chroma tiles
-    dim3 cgrid = grid;
-    if (mode != 0) {
-        if (mode == 2) {
-            hipError_t e = hipEventRecord(side->fork, s);
-            if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
-            if (e != hipSuccess) return e;
-            cs = side->stream;
-        }
-        if (aligned)
-            launch_444_luma<true>(Q, s);
-        else
-            launch_444_luma<false>(Q, s);
-        Q.tile0 = P.y_tiles;
-        cgrid = dim3((unsigned)(P.tiles_per_frame - P.y_tiles), (unsigned)P.n_frames, 1);
-    }
+    // P.tile0 = P.y_tiles: the chroma tiles alone (the luma planes went through k_decode_packed: hvc_capi.hip)
+    const dim3 cgrid((unsigned)(P.tiles_per_frame - P.tile0), (unsigned)P.n_frames, 1);
     if (!aligned)
-        launch_444_kernel<false, 1>(Q, cgrid, 0, cs);
+        launch_444_kernel<false, 1>(Q, cgrid, 0, s);
     else if (P.nw == 1)
-        launch_444_kernel<true, 1>(Q, cgrid, pad, cs);
+        launch_444_kernel<true, 1>(Q, cgrid, pad, s);
     else if (P.nw == 2)
-        launch_444_kernel<true, 2>(Q, cgrid, pad, cs);
+        launch_444_kernel<true, 2>(Q, cgrid, pad, s);
     else
-        launch_444_kernel<true, 4>(Q, cgrid, pad, cs);
-    if (mode == 2) {
-        hipError_t e = hipEventRecord(side->join, cs);
-        if (e == hipSuccess) e = hipStreamWaitEvent(s, side->join, 0);
-        if (e != hipSuccess) return e;
-    }
+        launch_444_kernel<true, 4>(Q, cgrid, pad, s);
     if (k1) (void)hipEventRecord(k1, s);
     hipLaunchKernelGGL(k_decode_wide_444, dim3(256), dim3(64), 0, s, P, (const unsigned *)P.fix_count,
                        (const unsigned *)P.fix_list, 0ull, (const long long *)nullptr);
