@@ -16,6 +16,7 @@
 #include <new>
 #include <thread>
 #include <deque>
+#include <functional>
 #include <vector>
 
 #include "../../include/hvc_jpeg.h"
@@ -1489,12 +1490,26 @@ int hvc_upsample420(hvc_ctx *c, const uint8_t *src, int cw, int ch, size_t src_s
 // ---------------------------------------------------------------------------
 // single-frame conveniences (host memory)
 
+// after_reader (optional): called once the reader's launches are enqueued and BEFORE its verdict is known -- the caller
+// enqueues what consumes the records (block stage, download) on the same stream, so that one call costs one host
+// synchronisation instead of two; *speculated tells whether what it enqueued ran on valid records.
+struct AfterReader {
+    std::function<int()> enqueue; // an hvc_status
+    bool speculated = false;      // out: enqueue() ran, and behind a reader run whose verdict was good
+    // The consumer is the block stage: the reader's DC pass then writes the DC values to this compact array
+    // (hvc::DecodeParams::dc_plane, one per block of the frame record) instead of 2 bytes into each 128-byte record --
+    // a partial-line write apiece, 35 of a single file's 430 us -- and the records keep the DC difference.
+    int16_t *dc_plane = nullptr;
+    size_t dc_fs = 0;
+};
 static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *sizes, int n_frames,
-                              const hvc_jpeg_info &info0, int16_t *d_coefs, size_t coef_fs, int *used_gpu);
+                              const hvc_jpeg_info &info0, int16_t *d_coefs, size_t coef_fs, int *used_gpu,
+                              AfterReader *after = nullptr);
 
 // One file: Huffman reader on the GPU (hvc_hdec.hip) into device scratch; *used = 0 when the stream needs the
 // host decoder (nothing usable on the device then).
-static int single_frame_coefs_on_device(hvc_ctx *c, const uint8_t *jpeg, size_t n, const hvc_jpeg_info *info, int *used) {
+static int single_frame_coefs_on_device(hvc_ctx *c, const uint8_t *jpeg, size_t n, const hvc_jpeg_info *info, int *used,
+                                        AfterReader *after = nullptr) {
     *used = 0;
     // Below ~128 kB the host reader is done before the GPU decoder's launches and synchronisations are
     // (tools/bench_single.py on 1080p: 64 kB file 0.39 ms on the host vs 0.8 ms; 228 kB 1.7 vs 0.8 ms; 967 kB 3.9 vs 1.6 ms).
@@ -1503,7 +1518,13 @@ static int single_frame_coefs_on_device(hvc_ctx *c, const uint8_t *jpeg, size_t 
     if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
     int r = grow(c, &c->gd_coefs, &c->gd_coefs_cap, info->coef_count * sizeof(int16_t));
     if (r) return r;
-    return gpu_entropy_decode(c, &jpeg, &n, 1, *info, (int16_t *)c->gd_coefs, info->coef_count, used);
+    if (after && c->decode_kernel != 1 && c->decode_kernel != 3) { // (the A/B alternates read the DC from the record)
+        const size_t blocks = info->coef_count / 64;
+        if ((r = grow(c, &c->gd_dcv, &c->gd_dcv_cap, ((blocks + 127) & ~(size_t)127) * sizeof(int16_t)))) return r;
+        after->dc_plane = (int16_t *)c->gd_dcv;
+        after->dc_fs = blocks;
+    }
+    return gpu_entropy_decode(c, &jpeg, &n, 1, *info, (int16_t *)c->gd_coefs, info->coef_count, used, after);
 }
 
 // One frame whose record came from the host reader with blocks on the wide-DC list: upload, block stage, the int64
@@ -1550,16 +1571,26 @@ int hvc_jpeg_decode_yuv444(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_i
         return HVC_E_INVALID_ARG;
     if (frame_cap < (size_t)3 * info->width * info->height) return HVC_E_INVALID_ARG;
     int on_gpu = 0;
-    if ((r = single_frame_coefs_on_device(c, jpeg, n, info, &on_gpu))) return r;
-    if (on_gpu) { // coefficient record already on the device: fused block stage there, one download
+    const size_t fb = (size_t)3 * info->width * info->height;
+    AfterReader after;
+    // coefficient record on the device: fused block stage there, one download -- enqueued behind the reader at once
+    auto block_stage = [&]() -> int {
         DeviceGuard g(c->device);
-        const size_t fb = (size_t)3 * info->width * info->height;
-        if ((r = grow(c, &c->d_out, &c->out_cap, fb))) return r;
-        r = hvc_decode_frames_yuv444(c, (const int16_t *)c->gd_coefs, info->coef_count, &info->qtabs[0][0], info->n_qtabs,
-                                     info->layout, info->n_comp, 1, info->width, info->height, (uint8_t *)c->d_out, fb,
-                                     HVC_MEM_DEVICE);
-        if (r) return r;
+        int e = grow(c, &c->d_out, &c->out_cap, fb);
+        if (e) return e;
+        e = decode_frames_yuv444_impl(c, (const int16_t *)c->gd_coefs, info->coef_count, &info->qtabs[0][0], info->n_qtabs,
+                                      info->layout, info->n_comp, 1, info->width, info->height, (uint8_t *)c->d_out, fb,
+                                      HVC_MEM_DEVICE, after.dc_plane, after.dc_fs);
+        if (e) return e;
         HIPCHK(c, hipMemcpyAsync(frame, c->d_out, fb, hipMemcpyDeviceToHost, c->stream));
+        return HVC_OK;
+    };
+    after.enqueue = block_stage;
+    if ((r = single_frame_coefs_on_device(c, jpeg, n, info, &on_gpu, &after))) return r;
+    if (on_gpu) {
+        if (after.speculated) return HVC_OK; // (the reader's one synchronisation covered the download)
+        DeviceGuard g(c->device);
+        if ((r = block_stage())) return r;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return HVC_OK;
     }
@@ -1584,14 +1615,25 @@ int hvc_jpeg_decode(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_info *in
     if (r) return r;
     if (pixel_cap < info->pixel_bytes) return HVC_E_INVALID_ARG;
     int on_gpu = 0;
-    if ((r = single_frame_coefs_on_device(c, jpeg, n, info, &on_gpu))) return r;
-    if (on_gpu) { // coefficient record already on the device: block stage there, one download
+    AfterReader after;
+    // coefficient record on the device: ALL components' block stage there in one launch, one download -- enqueued
+    // behind the reader at once
+    auto block_stage = [&]() -> int {
         DeviceGuard g(c->device);
-        if ((r = grow(c, &c->d_out, &c->out_cap, info->pixel_bytes))) return r;
-        r = hvc_decode_frames(c, (const int16_t *)c->gd_coefs, info->coef_count, &info->qtabs[0][0], info->n_qtabs, info->layout,
-                              info->n_comp, 1, (uint8_t *)c->d_out, info->pixel_bytes, HVC_MEM_DEVICE);
-        if (r) return r;
+        int e = grow(c, &c->d_out, &c->out_cap, info->pixel_bytes);
+        if (e) return e;
+        e = decode_frames_impl(c, (const int16_t *)c->gd_coefs, info->coef_count, &info->qtabs[0][0], info->n_qtabs, info->layout,
+                               info->n_comp, 1, (uint8_t *)c->d_out, info->pixel_bytes, HVC_MEM_DEVICE, after.dc_plane, after.dc_fs);
+        if (e) return e;
         HIPCHK(c, hipMemcpyAsync(pixels, c->d_out, info->pixel_bytes, hipMemcpyDeviceToHost, c->stream));
+        return HVC_OK;
+    };
+    after.enqueue = block_stage;
+    if ((r = single_frame_coefs_on_device(c, jpeg, n, info, &on_gpu, &after))) return r;
+    if (on_gpu) {
+        if (after.speculated) return HVC_OK; // (the reader's one synchronisation covered the download)
+        DeviceGuard g(c->device);
+        if ((r = block_stage())) return r;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return HVC_OK;
     }
@@ -2028,25 +2070,49 @@ static unsigned gd_component_selmask(const hvc::HdParams &P) {
     return m;
 }
 
-// Enqueue the whole decode on `st`: flags cleared, `rounds` synchronisation launches, finish passes.
-// P.changed afterwards holds the last launch's flag (0 = settled), P.status the error bits.
+// Enqueue the whole decode on `st`: the clearing launch (frame_of, flags, list lengths), `rounds` synchronisation
+// launches, the finish passes -- kernels only, no memset node in between.  Afterwards *P.changed holds the number of the
+// last launch that still changed something (gd_unsettled), *P.status the error bits.
 static hipError_t gd_enqueue(const hvc::HdParams &P, int rounds, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(P.changed, 0, 2 * sizeof(unsigned), st); // changed + status are adjacent
-    for (int r = 0; r < rounds && e == hipSuccess; r++) {
-        if (r > 0) e = hipMemsetAsync(P.changed, 0, sizeof(unsigned), st);
-        if (e == hipSuccess) e = hvc::launch_hd_round(P, r, st);
-    }
+    hipError_t e = hvc::launch_hd_frame_of(P, st);
+    for (int r = 0; r < rounds && e == hipSuccess; r++) e = hvc::launch_hd_round(P, r, st);
     if (e == hipSuccess) e = hvc::launch_hd_finish(P, rounds, st);
     return e;
 }
+// the `changed` word after gd_enqueue(P, rounds): the last of the launches 0 .. rounds - 1 still moved a hand-over
+static bool gd_unsettled(unsigned changed_word, int rounds) { return rounds > 1 && changed_word == (unsigned)(rounds - 1); }
 
 // ---------------------------------------------------------------------------
 // Huffman decoding on the GPU (hvc_hdec.hip).  Returns HVC_OK with *used_gpu = 1 when the coefficient
 // records at d_coefs are complete; HVC_OK with *used_gpu = 0 when the stream needs the host decoder
 // (nothing usable was written); or the error the host decoder would report while parsing headers.
+// HVC_CALL_TIMING=1 (experiments): where a single-file call spends its host time, to stderr
+static bool call_timing() {
+    static const bool on = std::getenv("HVC_CALL_TIMING") != nullptr;
+    return on;
+}
+struct StageClock {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    char line[512];
+    int n = 0;
+    void mark(const char *what) {
+        if (!call_timing()) return;
+        const auto now = std::chrono::steady_clock::now();
+        n += std::snprintf(line + n, sizeof line - (size_t)n, " %s %.1f", what, std::chrono::duration<double, std::micro>(now - last).count());
+        if (n > (int)sizeof line - 64) n = (int)sizeof line - 64;
+        last = now;
+    }
+    void done() {
+        if (!call_timing()) return;
+        std::fprintf(stderr, "hvc call timing (us):%s | total %.1f\n", line, std::chrono::duration<double, std::micro>(last - t0).count());
+    }
+};
+
 static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *sizes, int n_frames,
-                              const hvc_jpeg_info &info0, int16_t *d_coefs, size_t coef_fs, int *used_gpu) {
+                              const hvc_jpeg_info &info0, int16_t *d_coefs, size_t coef_fs, int *used_gpu, AfterReader *after) {
     *used_gpu = 0;
+    if (after) after->speculated = false;
+    StageClock clk;
     // Huffman tables per file (decoder.ml:238-259 picks them from the file's own DHT segments): the distinct sets of
     // the batch and which one every frame uses.  One set that fits two slots = the fast LDS-table kernels; anything
     // else = per-frame tables in device memory (PF mode, hvc_hdec.h).
@@ -2111,6 +2177,7 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
     } catch (const std::bad_alloc &) {
         return HVC_E_OUT_OF_MEMORY;
     }
+    clk.mark("headers+unstuff");
     const hvc::HdTables &tables0 = sets[0];
     hvc::HdParams P;
     if (!gd_geometry(info0, P)) return HVC_OK;
@@ -2185,15 +2252,33 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
     P.frame_blocks = d_frame_blocks;
     P.changed = d_flags;
     P.status = d_flags + 1;
+    if (after && after->dc_plane) {
+        P.dc_plane = after->dc_plane;
+        P.dc_fs = after->dc_fs;
+    }
     // (no clearing of the records: the write pass stores every index of every coded block exactly once)
     // Everything in one go, as the batch pipeline does: four synchronisation launches (all of k_hd_sync's rounds count
     // as the first), the finish passes, one look at the two flags.  Only a stream that has not settled by then -- smooth
     // content can take hundreds of rounds -- is done again round by round.
-    HIPCHK(c, hvc::launch_hd_frame_of(P, st));
-    HIPCHK(c, gd_enqueue(P, 4, st)); // clears the flags first
+    clk.mark("uploads-enqueued");
+    const int first_rounds = 4;
+    HIPCHK(c, gd_enqueue(P, first_rounds, st)); // (its first launch clears the flags and the list lengths)
+    clk.mark("reader-enqueued");
+    // The consumer of the records goes in behind the reader before anybody has looked at the reader's flags: a call
+    // that waited for them first and launched the block stage afterwards stood still for 75 us in between (one file:
+    // profiles/r03e_single_call_timeline_before.txt).  Records of a run that turns out unusable are garbage of the
+    // right size: the consumer's output is thrown away then.
+    bool consumer_enqueued = false;
+    if (after && after->enqueue) {
+        if ((r = after->enqueue())) return r;
+        consumer_enqueued = true;
+    }
+    clk.mark("consumer-enqueued");
     unsigned flags[2] = {0, 0};
     HIPCHK(c, hipMemcpyAsync(flags, P.changed, sizeof flags, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    clk.mark("synchronised");
+    clk.done();
 #ifdef HVC_HD_STATS // experiments: entries of k_hd_sync's work lists per round; walks / inner rounds of k_hd_round's launches
     {
         unsigned ln[HVC_HD_LIST_N];
@@ -2210,18 +2295,18 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
                      own, over, 100.0 * (double)over / (double)(own ? own : 1), hs[3], 100.0 * (double)(own + over) / (double)(hs[3] ? hs[3] : 1));
     }
 #endif
-    if (flags[0]) { // (the finish passes have turned the block counts into block indices: the rounds start over)
+    if (gd_unsettled(flags[0], first_rounds)) { // (the finish passes have turned the block counts into block indices: the rounds start over)
+        consumer_enqueued = false; // (it ran on records the write pass never stored)
         const int max_rounds = 48;
         int round = 0;
-        HIPCHK(c, hipMemsetAsync(P.changed, 0, 2 * sizeof(unsigned), st));
+        HIPCHK(c, hvc::launch_hd_frame_of(P, st)); // flags and list lengths cleared again
         for (;; round++) {
-            if (round > 0) HIPCHK(c, hipMemsetAsync(P.changed, 0, sizeof(unsigned), st));
             HIPCHK(c, hvc::launch_hd_round(P, round, st));
             if (round >= 4) {
                 unsigned changed = 0;
                 HIPCHK(c, hipMemcpyAsync(&changed, P.changed, sizeof changed, hipMemcpyDeviceToHost, st));
                 HIPCHK(c, hipStreamSynchronize(st));
-                if (!changed) break;
+                if (!gd_unsettled(changed, round + 1)) break;
                 if (round >= max_rounds) return HVC_OK; // does not settle: let the host decoder handle it
             }
         }
@@ -2232,6 +2317,7 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
     const unsigned status = flags[1];
     if (status) return HVC_OK; // the model raises / range / truncated stream: the host decoder reproduces it exactly
     *used_gpu = 1;
+    if (after) after->speculated = consumer_enqueued;
     return HVC_OK;
 }
 
@@ -2597,7 +2683,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
             }
             if (he != hipSuccess) { rc = fail_hip(c, he); break; }
             const unsigned *flags = (const unsigned *)c->gp_h_meta[slot] + (meta_words - 2);
-            if (flags[0] || flags[1]) chunk_host[(size_t)v] = 1; // not settled / the model raises / truncated: what was decoded is redone
+            if (gd_unsettled(flags[0], 4) || flags[1]) chunk_host[(size_t)v] = 1; // not settled / the model raises / truncated: what was decoded is redone
             float ms = 0; // stage times of the chunk that just finished (read late so that nothing waits for them)
             if (hipEventElapsedTime(&ms, c->ev_et[slot][0], c->ev_h2d[slot]) == hipSuccess) h2d_ms += ms;
             if (hipEventElapsedTime(&ms, c->ev_et[slot][1], c->ev_et[slot][2]) == hipSuccess) k_ms += ms;
@@ -2683,7 +2769,6 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         // (the slot's records and index arrays are free: the verdict above waited for chunk k - NB's block stage)
         if (he == hipSuccess) he = hipStreamWaitEvent(rs, c->ev_h2d[slot], 0);
         if (he == hipSuccess) he = hipEventRecord(c->ev_et[slot][1], rs);
-        if (he == hipSuccess) he = hvc::launch_hd_frame_of(P, rs);
         if (he == hipSuccess) he = gd_enqueue(P, 4, rs);
         if (he == hipSuccess) // changed + status -> the pinned copy of the index arrays
             he = hipMemcpyAsync(hm + (meta_words - 2), P.changed, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, rs);

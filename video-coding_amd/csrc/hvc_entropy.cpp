@@ -17,6 +17,7 @@
 #include <vector>
 
 #include <emmintrin.h>
+#include <tmmintrin.h>
 
 #include "../../include/hvc_jpeg.h"
 #include "hvc_hdec.h"
@@ -736,9 +737,66 @@ void default_enc_tables(uint32_t (*out)[16 + 256]) {
 // (decoder.ml:261-281): up to the first marker, 0xff00 -> 0xff
 // The entropy-coded segment without its stuffing (0xFF 0x00 -> 0xFF), up to the first marker, into dst[0, cap):
 // the number of bytes, or SIZE_MAX when cap is too small.
+// 16 bytes at a time (SSE2 compares, SSSE3 byte shuffle): the stuffed zeros -- a 0x00 right behind an 0xFF -- are
+// squeezed out through a table of shuffles, 8 bytes per look-up.  A chunk holding a marker (0xFF followed by anything
+// but 0x00) or too close to the end of the data is left to the byte-wise loop behind it.  A low-quality 1080p file has an
+// 0xFF every ~20 bytes (10 795 of them in 228 kB at quality 3): the memchr + memcpy pair per run that stood here cost a
+// single file's call 90 of its 650 us, and the batch pipelines' workers the same per file.
+struct UnstuffLut {
+    alignas(16) uint8_t shuf[256][8]; // [mask of bytes to keep]: their positions, packed to the front (0x80 = zero fill)
+    UnstuffLut() {
+        for (int m = 0; m < 256; m++) {
+            int k = 0;
+            for (int i = 0; i < 8; i++)
+                if (m & (1 << i)) shuf[m][k++] = (uint8_t)i;
+            while (k < 8) shuf[m][k++] = 0x80;
+        }
+    }
+};
+__attribute__((target("ssse3,popcnt"))) static void unstuff_chunks(const uint8_t *data, size_t n, size_t &pos, uint8_t *dst, size_t cap,
+                                                                   size_t &out) {
+    static const UnstuffLut lut;
+    const __m128i ff16 = _mm_set1_epi8((char)0xff), zero16 = _mm_setzero_si128();
+    unsigned prev_ff = 0; // the byte in front of the chunk was an 0xFF that belongs to the data
+    while (pos + 17 <= n && out + 16 <= cap) { // (+ 1: the byte behind the chunk decides about an 0xFF in its last place)
+        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(data + pos));
+        const unsigned m_ff = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(v, ff16));
+        if (!(m_ff | prev_ff)) {
+            _mm_storeu_si128(reinterpret_cast<__m128i *>(dst + out), v);
+            pos += 16;
+            out += 16;
+            continue;
+        }
+        const unsigned m_zero = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(v, zero16));
+        const unsigned next_zero = data[pos + 16] == 0x00 ? 1u : 0u;
+        // an 0xFF whose successor is not 0x00 is a marker (decoder.ml:261-281 stops there): the byte-wise loop takes over
+        if (m_ff & ~((m_zero >> 1) | (next_zero << 15)) & 0xffffu) break;
+        const unsigned drop = m_zero & ((m_ff << 1) | prev_ff) & 0xffffu; // zeros right behind an 0xFF
+        const unsigned keep = ~drop & 0xffffu;
+        const __m128i lo = _mm_shuffle_epi8(v, _mm_loadl_epi64(reinterpret_cast<const __m128i *>(lut.shuf[keep & 0xffu])));
+        const __m128i hi = _mm_shuffle_epi8(_mm_srli_si128(v, 8), _mm_loadl_epi64(reinterpret_cast<const __m128i *>(lut.shuf[keep >> 8])));
+        _mm_storel_epi64(reinterpret_cast<__m128i *>(dst + out), lo);
+        out += (size_t)__builtin_popcount(keep & 0xffu);
+        _mm_storel_epi64(reinterpret_cast<__m128i *>(dst + out), hi); // (8 bytes each: out + 16 <= cap was checked)
+        out += (size_t)__builtin_popcount(keep >> 8);
+        pos += 16;
+        prev_ff = (m_ff >> 15) & 1u;
+    }
+    // hand over on a boundary the byte-wise loop understands: it expects to look at an 0xFF itself, so if the chunk
+    // loop stopped right behind one (prev_ff), give that byte back
+    if (prev_ff) {
+        pos -= 1;
+        out -= 1;
+    }
+}
+
 static size_t extract_ecs_to(const uint8_t *data, size_t n, size_t pos, uint8_t *dst, size_t cap) {
     size_t out = 0;
+    static const bool simd = __builtin_cpu_supports("ssse3") && __builtin_cpu_supports("popcnt");
     while (pos < n) {
+        if (simd) unstuff_chunks(data, n, pos, dst, cap, out);
+        if (pos >= n) break;
+        // byte-wise from here to the next 0xFF pair (the end of the segment, a marker, or data the chunk loop left)
         const uint8_t *ff = (const uint8_t *)std::memchr(data + pos, 0xff, n - pos);
         const size_t stop = ff ? (size_t)(ff - data) : n;
         if (stop - pos > cap - out) return SIZE_MAX;
@@ -750,6 +808,22 @@ static size_t extract_ecs_to(const uint8_t *data, size_t n, size_t pos, uint8_t 
         if (out == cap) return SIZE_MAX;
         dst[out++] = 0xff;
         pos = stop + 2;
+        if (n - pos < 17 || cap - out < 16) { // too little left for the chunk loop: finish byte-wise
+            while (pos < n) {
+                const uint8_t *f2 = (const uint8_t *)std::memchr(data + pos, 0xff, n - pos);
+                const size_t st2 = f2 ? (size_t)(f2 - data) : n;
+                if (st2 - pos > cap - out) return SIZE_MAX;
+                std::memcpy(dst + out, data + pos, st2 - pos);
+                out += st2 - pos;
+                if (!f2) return out;
+                const int nx = st2 + 1 < n ? data[st2 + 1] : 0;
+                if (nx != 0x00) return out;
+                if (out == cap) return SIZE_MAX;
+                dst[out++] = 0xff;
+                pos = st2 + 2;
+            }
+            break;
+        }
     }
     return out;
 }

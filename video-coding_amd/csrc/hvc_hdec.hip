@@ -40,6 +40,12 @@ namespace {
 
 constexpr int S = HVC_HD_SUBSEQ_BITS;
 
+// After `rounds_done` synchronisation launches (0 .. rounds_done - 1): did the last one still change something?
+// k_hd_round stamps *P.changed with the number of the launch that changed something (launch 0 never does).
+__device__ __forceinline__ bool hd_unsettled(const HdParams &P, int rounds_done) {
+    return rounds_done > 1 && *P.changed == (unsigned)(rounds_done - 1);
+}
+
 __device__ __forceinline__ unsigned long long pack_state(unsigned p, int k, int b) {
     return (unsigned long long)p | ((unsigned long long)(unsigned)k << 32) | ((unsigned long long)(unsigned)b << 40);
 }
@@ -365,7 +371,10 @@ __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
         cur[i] = ex;
         P.start_used[i] = used;
         P.nblk[i] = nb;
-        if (changed && round > 0) *P.changed = 1u; // benign race: every writer stores the same value
+        // Stamped with the launch's number, not set to 1: "did the LAST launch change anything" is then `*P.changed ==
+        // last launch` with no clearing between launches (each clearing was a memset node: ~5 us of stream time apiece,
+        // which a batch hides and a single file's call does not).  Benign race: every writer stores the same value.
+        if (changed && round > 0) *P.changed = (unsigned)round;
     }
 }
 
@@ -717,7 +726,7 @@ __global__ __launch_bounds__(256) void k_hd_write(HdParams P, int final_round) {
     // Launched behind the synchronisation rounds without a look at their verdict (no host round trip): when the last
     // round still changed something the hand-overs are not consistent, block indices and states need not agree, and
     // nothing may be stored -- the caller sees the flag and redoes the chunk (k_hd_write2 and k_hd_dc likewise).
-    if (*P.changed) return;
+    if (hd_unsettled(P, final_round)) return;
     if (!valid) return;
     const unsigned first_block = P.nblk[i];
     if (first_block >= P.blocks_per_frame) return; // past the last coded block: the model never reads this far
@@ -798,7 +807,7 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
     const unsigned i = blockIdx.x * (unsigned)WG + (unsigned)tid;
     const bool valid = i < P.total_sub;
     const unsigned f = valid ? P.frame_of[i] : 0u, j = valid ? i - P.sub_off[f] : 0u;
-    if (*P.changed) return; // not settled: nothing is stored (see k_hd_write); uniform, before any barrier
+    if (hd_unsettled(P, final_round)) return; // not settled: nothing is stored (see k_hd_write); uniform, before any barrier
     // PF: the workgroup's subsequences are consecutive -- nearly always of ONE frame, whose tables (two components'
     // worth: HdFrameTabs::flags) then go to LDS like the batch-wide ones
     bool pf_lds = false;
@@ -1014,11 +1023,11 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
 
 // DC differences -> DC values (decoder.ml:143): inclusive prefix sum over the component's blocks in scan
 // order, one workgroup per (component, frame).
-__global__ __launch_bounds__(1024) void k_hd_dc(HdParams P) {
+__global__ __launch_bounds__(1024) void k_hd_dc(HdParams P, int final_round) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int comp = blockIdx.x, frame = blockIdx.y, lane = threadIdx.x, wave = lane >> 6, wl = lane & 63;
-    if (comp >= P.n_comp || *P.changed) return; // (not settled: the write pass stored nothing)
+    if (comp >= P.n_comp || hd_unsettled(P, final_round)) return; // (not settled: the write pass stored nothing)
     const HdComp &C = P.comp[comp];
     const int hv = C.h * C.v;
     const unsigned n = (unsigned)P.mbs_wide * (unsigned)P.mbs_high * (unsigned)hv;
@@ -1029,18 +1038,29 @@ __global__ __launch_bounds__(1024) void k_hd_dc(HdParams P) {
     if (lane == 0) carry_s = 0;
     __syncthreads();
     bool bad = false;
-    for (unsigned base = 0; base < n; base += 1024) {
-        const unsigned o = base + (unsigned)lane;
-        int16_t *dcp = nullptr;
-        int v = 0;
-        if (o < n) {
-            const unsigned m = o / (unsigned)hv, r = o - m * (unsigned)hv;
-            const unsigned sy = r / (unsigned)C.h, sx = r - sy * (unsigned)C.h;
-            const unsigned my = m / (unsigned)P.mbs_wide, mx = m - my * (unsigned)P.mbs_wide;
-            dcp = rec + ((size_t)(my * C.v + sy) * C.bw + (size_t)(mx * C.h + sx)) * 64;
-            v = dcd ? dcd[(size_t)m * (unsigned)P.blocks_per_mcu + (unsigned)C.mcu_base + r] : *dcp;
+    // DC_E consecutive blocks per lane and trip (a serial prefix in registers, then one scan of the lanes' totals): a
+    // 1080p luma component is 4 trips of the workgroup instead of 32 -- what a single file's call waits for (49 -> 10 us).
+    constexpr int DC_E = 8;
+    for (unsigned base = 0; base < n; base += 1024u * DC_E) {
+        int16_t *dcp[DC_E];
+        int v[DC_E];
+        int run = 0;
+#pragma unroll
+        for (int e = 0; e < DC_E; e++) {
+            const unsigned o = base + (unsigned)lane * DC_E + (unsigned)e;
+            dcp[e] = nullptr;
+            v[e] = 0;
+            if (o < n) {
+                const unsigned m = o / (unsigned)hv, r = o - m * (unsigned)hv;
+                const unsigned sy = r / (unsigned)C.h, sx = r - sy * (unsigned)C.h;
+                const unsigned my = m / (unsigned)P.mbs_wide, mx = m - my * (unsigned)P.mbs_wide;
+                dcp[e] = rec + ((size_t)(my * C.v + sy) * C.bw + (size_t)(mx * C.h + sx)) * 64;
+                v[e] = dcd ? dcd[(size_t)m * (unsigned)P.blocks_per_mcu + (unsigned)C.mcu_base + r] : *dcp[e];
+            }
+            run += v[e];
+            v[e] = run; // inclusive prefix inside the lane's run
         }
-        int incl = v;
+        int incl = run;
 #pragma unroll
         for (int s = 1; s < 64; s <<= 1) {
             const int t = __shfl_up(incl, s);
@@ -1050,16 +1070,19 @@ __global__ __launch_bounds__(1024) void k_hd_dc(HdParams P) {
         __syncthreads();
         int wbase = 0;
         for (int q = 0; q < wave; q++) wbase += wsum[q];
-        const int dc = carry_s + wbase + incl;
-        if (o < n) {
+        const int before = carry_s + wbase + incl - run; // everything in front of this lane's run
+#pragma unroll
+        for (int e = 0; e < DC_E; e++) {
+            if (!dcp[e]) continue;
+            const int dc = before + v[e];
             if (dc < -32768 || dc > 32767) bad = true;
             if (P.dc_plane) // 2 bytes into a compact array instead of 2 bytes into a 128-byte record (a partial-line write each)
-                P.dc_plane[(size_t)frame * P.dc_fs + (size_t)((dcp - (P.coefs + (size_t)frame * P.coef_fs)) >> 6)] = (int16_t)dc;
+                P.dc_plane[(size_t)frame * P.dc_fs + (size_t)((dcp[e] - (P.coefs + (size_t)frame * P.coef_fs)) >> 6)] = (int16_t)dc;
             else
-                *dcp = (int16_t)dc;
+                *dcp[e] = (int16_t)dc;
         }
         __syncthreads();
-        if (lane == 1023) carry_s = dc;
+        if (lane == 1023) carry_s = before + run;
         __syncthreads();
     }
     if (bad) atomicOr(P.status, 2u);
@@ -1121,22 +1144,33 @@ void make_frame_tabs(const HdTables &t, int n_comp, HdFrameTabs &out) {
 
 // frame_of[i] = the frame subsequence i belongs to, from sub_off (one workgroup per frame).  The batch pipeline used to
 // fill and upload this array per chunk: two million words written by the one thread that also feeds the copy engine.
-__global__ __launch_bounds__(256) void k_hd_frame_of(const unsigned *sub_off, unsigned *frame_of) {
-    const unsigned f = blockIdx.x, end = sub_off[f + 1];
-    for (unsigned q = sub_off[f] + threadIdx.x; q < end; q += 256u) frame_of[q] = f;
+// The same launch clears what the synchronisation launches count in -- the flags, the work lists' lengths (per batch and,
+// in PF mode, per frame): the reader's first launch, so that no memset node stands between an upload and round 0.
+__global__ __launch_bounds__(256) void k_hd_frame_of(HdParams P) {
+    const unsigned f = blockIdx.x, end = P.sub_off[f + 1];
+    unsigned *frame_of = const_cast<unsigned *>(P.frame_of);
+    for (unsigned q = P.sub_off[f] + threadIdx.x; q < end; q += 256u) frame_of[q] = f;
+    if (f == 0) {
+        if (threadIdx.x < HVC_HD_LIST_N) P.list_n[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) {
+            *P.changed = 0u;
+            *P.status = 0u;
+        }
+    }
+    if (P.list_fn && threadIdx.x < HVC_HD_LIST_N) P.list_fn[threadIdx.x * (unsigned)P.n_frames + f] = 0u;
 }
 
+// every reader run starts with this launch (launch_hd_round(P, 0, ...) relies on the cleared lists and flags)
 hipError_t launch_hd_frame_of(const HdParams &P, hipStream_t s) {
     if (P.total_sub == 0 || P.n_frames <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_hd_frame_of, dim3((unsigned)P.n_frames), dim3(256), 0, s, P.sub_off, const_cast<unsigned *>(P.frame_of));
+    hipLaunchKernelGGL(k_hd_frame_of, dim3((unsigned)P.n_frames), dim3(256), 0, s, P);
     return hipGetLastError();
 }
 
 template <bool PF>
 static hipError_t launch_hd_round_t(const HdParams &P, int round, hipStream_t s) {
     if (round == 0 && (PF || P.spec)) { // all the fast rounds; launches 1.. of k_hd_round verify and, if need be, continue
-        hipError_t e = hipMemsetAsync(P.list_n, 0, HVC_HD_LIST_N * sizeof(unsigned), s);
-        if (e != hipSuccess) return e;
+        // (list_n / list_fn are zero: launch_hd_frame_of)
         const unsigned all = (P.total_sub + (unsigned)SYNC_WG - 1u) / (unsigned)SYNC_WG;
         if (P.total_sub <= SYNC_TAIL_MAX_SUB) { // a few files: five rounds as launches, the rest inside one workgroup
             for (int r = 0; r < SYNC_TAIL_FROM; r++) hipLaunchKernelGGL(k_hd_sync<PF>, dim3(all), dim3(SYNC_WG), 0, s, P, r);
@@ -1155,8 +1189,6 @@ static hipError_t launch_hd_round_t(const HdParams &P, int round, hipStream_t s)
             return n < 2 ? 2 : n > HVC_HD_LIST_N - 4 ? HVC_HD_LIST_N - 4 : n;
         }();
         if (PF && P.list_fn && P.max_frame_sub) { // per-frame lists (k_hd_sync_pf)
-            e = hipMemsetAsync(P.list_fn, 0, (size_t)HVC_HD_LIST_N * (size_t)P.n_frames * sizeof(unsigned), s);
-            if (e != hipSuccess) return e;
             const unsigned per_frame = (P.max_frame_sub + (unsigned)SYNC_WG - 1u) / (unsigned)SYNC_WG;
             for (int r = 0; r < rounds; r++) hipLaunchKernelGGL(k_hd_sync_pf, dim3(per_frame, (unsigned)P.n_frames), dim3(SYNC_WG), 0, s, P, r);
             return hipGetLastError();
@@ -1204,7 +1236,7 @@ hipError_t launch_hd_finish(const HdParams &P, int rounds_done, hipStream_t s) {
         Q.dcd = nullptr; // k_hd_write leaves the differences in the records only
         hipLaunchKernelGGL(k_hd_write, dim3((P.total_sub + 255u) / 256u), dim3(256), 0, s, P, rounds_done);
     }
-    hipLaunchKernelGGL(k_hd_dc, dim3((unsigned)P.n_comp, (unsigned)P.n_frames), dim3(1024), 0, s, Q);
+    hipLaunchKernelGGL(k_hd_dc, dim3((unsigned)P.n_comp, (unsigned)P.n_frames), dim3(1024), 0, s, Q, rounds_done);
     return hipGetLastError();
 }
 
