@@ -69,11 +69,36 @@ def _cat(v):
     return int(abs(int(v))).bit_length()
 
 
-def jpeg_optimised_tables(w, h, chroma, qtabs, coefs, table_sets=2):
+def _many_prefix_lengths(freq):
+    """An AC table (valid, incomplete prefix code) whose codes of more than 10 bits sit under MORE 10-bit prefixes than
+    the GPU reader has sub-tables for (csrc/hvc_hdec.h HVC_HD_SUBTABLES = 8): the three most frequent symbols get 1, 2
+    and 3 bits, all 159 other run/size symbols 14 bits -- 16 codes per 10-bit prefix, ten prefixes.  Among the 14-bit
+    codes the FREQUENT symbols come last, i.e. under the ninth and tenth prefix, so that a stream really uses them."""
+    all_syms = [0x00, 0xF0] + [(r << 4) | s for r in range(16) for s in range(1, 11)]
+    assert all(f == 0 or sym in all_syms for sym, f in enumerate(freq)), "a symbol outside the baseline alphabet"
+    by_freq = sorted(all_syms, key=lambda sym: (-freq[sym], sym))
+    head, tail = by_freq[:3], sorted(by_freq[3:], key=lambda sym: (freq[sym], sym))
+    bits = [0] * 17
+    bits[1] = bits[2] = bits[3] = 1
+    bits[14] = len(tail)
+    return bits, head + tail
+
+
+def long_prefixes(bits, huffval):
+    """the 10-bit prefixes under which a table has codes of 11..16 bits, in canonical order"""
+    out = []
+    for sym, (code, ln) in sorted(_canonical(bits, huffval).items(), key=lambda kv: (kv[1][1], kv[1][0])):
+        if ln > 10 and (code >> (ln - 10)) not in out:
+            out.append(code >> (ln - 10))
+    return out
+
+
+def jpeg_optimised_tables(w, h, chroma, qtabs, coefs, table_sets=2, ac_shape=None, stats=None):
     """coefs: one frame's coefficient record in the C ABI's layout (int16, component planes back to back,
     zig-zag, DC absolute) for a w x h frame of the given sampling (the encoder's geometry, encoder.ml:437-472)
     -> a baseline JPEG whose Huffman tables are the optimal ones FOR THIS FILE (table_sets = 2: luma / chroma
     pairs as every common encoder writes them; 3: one pair per component; 1: one pair for all)."""
+    # (ac_shape / stats: below)
     hs, vs = {420: (2, 2), 422: (2, 2), 444: (1, 1)}[chroma]
     ch, cv = {420: (1, 1), 422: (1, 2), 444: (1, 1)}[chroma]  # Parameters.c422 = C 1x2 (sic), encoder.ml:347-349
     comps = [(1, hs, vs, 0), (2, ch, cv, 1), (3, ch, cv, 1)]
@@ -118,7 +143,18 @@ def jpeg_optimised_tables(w, h, chroma, qtabs, coefs, table_sets=2):
     freq = [[[0] * 256 for _ in range(2)] for _ in range(n_sets)]
     for ts, ac, sym, _, _ in syms:
         freq[ts][ac][sym] += 1
-    specs = [[_optimal_lengths(freq[ts][ac]) for ac in range(2)] for ts in range(n_sets)]
+    # ac_shape = "many_prefixes": see _many_prefix_lengths (tests of the GPU reader's overflow search); stats (a dict)
+    # receives, per table set, how many coded AC symbols sit under a prefix beyond the eighth
+    specs = [[_many_prefix_lengths(freq[ts][ac]) if (ac and ac_shape == "many_prefixes") else _optimal_lengths(freq[ts][ac])
+              for ac in range(2)] for ts in range(n_sets)]
+    if stats is not None:
+        stats["symbols_beyond_eight_prefixes"] = []
+        for ts in range(n_sets):
+            bits_, vals_ = specs[ts][1]
+            late = set(long_prefixes(bits_, vals_)[8:])
+            cd = _canonical(bits_, vals_)
+            stats["symbols_beyond_eight_prefixes"].append(
+                sum(f for sym, f in enumerate(freq[ts][1]) if f and cd[sym][1] > 10 and (cd[sym][0] >> (cd[sym][1] - 10)) in late))
     codes = [[_canonical(*specs[ts][ac]) for ac in range(2)] for ts in range(n_sets)]
     # pass 2: the bits
     acc, nb, out = 0, 0, bytearray()

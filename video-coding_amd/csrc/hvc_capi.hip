@@ -2026,26 +2026,30 @@ static void gd_carve_state(hvc::HdParams &P, void *mem, size_t n) {
 // sets, the synchronisation tables (HdSpec) behind them.  Fills P.tables / P.spec / P.slotmask.
 static int gd_upload_tables(hvc_ctx *c, const hvc::HdTables &t, hvc::HdParams &P, hipStream_t st) {
     int r;
-    if ((r = grow(c, &c->gd_tables, &c->gd_tables_cap, sizeof(hvc::HdTables) + sizeof(hvc::HdSpec)))) return r;
+    if ((r = grow(c, &c->gd_tables, &c->gd_tables_cap, sizeof(hvc::HdTables) + sizeof(hvc::HdSpec) + sizeof(hvc::HdSpecOvf)))) return r;
     hvc::HdSpec spec;
+    hvc::HdSpecOvf spec_ovf; // (the overflow records of tables with more than HVC_HD_SUBTABLES long prefixes: hvc_hdec.h)
     unsigned char slot[4];
     static const bool classic = std::getenv("HVC_HD_CLASSIC") != nullptr; // tests: force k_hd_round / k_hd_write
-    const bool have_spec = hvc::make_spec(t, P.n_comp, spec, slot, P.slot_rep) && !classic;
+    const bool have_spec = hvc::make_spec(t, P.n_comp, spec, slot, P.slot_rep, &spec_ovf) && !classic;
     // file after file with the same tables (the usual case: an encoder's fixed set) finds them on the device already
     if (!c->gd_tables_host) c->gd_tables_host = new (std::nothrow) hvc::HdTables;
     if (!c->gd_tables_host) return HVC_E_OUT_OF_MEMORY;
     if (!(c->gd_tables_valid && c->gd_tables_ncomp == P.n_comp && !std::memcmp(c->gd_tables_host, &t, sizeof t))) {
         c->gd_tables_valid = false;
         HIPCHK(c, hipMemcpyAsync(c->gd_tables, &t, sizeof t, hipMemcpyHostToDevice, st));
-        if (have_spec)
+        if (have_spec) {
             HIPCHK(c, hipMemcpyAsync((char *)c->gd_tables + sizeof t, &spec, sizeof spec, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipStreamSynchronize(st)); // both sources live on a stack frame
+            HIPCHK(c, hipMemcpyAsync((char *)c->gd_tables + sizeof t + sizeof spec, &spec_ovf, sizeof spec_ovf, hipMemcpyHostToDevice, st));
+        }
+        HIPCHK(c, hipStreamSynchronize(st)); // the sources live on a stack frame
         std::memcpy(c->gd_tables_host, &t, sizeof t);
         c->gd_tables_ncomp = P.n_comp;
         c->gd_tables_valid = true;
     }
     P.tables = (const hvc::HdTables *)c->gd_tables;
     P.spec = have_spec ? (const hvc::HdSpec *)((char *)c->gd_tables + sizeof t) : nullptr;
+    P.spec_ovf = have_spec ? (const hvc::HdSpecOvf *)((char *)c->gd_tables + sizeof t + sizeof(hvc::HdSpec)) : nullptr;
     P.ftabs = nullptr;
     P.tabset_of = nullptr;
     P.slotmask = P.selmask = 0;
@@ -2213,12 +2217,16 @@ static int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const siz
     HIPCHK(c, hipMemcpyAsync(c->gd_ecs, h_ecs, bytes, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(m, h_meta.data(), h_meta.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
     bool pf = sets.size() > 1;
+    bool any_ovf = false; // a table with prefixes beyond its sub-tables: only the fast kernels know the overflow search
+    for (const hvc::HdTables &ts : sets) any_ovf |= hvc::tables_use_overflow(ts, P.n_comp);
     if (!pf) {
         if ((r = gd_upload_tables(c, tables0, P, st))) return r;
         static const bool classic = std::getenv("HVC_HD_CLASSIC") != nullptr;
         pf = !P.spec && !classic; // one set, but three different table pairs in it: no slots for that, per-component tables
+        if (any_ovf && !P.spec && !pf) return HVC_OK; // (HVC_HD_CLASSIC: the general kernels -> the host reader has it)
     }
     P.coef_fs = coef_fs;
+    if (any_ovf && !hvc::hd_write2_fits(P)) return HVC_OK; // (k_hd_write, the general write pass, would be chosen)
     if (pf) {
         if (!hvc::hd_write2_fits(P)) return HVC_OK; // (PF mode has the fast write pass only)
         try {
@@ -2530,6 +2538,8 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     const bool uniform_ok = G.spec != nullptr;
     const bool pf_fits = (unsigned long long)C * info0.coef_count < (1ull << 35); // hvc::hd_write2_fits for a full chunk
     if (!uniform_ok && !pf_fits) return host_pipeline();
+    // tables with overflow prefixes (hvc_hdec.h HVC_HD_OVF) need the fast write pass, which a chunk this size may not fit
+    if (!pf_fits && hvc::tables_use_overflow(tables0, G.n_comp)) return host_pipeline();
     for (int i = 0; i < NB; i++) hvc::make_frame_tabs(tables0, G.n_comp, *(hvc::HdFrameTabs *)c->gp_h_ftabs[i]);
     const unsigned comp_selmask = gd_component_selmask(G);
     std::vector<char> frame_pf((size_t)n_frames, 0); // the frame has tables of its own
@@ -2569,7 +2579,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
             size_t got = 0;
             if (!e) e = hvc::prepare_gpu_decode_to(jpegs[f], sizes[f], &fi, t, dst, (nsub_max - 1) * SB, &got, ok);
             const bool own_tables = !e && ok && std::memcmp(&t, &tables0, sizeof t) != 0;
-            const bool unfit = !e && (!ok || (own_tables && !pf_fits));
+            const bool unfit = !e && (!ok || (own_tables && !pf_fits) || (!pf_fits && ok && hvc::tables_use_overflow(t, info0.n_comp)));
             if (own_tables && !unfit) { // its own Huffman tables: a record of its own
                 hvc::make_frame_tabs(t, info0.n_comp, ((hvc::HdFrameTabs *)c->gp_h_ftabs[slot])[1 + (f - k * C)]);
                 frame_pf[(size_t)f] = 1;

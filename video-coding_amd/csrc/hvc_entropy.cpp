@@ -850,14 +850,22 @@ static int prepare_gpu_decode_impl(const uint8_t *jpeg, size_t n, const ::hvc_jp
     int r = parse_header(jpeg, n, h);
     if (r) return r;
     std::memset(&t, 0, sizeof t);
-    auto fill = [&](const HuffSpec &s, HdTable &o) -> bool {
+    auto fill = [&](const HuffSpec &s, HdTable &o, HdOvfRaw &ov) -> bool {
         unsigned code = 0;
         int k = 0, nsub = 0;
         unsigned long long kraft = 0; // in units of 2^-16
         for (int len = 1; len <= 16; len++) {
+            if (len > 10) { // canonical form of the long codes (the overflow search; unused unless a prefix overflows)
+                ov.mincode[len - 11] = (uint16_t)code;
+                ov.count[len - 11] = (uint16_t)s.lengths[len - 1];
+                ov.valptr[len - 11] = (uint16_t)k;
+            }
             for (int i = 0; i < s.lengths[len - 1]; i++, k++) {
+                if (k >= 256) return false;
                 const unsigned cw = code + (unsigned)i; // canonical code of this symbol, `len` bits
                 const uint16_t entry = (uint16_t)((len << 8) | s.values[k]);
+                ov.vals[k] = (uint8_t)s.values[k];
+                ov.lens[k] = (uint8_t)len;
                 if (len <= 10) {
                     const unsigned f0 = cw << (10 - len), fc = 1u << (10 - len);
                     for (unsigned j = 0; j < fc && f0 + j < 1024u; j++) o.fast[f0 + j] = entry;
@@ -865,10 +873,13 @@ static int prepare_gpu_decode_impl(const uint8_t *jpeg, size_t n, const ::hvc_jp
                     const unsigned prefix = cw >> (len - 10);
                     if (prefix >= 1024u) return false;
                     if (!(o.fast[prefix] & 0x8000u)) {
-                        if (o.fast[prefix] != 0 || nsub == HVC_HD_SUBTABLES) return false; // no prefix code / pool exhausted
-                        o.fast[prefix] = (uint16_t)(0x8000u | (unsigned)nsub++);
+                        if (o.fast[prefix] != 0) return false; // no prefix code
+                        // the ninth prefix and those after it: no sub-table, the canonical search finds their symbols
+                        o.fast[prefix] = (uint16_t)(0x8000u | (nsub < HVC_HD_SUBTABLES ? (unsigned)nsub++ : HVC_HD_OVF));
+                        if ((o.fast[prefix] & 0x7fffu) == HVC_HD_OVF) ov.used = 1;
                     }
                     const unsigned sub = o.fast[prefix] & 0x7fffu;
+                    if (sub == HVC_HD_OVF) continue;
                     const unsigned rest = cw & ((1u << (len - 10)) - 1u); // the len - 10 bits after the prefix
                     const unsigned f0 = rest << (16 - len), fc = 1u << (16 - len);
                     for (unsigned j = 0; j < fc; j++) o.sub[sub * 64 + f0 + j] = entry;
@@ -890,8 +901,8 @@ static int prepare_gpu_decode_impl(const uint8_t *jpeg, size_t n, const ::hvc_jp
         Lut probe; // the host decoder's own validity check
         if (!probe.build(h.dht[di].spec) || !probe.build(h.dht[ai].spec)) return HVC_E_BAD_JPEG;
         if (i < 3) {
-            ok = ok && fill(h.dht[di].spec, t.dc[i]);
-            ok = ok && fill(h.dht[ai].spec, t.ac[i]);
+            ok = ok && fill(h.dht[di].spec, t.dc[i], t.ovf_dc[i]);
+            ok = ok && fill(h.dht[ai].spec, t.ac[i], t.ovf_ac[i]);
         }
     }
     size_t got;

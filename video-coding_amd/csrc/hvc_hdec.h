@@ -12,7 +12,13 @@ struct hvc_jpeg_info;
 
 namespace hvc {
 
-#define HVC_HD_SUBTABLES 8 /* 10-bit prefixes that continue into longer codes, per table */
+#define HVC_HD_SUBTABLES 8 /* 10-bit prefixes that continue into longer codes and have a 64-entry sub-table, per table */
+/* A table with MORE such prefixes (codes of 11..16 bits under more than 8 different 10-bit prefixes: the optimised
+ * tables of content with a large alphabet) keeps sub-tables for the first eight -- canonical order: the shortest, most
+ * frequent long codes -- and marks the other prefixes HVC_HD_OVF: their symbols are found by the canonical search of
+ * ITU-T T.81 F.2.2.3 (per length L: code - mincode[L] < count[L]) in a small record in DEVICE memory (HdOvf*), which
+ * any table fits whatever its shape.  Round 2 sent such a file's whole chunk to the host reader (94 -> 8 Gpixel/s). */
+#define HVC_HD_OVF 0x3ffu
 
 // One Huffman table as the GPU decoder reads it (built on the host from the DHT segment the model's
 // find_huffman_table picks, decoder.ml:238-259; canonical code assignment of tables.ml:27-45).
@@ -22,8 +28,24 @@ struct HdTable {
     uint16_t fast[1024];
     uint16_t sub[HVC_HD_SUBTABLES * 64];
 };
+// The codes of 11..16 bits of one table in canonical form (tables.ml:27-45 assigns them in this order): for length
+// 11 + i the first code, how many there are and where their symbols start in vals[] -- empty (count all zero) for a
+// table that needs no overflow.
+struct HdOvfRaw {
+    uint16_t mincode[6], count[6], valptr[6];
+    uint8_t vals[256]; // the table's symbol values, canonical order (all of them: valptr indexes this)
+    uint8_t lens[256]; // ... and their code lengths
+    uint16_t used, pad; // used != 0: some prefix of this table is marked HVC_HD_OVF
+};
 struct HdTables {
     HdTable dc[3], ac[3]; // per scan component (the GPU path takes at most three)
+    HdOvfRaw ovf_dc[3], ovf_ac[3];
+};
+// ... and as the walks read it: the entry of the symbol at canonical position k in the two entry formats
+struct HdOvf {
+    uint16_t mincode[6], count[6], valptr[6], pad[2];
+    uint16_t spec[256]; // HdSpec's format (synchronisation walk)
+    uint16_t val[256];  // val_entry's format (k_hd_write2)
 };
 
 // The same tables as the synchronisation walk wants them: it needs no values, only how far a symbol moves the
@@ -35,8 +57,13 @@ struct HdTables {
 struct HdSpec {
     uint16_t t[2][2][1024 + HVC_HD_SUBTABLES * 64]; // [slot][0 = DC, 1 = AC]
 };
+struct HdSpecOvf { // behind the HdSpec in device memory: the overflow records of the same four tables (never in LDS)
+    HdOvf o[2][2];
+};
 // slot of every component, or false when the frame uses more than two different (DC, AC) table pairs
-bool make_spec(const HdTables &t, int n_comp, HdSpec &out, unsigned char slot_of_comp[4], unsigned char slot_rep[2]);
+bool make_spec(const HdTables &t, int n_comp, HdSpec &out, unsigned char slot_of_comp[4], unsigned char slot_rep[2],
+               HdSpecOvf *ovf = nullptr);
+bool tables_use_overflow(const HdTables &t, int n_comp);
 
 // PER-FRAME tables ("PF mode"): a batch in which the files carry different Huffman tables -- optimised per file, as
 // libjpeg -optimize, cameras and most web encoders write them -- or a frame with three different table sets.  One
@@ -50,6 +77,7 @@ struct HdFrameTabs {
     // bit 0: the third component reads the second one's tables (or there is none): the frame's tables are the first
     // 12 KB of each form, and a workgroup whose subsequences all belong to this frame keeps them in LDS
     unsigned flags, pad[3];
+    HdOvf ovf[3][2];                    // overflow records [component][DC, AC] (read in place, never copied to LDS)
 };
 void make_frame_tabs(const HdTables &t, int n_comp, HdFrameTabs &out);
 
@@ -77,6 +105,7 @@ struct HdParams {
     const unsigned *frame_of;  // [total_sub] frame of every subsequence
     const HdTables *tables;    // device
     const HdSpec *spec;        // device, or null: synchronise with k_hd_round only
+    const HdSpecOvf *spec_ovf; // device: the overflow records of spec's tables (valid whenever spec is)
     const HdFrameTabs *ftabs;  // device, PF mode (then spec / tables are not used), or null
     const unsigned *tabset_of; // [n_frames] PF mode: index of the frame's record in ftabs
     unsigned selmask;          // 2 bits per block b of an MCU: which tables it reads -- the HdSpec slot (0 / 1), or in PF

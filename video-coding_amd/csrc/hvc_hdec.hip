@@ -265,9 +265,22 @@ __device__ __forceinline__ unsigned selmask_c2_as_c1(unsigned sel) {
     return (sel & ~hi) | (hi >> 1);
 }
 
+// A code under a prefix that has no sub-table (HVC_HD_OVF): the canonical search of ITU-T T.81 F.2.2.3 over the lengths
+// 11..16 in the table's overflow record (device memory; rare by construction -- the prefixes without a sub-table hold
+// the table's least frequent symbols).  w = the next 32 bits; VAL picks the entry format.  "No such code" = entry 1.
+template <bool VAL>
+__device__ __noinline__ unsigned ovf_lookup(const HdOvf *o, unsigned w) {
+    const unsigned w16 = w >> 16;
+    for (int i = 0; i < 6; i++) {
+        const unsigned d = (w16 >> (5 - i)) - (unsigned)o->mincode[i];
+        if (d < (unsigned)o->count[i]) return (VAL ? o->val : o->spec)[(unsigned)o->valptr[i] + d];
+    }
+    return 1u;
+}
+
 template <bool RD_FREE, bool SEL1, class RD> // the lean walk of the synchronisation rounds, defined with k_hd_sync below
-__device__ __forceinline__ void spec_walk(RD rd, const unsigned *row, const uint16_t *sp, unsigned sel, int B, unsigned base, unsigned &p,
-                                          int &k, int &b, unsigned &nb);
+__device__ __forceinline__ void spec_walk(RD rd, const unsigned *row, const uint16_t *sp, const HdOvf *ovf, unsigned sel, int B, unsigned base,
+                                          unsigned &p, int &k, int &b, unsigned &nb);
 
 // One synchronisation launch (see the header comment).  Even launches write exit_a, odd ones exit_b.
 // Inside the launch the 256 subsequences of a workgroup run up to INNER rounds among themselves through
@@ -341,9 +354,9 @@ __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
                 stage_row(row, reinterpret_cast<const uint8_t *>(slot));
                 auto rd = [row](unsigned q) { return row[q]; };
                 const uint16_t *lt = reinterpret_cast<const uint16_t *>(Traw);
-                if (MODE == 1) spec_walk<true, true>(rd, row, lt, P.slotmask, P.blocks_per_mcu, base, p, k, b, nb);
-                else if (pf_lds) spec_walk<true, false>(rd, row, lt, selmask_c2_as_c1(P.selmask), P.blocks_per_mcu, base, p, k, b, nb);
-                else spec_walk<true, false>(rd, row, &P.ftabs[P.tabset_of[f]].spec[0][0][0], P.selmask, P.blocks_per_mcu, base, p, k, b, nb);
+                if (MODE == 1) spec_walk<true, true>(rd, row, lt, &P.spec_ovf->o[0][0], P.slotmask, P.blocks_per_mcu, base, p, k, b, nb);
+                else if (pf_lds) spec_walk<true, false>(rd, row, lt, &P.ftabs[P.tabset_of[f]].ovf[0][0], selmask_c2_as_c1(P.selmask), P.blocks_per_mcu, base, p, k, b, nb);
+                else spec_walk<true, false>(rd, row, &P.ftabs[P.tabset_of[f]].spec[0][0][0], &P.ftabs[P.tabset_of[f]].ovf[0][0], P.selmask, P.blocks_per_mcu, base, p, k, b, nb);
             } else {
                 walk<false>(P, G, T, slot, base, base + (unsigned)S, p, k, b, nb, 0, nullptr, err);
             }
@@ -415,9 +428,10 @@ constexpr int SYNC_TAIL_FROM = 5;
 // function of ni), and nothing waits for it before the next table look-up has come back anyway.
 // RD_FREE: the row sits in LDS at `row` (SROW dwords and two more that may be read, whatever they hold).
 // SEL1: sel has one bit per block of an MCU (HdParams::slotmask: the two slots of HdSpec); otherwise two (selmask).
+// ovf = the overflow records of the same tables, [slot or component][DC, AC] (device memory).
 template <bool RD_FREE, bool SEL1, class RD>
-__device__ __forceinline__ void spec_walk(RD rd, const unsigned *row, const uint16_t *sp, unsigned sel, int B, unsigned base, unsigned &p,
-                                          int &k, int &b, unsigned &nb) {
+__device__ __forceinline__ void spec_walk(RD rd, const unsigned *row, const uint16_t *sp, const HdOvf *ovf, unsigned sel, int B, unsigned base,
+                                          unsigned &p, int &k, int &b, unsigned &nb) {
     // The bit position is kept as mm = ~(P + 31), P = bits consumed since the start of the row (P < 32 + S at the
     // start): its low five bits are what v_alignbit has to shift {hi, lo} by, the window moves on by a dword when mm
     // changes above bit 4, and "p < limit" is "mm > ~(S + 31)" -- one subtraction per symbol keeps all of that current.
@@ -441,7 +455,9 @@ __device__ __forceinline__ void spec_walk(RD rd, const unsigned *row, const uint
         unsigned e = t[w >> 22];
         unsigned used = e & 63u;
         if (used == 0u) { // the code is longer than the first level's 10 bits
-            e = t[1024u + (e >> 6) * 64u + ((w >> 16) & 63u)];
+            const unsigned sn = e >> 6;
+            if (sn != HVC_HD_OVF) e = t[1024u + sn * 64u + ((w >> 16) & 63u)];
+            else e = ovf_lookup<false>(ovf + ((SEL1 ? __builtin_amdgcn_ubfe(sel, (unsigned)b, 1u) : (sel >> (2 * b)) & 3u) * 2u + (k ? 1u : 0u)), w);
             used = e & 63u;
         }
         k += (int)((e >> 6) & 127u); // an EOB advances by 64
@@ -491,9 +507,9 @@ __device__ __forceinline__ bool sync_one(const HdParams &P, int round, bool vali
     unsigned p = (unsigned)st, nb = 0;
     int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
     auto rd = [row](unsigned q) { return row[q]; };
-    if (!PF) spec_walk<true, true>(rd, row, sp_lds, P.slotmask, P.blocks_per_mcu, base, p, k, b, nb);
-    else if (pf_lds) spec_walk<true, false>(rd, row, sp_lds, selmask_c2_as_c1(P.selmask), P.blocks_per_mcu, base, p, k, b, nb);
-    else spec_walk<true, false>(rd, row, &P.ftabs[P.tabset_of[f]].spec[0][0][0], P.selmask, P.blocks_per_mcu, base, p, k, b, nb);
+    if (!PF) spec_walk<true, true>(rd, row, sp_lds, &P.spec_ovf->o[0][0], P.slotmask, P.blocks_per_mcu, base, p, k, b, nb);
+    else if (pf_lds) spec_walk<true, false>(rd, row, sp_lds, &P.ftabs[P.tabset_of[f]].ovf[0][0], selmask_c2_as_c1(P.selmask), P.blocks_per_mcu, base, p, k, b, nb);
+    else spec_walk<true, false>(rd, row, &P.ftabs[P.tabset_of[f]].spec[0][0][0], &P.ftabs[P.tabset_of[f]].ovf[0][0], P.selmask, P.blocks_per_mcu, base, p, k, b, nb);
 #ifdef HVC_HD_STATS // experiments, round 0: symbols walked / 64 x the longest walk of each wavefront (what it costs)
     {
         const unsigned nsym = nb >> 16;
@@ -882,7 +898,7 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
     auto mm_of = [&](unsigned p) -> unsigned { return ~(p - base + 31u); };
     // The tables are in LDS or in device memory: the walk is written once and instantiated per address space (a
     // pointer that could be either would make every look-up a flat load).
-    auto decode_and_store = [&](const uint16_t *const tvb, const unsigned selmask) {
+    auto decode_and_store = [&](const uint16_t *const tvb, const HdOvf *const ovf, const unsigned selmask) {
     const uint16_t *bt = tvb + ((selmask >> (2 * b)) & 3u) * (2 * SPEC_T);
     const uint16_t *bt_ac = bt + SPEC_T;
     // the exit the synchronisation launches recorded for this subsequence must be the one this walk arrives at
@@ -913,7 +929,11 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
             const unsigned w = __builtin_amdgcn_alignbit(hi, lo, mm); // the next 32 bits: a whole symbol
             const uint16_t *t = k ? bt_ac : bt;
             unsigned e = t[__builtin_amdgcn_ubfe(w, 22u, 10u)];
-            if ((e & 31u) == 0u) e = t[1024u + (e >> 5) * 64u + __builtin_amdgcn_ubfe(w, 16u, 6u)];
+            if ((e & 31u) == 0u) { // a longer code: its prefix's sub-table, or (no sub-table: HVC_HD_OVF) the canonical search
+                const unsigned sn = e >> 5;
+                if (sn != HVC_HD_OVF) e = t[1024u + sn * 64u + __builtin_amdgcn_ubfe(w, 16u, 6u)];
+                else e = ovf_lookup<true>(ovf + (((selmask >> (2 * b)) & 3u) * 2u + (k ? 1u : 0u)), w);
+            }
             // One path for DC and AC symbols (a DC symbol advances the index from 0 to 1): see val_entry
             const unsigned used = e & 31u, size = __builtin_amdgcn_ubfe(e, 5u, 4u), adv = __builtin_amdgcn_ubfe(e, 9u, 5u);
             const bool eob = (int16_t)e < 0;
@@ -1015,9 +1035,9 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
     }
 #endif
     };
-    if (!PF) decode_and_store(tv, P.selmask);
-    else if (pf_lds) decode_and_store(tv, selmask_c2_as_c1(P.selmask));
-    else decode_and_store(&P.ftabs[P.tabset_of[f]].val[0][0][0], P.selmask);
+    if (!PF) decode_and_store(tv, &P.spec_ovf->o[0][0], P.selmask);
+    else if (pf_lds) decode_and_store(tv, &P.ftabs[P.tabset_of[f]].ovf[0][0], selmask_c2_as_c1(P.selmask));
+    else decode_and_store(&P.ftabs[P.tabset_of[f]].val[0][0][0], &P.ftabs[P.tabset_of[f]].ovf[0][0], P.selmask);
     if (err) atomicOr(P.status, err);
 }
 
@@ -1110,7 +1130,42 @@ static void convert_table(const HdTable &src, bool dc, uint16_t *spec, uint16_t 
     }
 }
 
-bool make_spec(const HdTables &t, int n_comp, HdSpec &out, unsigned char slot_of_comp[4], unsigned char slot_rep[2]) {
+// The overflow record of one table in the walks' form: the canonical search data as they are, and for every canonical
+// position the symbol's entry in the two formats.
+static void convert_ovf(const HdOvfRaw &src, bool dc, HdOvf &o) {
+    std::memset(&o, 0, sizeof o);
+    for (int i = 0; i < 6; i++) {
+        o.mincode[i] = src.mincode[i];
+        o.count[i] = src.used ? src.count[i] : (uint16_t)0; // (a table without overflow is never searched)
+        o.valptr[i] = src.valptr[i];
+    }
+    for (int k = 0; k < 256; k++) {
+        const unsigned len = src.lens[k], v = src.vals[k];
+        uint16_t sp = 1, vl = 1;
+        if (len) {
+            const HdTable *none = nullptr;
+            (void)none;
+            const unsigned e = (len << 8) | v;
+            // HdSpec's entry (see convert_table's conv)
+            if (dc) sp = (uint16_t)(v > 16 ? len : (len + v) | (1u << 6));
+            else {
+                const unsigned size = v & 15u, run = v >> 4;
+                sp = (!size && !run) ? (uint16_t)(len | (64u << 6)) : (uint16_t)((len + size) | ((run + 1u) << 6));
+            }
+            vl = (uint16_t)val_entry(e, dc, true);
+        }
+        o.spec[k] = sp;
+        o.val[k] = vl;
+    }
+}
+
+bool tables_use_overflow(const HdTables &t, int n_comp) {
+    for (int c = 0; c < n_comp && c < 3; c++)
+        if (t.ovf_dc[c].used || t.ovf_ac[c].used) return true;
+    return false;
+}
+
+bool make_spec(const HdTables &t, int n_comp, HdSpec &out, unsigned char slot_of_comp[4], unsigned char slot_rep[2], HdSpecOvf *ovf) {
     if (n_comp < 1 || n_comp > 3) return false;
     int rep[2] = {0, -1}; // the component whose tables a slot holds
     for (int c = 0; c < 4; c++) slot_of_comp[c] = 0;
@@ -1124,10 +1179,15 @@ bool make_spec(const HdTables &t, int n_comp, HdSpec &out, unsigned char slot_of
     slot_rep[0] = 0;
     slot_rep[1] = (unsigned char)(rep[1] < 0 ? 0 : rep[1]);
     std::memset(&out, 0, sizeof out);
+    if (ovf) std::memset(ovf, 0, sizeof *ovf);
     for (int sl = 0; sl < 2; sl++) {
         if (rep[sl] < 0) continue;
         convert_table(t.dc[rep[sl]], true, out.t[sl][0], nullptr);
         convert_table(t.ac[rep[sl]], false, out.t[sl][1], nullptr);
+        if (ovf) {
+            convert_ovf(t.ovf_dc[rep[sl]], true, ovf->o[sl][0]);
+            convert_ovf(t.ovf_ac[rep[sl]], false, ovf->o[sl][1]);
+        }
     }
     return true;
 }
@@ -1139,6 +1199,8 @@ void make_frame_tabs(const HdTables &t, int n_comp, HdFrameTabs &out) {
         const int s = c < n_comp ? c : 0; // components the frame does not have: a copy, never read
         convert_table(t.dc[s], true, out.spec[c][0], out.val[c][0]);
         convert_table(t.ac[s], false, out.spec[c][1], out.val[c][1]);
+        convert_ovf(t.ovf_dc[s], true, out.ovf[c][0]);
+        convert_ovf(t.ovf_ac[s], false, out.ovf[c][1]);
     }
 }
 
