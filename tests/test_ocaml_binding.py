@@ -39,3 +39,55 @@ def test_checker_catches_drift(tmp_path, monkeypatch):
         monkeypatch.setattr(chk, "BINDING", str(p))
         problems, _, _ = chk.check()
         assert problems, what
+
+
+def test_patch_uses_only_what_the_binding_defines(tmp_path):
+    missing, used = chk.check_patch()
+    assert missing == []
+    for name in ("ctx", "coefs", "coefs_ptr", "check", "decode_frames", "mem_host", "Component.t", "Component.stride"):
+        assert name in used, name
+    # ... and the check sees a name that is not there (round 2's sketch called helpers that existed nowhere)
+    text = open(chk.PATCH).read().replace("Hvc.coefs_ptr record", "Hvc.coefs_pointer record")
+    p = tmp_path / "bad.patch"
+    p.write_text(text)
+    assert chk.check_patch(str(p))[0] == ["coefs_pointer"]
+
+
+REF = "/root/reference"
+
+
+def test_patch_applies_to_the_reference(tmp_path):
+    """integration/ocaml/hvc_backend.patch is a real unified diff against the reference's decoder.ml / decoder.mli /
+    dune / plane.mli: `patch --dry-run` accepts it, and applied it leaves the functions INTEGRATION.md names.  (The
+    reference exists in the build container only; its files are copied to a temporary directory and never travel.)"""
+    import shutil
+    import subprocess
+    import pytest
+    files = ["jpeg/model/src/decoder.ml", "jpeg/model/src/decoder.mli", "jpeg/model/src/dune", "common/src/plane.mli"]
+    if not all(os.path.exists(os.path.join(REF, f)) for f in files):
+        pytest.skip("the reference tree is not on this machine")
+    for f in files:
+        os.makedirs(os.path.dirname(tmp_path / f), exist_ok=True)
+        shutil.copy(os.path.join(REF, f), tmp_path / f)
+    for flag in (["--dry-run"], []):
+        r = subprocess.run(["patch", "-p1", "--no-backup-if-mismatch"] + flag, stdin=open(chk.PATCH), cwd=tmp_path, capture_output=True, text=True)
+        assert r.returncode == 0 and "FAILED" not in r.stdout and "fuzz" not in r.stdout, r.stdout + r.stderr
+    ml = (tmp_path / "jpeg/model/src/decoder.ml").read_text()
+    mli = (tmp_path / "jpeg/model/src/decoder.mli").read_text()
+    for name in ("let decode_gpu ", "let decode_a_frame_gpu ", "module Gpu = struct", "?(decode_block = decode_block)"):
+        assert name in ml, name
+    assert "val decode_gpu : Hvc.ctx -> t -> unit" in mli and "val decode_a_frame_gpu" in mli
+    assert "val plane : t -> Base_bigstring.t" in (tmp_path / "common/src/plane.mli").read_text()
+    assert "ctypes.foreign" in (tmp_path / "jpeg/model/src/dune").read_text()
+    # balanced: what the patch ADDS opens and closes its own brackets, comments and modules (a cheap stand-in for the
+    # parser this image does not have), hunk by hunk
+    added = "\n".join(ln[1:] for ln in open(chk.PATCH).read().split("\n") if ln.startswith("+") and not ln.startswith("+++"))
+    assert added.count("(*") == added.count("*)")
+    code = chk.strip_comments(added, ml=True)
+    depth = 0
+    for ch in code:
+        depth += {"(": 1, ")": -1, "[": 1, "]": -1, "{": 1, "}": -1}.get(ch, 0)
+        assert depth >= 0
+    assert depth == 0
+    import re
+    assert len(re.findall(r"\bstruct\b", code)) == len(re.findall(r"^end\b", code, flags=re.M))

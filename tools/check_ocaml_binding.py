@@ -157,8 +157,43 @@ def check():
     return problems, sorted(set(funcs) - bound), len(bound)
 
 
+PATCH = os.path.join(ROOT, "integration", "ocaml", "hvc_backend.patch")
+
+
+def binding_names(text):
+    """what hvc.ml defines at its top level and inside its modules: {"check", "Component.blocks_w", ...}"""
+    names, module = set(), None
+    for line in text.split("\n"):
+        m = re.match(r"^module (\w+) = struct", line)
+        if m:
+            module = m.group(1)
+            names.add(module)
+            continue
+        if re.match(r"^end\b", line):
+            module = None
+            continue
+        m = re.match(r"^(?:  )?(?:let|type)(?: rec)? (?:\(\) |)(\w+)", line)
+        if m and m.group(1) != "_":
+            names.add(("%s.%s" % (module, m.group(1))) if (module and line.startswith("  ")) else m.group(1))
+    return names
+
+
+def check_patch(patch=None, binding=None):
+    """Every `Hvc.<path>` the patch's added lines use must be defined by hvc.ml (the patch cannot be compiled here:
+    at least it must not call what does not exist -- round 2's sketch did)."""
+    added = "\n".join(ln[1:] for ln in open(patch or PATCH).read().split("\n") if ln.startswith("+") and not ln.startswith("+++"))
+    added = strip_comments(added, ml=True)
+    defined = binding_names(strip_comments(open(binding or BINDING).read(), ml=True))
+    used = sorted(set(re.findall(r"\bHvc\.((?:[A-Z]\w*\.)*\w+)", added)))
+    return [u for u in used if u not in defined], used
+
+
 def main():
     problems, unbound, n = check()
+    missing, used = check_patch()
+    for u in missing:
+        problems.append("hvc_backend.patch uses Hvc.%s, which hvc.ml does not define" % u)
+    print("hvc_backend.patch: %d Hvc identifiers used, %d undefined" % (len(used), len(missing)))
     for p in problems:
         print("MISMATCH", p)
     print("%d foreign declarations checked against include/hvc_jpeg.h, %d mismatches, %d functions of the header unbound"
