@@ -315,3 +315,41 @@ def test_dc_beyond_int16_is_refused_not_wrapped(hvc):
     jpg2 = jpeg_optimised_tables(w, h, 444, qt, ok.reshape(-1), table_sets=2)
     _, got = hvc.jpeg_entropy_decode(jpg2)
     assert np.array_equal(got, orc.Decoder(jpg2).coef_record()) and got.max() == 32767
+
+
+def test_two_files_in_turn_equal_two_files_one_after_the_other():
+    """hvc_jpeg_entropy_decode2 (the batch pipelines' inner routine: two walks stepped alternately so that the core has two
+    dependency chains to overlap): records and per-file status as hvc_jpeg_entropy_decode gives them -- files of
+    different sizes and geometries, one of them broken (the other must still come out whole), a pair of the same file."""
+    import video_coding_amd as hvc
+    mini, mouse = golden_bytes("mini.jpg"), golden_bytes("Mouse480.jpg")
+    rng = np.random.Generator(np.random.PCG64(5))
+    y, u, v = (rng.integers(0, 256, size=s, dtype=np.uint8) for s in ((120, 200), (60, 100), (60, 100)))
+    noisy = orc.encode_yuv(y, u, v, 200, 120, 420, 92)
+    y422 = orc.encode_yuv(y, rng.integers(0, 256, size=(120, 100), dtype=np.uint8), rng.integers(0, 256, size=(120, 100), dtype=np.uint8), 200, 120, 422, 35)
+    files = [mini, mouse, noisy, y422]
+    single = [hvc.hvc.jpeg_entropy_decode(j)[1] for j in files]
+    for a in range(len(files)):
+        for b in range(len(files)):
+            (sa, _, ra), (sb, _, rb) = hvc.hvc.jpeg_entropy_decode2(files[a], files[b])
+            assert (sa, sb) == (0, 0)
+            assert np.array_equal(ra, single[a]) and np.array_equal(rb, single[b]), (a, b)
+            assert np.array_equal(ra, orc.Decoder(files[a]).coef_record().astype(np.int16))
+    # a stream that breaks half-way (an invalid code / index out of range somewhere after the cut): its own status says
+    # so, exactly as the single-file entry point does, and its partner is untouched
+    info = hvc.hvc.jpeg_read_header(mouse)
+    broken = bytearray(mouse)
+    for i in range(info.ecs_offset + 3000, info.ecs_offset + 3400):
+        broken[i] = 0xFF if i % 2 == 0 else 0x00   # (0xFF 0x00 = a stuffed 0xFF: all-ones data, codes that do not exist)
+    broken = bytes(broken)
+    try:
+        hvc.hvc.jpeg_entropy_decode(broken)
+        want = 0
+    except hvc.HvcError as e:
+        want = e.code
+    assert want != 0
+    for first in (True, False):
+        pair = (broken, noisy) if first else (noisy, broken)
+        (sa, _, ra), (sb, _, rb) = hvc.hvc.jpeg_entropy_decode2(*pair)
+        assert (sa, sb) == ((want, 0) if first else (0, want))
+        assert np.array_equal(rb if first else ra, single[2])

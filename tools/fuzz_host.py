@@ -36,6 +36,34 @@ for it in range(6000):
     except hvc.HvcError:
         err += 1
 print("decoded", ok, "rejected", err)
+# two files in turn (hvc_jpeg_entropy_decode2): a mutated stream beside an intact one -- every pair gives each file the
+# status and the record the single-file entry point gives it
+pair_ok = pair_err = 0
+whole = [hvc.hvc.jpeg_entropy_decode(b)[1] for b in base]
+for it in range(1500):
+    b = bytearray(base[it & 1])
+    if it % 4 == 3:
+        b = b[:int(rng.integers(2, len(b)))]
+    else:
+        for _ in range(int(rng.integers(1, 6))):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+    b = bytes(b)
+    try:
+        info = hvc.hvc.jpeg_read_header(b)
+        if info.coef_count > 1 << 24: continue
+    except hvc.HvcError:
+        continue
+    try:
+        want, rec = 0, hvc.hvc.jpeg_entropy_decode(b, info)[1]
+    except hvc.HvcError as e:
+        want, rec = e.code, None
+    other = (it >> 1) & 1
+    (sa, _, ra), (sb, _, rb) = hvc.hvc.jpeg_entropy_decode2(b, base[other]) if it % 3 else hvc.hvc.jpeg_entropy_decode2(base[other], b)[::-1]
+    assert sa == want and sb == 0, (it, sa, want, sb)
+    assert np.array_equal(rb, whole[other]) and (rec is None or np.array_equal(ra, rec)), it
+    pair_ok += want == 0
+    pair_err += want != 0
+print("pairs: mutated file decoded", pair_ok, "rejected", pair_err)
 # the host coder with arbitrary int16 records (values without a code must be refused, never written past a buffer)
 enc_ok = enc_err = 0
 for it in range(300):

@@ -299,138 +299,288 @@ int hvc_jpeg_read_header(const uint8_t *data, size_t n, hvc_jpeg_info *info) try
 // The Huffman half of Decoder.decode (decode_seq order, decoder.ml:362-395; huffman_decode :118-140;
 // the DC predictor add of :143) into one frame's coefficient record: int16, zig-zag order, DC absolute,
 // block (bx,by) of component i at coefs + layout[i].coef_offset + (by*blocks_w + bx)*64.
+//
+// One file's reader as a resumable walk: step() decodes ONE symbol of the block in progress, or begins the next block
+// (position check, clear_block, the DC symbol and its predictor).  A file is one stream and its symbols form one
+// dependency chain -- shift, table load, shift, or: ~8 cycles a symbol with nothing else for the core to do -- but
+// two FILES are two chains: entropy_decode_two() below steps two walks alternately and the out-of-order core overlaps
+// them (what the batch pipelines' workers do: 515 -> 750+ Mpixel/s per thread).
+namespace hvc {
+size_t extract_ecs_to(const uint8_t *data, size_t n, size_t pos, uint8_t *dst, size_t cap);
+}
+namespace {
+struct Walk {
+    const hvc_jpeg_info *info = nullptr;
+    int16_t *coefs = nullptr;
+    std::vector<hvc::WideDc> *wide = nullptr; // nullptr: an absolute DC outside int16 is HVC_E_RANGE; otherwise the record
+                                              // gets the saturated value and the block goes on the list with its true DC
+    Lut dc[4], ac[4];
+    std::vector<uint8_t> ecs;
+    BitReader br{nullptr, 0};
+    long long dc_pred[4] = {0, 0, 0, 0}; // (the model's 63-bit ints: 67 M blocks of +-65535 stay far inside)
+    int mbs_wide = 0, mbs_high = 0;
+    int my = 0, mx = 0, ci = 0, sy = 0, sx = 0; // the NEXT block, decode_seq order (decoder.ml:362-395)
+    int16_t *blk = nullptr;
+    int k = 64;                 // index of the next coefficient of the block in progress; 64 = none in progress
+    const Lut::Whole *acw = nullptr;
+    const uint16_t *acf = nullptr, *act = nullptr;
+    int amax = 0;
+    bool done = false;
+
+    int prepare(const uint8_t *data, size_t n, const hvc_jpeg_info *info_, int16_t *coefs_, std::vector<hvc::WideDc> *wide_) {
+        if (!data || !info_ || !coefs_) return HVC_E_INVALID_ARG;
+        info = info_;
+        coefs = coefs_;
+        wide = wide_;
+        Header h;
+        int r = parse_header(data, n, h);
+        if (r) return r;
+        for (int i = 0; i < info->n_comp; i++) {
+            int di = -1, ai = -1; // find_huffman_table (decoder.ml:238-259): newest match
+            for (int q = (int)h.dht.size() - 1; q >= 0; q--) {
+                if (di < 0 && h.dht[q].tclass == 0 && h.dht[q].id == info->comp[i].dc_table) di = q;
+                if (ai < 0 && h.dht[q].tclass == 1 && h.dht[q].id == info->comp[i].ac_table) ai = q;
+            }
+            if (di < 0 || ai < 0) return HVC_E_BAD_JPEG;
+            if (!dc[i].build(h.dht[di].spec) || !ac[i].build(h.dht[ai].spec)) return HVC_E_BAD_JPEG;
+            ac[i].build_whole();
+        }
+        // extract_entropy_coded_bits (decoder.ml:261-281): up to the first marker, 0xff00 -> 0xff.  (A missing EOI just
+        // ends the segment: the model would spin on zero bytes there.)
+        const size_t pos = h.ecs_pos, room = (n > pos ? n - pos : 0) + 32;
+        ecs.resize(room);
+        size_t got = hvc::extract_ecs_to(data, n, pos, ecs.data(), room - 16);
+        if (got == SIZE_MAX) return HVC_E_BAD_JPEG; // (cannot happen: unstuffing only ever shortens)
+        std::memset(ecs.data() + got, 0, room - got); // zero padding: the reader loads 8 bytes at a time
+        br = BitReader{ecs.data(), got};
+        const hvc_jpeg_component &c0 = info->comp[0];
+        mbs_wide = c0.decoded_width / (8 * c0.hscale);
+        mbs_high = c0.decoded_height / (8 * c0.vscale);
+        done = mbs_wide <= 0 || mbs_high <= 0 || info->n_comp <= 0;
+        return HVC_OK;
+    }
+
+    // the block at (my, mx, ci, sy, sx): bounds, clear_block (decoder.ml:109-116, right before the block is written: one
+    // pass over the record instead of a 6 MB memset that has left the cache by the time the block comes up), the DC
+    // symbol; then the position moves on
+    int begin_block() {
+        const int i = ci;
+        const hvc_jpeg_component &c = info->comp[i];
+        const hvc_component &L = info->layout[i];
+        const int bx = mx * c.hscale + sx, by = my * c.vscale + sy;
+        if (bx >= L.blocks_w || by >= L.blocks_h) return HVC_E_BAD_JPEG; // Plane.set out of bounds
+        blk = coefs + L.coef_offset + ((size_t)by * L.blocks_w + bx) * 64;
+        std::memset(blk, 0, 64 * sizeof(int16_t));
+        br.refill();
+        unsigned e = dc[i].fast[br.peek(Lut::FAST_BITS)];
+        if (!e) e = dc[i].e[br.peek(dc[i].max_bits)];
+        if (!e) return HVC_E_BAD_JPEG; // "Can't find dc code"
+        br.skip(e >> 8);
+        const int cat = e & 0xff;
+        long long diff = 0;
+        if (cat > 16) {
+            // No JPEG has DC categories above 11 (baseline) / 16; the model, though, reads `cat`
+            // magnitude bits for whatever the table says (decoder.ml:81-96: no check).  Up to 32 bits
+            // this reader follows it -- such a difference never fits the int16 record (|d| >= 65536),
+            // so only the wide-DC mode goes on -- beyond that the stream is refused.
+            if (cat > 32) return HVC_E_BAD_JPEG;
+            if (!wide) return HVC_E_RANGE;
+            br.refill();
+            const unsigned code = br.peek(cat);
+            diff = ((code >> (cat - 1)) & 1u) ? (long long)code : (long long)code - ((1ll << cat) - 1);
+            br.skip(cat);
+        } else if (cat) {
+            br.refill();
+            diff = extend(cat, br.peek(cat));
+            br.skip(cat);
+        }
+        const long long dcv = diff + dc_pred[i];
+        dc_pred[i] = dcv;
+        if (dcv < -32768 || dcv > 32767) {
+            if (!wide) return HVC_E_RANGE;
+            try {
+                wide->push_back(hvc::WideDc{(uint32_t)((size_t)(blk - coefs) >> 6), dcv});
+            } catch (const std::bad_alloc &) {
+                return HVC_E_OUT_OF_MEMORY;
+            }
+            blk[0] = (int16_t)(dcv < 0 ? -32767 : 32767);
+        } else {
+            blk[0] = (int16_t)dcv;
+        }
+        k = 1;
+        acw = ac[i].whole;
+        acf = ac[i].fast;
+        act = ac[i].e.data();
+        amax = ac[i].max_bits;
+        // decode_seq order: sx, sy inside the component's part of the MCU, then the components, then the MCUs
+        if (++sx == c.hscale) {
+            sx = 0;
+            if (++sy == c.vscale) {
+                sy = 0;
+                if (++ci == info->n_comp) {
+                    ci = 0;
+                    if (++mx == mbs_wide) {
+                        mx = 0;
+                        ++my;
+                    }
+                }
+            }
+        }
+        return HVC_OK;
+    }
+
+    bool finished() const { return my >= mbs_high; }
+};
+
+// One AC symbol of the block in progress, on LOCAL copies of the walk's hot state (bit reader, index, block and table
+// pointers: they must live in registers -- through the Walk object every symbol paid loads and stores of them).
+// K becomes 64 at the end of the block; ERR receives the model's error, if any.
+#define HVC_AC_SYMBOL(BR, K, BLK, ACW, ACF, ACT, AMAX, ERR)                                                        \
+    do {                                                                                                             \
+        (BR).refill();                                                                                               \
+        /* symbol + magnitude in one lookup when both fit the look-ahead window */                                  \
+        const Lut::Whole wh_ = (ACW)[(BR).peek(Lut::FAST_BITS)];                                                     \
+        if (wh_.bits) {                                                                                              \
+            (BR).skip(wh_.bits);                                                                                     \
+            if (wh_.run == Lut::EOB) {                                                                               \
+                (K) = 64;                                                                                            \
+            } else {                                                                                                 \
+                (K) += wh_.run;                                                                                      \
+                if ((K) >= 64) (ERR) = HVC_E_BAD_JPEG; /* "coefficient index out of range" */                       \
+                else (BLK)[(K)++] = wh_.value;                                                                       \
+            }                                                                                                        \
+        } else {                                                                                                     \
+            unsigned e_ = (ACF)[(BR).peek(Lut::FAST_BITS)];                                                          \
+            if (!e_) e_ = (ACT)[(BR).peek(AMAX)];                                                                    \
+            if (!e_) {                                                                                               \
+                (ERR) = HVC_E_BAD_JPEG; /* "Can't find ac code" */                                                  \
+            } else {                                                                                                 \
+                (BR).skip(e_ >> 8);                                                                                  \
+                const int run_ = (e_ >> 4) & 15, size_ = e_ & 15;                                                    \
+                int mag_ = 0;                                                                                        \
+                if (size_) {                                                                                         \
+                    mag_ = extend(size_, (BR).peek(size_));                                                          \
+                    (BR).skip(size_);                                                                                \
+                }                                                                                                    \
+                if (mag_ == 0 && run_ == 0) { /* decoder.ml:131-132 (EOB, or a zero-size code) */                   \
+                    (K) = 64;                                                                                        \
+                } else {                                                                                             \
+                    (K) += run_;                                                                                     \
+                    if ((K) >= 64) (ERR) = HVC_E_BAD_JPEG; /* "coefficient index out of range" */                   \
+                    else (BLK)[(K)++] = (int16_t)mag_;                                                               \
+                }                                                                                                    \
+            }                                                                                                        \
+        }                                                                                                            \
+    } while (0)
+
+// the whole file, block after block
+static int walk_alone(Walk &w) {
+    while (!w.finished()) {
+        int r = w.begin_block();
+        if (r) return r;
+        BitReader br = w.br;
+        int k = w.k, err = 0;
+        int16_t *const blk = w.blk;
+        const Lut::Whole *const acw = w.acw;
+        const uint16_t *const acf = w.acf, *const act = w.act;
+        const int amax = w.amax;
+        while (k < 64 && !err) HVC_AC_SYMBOL(br, k, blk, acw, acf, act, amax, err);
+        w.br = br;
+        w.k = 64;
+        if (err) return err;
+    }
+    w.done = true;
+    return HVC_OK;
+}
+} // namespace
+
 static int entropy_decode_impl(const uint8_t *data, size_t n, const hvc_jpeg_info *info, int16_t *coefs,
-                               std::vector<hvc::WideDc> *wide);
+                               std::vector<hvc::WideDc> *wide) {
+    Walk w;
+    const int r = w.prepare(data, n, info, coefs, wide);
+    return r ? r : w.done ? HVC_OK : walk_alone(w);
+}
+
 int hvc_jpeg_entropy_decode(const uint8_t *data, size_t n, const hvc_jpeg_info *info, int16_t *coefs) try {
     return entropy_decode_impl(data, n, info, coefs, nullptr);
 } HVC_ABI_CATCH
 
-// wide == nullptr: an absolute DC outside int16 is HVC_E_RANGE (the int16 record cannot carry it).  Otherwise the
-// record gets the saturated value and the block goes on the list with its true DC (hvc_huff.h WideDc).
-static int entropy_decode_impl(const uint8_t *data, size_t n, const hvc_jpeg_info *info, int16_t *coefs,
-                               std::vector<hvc::WideDc> *wide) {
-    if (!data || !info || !coefs) return HVC_E_INVALID_ARG;
-    Header h;
-    int r = parse_header(data, n, h);
-    if (r) return r;
-    Lut dc[4], ac[4];
-    for (int i = 0; i < info->n_comp; i++) {
-        int di = -1, ai = -1; // find_huffman_table (decoder.ml:238-259): newest match
-        for (int k = (int)h.dht.size() - 1; k >= 0; k--) {
-            if (di < 0 && h.dht[k].tclass == 0 && h.dht[k].id == info->comp[i].dc_table) di = k;
-            if (ai < 0 && h.dht[k].tclass == 1 && h.dht[k].id == info->comp[i].ac_table) ai = k;
-        }
-        if (di < 0 || ai < 0) return HVC_E_BAD_JPEG;
-        if (!dc[i].build(h.dht[di].spec) || !ac[i].build(h.dht[ai].spec)) return HVC_E_BAD_JPEG;
-        ac[i].build_whole();
+// Two files on one thread, symbol by symbol in turn; st[0] / st[1] receive each file's own status (what
+// entropy_decode_impl would have returned for it): an error in one does not stop the other.
+static void entropy_decode_two_impl(const uint8_t *const data[2], const size_t n[2], const hvc_jpeg_info *const info[2],
+                                    int16_t *const coefs[2], std::vector<hvc::WideDc> *const wide[2], int st[2]) {
+    Walk a, b;
+    st[0] = a.prepare(data[0], n[0], info[0], coefs[0], wide[0]);
+    st[1] = b.prepare(data[1], n[1], info[1], coefs[1], wide[1]);
+    if (st[0] || st[1] || a.done || b.done) { // one of them cannot start (or has nothing to do): the other runs alone
+        if (!st[0] && !a.done) st[0] = walk_alone(a);
+        if (!st[1] && !b.done) st[1] = walk_alone(b);
+        return;
     }
-    // extract_entropy_coded_bits (decoder.ml:261-281): up to the first marker, 0xff00 -> 0xff
-    std::vector<uint8_t> ecs;
-    {
-        size_t pos = h.ecs_pos;
-        ecs.reserve((n > pos ? n - pos : 0) + 16);
-        while (pos < n) {
-            const uint8_t *ff = (const uint8_t *)std::memchr(data + pos, 0xff, n - pos);
-            const size_t stop = ff ? (size_t)(ff - data) : n;
-            ecs.insert(ecs.end(), data + pos, data + stop);
-            if (!ff) break; // the model would spin on zero bytes here; a missing EOI just ends the segment
-            const int next = stop + 1 < n ? data[stop + 1] : 0; // past the end reads as 0x00 = stuffing
-            if (next != 0x00) break;
-            ecs.push_back(0xff);
-            pos = stop + 2;
-        }
+    // both have a block in progress inside the hot loop; whoever ends one starts its next block and comes back
+    if ((st[0] = a.begin_block()) || (st[1] = b.begin_block())) { // (the other one alone, from its first block)
+        // restart whichever is intact from the top: nothing of it has been consumed beyond its first block's DC
+        if (!st[0]) { Walk a2; st[0] = a2.prepare(data[0], n[0], info[0], coefs[0], wide[0]); if (wide[0]) wide[0]->clear(); if (!st[0] && !a2.done) st[0] = walk_alone(a2); }
+        else if (!st[1]) { Walk b2; st[1] = b2.prepare(data[1], n[1], info[1], coefs[1], wide[1]); if (wide[1]) wide[1]->clear(); if (!st[1] && !b2.done) st[1] = walk_alone(b2); }
+        return;
     }
-    const size_t ecs_len = ecs.size();
-    ecs.insert(ecs.end(), 16, 0); // zero padding: the reader loads 8 bytes at a time
-    // clear_block (decoder.ml:109-116) happens per block below, right before the block is written: one
-    // pass over the record instead of a 6 MB memset that has left the cache by the time the block comes up
-    BitReader br{ecs.data(), ecs_len};
-    long long dc_pred[4] = {0, 0, 0, 0}; // (the model's 63-bit ints: 67 M blocks of +-65535 stay far inside)
-    const hvc_jpeg_component &c0 = info->comp[0];
-    const int mbs_wide = c0.decoded_width / (8 * c0.hscale), mbs_high = c0.decoded_height / (8 * c0.vscale);
-    for (int my = 0; my < mbs_high; my++)
-        for (int mx = 0; mx < mbs_wide; mx++)
-            for (int i = 0; i < info->n_comp; i++) {
-                const hvc_jpeg_component &c = info->comp[i];
-                const hvc_component &L = info->layout[i];
-                const uint16_t *dct = dc[i].e.data(), *act = ac[i].e.data();
-                const uint16_t *dcf = dc[i].fast, *acf = ac[i].fast;
-                const Lut::Whole *acw = ac[i].whole;
-                const int dmax = dc[i].max_bits, amax = ac[i].max_bits;
-                for (int sy = 0; sy < c.vscale; sy++)
-                    for (int sx = 0; sx < c.hscale; sx++) {
-                        const int bx = mx * c.hscale + sx, by = my * c.vscale + sy;
-                        if (bx >= L.blocks_w || by >= L.blocks_h) return HVC_E_BAD_JPEG; // Plane.set out of bounds
-                        int16_t *blk = coefs + L.coef_offset + ((size_t)by * L.blocks_w + bx) * 64;
-                        std::memset(blk, 0, 64 * sizeof(int16_t));
-                        br.refill();
-                        unsigned e = dcf[br.peek(Lut::FAST_BITS)];
-                        if (!e) e = dct[br.peek(dmax)];
-                        if (!e) return HVC_E_BAD_JPEG; // "Can't find dc code"
-                        br.skip(e >> 8);
-                        const int cat = e & 0xff;
-                        long long diff = 0;
-                        if (cat > 16) {
-                            // No JPEG has DC categories above 11 (baseline) / 16; the model, though, reads `cat`
-                            // magnitude bits for whatever the table says (decoder.ml:81-96: no check).  Up to 32 bits
-                            // this reader follows it -- such a difference never fits the int16 record (|d| >= 65536),
-                            // so only the wide-DC mode goes on -- beyond that the stream is refused.
-                            if (cat > 32) return HVC_E_BAD_JPEG;
-                            if (!wide) return HVC_E_RANGE;
-                            br.refill();
-                            const unsigned code = br.peek(cat);
-                            diff = ((code >> (cat - 1)) & 1u) ? (long long)code : (long long)code - ((1ll << cat) - 1);
-                            br.skip(cat);
-                        } else if (cat) {
-                            br.refill();
-                            diff = extend(cat, br.peek(cat));
-                            br.skip(cat);
-                        }
-                        const long long dcv = diff + dc_pred[i];
-                        dc_pred[i] = dcv;
-                        if (dcv < -32768 || dcv > 32767) {
-                            if (!wide) return HVC_E_RANGE;
-                            try {
-                                wide->push_back(hvc::WideDc{(uint32_t)((size_t)(blk - coefs) >> 6), dcv});
-                            } catch (const std::bad_alloc &) {
-                                return HVC_E_OUT_OF_MEMORY;
-                            }
-                            blk[0] = (int16_t)(dcv < 0 ? -32767 : 32767);
-                        } else {
-                            blk[0] = (int16_t)dcv;
-                        }
-                        int k = 1;
-                        while (k < 64) {
-                            br.refill();
-                            // symbol + magnitude in one lookup when both fit the look-ahead window
-                            const Lut::Whole wh = acw[br.peek(Lut::FAST_BITS)];
-                            if (wh.bits) {
-                                br.skip(wh.bits);
-                                if (wh.run == Lut::EOB) break;
-                                k += wh.run;
-                                if (k >= 64) return HVC_E_BAD_JPEG; // "coefficient index out of range"
-                                blk[k++] = wh.value;
-                                continue;
-                            }
-                            e = acf[br.peek(Lut::FAST_BITS)];
-                            if (!e) e = act[br.peek(amax)];
-                            if (!e) return HVC_E_BAD_JPEG; // "Can't find ac code"
-                            br.skip(e >> 8);
-                            const int run = (e >> 4) & 15, size = e & 15;
-                            int mag = 0;
-                            if (size) {
-                                mag = extend(size, br.peek(size));
-                                br.skip(size);
-                            }
-                            if (mag == 0 && run == 0) break; // decoder.ml:131-132 (EOB, or a zero-size code)
-                            k += run;
-                            if (k >= 64) return HVC_E_BAD_JPEG; // "coefficient index out of range"
-                            blk[k++] = (int16_t)mag;
-                        }
-                    }
+    BitReader bra = a.br, brb = b.br;
+    int ka = a.k, kb = b.k, ea = 0, eb = 0;
+    int16_t *blka = a.blk, *blkb = b.blk;
+    const Lut::Whole *acwa = a.acw, *acwb = b.acw;
+    const uint16_t *acfa = a.acf, *acta = a.act, *acfb = b.acf, *actb = b.act;
+    int amaxa = a.amax, amaxb = b.amax;
+    bool alive_a = true, alive_b = true;
+    while (alive_a && alive_b) {
+        while (ka < 64 && kb < 64 && !(ea | eb)) {
+            HVC_AC_SYMBOL(bra, ka, blka, acwa, acfa, acta, amaxa, ea);
+            HVC_AC_SYMBOL(brb, kb, blkb, acwb, acfb, actb, amaxb, eb);
+        }
+        if (ea || ka >= 64) { // A: error, or its block is complete
+            a.br = bra;
+            a.k = 64;
+            if (ea) st[0] = ea;
+            if (ea || a.finished() || (st[0] = a.begin_block())) alive_a = false;
+            else {
+                bra = a.br; ka = a.k; blka = a.blk; acwa = a.acw; acfa = a.acf; acta = a.act; amaxa = a.amax;
             }
-    return HVC_OK;
+        }
+        if (eb || kb >= 64) {
+            b.br = brb;
+            b.k = 64;
+            if (eb) st[1] = eb;
+            if (eb || b.finished() || (st[1] = b.begin_block())) alive_b = false;
+            else {
+                brb = b.br; kb = b.k; blkb = b.blk; acwb = b.acw; acfb = b.acf; actb = b.act; amaxb = b.amax;
+            }
+        }
+    }
+    // the survivor finishes alone: the block it has in progress first
+    auto finish = [](Walk &w, BitReader br, int k, int16_t *blk, int &status) {
+        int err = 0;
+        while (k < 64 && !err) HVC_AC_SYMBOL(br, k, blk, w.acw, w.acf, w.act, w.amax, err);
+        w.br = br;
+        w.k = 64;
+        status = err ? err : walk_alone(w);
+    };
+    if (alive_a) finish(a, bra, ka, blka, st[0]);
+    if (alive_b) finish(b, brb, kb, blkb, st[1]);
 }
+
+int hvc_jpeg_entropy_decode2(const uint8_t *jpeg_a, size_t n_a, const hvc_jpeg_info *info_a, int16_t *coefs_a, int *status_a,
+                             const uint8_t *jpeg_b, size_t n_b, const hvc_jpeg_info *info_b, int16_t *coefs_b, int *status_b) try {
+    if (!status_a || !status_b) return HVC_E_INVALID_ARG;
+    const uint8_t *const data[2] = {jpeg_a, jpeg_b};
+    const size_t n[2] = {n_a, n_b};
+    const hvc_jpeg_info *const info[2] = {info_a, info_b};
+    int16_t *const coefs[2] = {coefs_a, coefs_b};
+    std::vector<hvc::WideDc> *const wide[2] = {nullptr, nullptr};
+    int st[2] = {HVC_OK, HVC_OK};
+    entropy_decode_two_impl(data, n, info, coefs, wide, st);
+    *status_a = st[0];
+    *status_b = st[1];
+    return HVC_OK;
+} HVC_ABI_CATCH
 
 // Decoder.crop / get_yuv_frame (decoder.ml:403-420): the actual_w x actual_h top-left part of every
 // padded plane, planes back to back (the layout Frame.output writes, common/src/frame.ml:66-70).
@@ -677,6 +827,13 @@ int entropy_decode_wide(const uint8_t *data, size_t n, const ::hvc_jpeg_info *in
     wide.clear();
     return entropy_decode_impl(data, n, info, coefs, &wide);
 }
+// two files on one thread (entropy_decode_two_impl): the batch pipeline's workers
+void entropy_decode_wide2(const uint8_t *const data[2], const size_t n[2], const ::hvc_jpeg_info *const info[2], int16_t *const coefs[2],
+                          std::vector<WideDc> *const wide[2], int st[2]) {
+    wide[0]->clear();
+    wide[1]->clear();
+    entropy_decode_two_impl(data, n, info, coefs, wide, st);
+}
 
 // Encoder.write_headers (encoder.ml:371-418) for `info`: SOI .. SOS, appended to o
 void jpeg_header_bytes(const hvc_jpeg_info *info, std::vector<uint8_t> &o) {
@@ -790,7 +947,7 @@ __attribute__((target("ssse3,popcnt"))) static void unstuff_chunks(const uint8_t
     }
 }
 
-static size_t extract_ecs_to(const uint8_t *data, size_t n, size_t pos, uint8_t *dst, size_t cap) {
+size_t extract_ecs_to(const uint8_t *data, size_t n, size_t pos, uint8_t *dst, size_t cap) {
     size_t out = 0;
     static const bool simd = __builtin_cpu_supports("ssse3") && __builtin_cpu_supports("popcnt");
     while (pos < n) {

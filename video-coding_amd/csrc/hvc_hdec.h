@@ -169,6 +169,10 @@ struct WideDc {
 // hvc_jpeg_entropy_decode that goes on where that one answers HVC_E_RANGE: such blocks are listed in `wide` (the
 // file-level decode entry points then recompute them in int64 with their true DC, as the model does)
 int entropy_decode_wide(const uint8_t *data, size_t n, const ::hvc_jpeg_info *info, int16_t *coefs, std::vector<WideDc> &wide);
+// the same for two files at once on one thread, their symbols decoded in turn (two dependency chains for the core to
+// overlap); st[i] = what entropy_decode_wide would have returned for file i
+void entropy_decode_wide2(const uint8_t *const data[2], const size_t n[2], const ::hvc_jpeg_info *const info[2], int16_t *const coefs[2],
+                          std::vector<WideDc> *const wide[2], int st[2]);
 
 } // namespace hvc
 #endif

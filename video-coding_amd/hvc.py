@@ -22,7 +22,7 @@ SYMBOLS = [
     "hvc_jpeg_decode_batch", "hvc_quant_table", "hvc_jpeg_encoder_layout", "hvc_jpeg_entropy_encode",
     "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444", "hvc_jpeg_decode_yuv444", "hvc_compare_planes", "hvc_jpeg_encode_batch", "hvc_jpeg_decode_batch_yuv444", "hvc_jpeg_encoder_check", "hvc_huffman_encode_frames", "hvc_jpeg_header", "hvc_jpeg_encode_batch_gpu", "hvc_jpeg_entropy_decode_gpu", "hvc_jpeg_decode_batch_gpu",
     "hvc_checksum_records", "hvc_encode_frames_recon", "hvc_set_host_cpus", "hvc_get_host_cpus",
-    "hvc_host_threads", "hvc_host_threads_probe",
+    "hvc_host_threads", "hvc_host_threads_probe", "hvc_jpeg_entropy_decode2",
 ]
 
 
@@ -124,6 +124,7 @@ def lib():
         L.hvc_jpeg_read_header.argtypes = [vp, sz, ip]
         L.hvc_jpeg_entropy_decode.argtypes = [vp, sz, ip, vp]
         L.hvc_jpeg_get_yuv_frame.argtypes = [ip, vp, vp, sz, C.POINTER(sz)]
+        L.hvc_jpeg_entropy_decode2.argtypes = [vp, sz, ip, vp, C.POINTER(i), vp, sz, ip, vp, C.POINTER(i)]
         L.hvc_jpeg_decode.argtypes = [vp, vp, sz, ip, vp, sz]
         L.hvc_jpeg_decode_yuv444.argtypes = [vp, vp, sz, ip, vp, sz]
         L.hvc_jpeg_decode_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), i, i, i, vp, sz, i,
@@ -206,6 +207,16 @@ def jpeg_entropy_decode(data: bytes, info=None):
     coefs = np.empty(info.coef_count, dtype=np.int16)
     _chk(lib().hvc_jpeg_entropy_decode(data, len(data), C.byref(info), coefs.ctypes.data), "hvc_jpeg_entropy_decode")
     return info, coefs
+
+
+def jpeg_entropy_decode2(data_a: bytes, data_b: bytes):
+    """hvc_jpeg_entropy_decode2: two files decoded in turn on this thread -> ((status, info, record), (status, info, record))"""
+    ia, ib = jpeg_read_header(data_a), jpeg_read_header(data_b)
+    ca, cb = np.empty(ia.coef_count, dtype=np.int16), np.empty(ib.coef_count, dtype=np.int16)
+    sa, sb = C.c_int(1), C.c_int(1)
+    _chk(lib().hvc_jpeg_entropy_decode2(data_a, len(data_a), C.byref(ia), ca.ctypes.data, C.byref(sa),
+                                        data_b, len(data_b), C.byref(ib), cb.ctypes.data, C.byref(sb)), "hvc_jpeg_entropy_decode2")
+    return (sa.value, ia, ca), (sb.value, ib, cb)
 
 
 def jpeg_get_yuv_frame(info, pixels):
