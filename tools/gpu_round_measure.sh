@@ -27,7 +27,16 @@ python tools/bench_configs.py --config 3 --frames 4096 --threads 16 --gpu-entrop
 python tools/bench_configs.py --config 8 --gpu-entropy > gpurun_out/m_c5_files_gpu_entropy.json 2> gpurun_out/m_c5g.err
 python tools/bench_configs.py --config 9 > gpurun_out/m_huffman_gpu.json 2> gpurun_out/m_huffman_gpu.err
 python tools/bench_single.py > gpurun_out/m_single_file.jsonl 2> gpurun_out/m_single_file.err
+python tools/bench_small_batches.py > gpurun_out/m_small_batches.jsonl 2> gpurun_out/m_small_batches.err
+python tools/bench_photo.py > gpurun_out/m_photo.jsonl 2> gpurun_out/m_photo.err
+HVC_BENCH_REHEARSAL=1 python bench.py --gpus 4 --steps 20 --no-cpu-baseline --sustain-seconds 0.5 > gpurun_out/m_bench_rehearsal4.json 2> gpurun_out/m_bench_rehearsal4.err
+HVC_BENCH_REHEARSAL=1 python bench.py --gpus 4 --config 4 --steps 1 --warmup 0 --frames 16 --shard 64 --no-cpu-baseline --sustain-seconds 0 > gpurun_out/m_bench_rehearsal4_c4.json 2> gpurun_out/m_bench_rehearsal4_c4.err
 echo "configs done"
+# one hvc_jpeg_decode call on one 1080p file: the timeline of its launches
+D=$ROOT/gpurun_out/prof_${TAG}_single; mkdir -p $D
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace -d $D -o trace -- python3 $ROOT/tools/trace_single_call.py --quality 3 > $D/log.txt 2>&1) || true
+python3 tools/trace_single_call.py --timeline $D > gpurun_out/m_single_call_timeline.txt 2>&1 || true
+rm -rf $D
 # the GPU Huffman reader alone on one 256-file chunk, one stream: per-kernel durations that do not depend on what the
 # other reader stream of the pipeline is doing (model's tables; every file with its own optimised tables)
 for v in "" "--own-tables"; do
@@ -40,6 +49,11 @@ done
 echo "reader chunk done"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mem_ubench3 tools/ubench/mem_ubench3.hip 2> /dev/null
 /tmp/mem_ubench3 > gpurun_out/m_mem_ubench3.txt 2>&1 || true
+# the ceilings by bytes per lane (the block kernels move 192 - 384 B per lane: their ceiling is not the 16-B-per-lane one),
+# and the kernels' real / ideal load and store halves
+for u in inflight_ubench shape_ubench k1_ubench; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/$u tools/ubench/$u.hip 2> /dev/null && /tmp/$u > gpurun_out/m_$u.txt 2>&1 || true
+done
 # every kernel against the memory ceiling of its own access shape (traffic-only measurement build)
 if [ -f build/variants/libhvc_traffic.so ]; then
   T=$ROOT/build/variants/libhvc_traffic.so

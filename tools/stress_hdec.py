@@ -64,7 +64,8 @@ def main():
             continue
         if case % 3 == 2:   # a third of the cases: files with their own optimised Huffman tables, 1 to 3 table sets each
             qt = np.stack([hvc.hvc.quant_table(0, q), hvc.hvc.quant_table(1, q)])
-            files = [jpeg_optimised_tables(w, h, chroma, qt, hvc.hvc.jpeg_entropy_decode(j)[1], int(rng.integers(1, 4)))
+            files = [jpeg_optimised_tables(w, h, chroma, qt, hvc.hvc.jpeg_entropy_decode(j)[1], int(rng.integers(1, 4)),
+                                           ac_shape="many_prefixes" if rng.integers(0, 3) == 0 else None)  # (a third: tables past the sub-table limit)
                      if rng.integers(0, 5) else j for j in files]
         _, got, used = ctx.jpeg_entropy_decode_gpu(files, device=bool(case & 1))
         used_gpu += used == 1

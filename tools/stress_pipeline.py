@@ -43,7 +43,8 @@ def main():
             qt = np.stack([hvc.hvc.quant_table(0, q), hvc.hvc.quant_table(1, q)])
             for d in range(n_distinct):
                 if n_distinct == 1 or rng.integers(0, 4) != 0:
-                    files[d] = jpeg_optimised_tables(w, h, 420, qt, hvc.hvc.jpeg_entropy_decode(files[d])[1], int(rng.integers(1, 4)))
+                    files[d] = jpeg_optimised_tables(w, h, 420, qt, hvc.hvc.jpeg_entropy_decode(files[d])[1], int(rng.integers(1, 4)),
+                                                     ac_shape="many_prefixes" if rng.integers(0, 3) == 0 else None)
             own_batches += 1
         n = int(rng.integers(1, 41))
         batch = [files[int(rng.integers(0, n_distinct))] for _ in range(n)]
