@@ -5,6 +5,9 @@ set -e
 TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out
+# PART=a: the bench lines and microbenchmarks; PART=b: the rocprofv3 profiles; default: both (a call has 20 minutes)
+PART=${PART:-all}
+if [ "$PART" != "b" ]; then
 python bench.py > gpurun_out/m_bench.json 2> gpurun_out/m_bench.err
 python bench.py --config 4 --no-cpu-baseline > gpurun_out/m_bench_c4.json 2> gpurun_out/m_bench_c4.err
 HVC_BENCH_REHEARSAL=1 python bench.py --gpus 2 --steps 20 --no-cpu-baseline > gpurun_out/m_bench_rehearsal2.json 2> gpurun_out/m_bench_rehearsal2.err
@@ -68,6 +71,8 @@ if [ -f build/variants/libhvc_traffic.so ]; then
     done; } > gpurun_out/m_shape_ceilings.txt 2> /dev/null
 fi
 echo "ceilings done"
+fi
+if [ "$PART" = "a" ]; then exit 0; fi
 bash tools/gpu_profile.sh ${TAG}_decode
 echo "decode profile done"
 bash tools/gpu_profile.sh ${TAG}_decode_c4 --config 4 --steps 2 --warmup 1

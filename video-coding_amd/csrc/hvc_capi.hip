@@ -1799,10 +1799,11 @@ static int decode_batch_impl(hvc_ctx *c, const uint8_t *const *jpegs, const size
         // Frames are taken TWO at a time and decoded symbol by symbol in turn (hvc::entropy_decode_wide2): one stream is
         // one dependency chain, two streams are two chains the core overlaps -- 1.4x the frames per second per thread.
         std::vector<hvc::WideDc> wide2[2];
+        static const int take = [] { const char *v = std::getenv("HVC_HOST_PAIRS"); return v && v[0] == '0' ? 1 : 2; }(); // (A/B: 0 = one file at a time)
         for (;;) {
-            const int f0 = next_frame.fetch_add(2);
+            const int f0 = next_frame.fetch_add(take);
             if (f0 >= n_frames || error.load()) return;
-            const int cnt = f0 + 1 < n_frames ? 2 : 1;
+            const int cnt = (take == 2 && f0 + 1 < n_frames) ? 2 : 1;
             const int k_last = (f0 + cnt - 1) / C;
             {
                 std::unique_lock<std::mutex> lk(mu);
