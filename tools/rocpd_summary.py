@@ -42,17 +42,15 @@ def main(d):
                 for line in open(lp):
                     if line.startswith("{"):
                         print("bench line of this very run (HIP events inside the profiled process):\n  " + line.strip())
-        # The trace's vgpr_count is the ARCHITECTURAL registers only; on gfx950 a kernel's allocation is arch + accumulation
-        # registers out of one file (k_decode_packed: 60 + 56 = the 116 of its code object, which is what sets its 4 waves
-        # per SIMD).  Print both and their sum where the trace has them (the column read "vgpr=60").
-        cols = [r[1] for r in q(tr[0], "pragma table_info(kernels)")]
-        acc = next((c for c in ("accum_vgpr_count", "agpr_count", "accum_vgprs") if c in cols), None)
-        rows = q(tr[0], "select name, duration, vgpr_count, %s, sgpr_count, grid_x, grid_y, workgroup_x from kernels "
-                        "where name like '%%hvc::%%' order by start" % (acc or "0"))
-        print("\nper-dispatch (hvc kernels): name duration_ns registers (arch vgpr + accum vgpr = allocation) sgpr grid wg")
+        # The trace's vgpr_count column is HALF the kernel's register allocation (rounded up to the granule of 8) on gfx950:
+        # k_decode_packed 60 for the 116 of its code object (-> 120), k_decode_wide 108 for 216, k_decode_444 40 for 76
+        # (-> 80) -- compared against the .vgpr_count of the code objects (the column read "vgpr=60" for a
+        # kernel whose 116 registers are what holds it to 4 waves per SIMD).  Printed as the allocation it stands for.
+        rows = q(tr[0], "select name, duration, vgpr_count, sgpr_count, grid_x, grid_y, workgroup_x from kernels "
+                        "where name like '%hvc::%' order by start")
+        print("\nper-dispatch (hvc kernels): name duration_ns vgpr_alloc (= 2 x the trace's vgpr_count column) sgpr grid wg")
         for r in rows:
-            print("  %-48s %9d vgpr=%d+%d=%d%s sgpr=%d grid=%dx%d wg=%d" % (r[0][:48], r[1], r[2], r[3], r[2] + r[3],
-                  "" if acc else " (arch only: the trace has no accumulation-register column)", r[4], r[5], r[6], r[7]))
+            print("  %-48s %9d vgpr_alloc=%d sgpr=%d grid=%dx%d wg=%d" % (r[0][:48], r[1], 2 * r[2], r[3], r[4], r[5], r[6]))
     print("\n## --pmc passes (average per dispatch of each hvc kernel)")
     for sub in sorted(glob.glob(os.path.join(d, "pmc_*"))):
         dbs = glob.glob(os.path.join(sub, "*.db"))
