@@ -36,12 +36,25 @@ def main(d):
             w = WARMUP if len(ds) > WARMUP else 0
             print("\ndominant kernel %s: %d dispatches, avg %.1f ns; without the first %d (setup / warm-up): avg %.1f ns"
                   % (dom[0][0][:60], len(ds), sum(ds) / len(ds), w, sum(ds[w:]) / len(ds[w:])))
+        timed = None
         for log in ("trace_bench.log", "trace.log"):
             lp = os.path.join(d_, log)
             if os.path.exists(lp):
                 for line in open(lp):
                     if line.startswith("{"):
                         print("bench line of this very run (HIP events inside the profiled process):\n  " + line.strip())
+                        try:
+                            import json
+                            rec = json.loads(line)
+                            cfg = rec.get("config", {})
+                            timed = rec["steps"] * (cfg["frames_per_gpu_per_step"] // cfg["frames_per_launch"])
+                        except (ValueError, KeyError, TypeError):
+                            pass
+        if dom and timed:  # bench.py: setup + warm-up, then exactly K timed steps, then the `sustained` run
+            t = ds[WARMUP:WARMUP + timed]
+            if t:
+                print("dominant kernel, the %d TIMED dispatches (after %d of setup / warm-up; %d more belong to the sustained run): avg %.1f ns"
+                      % (len(t), WARMUP, max(0, len(ds) - WARMUP - timed), sum(t) / len(t)))
         # The trace's vgpr_count column is HALF the kernel's register allocation (rounded up to the granule of 8) on gfx950:
         # k_decode_packed 60 for the 116 of its code object (-> 120), k_decode_wide 108 for 216, k_decode_444 40 for 76
         # (-> 80) -- compared against the .vgpr_count of the code objects (the column read "vgpr=60" for a
@@ -49,8 +62,10 @@ def main(d):
         rows = q(tr[0], "select name, duration, vgpr_count, sgpr_count, grid_x, grid_y, workgroup_x from kernels "
                         "where name like '%hvc::%' order by start")
         print("\nper-dispatch (hvc kernels): name duration_ns vgpr_alloc (= 2 x the trace's vgpr_count column) sgpr grid wg")
-        for r in rows:
+        for r in rows[:160]:
             print("  %-48s %9d vgpr_alloc=%d sgpr=%d grid=%dx%d wg=%d" % (r[0][:48], r[1], 2 * r[2], r[3], r[4], r[5], r[6]))
+        if len(rows) > 160:
+            print("  ... %d more dispatches (the totals above cover them)" % (len(rows) - 160))
     print("\n## --pmc passes (average per dispatch of each hvc kernel)")
     for sub in sorted(glob.glob(os.path.join(d, "pmc_*"))):
         dbs = glob.glob(os.path.join(sub, "*.db"))
