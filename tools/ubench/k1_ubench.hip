@@ -83,6 +83,39 @@ __global__ __launch_bounds__(256) void k1(P p) {
     }
 }
 
+// TWO lanes per block: both lanes of a pair load the block's 128 B (the same addresses: one request), lane 0 of the pair
+// stores rows 0-3, lane 1 rows 4-7 -- a wave moves 4 KiB in + 2 KiB out instead of 8 + 4.  LANES = 2 or 4 (4 lanes per
+// block: two rows each).
+template <int LANES>
+__global__ __launch_bounds__(256) void k1_split(ParamsSmall p) {
+    extern __shared__ unsigned char dyn_lds[];
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    constexpr int BPW = 256 / LANES; // blocks per workgroup
+    int c = 0;
+#pragma unroll
+    for (int i = 1; i < 3; i++)
+        if (i < p.n_comp && tile >= p.comp[i].tile0) c = i;
+    const Comp &K = p.comp[c];
+    int b = (tile - K.tile0) * BPW + lane / LANES;
+    const int part = lane % LANES;
+    const bool active = b < K.nblk;
+    b = active ? b : K.nblk - 1;
+    const unsigned by = __umulhi((unsigned)b, K.magic), bx = (unsigned)b - by * (unsigned)K.bw;
+    const uint4 *src = p.coefs + (size_t)blockIdx.y * p.coef_fs + K.coef_off + (size_t)b * 8;
+    uint4 r[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = src[j];
+    unsigned char *dst = p.pixels + (size_t)blockIdx.y * p.pixel_fs + K.plane_off + (size_t)by * 8 * K.stride + (size_t)bx * 8;
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 8 / LANES; j++) {
+            const int row = part * (8 / LANES) + j;
+            const u2v t = {r[j].x ^ r[j + 8 / LANES > 7 ? 7 : j + 8 / LANES].z ^ r[(j + 3) & 7].y, r[j].y ^ r[(j + 5) & 7].w ^ r[(j + 6) & 7].x};
+            __builtin_nontemporal_store(t, reinterpret_cast<u2v *>(dst + (size_t)row * K.stride));
+        }
+    }
+}
+
 template <class F>
 double timeit(F launch, int reps) {
     hipEvent_t e0, e1;
@@ -166,6 +199,29 @@ int main() {
             if (pr) report("  + 2 KB kernarg", t, bytes);
             t = timeit([&] { hipLaunchKernelGGL((k1<Params, true>), grid, dim3(256), 0, 0, pl); }, reps);
             if (pr) report("  + 2 KB kernarg + fix-list tail", t, bytes);
+            { // the granule halved / quartered: two / four lanes per block (tiles of 128 / 64 blocks)
+                fill(ps, chroma, a, b, fix, tiles, blocks);
+                for (int lanes : {2, 4}) {
+                    ParamsSmall q2 = ps;
+                    int t2 = 0;
+                    for (int i = 0; i < q2.n_comp; i++) {
+                        q2.comp[i].tile0 = t2;
+                        t2 += (q2.comp[i].nblk + 256 / lanes - 1) / (256 / lanes);
+                    }
+                    for (int wg : {8, 4}) {
+                        const unsigned lds = wg >= 8 ? 0u : (unsigned)(160 * 1024 / wg - 1024) & ~255u;
+                        if (lanes == 2) {
+                            CHECK(hipFuncSetAttribute((const void *)k1_split<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+                            t = timeit([&] { hipLaunchKernelGGL((k1_split<2>), dim3(t2, frames), dim3(256), lds, 0, q2); }, reps);
+                        } else {
+                            CHECK(hipFuncSetAttribute((const void *)k1_split<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+                            t = timeit([&] { hipLaunchKernelGGL((k1_split<4>), dim3(t2, frames), dim3(256), lds, 0, q2); }, reps);
+                        }
+                        snprintf(name, sizeof name, "  %d lanes per block (each stores %d rows), %d workgroups per CU", lanes, 8 / lanes, wg);
+                        if (pr) report(name, t, bytes);
+                    }
+                }
+            }
             for (int wg : {8, 6, 5, 4, 3, 2, 1}) { // workgroups per CU by dynamic LDS (160 KB per CU)
                 const unsigned lds = wg >= 8 ? 0u : (unsigned)(160 * 1024 / wg - 1024) & ~255u;
                 CHECK(hipFuncSetAttribute((const void *)k1<ParamsSmall, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));

@@ -2630,6 +2630,8 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     const auto wall0 = std::chrono::steady_clock::now();
     if ((r = pool_ready(c, threads, where == HVC_MEM_HOST ? 1 : 0))) return r;
     std::atomic<int> stage_done{0}, dl_abort{0}, dl_err{0}; // chunks whose block stage is enqueued
+    std::vector<char> downloaded((size_t)n_chunks, 0);      // (everything a pool task touches is declared BEFORE the scope
+                                                            // that waits for the tasks: destroyed after it has waited)
     bool completed = false; // (the workers have run out of frames, the downloader out of chunks)
     hvc::PoolScope scope(c->pool, [&] {
         std::lock_guard<std::mutex> lk(mu);
@@ -2641,7 +2643,6 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     // Host output: a thread of its own downloads chunk after chunk on c->down_stream (copies to pageable memory hold
     // their caller -- issued from the loop below they kept the next chunk's launches waiting, and on the block
     // stage's stream its kernels too: 18 Gpixel/s, 33 with this).
-    std::vector<char> downloaded((size_t)n_chunks, 0);
     auto submit_failed = [&](int e) {
         std::lock_guard<std::mutex> lk(mu);
         error.store(e);
