@@ -353,3 +353,67 @@ def test_two_files_in_turn_equal_two_files_one_after_the_other():
         (sa, _, ra), (sb, _, rb) = hvc.hvc.jpeg_entropy_decode2(*pair)
         assert (sa, sb) == ((want, 0) if first else (0, want))
         assert np.array_equal(rb if first else ra, single[2])
+
+
+def test_groups_of_four_symbols_end_in_every_slot(hvc):
+    """The reader decodes AC symbols in groups of four behind one refill (csrc/hvc_entropy.cpp, HVC_AC_GROUP); a group ends
+    early at an end of block, at the block's 64th coefficient, and at a symbol the one-lookup table does not cover (a long
+    code or a large magnitude: two-step path after a refill of its own).  Blocks built so that each of these lands in each
+    of the four slots, behind 0..7 short symbols, with short and long symbols alternating, and with 26-bit symbols (16-bit
+    code + 10 magnitude bits) back to back; alone and in turn with a second file; against the model restatement."""
+    info = hvc.jpeg_encoder_layout(64, 48, 420, 50)
+    nblk = info.coef_count // 64
+    blocks = np.zeros((nblk, 64), dtype=np.int16)
+    for b in range(nblk):
+        kind, lead = b % 6, (b // 6) % 8
+        blocks[b, 1:1 + lead] = np.where(np.arange(lead) % 2 == 0, 1, -1)  # `lead` short symbols (2-bit code + 1 bit)
+        nxt = 1 + lead
+        if kind == 0:
+            pass                                     # ... then the end of block
+        elif kind == 1:
+            blocks[b, nxt] = 1023                    # ... then a large magnitude (two-step path), then the end of block
+        elif kind == 2:
+            blocks[b, nxt + 9] = -700                # ... then run 9 / size 10: a 16-bit code + 10 bits
+            blocks[b, nxt + 10] = 2
+        elif kind == 3:
+            blocks[b, nxt:] = 1                      # ... short symbols up to the 64th coefficient (no end of block)
+        elif kind == 4:
+            blocks[b, nxt:64:2] = 1                  # ... run-1 symbols; the last coefficient may or may not be index 63
+            blocks[b, nxt + 1:64:4] = -1000
+        else:
+            blocks[b, nxt:nxt + 12] = [-1023, 1, 1023, -1, 600, 2, -600, 1, 1, 1, 900, -900]
+    for i in range(info.n_comp):
+        L = info.layout[i]
+        n = L.blocks_w * L.blocks_h
+        blocks[L.coef_offset // 64:L.coef_offset // 64 + n, 0] = np.resize(np.array([3, -60, 1000, -1000, 0], dtype=np.int16), n)
+    rec = blocks.reshape(-1)
+    jpg = hvc.jpeg_entropy_encode(info, rec)
+    _, got = hvc.jpeg_entropy_decode(jpg)
+    assert np.array_equal(got, rec)
+    assert np.array_equal(got, orc.Decoder(jpg).coef_record().astype(np.int16))
+    other = golden_bytes("Mouse480.jpg")
+    _, want_other = hvc.jpeg_entropy_decode(other)
+    for pair in ((jpg, other), (other, jpg), (jpg, jpg)):
+        (sa, _, ra), (sb, _, rb) = hvc.jpeg_entropy_decode2(*pair)
+        assert (sa, sb) == (0, 0)
+        assert np.array_equal(ra, rec if pair[0] is jpg else want_other)
+        assert np.array_equal(rb, rec if pair[1] is jpg else want_other)
+    # cut anywhere inside the last blocks: the rest reads as zero bits (bitstream_reader.ml:19-22) -- the same record as
+    # the model's, whatever the reader had loaded ahead
+    dinfo = hvc.jpeg_read_header(jpg)
+    for cut in (1, 2, 3, 5, 8, 13, 40, 200):
+        short = jpg[:len(jpg) - 2 - cut] + b"\xff\xd9"  # `cut` bytes of the segment gone, the EOI marker kept (without a
+        # marker behind the scan the model's extract_entropy_coded_bits never ends: no behaviour to match)
+        try:
+            mine = hvc.jpeg_entropy_decode(short)[1]
+        except hvc.HvcError as e:
+            mine = e.code
+        try:
+            model = orc.Decoder(short).coef_record().astype(np.int16)
+        except Exception:
+            model = None
+        if model is None:
+            assert isinstance(mine, int), cut
+        else:
+            assert not isinstance(mine, int) and np.array_equal(mine, model), cut
+    assert dinfo.coef_count == info.coef_count

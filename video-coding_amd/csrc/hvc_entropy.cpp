@@ -168,13 +168,14 @@ struct Lut {
     }
 
     // AC tables only: code AND magnitude bits decoded by one lookup when length + size <= FAST_BITS
-    // (most coefficients of real streams).  bits = 0: not covered, take the two-step path.
-    struct Whole { uint8_t bits, run; int16_t value; };
-    static constexpr uint8_t EOB = 0xff;
-    Whole whole[1 << FAST_BITS];
+    // (most coefficients of real streams).  One 32-bit entry, one load: bits 0-7 the bits consumed (0: not covered, take
+    // the two-step path), bits 8-15 how far the coefficient index moves (run + 1; WHOLE_EOB for an end of block, so that
+    // "index >= 64" is the one test that ends a block), bits 16-31 the coefficient.
+    static constexpr unsigned WHOLE_EOB = 128;
+    uint32_t whole[1 << FAST_BITS];
     void build_whole() {
         for (unsigned w = 0; w < (1u << FAST_BITS); w++) {
-            Whole o{0, 0, 0};
+            uint32_t o = 0;
             const unsigned e = fast[w];
             if (e) {
                 const int len = (int)(e >> 8), run = (int)((e >> 4) & 15), size = (int)(e & 15);
@@ -184,9 +185,28 @@ struct Lut {
                         const unsigned code = (w >> (FAST_BITS - len - size)) & ((1u << size) - 1u);
                         mag = (code & (1u << (size - 1))) ? (int)code : (int)code - (int)((1u << size) - 1); // mag'
                     }
-                    o.bits = (uint8_t)(len + size);
-                    o.run = (mag == 0 && run == 0) ? EOB : (uint8_t)run; // decoder.ml:131-132
-                    o.value = (int16_t)mag;
+                    const unsigned step = (mag == 0 && run == 0) ? WHOLE_EOB : (unsigned)run + 1u; // decoder.ml:131-132
+                    o = (uint32_t)(len + size) | step << 8 | (uint32_t)(uint16_t)(int16_t)mag << 16;
+                }
+            }
+            whole[w] = o;
+        }
+    }
+    // DC tables: the same for a DC symbol -- bits 0-7 the bits consumed (code + magnitude; 0: not covered), bits 16-31
+    // the DC difference (mag, decoder.ml:73-96) -- when the two fit FAST_BITS; differences of 7+ bits take the two steps
+    void build_whole_dc() {
+        for (unsigned w = 0; w < (1u << FAST_BITS); w++) {
+            uint32_t o = 0;
+            const unsigned e = fast[w];
+            if (e) {
+                const int len = (int)(e >> 8), cat = (int)(e & 0xff);
+                if (len + cat <= FAST_BITS) {
+                    int mag = 0;
+                    if (cat) {
+                        const unsigned code = (w >> (FAST_BITS - len - cat)) & ((1u << cat) - 1u);
+                        mag = (code & (1u << (cat - 1))) ? (int)code : (int)code - (int)((1u << cat) - 1);
+                    }
+                    o = (uint32_t)(len + cat) | (uint32_t)(uint16_t)(int16_t)mag << 16;
                 }
             }
             whole[w] = o;
@@ -197,27 +217,29 @@ struct Lut {
 // ---------------------------------------------------------------------------
 // bit reader over the extracted entropy-coded segment (stuffing already removed)
 struct BitReader {
-    const uint8_t *p; // the segment, followed by >= 8 readable zero bytes
-    size_t n, pos = 0;
-    uint64_t buf = 0; // MSB-aligned
-    int cnt = 0;
-    // after refill() at least 57 bits are valid; past the end the stream reads as zero bits
-    // (bitstream_reader.ml:19-22)
+    const uint8_t *p; // the segment, followed by >= PAD readable zero bytes
+    size_t n;         // its length in bytes
+    size_t pos = 0;   // bytes loaded so far
+    uint64_t buf = 0; // the next bits, MSB-aligned
+    int cnt = 0;      // how many of them are valid
+    // refill() tops the window up to 57..64 valid bits: enough for several symbols (a symbol of the one-lookup path is
+    // <= 10 bits, any symbol <= 16 + 15), so the hot loop refills once per GROUP of symbols and a symbol costs
+    // `buf <<= bits; cnt -= bits`.  The load address depends on nothing the symbols compute, so the load is off the
+    // symbols' dependency chain -- only the `or` is on it.  There is no end test: past the end the stream reads as zero
+    // bits (bitstream_reader.ml:19-22), the padding is zero, and hold() at every block start keeps the load position
+    // inside it -- a block consumes at most 48 + 63 * 31 bits = 251 bytes.
+    static constexpr size_t PAD = 288;
     inline void refill() {
-        if (pos + 8 <= n + 8) { // one unaligned big-endian 64-bit load (the padding makes it safe)
-            uint64_t w;
-            std::memcpy(&w, p + pos, 8);
-            w = __builtin_bswap64(w);
-            buf |= w >> cnt;
-            const int adv = (63 - cnt) >> 3;
-            pos += (size_t)adv;
-            cnt += adv * 8;
-        } else {
-            cnt = 64; // far past the end: zeros only
-        }
+        uint64_t w;
+        std::memcpy(&w, p + pos, 8);
+        buf |= __builtin_bswap64(w) >> cnt;
+        const int adv = (63 - cnt) >> 3;
+        pos += (size_t)adv;
+        cnt += adv * 8;
     }
-    inline unsigned peek(int k) const { return k ? (unsigned)(buf >> (64 - k)) : 0u; }
-    inline void skip(int k) { buf <<= k; cnt -= k; }
+    inline void hold() {
+        if (pos > n + 8) pos = n + 8; // (everything in the window is padding by then)
+    }
 };
 
 // decoder.ml:73-79 mag'
@@ -314,15 +336,29 @@ struct Walk {
     int16_t *coefs = nullptr;
     std::vector<hvc::WideDc> *wide = nullptr; // nullptr: an absolute DC outside int16 is HVC_E_RANGE; otherwise the record
                                               // gets the saturated value and the block goes on the list with its true DC
-    Lut dc[4], ac[4];
+    Lut dc_tab[4], ac_tab[4];
+    const Lut *dc[4] = {nullptr, nullptr, nullptr, nullptr}, *ac[4] = {nullptr, nullptr, nullptr, nullptr}; // per component:
+                                              // components that name the same DHT segment share one table (Cb and Cr
+                                              // do in every file an encoder writes: 12 KB less for the L1 to hold)
     std::vector<uint8_t> ecs;
     BitReader br{nullptr, 0};
     long long dc_pred[4] = {0, 0, 0, 0}; // (the model's 63-bit ints: 67 M blocks of +-65535 stay far inside)
     int mbs_wide = 0, mbs_high = 0;
-    int my = 0, mx = 0, ci = 0, sy = 0, sx = 0; // the NEXT block, decode_seq order (decoder.ml:362-395)
+    // The NEXT block, decode_seq order (decoder.ml:362-395: sx, sy inside the component's part of the MCU, then the
+    // components, then the MCUs): block `bi` of MCU (my, mx).  The blocks of one MCU are listed once (component, place
+    // inside the component's part, offset from the part's first block); per component the offset of that first block
+    // moves along with (my, mx).
+    struct McuBlock {
+        uint8_t comp, dx, dy;
+        uint32_t off; // int16 elements from the first block of the component's part of the MCU
+    };
+    std::vector<McuBlock> mcu;
+    size_t part[4] = {0, 0, 0, 0}; // per component: int16 elements from `coefs` to block (my * vscale, mx * hscale)
+    bool regular = true;            // every block of every MCU lies inside its component's planes: no per-block test
+    int my = 0, mx = 0, bi = 0;
     int16_t *blk = nullptr;
     int k = 64;                 // index of the next coefficient of the block in progress; 64 = none in progress
-    const Lut::Whole *acw = nullptr;
+    const uint32_t *acw = nullptr;
     const uint16_t *acf = nullptr, *act = nullptr;
     int amax = 0;
     bool done = false;
@@ -335,6 +371,7 @@ struct Walk {
         Header h;
         int r = parse_header(data, n, h);
         if (r) return r;
+        int dseg[4], aseg[4];
         for (int i = 0; i < info->n_comp; i++) {
             int di = -1, ai = -1; // find_huffman_table (decoder.ml:238-259): newest match
             for (int q = (int)h.dht.size() - 1; q >= 0; q--) {
@@ -342,42 +379,96 @@ struct Walk {
                 if (ai < 0 && h.dht[q].tclass == 1 && h.dht[q].id == info->comp[i].ac_table) ai = q;
             }
             if (di < 0 || ai < 0) return HVC_E_BAD_JPEG;
-            if (!dc[i].build(h.dht[di].spec) || !ac[i].build(h.dht[ai].spec)) return HVC_E_BAD_JPEG;
-            ac[i].build_whole();
+            dseg[i] = di;
+            aseg[i] = ai;
+            dc[i] = ac[i] = nullptr;
+            for (int j = 0; j < i; j++) {
+                if (dseg[j] == di) dc[i] = dc[j];
+                if (aseg[j] == ai) ac[i] = ac[j];
+            }
+            if (!dc[i]) {
+                if (!dc_tab[i].build(h.dht[di].spec)) return HVC_E_BAD_JPEG;
+                dc_tab[i].build_whole_dc();
+                dc[i] = &dc_tab[i];
+            }
+            if (!ac[i]) {
+                if (!ac_tab[i].build(h.dht[ai].spec)) return HVC_E_BAD_JPEG;
+                ac_tab[i].build_whole();
+                ac[i] = &ac_tab[i];
+            }
         }
         // extract_entropy_coded_bits (decoder.ml:261-281): up to the first marker, 0xff00 -> 0xff.  (A missing EOI just
         // ends the segment: the model would spin on zero bytes there.)
-        const size_t pos = h.ecs_pos, room = (n > pos ? n - pos : 0) + 32;
+        const size_t pos = h.ecs_pos, room = (n > pos ? n - pos : 0) + 16 + BitReader::PAD;
         ecs.resize(room);
-        size_t got = hvc::extract_ecs_to(data, n, pos, ecs.data(), room - 16);
+        size_t got = hvc::extract_ecs_to(data, n, pos, ecs.data(), room - BitReader::PAD);
         if (got == SIZE_MAX) return HVC_E_BAD_JPEG; // (cannot happen: unstuffing only ever shortens)
-        std::memset(ecs.data() + got, 0, room - got); // zero padding: the reader loads 8 bytes at a time
+        std::memset(ecs.data() + got, 0, room - got); // zero padding: see BitReader
         br = BitReader{ecs.data(), got};
         const hvc_jpeg_component &c0 = info->comp[0];
         mbs_wide = c0.decoded_width / (8 * c0.hscale);
         mbs_high = c0.decoded_height / (8 * c0.vscale);
         done = mbs_wide <= 0 || mbs_high <= 0 || info->n_comp <= 0;
+        if (done) return HVC_OK;
+        try {
+            for (int i = 0; i < info->n_comp; i++) {
+                const hvc_jpeg_component &c = info->comp[i];
+                const hvc_component &L = info->layout[i];
+                if ((long long)mbs_wide * c.hscale > L.blocks_w || (long long)mbs_high * c.vscale > L.blocks_h) regular = false;
+                for (int y = 0; y < c.vscale; y++)
+                    for (int x = 0; x < c.hscale; x++)
+                        mcu.push_back(McuBlock{(uint8_t)i, (uint8_t)x, (uint8_t)y, (uint32_t)(((size_t)y * L.blocks_w + x) * 64)});
+            }
+        } catch (const std::bad_alloc &) {
+            return HVC_E_OUT_OF_MEMORY;
+        }
+        if (mcu.empty()) { // (components without blocks: nothing to read)
+            done = true;
+            return HVC_OK;
+        }
+        row_parts();
         return HVC_OK;
     }
 
-    // the block at (my, mx, ci, sy, sx): bounds, clear_block (decoder.ml:109-116, right before the block is written: one
-    // pass over the record instead of a 6 MB memset that has left the cache by the time the block comes up), the DC
-    // symbol; then the position moves on
+    void row_parts() { // MCU (my, 0)
+        for (int i = 0; i < info->n_comp; i++)
+            part[i] = info->layout[i].coef_offset + (size_t)my * info->comp[i].vscale * info->layout[i].blocks_w * 64;
+    }
+
+    // block bi of MCU (my, mx): bounds, clear_block (decoder.ml:109-116, right before the block is written: one pass
+    // over the record instead of a 6 MB memset that has left the cache by the time the block comes up), the DC symbol;
+    // then the position moves on
     int begin_block() {
-        const int i = ci;
-        const hvc_jpeg_component &c = info->comp[i];
-        const hvc_component &L = info->layout[i];
-        const int bx = mx * c.hscale + sx, by = my * c.vscale + sy;
-        if (bx >= L.blocks_w || by >= L.blocks_h) return HVC_E_BAD_JPEG; // Plane.set out of bounds
-        blk = coefs + L.coef_offset + ((size_t)by * L.blocks_w + bx) * 64;
+        const McuBlock mb = mcu[(size_t)bi];
+        const int i = mb.comp;
+        if (!regular) {
+            const hvc_jpeg_component &c = info->comp[i];
+            const hvc_component &L = info->layout[i];
+            if (mx * c.hscale + mb.dx >= L.blocks_w || my * c.vscale + mb.dy >= L.blocks_h) return HVC_E_BAD_JPEG; // Plane.set out of bounds
+        }
+        blk = coefs + part[i] + mb.off;
         std::memset(blk, 0, 64 * sizeof(int16_t));
+        br.hold();
         br.refill();
-        unsigned e = dc[i].fast[br.peek(Lut::FAST_BITS)];
-        if (!e) e = dc[i].e[br.peek(dc[i].max_bits)];
-        if (!e) return HVC_E_BAD_JPEG; // "Can't find dc code"
-        br.skip(e >> 8);
-        const int cat = e & 0xff;
         long long diff = 0;
+        const uint32_t dw = dc[i]->whole[br.buf >> (64 - Lut::FAST_BITS)];
+        if (dw & 0xffu) { // code and magnitude in one lookup
+            br.buf <<= dw & 0xffu;
+            br.cnt -= (int)(dw & 0xffu);
+            diff = (int16_t)(dw >> 16);
+        } else if (int r = dc_two_steps(i, diff)) {
+            return r;
+        }
+        return finish_begin(i, diff);
+    }
+
+    int dc_two_steps(int i, long long &diff) {
+        unsigned e = dc[i]->fast[br.buf >> (64 - Lut::FAST_BITS)];
+        if (!e) e = dc[i]->e[dc[i]->max_bits ? br.buf >> (64 - dc[i]->max_bits) : 0];
+        if (!e) return HVC_E_BAD_JPEG; // "Can't find dc code"
+        br.buf <<= e >> 8;
+        br.cnt -= (int)(e >> 8);
+        const int cat = e & 0xff;
         if (cat > 16) {
             // No JPEG has DC categories above 11 (baseline) / 16; the model, though, reads `cat`
             // magnitude bits for whatever the table says (decoder.ml:81-96: no check).  Up to 32 bits
@@ -386,14 +477,19 @@ struct Walk {
             if (cat > 32) return HVC_E_BAD_JPEG;
             if (!wide) return HVC_E_RANGE;
             br.refill();
-            const unsigned code = br.peek(cat);
+            const unsigned code = (unsigned)(br.buf >> (64 - cat));
             diff = ((code >> (cat - 1)) & 1u) ? (long long)code : (long long)code - ((1ll << cat) - 1);
-            br.skip(cat);
-        } else if (cat) {
-            br.refill();
-            diff = extend(cat, br.peek(cat));
-            br.skip(cat);
+            br.buf <<= cat;
+            br.cnt -= cat;
+        } else if (cat) { // code + magnitude <= 32 bits: still inside the window
+            diff = extend(cat, (unsigned)(br.buf >> (64 - cat)));
+            br.buf <<= cat;
+            br.cnt -= cat;
         }
+        return HVC_OK;
+    }
+
+    inline int finish_begin(int i, long long diff) {
         const long long dcv = diff + dc_pred[i];
         dc_pred[i] = dcv;
         if (dcv < -32768 || dcv > 32767) {
@@ -408,22 +504,18 @@ struct Walk {
             blk[0] = (int16_t)dcv;
         }
         k = 1;
-        acw = ac[i].whole;
-        acf = ac[i].fast;
-        act = ac[i].e.data();
-        amax = ac[i].max_bits;
-        // decode_seq order: sx, sy inside the component's part of the MCU, then the components, then the MCUs
-        if (++sx == c.hscale) {
-            sx = 0;
-            if (++sy == c.vscale) {
-                sy = 0;
-                if (++ci == info->n_comp) {
-                    ci = 0;
-                    if (++mx == mbs_wide) {
-                        mx = 0;
-                        ++my;
-                    }
-                }
+        acw = ac[i]->whole;
+        acf = ac[i]->fast;
+        act = ac[i]->e.data();
+        amax = ac[i]->max_bits;
+        if (++bi == (int)mcu.size()) {
+            bi = 0;
+            if (++mx == mbs_wide) {
+                mx = 0;
+                ++my;
+                row_parts();
+            } else {
+                for (int j = 0; j < info->n_comp; j++) part[j] += (size_t)info->comp[j].hscale * 64;
             }
         }
         return HVC_OK;
@@ -432,35 +524,29 @@ struct Walk {
     bool finished() const { return my >= mbs_high; }
 };
 
-// One AC symbol of the block in progress, on LOCAL copies of the walk's hot state (bit reader, index, block and table
-// pointers: they must live in registers -- through the Walk object every symbol paid loads and stores of them).
-// K becomes 64 at the end of the block; ERR receives the model's error, if any.
-#define HVC_AC_SYMBOL(BR, K, BLK, ACW, ACF, ACT, AMAX, ERR)                                                        \
-    do {                                                                                                             \
-        (BR).refill();                                                                                               \
-        /* symbol + magnitude in one lookup when both fit the look-ahead window */                                  \
-        const Lut::Whole wh_ = (ACW)[(BR).peek(Lut::FAST_BITS)];                                                     \
-        if (wh_.bits) {                                                                                              \
-            (BR).skip(wh_.bits);                                                                                     \
-            if (wh_.run == Lut::EOB) {                                                                               \
-                (K) = 64;                                                                                            \
-            } else {                                                                                                 \
-                (K) += wh_.run;                                                                                      \
-                if ((K) >= 64) (ERR) = HVC_E_BAD_JPEG; /* "coefficient index out of range" */                       \
-                else (BLK)[(K)++] = wh_.value;                                                                       \
-            }                                                                                                        \
-        } else {                                                                                                     \
-            unsigned e_ = (ACF)[(BR).peek(Lut::FAST_BITS)];                                                          \
-            if (!e_) e_ = (ACT)[(BR).peek(AMAX)];                                                                    \
-            if (!e_) {                                                                                               \
+// Up to four AC symbols of the block in progress, on a LOCAL copy of the walk's hot state (bit reader, index, block
+// and table pointers: they must live in registers -- through the Walk object every symbol paid loads and stores of
+// them).  One refill for the group; a symbol the one-lookup table does not cover is decoded by the two-step path
+// after a refill of its own and ends the group.  K becomes 64 at the end of the block; ERR receives the model's error.
+#define HVC_AC_ONE_(BR, K, BLK, ACW, ACF, ACT, AMAX, ERR)                                                            \
+    {                                                                                                                \
+        const uint32_t e_ = (ACW)[(BR).buf >> (64 - Lut::FAST_BITS)];                                                \
+        const unsigned b_ = e_ & 0xffu;                                                                              \
+        if (!b_) {                                                                                                   \
+            (BR).refill();                                                                                           \
+            unsigned s_ = (ACF)[(BR).buf >> (64 - Lut::FAST_BITS)];                                                  \
+            if (!s_) s_ = (ACT)[(AMAX) ? (BR).buf >> (64 - (AMAX)) : 0];                                             \
+            if (!s_) {                                                                                               \
                 (ERR) = HVC_E_BAD_JPEG; /* "Can't find ac code" */                                                  \
             } else {                                                                                                 \
-                (BR).skip(e_ >> 8);                                                                                  \
-                const int run_ = (e_ >> 4) & 15, size_ = e_ & 15;                                                    \
+                (BR).buf <<= s_ >> 8;                                                                                \
+                (BR).cnt -= (int)(s_ >> 8);                                                                          \
+                const int run_ = (s_ >> 4) & 15, size_ = s_ & 15;                                                    \
                 int mag_ = 0;                                                                                        \
                 if (size_) {                                                                                         \
-                    mag_ = extend(size_, (BR).peek(size_));                                                          \
-                    (BR).skip(size_);                                                                                \
+                    mag_ = extend(size_, (unsigned)((BR).buf >> (64 - size_)));                                      \
+                    (BR).buf <<= size_;                                                                              \
+                    (BR).cnt -= size_;                                                                               \
                 }                                                                                                    \
                 if (mag_ == 0 && run_ == 0) { /* decoder.ml:131-132 (EOB, or a zero-size code) */                   \
                     (K) = 64;                                                                                        \
@@ -470,7 +556,26 @@ struct Walk {
                     else (BLK)[(K)++] = (int16_t)mag_;                                                               \
                 }                                                                                                    \
             }                                                                                                        \
+            break;                                                                                                   \
         }                                                                                                            \
+        (BR).buf <<= b_;                                                                                             \
+        (BR).cnt -= (int)b_;                                                                                         \
+        (K) += (int)((e_ >> 8) & 0xffu);                                                                             \
+        if ((K) >= 64) { /* the block's last coefficient, an end of block, or an index out of range */              \
+            if ((K) == 64) (BLK)[63] = (int16_t)(e_ >> 16);                                                          \
+            else if ((K) < (int)Lut::WHOLE_EOB) (ERR) = HVC_E_BAD_JPEG; /* "coefficient index out of range" */      \
+            (K) = 64;                                                                                                \
+            break;                                                                                                   \
+        }                                                                                                            \
+        (BLK)[(K) - 1] = (int16_t)(e_ >> 16);                                                                        \
+    }
+#define HVC_AC_GROUP(BR, K, BLK, ACW, ACF, ACT, AMAX, ERR)                                                           \
+    do {                                                                                                             \
+        (BR).refill();                                                                                               \
+        HVC_AC_ONE_(BR, K, BLK, ACW, ACF, ACT, AMAX, ERR)                                                            \
+        HVC_AC_ONE_(BR, K, BLK, ACW, ACF, ACT, AMAX, ERR)                                                            \
+        HVC_AC_ONE_(BR, K, BLK, ACW, ACF, ACT, AMAX, ERR)                                                            \
+        HVC_AC_ONE_(BR, K, BLK, ACW, ACF, ACT, AMAX, ERR)                                                            \
     } while (0)
 
 // the whole file, block after block
@@ -481,10 +586,10 @@ static int walk_alone(Walk &w) {
         BitReader br = w.br;
         int k = w.k, err = 0;
         int16_t *const blk = w.blk;
-        const Lut::Whole *const acw = w.acw;
+        const uint32_t *const acw = w.acw;
         const uint16_t *const acf = w.acf, *const act = w.act;
         const int amax = w.amax;
-        while (k < 64 && !err) HVC_AC_SYMBOL(br, k, blk, acw, acf, act, amax, err);
+        while (k < 64 && !err) HVC_AC_GROUP(br, k, blk, acw, acf, act, amax, err);
         w.br = br;
         w.k = 64;
         if (err) return err;
@@ -527,14 +632,14 @@ static void entropy_decode_two_impl(const uint8_t *const data[2], const size_t n
     BitReader bra = a.br, brb = b.br;
     int ka = a.k, kb = b.k, ea = 0, eb = 0;
     int16_t *blka = a.blk, *blkb = b.blk;
-    const Lut::Whole *acwa = a.acw, *acwb = b.acw;
+    const uint32_t *acwa = a.acw, *acwb = b.acw;
     const uint16_t *acfa = a.acf, *acta = a.act, *acfb = b.acf, *actb = b.act;
     int amaxa = a.amax, amaxb = b.amax;
     bool alive_a = true, alive_b = true;
     while (alive_a && alive_b) {
         while (ka < 64 && kb < 64 && !(ea | eb)) {
-            HVC_AC_SYMBOL(bra, ka, blka, acwa, acfa, acta, amaxa, ea);
-            HVC_AC_SYMBOL(brb, kb, blkb, acwb, acfb, actb, amaxb, eb);
+            HVC_AC_GROUP(bra, ka, blka, acwa, acfa, acta, amaxa, ea);
+            HVC_AC_GROUP(brb, kb, blkb, acwb, acfb, actb, amaxb, eb);
         }
         if (ea || ka >= 64) { // A: error, or its block is complete
             a.br = bra;
@@ -558,7 +663,7 @@ static void entropy_decode_two_impl(const uint8_t *const data[2], const size_t n
     // the survivor finishes alone: the block it has in progress first
     auto finish = [](Walk &w, BitReader br, int k, int16_t *blk, int &status) {
         int err = 0;
-        while (k < 64 && !err) HVC_AC_SYMBOL(br, k, blk, w.acw, w.acf, w.act, w.amax, err);
+        while (k < 64 && !err) HVC_AC_GROUP(br, k, blk, w.acw, w.acf, w.act, w.amax, err);
         w.br = br;
         w.k = 64;
         status = err ? err : walk_alone(w);
