@@ -301,6 +301,21 @@ int check_qtabs(const uint16_t *qtabs, int n_qtabs) {
     return HVC_OK;
 }
 
+// The batch pipelines' orchestrating thread waits most of the call (an upload's end, a chunk's kernels).
+// hipEventSynchronize spins -- also on an event created with hipEventBlockingSync, on this ROCm (measured: CPU time =
+// wall time) -- and on a box whose processes own a fixed share of CPU time (16 CPUs for one GPU here) a spinning thread
+// takes its CPU from the workers that are the bound of the pipeline.  So: poll and sleep, 20 us at first, 200 us from
+// the tenth poll on (the waits are milliseconds long).  HVC_EVENT_SPIN=1: hipEventSynchronize (A/B).
+static hipError_t wait_event(hipEvent_t e) {
+    static const bool spin = [] { const char *v = std::getenv("HVC_EVENT_SPIN"); return v && v[0] == '1'; }();
+    if (spin) return hipEventSynchronize(e);
+    for (int polls = 0;; polls++) {
+        const hipError_t r = hipEventQuery(e);
+        if (r != hipErrorNotReady) return r;
+        std::this_thread::sleep_for(std::chrono::microseconds(polls < 10 ? 20 : 200));
+    }
+}
+
 // Host buffers, large batches: four parts; while part k + 1 is uploaded (c->stream), part k runs through the kernels
 // (c->stream) and is downloaded (a second thread on c->down_stream: copies to and from pageable memory hold
 // their caller), so the link carries both directions at once.  up(f0, cnt) / run(k, f0, cnt) enqueue on c->stream,
@@ -1917,7 +1932,7 @@ static int decode_batch_impl(hvc_ctx *c, const uint8_t *const *jpegs, const size
         if (he == hipSuccess) he = hipEventRecord(c->ev_kern[slot], compute);
         if (he == hipSuccess) he = hipEventRecord(c->ev_t[3], compute);
         // wait for this chunk's upload, then hand the pinned slot to chunk k + NB
-        if (he == hipSuccess) he = hipEventSynchronize(c->ev_h2d[slot]);
+        if (he == hipSuccess) he = wait_event(c->ev_h2d[slot]);
         if (he != hipSuccess) { rc = fail_hip(c, he); break; }
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -1929,7 +1944,7 @@ static int decode_batch_impl(hvc_ctx *c, const uint8_t *const *jpegs, const size
         // kernel / d2h times of this chunk: the events are shared by all chunks, so they are read (and the
         // chunk waited for) before the next one records them; the worker threads -- the bound of this
         // pipeline -- keep decoding into the other ring slots meanwhile
-        if (hipEventSynchronize(c->ev_t[3]) == hipSuccess) {
+        if (wait_event(c->ev_t[3]) == hipSuccess) {
             if (hipEventElapsedTime(&ms, c->ev_t[1], c->ev_t[2]) == hipSuccess) k_ms += ms;
             if (hipEventElapsedTime(&ms, c->ev_t[2], c->ev_t[3]) == hipSuccess) d2h_ms += ms;
         }
@@ -2691,7 +2706,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     c->profiling = false;
     int pending_release = -1; // the chunk whose pinned segment slot is handed on once its upload has finished
     auto release_after_upload = [&](int k) -> hipError_t {
-        const hipError_t he = hipEventSynchronize(c->ev_h2d[k % NB]);
+        const hipError_t he = wait_event(c->ev_h2d[k % NB]);
         if (he != hipSuccess) return he;
         std::lock_guard<std::mutex> lk(mu);
         released_upto = k + NB;
@@ -2710,7 +2725,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
                 cv.wait(lk, [&] { return downloaded[(size_t)v] != 0 || dl_err.load(); });
                 if (dl_err.load()) he = (hipError_t)dl_err.load();
             } else {
-                he = hipEventSynchronize(c->ev_kern[slot]);
+                he = wait_event(c->ev_kern[slot]);
             }
             if (he != hipSuccess) { rc = fail_hip(c, he); break; }
             const unsigned *flags = (const unsigned *)c->gp_h_meta[slot] + (meta_words - 2);
@@ -3240,13 +3255,13 @@ static int encode_batch_impl(hvc_ctx *c, const uint8_t *const *frames, int n_fra
             const int slot = e % NB;
             float ms = 0;
             if (!gpu_entropy) {
-                hipError_t he = hipEventSynchronize(c->ev_down[slot]);
+                hipError_t he = wait_event(c->ev_down[slot]);
                 if (he != hipSuccess) { rc = fail_hip(c, he); break; }
                 submit(1, e);
                 if (hipEventElapsedTime(&ms, c->ev_et[slot][0], c->ev_up[slot]) == hipSuccess) h2d_ms += ms;
                 if (hipEventElapsedTime(&ms, c->ev_et[slot][2], c->ev_down[slot]) == hipSuccess) d2h_ms += ms;
             } else {
-                hipError_t he = hipEventSynchronize(c->ev_gpu[slot]);
+                hipError_t he = wait_event(c->ev_gpu[slot]);
                 if (he != hipSuccess) { rc = fail_hip(c, he); break; }
                 if (hipEventElapsedTime(&ms, c->ev_et[slot][0], c->ev_up[slot]) == hipSuccess) h2d_ms += ms;
                 const unsigned long long *off = (const unsigned long long *)c->eh_off[slot];
@@ -3269,7 +3284,7 @@ static int encode_batch_impl(hvc_ctx *c, const uint8_t *const *frames, int n_fra
         const int a = it - 3;
         if (gpu_entropy && a >= 0 && a < n_chunks) {
             const int slot = a % NB;
-            hipError_t he = hipEventSynchronize(c->ev_down[slot]);
+            hipError_t he = wait_event(c->ev_down[slot]);
             if (he != hipSuccess) { rc = fail_hip(c, he); break; }
             float ms = 0;
             if (hipEventElapsedTime(&ms, c->ev_et[slot][0], c->ev_down[slot]) == hipSuccess) d2h_ms += ms;

@@ -134,8 +134,12 @@ int parse_header(const uint8_t *data, size_t n, Header &h) {
 
 // ---------------------------------------------------------------------------
 // Huffman decode tables (Tables.Specification.create_code_table, tables.ml:27-45; Tables.Lut.create :490-501)
+#ifndef HVC_FAST_BITS
+#define HVC_FAST_BITS 10 /* 11 (tables twice the size) and BMI2 shifts were measured on the GPU box's Zen 5 cores: +-1 %
+                            (profiles/r03t_reader_variants.txt) */
+#endif
 struct Lut {
-    static constexpr int FAST_BITS = 10;
+    static constexpr int FAST_BITS = HVC_FAST_BITS;
     int max_bits = 0;
     std::vector<uint16_t> e; // (length << 8) | data ; 0 = no code; indexed by max_bits peeked bits (Tables.Lut)
     uint16_t fast[1 << FAST_BITS]; // the same entries for codes of <= FAST_BITS bits, indexed by FAST_BITS bits:
@@ -356,7 +360,14 @@ struct Walk {
     size_t part[4] = {0, 0, 0, 0}; // per component: int16 elements from `coefs` to block (my * vscale, mx * hscale)
     bool regular = true;            // every block of every MCU lies inside its component's planes: no per-block test
     int my = 0, mx = 0, bi = 0;
-    int16_t *blk = nullptr;
+    // The block in progress is assembled HERE (one address for the whole file: L1-resident) and leaves for the record in
+    // one piece when the next block begins -- eight 16-byte streaming stores where the record is 16-byte aligned: the
+    // record (6 MB a frame) is written once and never read by this thread, so its lines need not be fetched for ownership
+    // nor kept in the cache; clear_block (decoder.ml:109-116) is the re-zeroing of these 128 bytes.
+    alignas(64) int16_t cur[64] = {};
+    int16_t *const blk = cur;
+    int16_t *dst = nullptr;     // where the block in progress belongs, or null: none
+    bool stream_out = false;
     int k = 64;                 // index of the next coefficient of the block in progress; 64 = none in progress
     const uint32_t *acw = nullptr;
     const uint16_t *acf = nullptr, *act = nullptr;
@@ -367,6 +378,7 @@ struct Walk {
         if (!data || !info_ || !coefs_) return HVC_E_INVALID_ARG;
         info = info_;
         coefs = coefs_;
+        stream_out = ((uintptr_t)coefs_ & 15) == 0;
         wide = wide_;
         Header h;
         int r = parse_header(data, n, h);
@@ -446,8 +458,8 @@ struct Walk {
             const hvc_component &L = info->layout[i];
             if (mx * c.hscale + mb.dx >= L.blocks_w || my * c.vscale + mb.dy >= L.blocks_h) return HVC_E_BAD_JPEG; // Plane.set out of bounds
         }
-        blk = coefs + part[i] + mb.off;
-        std::memset(blk, 0, 64 * sizeof(int16_t));
+        flush();
+        dst = coefs + part[i] + mb.off;
         br.hold();
         br.refill();
         long long diff = 0;
@@ -495,7 +507,7 @@ struct Walk {
         if (dcv < -32768 || dcv > 32767) {
             if (!wide) return HVC_E_RANGE;
             try {
-                wide->push_back(hvc::WideDc{(uint32_t)((size_t)(blk - coefs) >> 6), dcv});
+                wide->push_back(hvc::WideDc{(uint32_t)((size_t)(dst - coefs) >> 6), dcv});
             } catch (const std::bad_alloc &) {
                 return HVC_E_OUT_OF_MEMORY;
             }
@@ -522,6 +534,25 @@ struct Walk {
     }
 
     bool finished() const { return my >= mbs_high; }
+
+    inline void flush() {
+        if (!dst) return;
+        if (stream_out) {
+            const __m128i zero = _mm_setzero_si128();
+            for (int q = 0; q < 8; q++) {
+                _mm_stream_si128((__m128i *)dst + q, _mm_load_si128((const __m128i *)cur + q));
+                _mm_store_si128((__m128i *)cur + q, zero);
+            }
+        } else {
+            std::memcpy(dst, cur, sizeof cur);
+            std::memset(cur, 0, sizeof cur);
+        }
+        dst = nullptr;
+    }
+    void end_walk() { // the last block leaves; the streaming stores are ordered before whatever publishes the record
+        flush();
+        _mm_sfence();
+    }
 };
 
 // Up to four AC symbols of the block in progress, on a LOCAL copy of the walk's hot state (bit reader, index, block
@@ -585,7 +616,7 @@ static int walk_alone(Walk &w) {
         if (r) return r;
         BitReader br = w.br;
         int k = w.k, err = 0;
-        int16_t *const blk = w.blk;
+        int16_t *const blk = w.cur;
         const uint32_t *const acw = w.acw;
         const uint16_t *const acf = w.acf, *const act = w.act;
         const int amax = w.amax;
@@ -594,6 +625,7 @@ static int walk_alone(Walk &w) {
         w.k = 64;
         if (err) return err;
     }
+    w.end_walk();
     w.done = true;
     return HVC_OK;
 }
@@ -631,7 +663,7 @@ static void entropy_decode_two_impl(const uint8_t *const data[2], const size_t n
     }
     BitReader bra = a.br, brb = b.br;
     int ka = a.k, kb = b.k, ea = 0, eb = 0;
-    int16_t *blka = a.blk, *blkb = b.blk;
+    int16_t *const blka = a.cur, *const blkb = b.cur;
     const uint32_t *acwa = a.acw, *acwb = b.acw;
     const uint16_t *acfa = a.acf, *acta = a.act, *acfb = b.acf, *actb = b.act;
     int amaxa = a.amax, amaxb = b.amax;
@@ -645,18 +677,20 @@ static void entropy_decode_two_impl(const uint8_t *const data[2], const size_t n
             a.br = bra;
             a.k = 64;
             if (ea) st[0] = ea;
+            if (!ea && a.finished()) a.end_walk();
             if (ea || a.finished() || (st[0] = a.begin_block())) alive_a = false;
             else {
-                bra = a.br; ka = a.k; blka = a.blk; acwa = a.acw; acfa = a.acf; acta = a.act; amaxa = a.amax;
+                bra = a.br; ka = a.k; acwa = a.acw; acfa = a.acf; acta = a.act; amaxa = a.amax;
             }
         }
         if (eb || kb >= 64) {
             b.br = brb;
             b.k = 64;
             if (eb) st[1] = eb;
+            if (!eb && b.finished()) b.end_walk();
             if (eb || b.finished() || (st[1] = b.begin_block())) alive_b = false;
             else {
-                brb = b.br; kb = b.k; blkb = b.blk; acwb = b.acw; acfb = b.acf; actb = b.act; amaxb = b.amax;
+                brb = b.br; kb = b.k; acwb = b.acw; acfb = b.acf; actb = b.act; amaxb = b.amax;
             }
         }
     }
