@@ -12,6 +12,9 @@
 // first marker (restart markers unsupported), reads past the end yield zero bits.
 #include <cstdint>
 #include <cstdlib>
+#include <chrono>
+#include <atomic>
+#include <cstdio>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -196,6 +199,37 @@ struct Lut {
             whole[w] = o;
         }
     }
+    // ... and the table the hot loop reads: ONE OR TWO symbols per lookup.  Where a second whole symbol (code + magnitude)
+    // follows the first inside the FAST_BITS index, the entry carries both -- the dependency chain of the walk (shift,
+    // load, shift) is then paid once for two symbols.  64-bit entry: byte 0 the bits consumed by all of it (0: the first
+    // symbol is not covered), byte 1 / byte 2 the index steps of the first / second symbol (second: 0 when there is
+    // none), byte 3 the bits of the first symbol alone (to step back when the first one completed the block and the
+    // "second" is the next block's), bits 32-47 / 48-63 the two coefficients (the second = the first when there is none:
+    // the loop always stores twice, the second time over the first).  An end of block is never followed by a second symbol.
+    uint64_t pair[1 << FAST_BITS];
+    void build_pair() {
+        build_whole();
+        for (unsigned w = 0; w < (1u << FAST_BITS); w++) {
+            const uint32_t a = whole[w];
+            uint64_t o = 0;
+            if (a & 0xffu) {
+                const unsigned b1 = a & 0xffu, s1 = (a >> 8) & 0xffu, v1 = a >> 16;
+                unsigned btot = b1, s2 = 0, v2 = v1;
+                if (s1 != WHOLE_EOB && b1 < (unsigned)FAST_BITS) {
+                    const unsigned rem = (unsigned)FAST_BITS - b1;
+                    const uint32_t b = whole[(w << b1) & ((1u << FAST_BITS) - 1u)]; // (the bits behind the window read as zeros:
+                    if ((b & 0xffu) && (b & 0xffu) <= rem) {                        //  a symbol that needs any of them is too long)
+                        btot = b1 + (b & 0xffu);
+                        s2 = (b >> 8) & 0xffu;
+                        v2 = b >> 16;
+                    }
+                }
+                o = (uint64_t)btot | (uint64_t)s1 << 8 | (uint64_t)s2 << 16 | (uint64_t)b1 << 24 | (uint64_t)(v1 & 0xffffu) << 32 |
+                    (uint64_t)(v2 & 0xffffu) << 48;
+            }
+            pair[w] = o;
+        }
+    }
     // DC tables: the same for a DC symbol -- bits 0-7 the bits consumed (code + magnitude; 0: not covered), bits 16-31
     // the DC difference (mag, decoder.ml:73-96) -- when the two fit FAST_BITS; differences of 7+ bits take the two steps
     void build_whole_dc() {
@@ -364,12 +398,14 @@ struct Walk {
     // one piece when the next block begins -- eight 16-byte streaming stores where the record is 16-byte aligned: the
     // record (6 MB a frame) is written once and never read by this thread, so its lines need not be fetched for ownership
     // nor kept in the cache; clear_block (decoder.ml:109-116) is the re-zeroing of these 128 bytes.
-    alignas(64) int16_t cur[64] = {};
+    // (behind its 64 coefficients: room for the stores of symbols that step past the block -- an end of block steps 128,
+    // an index out of range up to 15 + 16 -- which the loop performs before it looks at the index)
+    alignas(64) int16_t cur[64 + 2 * 128 + 64] = {};
     int16_t *const blk = cur;
     int16_t *dst = nullptr;     // where the block in progress belongs, or null: none
     bool stream_out = false;
     int k = 64;                 // index of the next coefficient of the block in progress; 64 = none in progress
-    const uint32_t *acw = nullptr;
+    const uint64_t *acw = nullptr;
     const uint16_t *acf = nullptr, *act = nullptr;
     int amax = 0;
     bool done = false;
@@ -405,7 +441,7 @@ struct Walk {
             }
             if (!ac[i]) {
                 if (!ac_tab[i].build(h.dht[ai].spec)) return HVC_E_BAD_JPEG;
-                ac_tab[i].build_whole();
+                ac_tab[i].build_pair();
                 ac[i] = &ac_tab[i];
             }
         }
@@ -516,7 +552,7 @@ struct Walk {
             blk[0] = (int16_t)dcv;
         }
         k = 1;
-        acw = ac[i]->whole;
+        acw = ac[i]->pair;
         acf = ac[i]->fast;
         act = ac[i]->e.data();
         amax = ac[i]->max_bits;
@@ -544,8 +580,8 @@ struct Walk {
                 _mm_store_si128((__m128i *)cur + q, zero);
             }
         } else {
-            std::memcpy(dst, cur, sizeof cur);
-            std::memset(cur, 0, sizeof cur);
+            std::memcpy(dst, cur, 64 * sizeof(int16_t));
+            std::memset(cur, 0, 64 * sizeof(int16_t));
         }
         dst = nullptr;
     }
@@ -561,8 +597,8 @@ struct Walk {
 // after a refill of its own and ends the group.  K becomes 64 at the end of the block; ERR receives the model's error.
 #define HVC_AC_ONE_(BR, K, BLK, ACW, ACF, ACT, AMAX, ERR)                                                            \
     {                                                                                                                \
-        const uint32_t e_ = (ACW)[(BR).buf >> (64 - Lut::FAST_BITS)];                                                \
-        const unsigned b_ = e_ & 0xffu;                                                                              \
+        const uint64_t e_ = (ACW)[(BR).buf >> (64 - Lut::FAST_BITS)];                                                \
+        const unsigned b_ = (unsigned)(e_ & 0xffu);                                                                  \
         if (!b_) {                                                                                                   \
             (BR).refill();                                                                                           \
             unsigned s_ = (ACF)[(BR).buf >> (64 - Lut::FAST_BITS)];                                                  \
@@ -589,16 +625,29 @@ struct Walk {
             }                                                                                                        \
             break;                                                                                                   \
         }                                                                                                            \
+        const uint64_t buf0_ = (BR).buf;                                                                             \
         (BR).buf <<= b_;                                                                                             \
         (BR).cnt -= (int)b_;                                                                                         \
-        (K) += (int)((e_ >> 8) & 0xffu);                                                                             \
-        if ((K) >= 64) { /* the block's last coefficient, an end of block, or an index out of range */              \
-            if ((K) == 64) (BLK)[63] = (int16_t)(e_ >> 16);                                                          \
-            else if ((K) < (int)Lut::WHOLE_EOB) (ERR) = HVC_E_BAD_JPEG; /* "coefficient index out of range" */      \
+        const int k1_ = (K) + (int)((e_ >> 8) & 0xffu);  /* behind the first symbol */                               \
+        const int k2_ = k1_ + (int)((e_ >> 16) & 0xffu); /* behind the second one (= k1_ when there is none) */      \
+        (BLK)[k1_ - 1] = (int16_t)(e_ >> 32);            /* (past index 63: into the room behind the block) */       \
+        (BLK)[k2_ - 1] = (int16_t)(e_ >> 48);                                                                        \
+        (K) = k2_;                                                                                                   \
+        if (k2_ >= 64) { /* a last coefficient at index 63, an end of block, or an index out of range */            \
+            if (k1_ >= 64) {                                                                                         \
+                if (k1_ == 64) { /* the first symbol completed the block: what followed it is the next block's */   \
+                    const unsigned b1_ = (unsigned)((e_ >> 24) & 0xffu);                                             \
+                    (BR).cnt += (int)(b_ - b1_);                                                                     \
+                    (BR).buf = buf0_ << b1_;                                                                         \
+                } else if (k1_ < (int)Lut::WHOLE_EOB) {                                                              \
+                    (ERR) = HVC_E_BAD_JPEG; /* "coefficient index out of range" */                                  \
+                }                                                                                                    \
+            } else if (k2_ > 64 && k2_ < (int)Lut::WHOLE_EOB) {                                                      \
+                (ERR) = HVC_E_BAD_JPEG; /* "coefficient index out of range" */                                      \
+            }                                                                                                        \
             (K) = 64;                                                                                                \
             break;                                                                                                   \
         }                                                                                                            \
-        (BLK)[(K) - 1] = (int16_t)(e_ >> 16);                                                                        \
     }
 #define HVC_AC_GROUP(BR, K, BLK, ACW, ACF, ACT, AMAX, ERR)                                                           \
     do {                                                                                                             \
@@ -617,7 +666,7 @@ static int walk_alone(Walk &w) {
         BitReader br = w.br;
         int k = w.k, err = 0;
         int16_t *const blk = w.cur;
-        const uint32_t *const acw = w.acw;
+        const uint64_t *const acw = w.acw;
         const uint16_t *const acf = w.acf, *const act = w.act;
         const int amax = w.amax;
         while (k < 64 && !err) HVC_AC_GROUP(br, k, blk, acw, acf, act, amax, err);
@@ -646,9 +695,26 @@ int hvc_jpeg_entropy_decode(const uint8_t *data, size_t n, const hvc_jpeg_info *
 // entropy_decode_impl would have returned for it): an error in one does not stop the other.
 static void entropy_decode_two_impl(const uint8_t *const data[2], const size_t n[2], const hvc_jpeg_info *const info[2],
                                     int16_t *const coefs[2], std::vector<hvc::WideDc> *const wide[2], int st[2]) {
+#ifdef HVC_READER_PROFILE /* experiments: where a pair of files spends its time (stderr, every 64 pairs) */
+    struct Prof {
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), t1;
+        ~Prof() {
+            static std::atomic<long long> prep{0}, walk{0}, calls{0};
+            const auto t2 = std::chrono::steady_clock::now();
+            prep += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+            walk += std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count();
+            if (++calls % 64 == 0)
+                std::fprintf(stderr, "reader profile: prepare %.3f ms, walk %.3f ms per pair of files\n", (double)prep / calls * 1e-6,
+                             (double)walk / calls * 1e-6);
+        }
+    } prof;
+#endif
     Walk a, b;
     st[0] = a.prepare(data[0], n[0], info[0], coefs[0], wide[0]);
     st[1] = b.prepare(data[1], n[1], info[1], coefs[1], wide[1]);
+#ifdef HVC_READER_PROFILE
+    prof.t1 = std::chrono::steady_clock::now();
+#endif
     if (st[0] || st[1] || a.done || b.done) { // one of them cannot start (or has nothing to do): the other runs alone
         if (!st[0] && !a.done) st[0] = walk_alone(a);
         if (!st[1] && !b.done) st[1] = walk_alone(b);
@@ -664,7 +730,7 @@ static void entropy_decode_two_impl(const uint8_t *const data[2], const size_t n
     BitReader bra = a.br, brb = b.br;
     int ka = a.k, kb = b.k, ea = 0, eb = 0;
     int16_t *const blka = a.cur, *const blkb = b.cur;
-    const uint32_t *acwa = a.acw, *acwb = b.acw;
+    const uint64_t *acwa = a.acw, *acwb = b.acw;
     const uint16_t *acfa = a.acf, *acta = a.act, *acfb = b.acf, *actb = b.act;
     int amaxa = a.amax, amaxb = b.amax;
     bool alive_a = true, alive_b = true;
