@@ -89,7 +89,7 @@ void make_frame_tabs(const HdTables &t, int n_comp, HdFrameTabs &out);
 // from global memory looks up to four subsequences past the start of the last one
 #define HVC_HD_ECS_SLACK 1024
 #define HVC_HD_LIST_N 32 /* >= rounds of k_hd_sync + 2 (+ 2 counters of experiment builds) */
-// device bytes of the per-subsequence state for n subsequences (hvc_capi.hip carves HdParams' arrays out of it)
+// device bytes of the per-subsequence state for n subsequences (hvc_capi_reader.hip carves HdParams' arrays out of it)
 #define HVC_HD_STATE_BYTES(n) ((size_t)(n) * (4 * sizeof(unsigned long long) + 3 * sizeof(unsigned)) + HVC_HD_LIST_N * sizeof(unsigned) + 64)
 
 struct HdComp {

@@ -1668,7 +1668,7 @@ hipError_t launch_decode_444(const Decode444Params &P, bool wide_only, hipStream
     // HVC_444_LDS_PAD=bytes (experiments): dynamic LDS nobody uses, to hold the kernel to fewer workgroups per CU
     static const unsigned pad = [] { const char *v = getenv("HVC_444_LDS_PAD"); return v ? (unsigned)atoi(v) : 0u; }();
     if (!aligned && P.nw != 1) return hipErrorInvalidValue; // (plan_decode_444 was told otherwise)
-    // P.tile0 = P.y_tiles: the chroma tiles alone (the luma planes went through k_decode_packed: hvc_capi.hip)
+    // P.tile0 = P.y_tiles: the chroma tiles alone (the luma planes went through k_decode_packed: hvc_capi.hip, decode_frames_yuv444_impl)
     const dim3 cgrid((unsigned)(P.tiles_per_frame - P.tile0), (unsigned)P.n_frames, 1);
     if (!aligned)
         launch_444_kernel<false, 1>(Q, cgrid, 0, s);
