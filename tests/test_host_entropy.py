@@ -417,3 +417,60 @@ def test_groups_of_four_symbols_end_in_every_slot(hvc):
         else:
             assert not isinstance(mine, int) and np.array_equal(mine, model), cut
     assert dinfo.coef_count == info.coef_count
+
+
+UNUSUAL_SAMPLINGS = [
+    [(1, 2), (1, 1), (1, 1)],          # 4:4:0
+    [(4, 1), (1, 1), (1, 1)],          # 4:1:1
+    [(1, 4), (1, 2), (1, 1)],
+    [(2, 2), (2, 1), (1, 2)],          # every component its own factors
+    [(1, 1), (2, 2), (2, 2)],          # the FIRST component is not the largest (the MCU grid comes from it, decoder.ml:362-373)
+    [(2, 1), (1, 2), (2, 2)],
+    [(3, 1), (1, 1), (1, 1)],          # a factor that is no power of two
+    [(3, 2), (1, 2), (3, 1)],
+    [(4, 4), (2, 2), (1, 1)],          # 21 blocks per MCU
+    [(2, 2)],                          # one component with factors (its MCU is still 2 x 2 blocks, decoder.ml:374-395)
+    [(2, 1), (1, 1)],                  # two components
+    [(2, 2), (1, 1), (1, 1), (2, 2)],  # four components
+]
+
+
+def unusual_sampling_file(sampling, w, h, seed):
+    """a file of that sampling with random sparse coefficients, through tools/jpeg_opt_writer.py -> (file, its record)"""
+    from helpers import jpeg_optimised_tables
+    mh, mv = max(s[0] for s in sampling), max(s[1] for s in sampling)
+    Wr, Hr = -(-w // (8 * mh)) * 8 * mh, -(-h // (8 * mv)) * 8 * mv
+    nblk = sum((Wr * sh // mh // 8) * (Hr * sv // mv // 8) for sh, sv in sampling)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    blocks = np.zeros((nblk, 64), dtype=np.int16)
+    blocks[:, 0] = rng.integers(-300, 301, size=nblk)
+    for b in range(nblk):
+        k = rng.integers(0, 12)
+        pos = rng.choice(np.arange(1, 64), size=k, replace=False)
+        blocks[b, pos] = rng.integers(-60, 61, size=k)
+    qt = np.stack([np.arange(1, 65), np.arange(64, 0, -1)]).astype(np.uint16)
+    rec = blocks.reshape(-1)
+    return jpeg_optimised_tables(w, h, sampling, qt, rec, table_sets=min(3, len(sampling))), rec
+
+
+@pytest.mark.parametrize("si", range(len(UNUSUAL_SAMPLINGS)))
+def test_sampling_factors_the_encoder_never_writes(hvc, si):
+    """Decoder.init / decode_seq (decoder.ml:294-345, 362-395) take any sampling factors: 4:4:0, 4:1:1, a first component
+    that is not the largest, factors of three, one, two and four components.  Header geometry and coefficient record
+    against the model restatement, on frame sizes that are no multiple of the MCU."""
+    sampling = UNUSUAL_SAMPLINGS[si]
+    for (w, h) in ((40, 24), (97, 51)):
+        jpg, rec = unusual_sampling_file(sampling, w, h, 100 * si + w)
+        info = hvc.jpeg_read_header(jpg)
+        d = orc.Decoder(jpg)
+        assert info.n_comp == d.ncomp == len(sampling)
+        for i in range(info.n_comp):
+            m = d.info(i)
+            c = info.comp[i]
+            assert (c.decoded_width, c.decoded_height, c.actual_width, c.actual_height, c.hscale, c.vscale) == \
+                   (m["decoded_width"], m["decoded_height"], m["actual_width"], m["actual_height"], m["hscale"], m["vscale"])
+        _, got = hvc.jpeg_entropy_decode(jpg, info)
+        assert np.array_equal(got, rec)
+        assert np.array_equal(got, d.coef_record().astype(np.int16))
+        (sa, _, ra), (sb, _, rb) = hvc.jpeg_entropy_decode2(jpg, golden_bytes("mini.jpg"))
+        assert (sa, sb) == (0, 0) and np.array_equal(ra, rec)

@@ -99,9 +99,16 @@ def jpeg_optimised_tables(w, h, chroma, qtabs, coefs, table_sets=2, ac_shape=Non
     -> a baseline JPEG whose Huffman tables are the optimal ones FOR THIS FILE (table_sets = 2: luma / chroma
     pairs as every common encoder writes them; 3: one pair per component; 1: one pair for all)."""
     # (ac_shape / stats: below)
-    hs, vs = {420: (2, 2), 422: (2, 2), 444: (1, 1)}[chroma]
-    ch, cv = {420: (1, 1), 422: (1, 2), 444: (1, 1)}[chroma]  # Parameters.c422 = C 1x2 (sic), encoder.ml:347-349
-    comps = [(1, hs, vs, 0), (2, ch, cv, 1), (3, ch, cv, 1)]
+    # chroma may also be a list of (h, v) sampling factors, one per component (1..4 components, any factors 1..4): the
+    # DECODER's geometry then (Decoder.init, decoder.ml:294-345: every plane = the frame rounded up to whole MCUs, scaled
+    # by the component's share of the largest factors) -- samplings the model's encoder never writes but its decoder reads
+    if isinstance(chroma, int):
+        hs, vs = {420: (2, 2), 422: (2, 2), 444: (1, 1)}[chroma]
+        ch, cv = {420: (1, 1), 422: (1, 2), 444: (1, 1)}[chroma]  # Parameters.c422 = C 1x2 (sic), encoder.ml:347-349
+        comps = [(1, hs, vs, 0), (2, ch, cv, 1), (3, ch, cv, 1)]
+    else:
+        comps = [(i + 1, hh, vv, 0 if i == 0 else 1) for i, (hh, vv) in enumerate(chroma)]
+        hs, vs = max(c[1] for c in comps), max(c[2] for c in comps)
     r_up = lambda x, m: (x + m - 1) // m * m
     Wr, Hr = r_up(w, 8 * hs), r_up(h, 8 * vs)
     dims = [(Wr * ch_ // hs // 8, Hr * cv_ // vs // 8) for _, ch_, cv_, _ in comps]  # (bw, bh) per component
@@ -111,10 +118,10 @@ def jpeg_optimised_tables(w, h, chroma, qtabs, coefs, table_sets=2, ac_shape=Non
         at += bw * bh * 64
     coefs = np.asarray(coefs).reshape(-1)
     assert coefs.size == at, (coefs.size, at)
-    tset = {1: [0, 0, 0], 2: [0, 1, 1], 3: [0, 1, 2]}[table_sets]
+    tset = {1: [0] * len(comps), 2: [0] + [1] * (len(comps) - 1), 3: list(range(len(comps)))}[table_sets]
     # pass 1: symbols in scan order (decode_seq order, decoder.ml:374-395)
     syms = []  # (table set, is_ac, symbol, extra value, extra bits)
-    pred = [0, 0, 0]
+    pred = [0] * len(comps)
     for my in range(Hr // (8 * vs)):
         for mx in range(Wr // (8 * hs)):
             for ci, (_, hh, vv, _) in enumerate(comps):
@@ -179,12 +186,12 @@ def jpeg_optimised_tables(w, h, chroma, qtabs, coefs, table_sets=2, ac_shape=Non
     qtabs = np.asarray(qtabs).reshape(-1, 64)
     for t in range(2):
         hdr += seg(0xDB, bytes([t]) + bytes(int(x) for x in qtabs[t]))
-    hdr += seg(0xC0, bytes([8]) + h.to_bytes(2, "big") + w.to_bytes(2, "big") + bytes([3]) +
+    hdr += seg(0xC0, bytes([8]) + h.to_bytes(2, "big") + w.to_bytes(2, "big") + bytes([len(comps)]) +
                b"".join(bytes([cid, (hh << 4) | vv, tq]) for cid, hh, vv, tq in comps))
     for ts in range(n_sets):
         for ac in range(2):
             bits, vals = specs[ts][ac]
             hdr += seg(0xC4, bytes([(ac << 4) | ts]) + bytes(bits[1:17]) + bytes(vals))
-    hdr += seg(0xDA, bytes([3]) + b"".join(bytes([cid, (tset[i] << 4) | tset[i]]) for i, (cid, _, _, _) in enumerate(comps)) +
+    hdr += seg(0xDA, bytes([len(comps)]) + b"".join(bytes([cid, (tset[i] << 4) | tset[i]]) for i, (cid, _, _, _) in enumerate(comps)) +
                bytes([0, 63, 0]))
     return bytes(hdr) + bytes(out) + b"\xff\xd9"
