@@ -264,8 +264,8 @@ HVC_API int hvc_jpeg_read_header(const uint8_t *jpeg, size_t n, hvc_jpeg_info *i
  * 261-281, 362-395) into one frame's coefficient record (host memory, info->coef_count int16). */
 HVC_API int hvc_jpeg_entropy_decode(const uint8_t *jpeg, size_t n, const hvc_jpeg_info *info, int16_t *coefs);
 /* The same for TWO files on the calling thread, their symbols decoded in turn: a file is one stream and its symbols one
- * dependency chain (~8 cycles each with nothing else for the core to do), two files are two chains the core overlaps --
- * about 1.5x the files per second per thread (what the batch pipelines' workers do).  *status_a / *status_b receive
+ * dependency chain (shift, table load, shift), two files are two chains the core overlaps -- 1.07x (Zen 5) to 1.3x (Golden
+ * Cove) the files per second per thread on the bench's content (what the batch pipelines' workers do).  *status_a / *status_b receive
  * what hvc_jpeg_entropy_decode would have returned for each file; an error in one does not stop the other. */
 HVC_API int hvc_jpeg_entropy_decode2(const uint8_t *jpeg_a, size_t n_a, const hvc_jpeg_info *info_a, int16_t *coefs_a,
                                      int *status_a, const uint8_t *jpeg_b, size_t n_b, const hvc_jpeg_info *info_b,

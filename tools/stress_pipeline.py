@@ -27,7 +27,7 @@ def main():
     import torch
     rng = np.random.Generator(np.random.PCG64(args.seed))
     ctx = hvc.Context(0)
-    bad = odd = own_batches = 0
+    bad = odd = own_batches = odd_samplings = 0
     for case in range(args.cases):
         w = int(rng.integers(1, 30)) * 16
         h = int(rng.integers(1, 20)) * 16
@@ -38,7 +38,23 @@ def main():
             s = int(rng.integers(0, 1 << 30))
             files.append(ctx.jpeg_encode(synth_pixels(s, h, w), synth_pixels(s + 1, h // 2, w // 2), synth_pixels(s + 2, h // 2, w // 2),
                                          w, h, 420, q))
-        own = int(rng.integers(0, 3))   # a third of the batches: some or all files re-written with their own optimised Huffman
+        sampling = None
+        if rng.integers(0, 4) == 0:     # a quarter of the batches: sampling factors the encoder never writes (any factors 1..4,
+            ncomp = int(rng.integers(1, 5))  # one to four components), random sparse coefficient records
+            sampling = [(int(rng.integers(1, 5)), int(rng.integers(1, 5))) for _ in range(ncomp)]
+            mh, mv = max(a for a, _ in sampling), max(b for _, b in sampling)
+            Wr, Hr = -(-w // (8 * mh)) * 8 * mh, -(-h // (8 * mv)) * 8 * mv
+            nblk = sum((Wr * a // mh // 8) * (Hr * b // mv // 8) for a, b in sampling)
+            qt = np.stack([hvc.hvc.quant_table(0, q), hvc.hvc.quant_table(1, q)])
+            files = []
+            for d in range(n_distinct):
+                blocks = np.zeros((nblk, 64), dtype=np.int16)
+                blocks[:, 0] = rng.integers(-200, 201, size=nblk)
+                dense = rng.random((nblk, 63)) < rng.choice([0.02, 0.1, 0.4])
+                blocks[:, 1:][dense] = rng.integers(-50, 51, size=int(dense.sum()))
+                files.append(jpeg_optimised_tables(w, h, sampling, qt, blocks.reshape(-1), min(len(sampling), int(rng.integers(1, 4)))))
+            odd_samplings += 1
+        own = int(rng.integers(0, 3)) if sampling is None else 0   # a third of the batches: some or all files re-written with their own optimised Huffman
         if own == 1:                    # tables (1, 2 or 3 table sets): the GPU pipeline's per-frame-table mode
             qt = np.stack([hvc.hvc.quant_table(0, q), hvc.hvc.quant_table(1, q)])
             for d in range(n_distinct):
@@ -55,7 +71,7 @@ def main():
                 cut = info.ecs_offset + int(rng.integers(1, max(2, len(batch[f]) - info.ecs_offset - 2)))
                 batch[f] = batch[f][:cut] + b"\xff\xd9"
             odd += 1
-        yuv444 = bool(rng.integers(0, 2))
+        yuv444 = bool(rng.integers(0, 2)) and sampling is None
         fs = 3 * w * h if yuv444 else info.pixel_bytes
         chunk = int(rng.integers(1, 10))
         threads = int(rng.integers(1, 9))
@@ -86,7 +102,8 @@ def main():
         if not same:
             bad += 1
             print("MISMATCH", case, (w, h, q, n, chunk, threads, host_out, yuv444), file=sys.stderr)
-    print({"cases": args.cases, "batches_with_truncated_files": odd, "batches_with_per_file_tables": own_batches, "mismatches": bad})
+    print({"cases": args.cases, "batches_with_truncated_files": odd, "batches_with_per_file_tables": own_batches,
+           "batches_with_unusual_samplings": odd_samplings, "mismatches": bad})
     ctx.close()
     sys.exit(1 if bad else 0)
 
