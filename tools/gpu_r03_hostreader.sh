@@ -2,6 +2,11 @@
 # round-3 host-reader session: config 3 as BASELINE words it (host Huffman reader, 16 threads), the library as built
 # against the same library with the PREVIOUS reader (build/variants/libhvc_oldreader.so: one symbol per refill, 37
 # instructions a symbol), same box, alternating; then the tests that lean on the host reader.
+# The other library is built once, here, from the commit before the rewrite (it is not kept in the tree):
+#   git show c92bbc9:video-coding_amd/csrc/hvc_entropy.cpp > build/variants/old/hvc_entropy_old.cpp
+#   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -pthread -Ivideo-coding_amd/csrc -c -o build/variants/old/hvc_entropy.o build/variants/old/hvc_entropy_old.cpp
+#   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -pthread -shared -o build/variants/libhvc_oldreader.so build/obj/hvc_kernels.o build/obj/hvc_huff.o build/obj/hvc_hdec.o build/obj/hvc_capi*.o build/variants/old/hvc_entropy.o
+# (tools/gpu_ab_libs.sh is the general form: any number of such builds against the library as built)
 set -e
 TAG=${1:-r03p}
 mkdir -p gpurun_out
