@@ -866,51 +866,59 @@ void build_enc(EncTable &t, const uint8_t *dc_bits, const uint8_t *dc_vals, cons
     }
 }
 
-// Bitstream_writer (common/src/bitstream_writer.ml): MSB first, 0xff -> 0xff00 stuffing
+// Bitstream_writer (common/src/bitstream_writer.ml): MSB first, 0xff -> 0xff00 stuffing -- in two stages.
+// Stage 1, per field: the bits go to a scratch buffer WITHOUT stuffing and without a branch -- the accumulator is kept
+// MSB-aligned, its eight bytes are stored at the cursor every time (whatever of them is not complete yet is stored
+// again by the next field), and the cursor moves on by the bytes that are complete.  Stage 2, per MCU row: the complete
+// bytes are appended to the output with a 0x00 behind every 0xff, sixteen at a time where there is none.
+// (Round 2's writer tested the accumulator for a full 32-bit word and that word for 0xff bytes behind every field: a
+// branch mispredicted every fifth field.)
 struct BitWriter {
-    std::vector<uint8_t> &out; // grown in large steps; `pos` is the logical size while writing
-    size_t pos;
-    uint64_t acc = 0;
-    int nbits = 0;
-    explicit BitWriter(std::vector<uint8_t> &o) : out(o), pos(o.size()) {}
-    // room for one block's worst case (64 x 26 bits, every byte stuffed) without further checks
-    inline void reserve_block() {
-        if (out.size() - pos < 512) out.resize(out.size() * 2 + 4096);
-    }
-    inline void put(unsigned value, int bits) { // bits <= 27 (nbits < 32 on entry: the accumulator holds 64)
-        acc = (acc << bits) | (value & ((1u << bits) - 1u));
+    uint8_t *cur;     // scratch cursor: the next byte that is not complete yet
+    uint64_t acc = 0; // the bits of that byte and what follows, MSB-aligned
+    int nbits = 0;    // how many of them are valid (< 8 between fields)
+    explicit BitWriter(uint8_t *scratch) : cur(scratch) {}
+    inline void put(unsigned value, int bits) { // 1 <= bits <= 27; needs 8 writable bytes at the cursor
+        acc |= (uint64_t)(value & ((1u << bits) - 1u)) << (64 - nbits - bits);
         nbits += bits;
-        if (nbits >= 32) {
-            const uint32_t w = (uint32_t)(acc >> (nbits - 32));
-            nbits -= 32;
-            uint8_t *o = out.data() + pos;
-            if ((((~w) - 0x01010101u) & w & 0x80808080u) == 0) { // no 0xff byte: four bytes at once
-                o[0] = (uint8_t)(w >> 24);
-                o[1] = (uint8_t)(w >> 16);
-                o[2] = (uint8_t)(w >> 8);
-                o[3] = (uint8_t)w;
-                pos += 4;
-            } else {
-                for (int sh = 24; sh >= 0; sh -= 8) {
-                    const uint8_t d = (uint8_t)(w >> sh);
-                    out[pos++] = d;
-                    if (d == 0xff) out[pos++] = 0;
-                }
-            }
-        }
+        const uint64_t be = __builtin_bswap64(acc);
+        std::memcpy(cur, &be, 8);
+        const int whole = nbits & ~7;
+        cur += whole >> 3;
+        acc <<= whole; // (whole <= 32)
+        nbits &= 7;
     }
-    void finish_with_1s() { // Bitstream_writer.flush_with_1s (bitstream_writer.ml:45-49), then trim
-        while (nbits & 7) { acc = (acc << 1) | 1u; nbits++; }
-        reserve_block();
-        while (nbits >= 8) {
-            const uint8_t d = (uint8_t)(acc >> (nbits - 8));
-            out[pos++] = d;
-            if (d == 0xff) out[pos++] = 0;
-            nbits -= 8;
-        }
-        out.resize(pos);
+    void pad_with_1s() { // Bitstream_writer.flush_with_1s (bitstream_writer.ml:45-49)
+        if (nbits) put((1u << (8 - nbits)) - 1u, 8 - nbits);
     }
 };
+
+// scratch[0, n) -> appended to o with the stuffing (stage 2)
+__attribute__((target("sse2"))) static void append_stuffed(std::vector<uint8_t> &o, const uint8_t *src, size_t n) {
+    const size_t at = o.size();
+    o.resize(at + 2 * n); // (every byte an 0xff: trimmed below)
+    uint8_t *d = o.data() + at;
+    const __m128i ff = _mm_set1_epi8((char)0xff);
+    size_t i = 0;
+    while (i < n) {
+        if (i + 16 <= n) {
+            const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i));
+            if (!_mm_movemask_epi8(_mm_cmpeq_epi8(v, ff))) {
+                _mm_storeu_si128(reinterpret_cast<__m128i *>(d), v);
+                d += 16;
+                i += 16;
+                continue;
+            }
+        }
+        const size_t stop = i + 16 <= n ? i + 16 : n;
+        for (; i < stop; i++) {
+            const uint8_t b = src[i];
+            *d++ = b;
+            if (b == 0xff) *d++ = 0;
+        }
+    }
+    o.resize((size_t)(d - o.data()));
+}
 
 // bit k set <=> q[k] != 0
 inline uint64_t nonzero_mask(const int16_t *q) {
@@ -1294,11 +1302,15 @@ int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uin
     EncTable et[2];
     build_enc(et[0], K_DC_LUMA_BITS, K_DC_VALS, K_AC_LUMA_BITS, K_AC_LUMA_VALS);
     build_enc(et[1], K_DC_CHROMA_BITS, K_DC_VALS, K_AC_CHROMA_BITS, K_AC_CHROMA_VALS);
-    BitWriter bw(o);
     int dc_pred[3] = {0, 0, 0};
     const hvc_jpeg_component &c0 = info->comp[0];
     const int mbs_wide = c0.decoded_width / (8 * c0.hscale), mbs_high = c0.decoded_height / (8 * c0.vscale);
-    for (int my = 0; my < mbs_high; my++)
+    int per_mcu = 0;
+    for (int i = 0; i < 3; i++) per_mcu += info->comp[i].hscale * info->comp[i].vscale;
+    // one MCU row of bits without stuffing: a block is at most 64 fields of 27 bits (216 bytes)
+    std::vector<uint8_t> scratch((size_t)mbs_wide * (size_t)per_mcu * 216 + 64);
+    BitWriter bw(scratch.data());
+    for (int my = 0; my < mbs_high; my++) {
         for (int mx = 0; mx < mbs_wide; mx++)
             for (int i = 0; i < 3; i++) {
                 const hvc_jpeg_component &c = info->comp[i];
@@ -1308,7 +1320,6 @@ int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uin
                     for (int sx = 0; sx < c.hscale; sx++) {
                         const int bx = mx * c.hscale + sx, by = my * c.vscale + sy;
                         const int16_t *q = coefs + L.coef_offset + ((size_t)by * L.blocks_w + bx) * 64;
-                        bw.reserve_block();
                         // DC: difference to the predictor (encoder.ml:138-140), size + magnitude (:155-160)
                         const int diff = q[0] - dc_pred[i];
                         dc_pred[i] = q[0];
@@ -1337,7 +1348,11 @@ int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uin
                         if (prev != 63) bw.put(t.ac[0].bits, t.ac[0].len);
                     }
             }
-    bw.finish_with_1s();
+        if (my + 1 == mbs_high) bw.pad_with_1s();
+        // the row's complete bytes leave; the byte in progress stays in the accumulator
+        append_stuffed(o, scratch.data(), (size_t)(bw.cur - scratch.data()));
+        bw.cur = scratch.data();
+    }
     put_marker(o, 0xd9);
     *out_len = o.size();
     if (!out || o.size() > cap) return HVC_E_INVALID_ARG;
