@@ -848,7 +848,10 @@ const uint8_t K_Q_CHROMA[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 
                                 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
 
 struct EncCode { uint16_t bits; uint8_t len; };
-struct EncTable { EncCode dc[16]; EncCode ac[256]; }; // ac indexed by (run << 4) | size
+// ... and as the coder wants them: the code already shifted past the magnitude bits, the magnitude's mask, code + magnitude
+// bits -- a field is `hi | (magnitude & mask)`, `total` bits long
+struct EncField { uint32_t hi; uint16_t mask; uint8_t total, pad; };
+struct EncTable { EncCode dc[16]; EncCode ac[256]; EncField dcf[16]; EncField acf[256]; }; // ac indexed by (run << 4) | size
 
 void build_enc(EncTable &t, const uint8_t *dc_bits, const uint8_t *dc_vals, const uint8_t *ac_bits, const uint8_t *ac_vals) {
     std::memset(&t, 0, sizeof t);
@@ -864,6 +867,12 @@ void build_enc(EncTable &t, const uint8_t *dc_bits, const uint8_t *dc_vals, cons
         for (int i = 0; i < ac_bits[len - 1]; i++, k++) t.ac[ac_vals[k]] = EncCode{(uint16_t)(code + i), (uint8_t)len};
         code = (code + ac_bits[len - 1]) << 1;
     }
+    for (int s = 0; s < 16; s++) // (a DC category above 11 / an AC size above 10 has no code in the default tables: refused before use)
+        t.dcf[s] = EncField{(uint32_t)t.dc[s].bits << s, (uint16_t)((1u << s) - 1u), (uint8_t)(t.dc[s].len + s), 0};
+    for (int rs = 0; rs < 256; rs++) {
+        const int s = rs & 15;
+        t.acf[rs] = EncField{(uint32_t)t.ac[rs].bits << s, (uint16_t)((1u << s) - 1u), (uint8_t)(t.ac[rs].len + s), 0};
+    }
 }
 
 // Bitstream_writer (common/src/bitstream_writer.ml): MSB first, 0xff -> 0xff00 stuffing -- in two stages.
@@ -878,8 +887,8 @@ struct BitWriter {
     uint64_t acc = 0; // the bits of that byte and what follows, MSB-aligned
     int nbits = 0;    // how many of them are valid (< 8 between fields)
     explicit BitWriter(uint8_t *scratch) : cur(scratch) {}
-    inline void put(unsigned value, int bits) { // 1 <= bits <= 27; needs 8 writable bytes at the cursor
-        acc |= (uint64_t)(value & ((1u << bits) - 1u)) << (64 - nbits - bits);
+    inline void put(unsigned value, int bits) { // 1 <= bits <= 27, value < 2^bits; needs 8 writable bytes at the cursor
+        acc |= (uint64_t)value << (64 - nbits - bits);
         nbits += bits;
         const uint64_t be = __builtin_bswap64(acc);
         std::memcpy(cur, &be, 8);
@@ -1325,9 +1334,9 @@ int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uin
                         dc_pred[i] = q[0];
                         int size = bit_size(diff);
                         if (size > 11) return HVC_E_RANGE; // no code in the default DC tables
-                        // code and magnitude bits leave as one field (<= 16 + 11 bits)
-                        bw.put((t.dc[size].bits << size) | ((unsigned)(diff >= 0 ? diff : diff - 1) & ((1u << size) - 1u)),
-                               t.dc[size].len + size);
+                        // code and magnitude bits leave as one field (<= 16 + 11 bits); a negative value's bits are those
+                        // of value - 1 (encoder.ml:155-160)
+                        bw.put(t.dcf[size].hi | ((unsigned)(diff + (diff >> 31)) & t.dcf[size].mask), t.dcf[size].total);
                         // AC: runs of zeros, ZRL for runs >= 16, EOB when the tail is zero (:127-141, 162-187).
                         // The non-zero positions come from one 64-bit mask (SSE2 compares), so the loop runs
                         // once per coded coefficient with no data-dependent "is it zero" branch.
@@ -1338,14 +1347,14 @@ int hvc_jpeg_entropy_encode(const hvc_jpeg_info *info, const int16_t *coefs, uin
                             nz &= nz - 1;
                             int run = k - prev - 1;
                             prev = k;
-                            while (run >= 16) { bw.put(t.ac[0xf0].bits, t.ac[0xf0].len); run -= 16; }
+                            while (run >= 16) { bw.put(t.acf[0xf0].hi, t.acf[0xf0].total); run -= 16; }
                             const int v = q[k];
                             size = bit_size(v);
                             if (size > 10) return HVC_E_RANGE; // no code in the default AC tables
-                            const EncCode e = t.ac[(run << 4) | size];
-                            bw.put((e.bits << size) | ((unsigned)(v >= 0 ? v : v - 1) & ((1u << size) - 1u)), e.len + size);
+                            const EncField e = t.acf[(run << 4) | size];
+                            bw.put(e.hi | ((unsigned)(v + (v >> 31)) & e.mask), e.total);
                         }
-                        if (prev != 63) bw.put(t.ac[0].bits, t.ac[0].len);
+                        if (prev != 63) bw.put(t.acf[0].hi, t.acf[0].total);
                     }
             }
         if (my + 1 == mbs_high) bw.pad_with_1s();
