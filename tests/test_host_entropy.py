@@ -474,3 +474,41 @@ def test_sampling_factors_the_encoder_never_writes(hvc, si):
         assert np.array_equal(got, d.coef_record().astype(np.int16))
         (sa, _, ra), (sb, _, rb) = hvc.jpeg_entropy_decode2(jpg, golden_bytes("mini.jpg"))
         assert (sa, sb) == (0, 0) and np.array_equal(ra, rec)
+
+
+@pytest.mark.parametrize("chroma,w,h", [(420, 64, 48), (444, 40, 24)])
+def test_coder_output_full_of_ff_bytes(hvc, chroma, w, h):
+    """The coder writes its bits to a scratch buffer without stuffing and stuffs per MCU row (csrc/hvc_entropy.cpp,
+    BitWriter / append_stuffed): records whose fields are mostly one-bits -- magnitudes 2^s - 1, long codes, ZRL runs -- so
+    that 0xFF bytes come singly, in runs, at the 16-byte steps of the stuffing pass and at the ends of MCU rows; the file
+    must decode back to the record through the front end and through the model restatement."""
+    info = hvc.jpeg_encoder_layout(w, h, chroma, 50)
+    nblk = info.coef_count // 64
+    rng = np.random.Generator(np.random.PCG64(7 * chroma + w))
+    blocks = np.zeros((nblk, 64), dtype=np.int16)
+    ones = np.array([1, 3, 7, 15, 31, 63, 127, 255, 511, 1023], dtype=np.int16)
+    for b in range(nblk):
+        kind = b % 5
+        if kind == 0:
+            blocks[b, 1:] = ones[rng.integers(0, 10, size=63)]                 # dense, every magnitude all ones
+        elif kind == 1:
+            blocks[b, 1:] = 1023                                                # 26-bit fields back to back
+        elif kind == 2:
+            pos = rng.choice(np.arange(1, 64), size=6, replace=False)
+            blocks[b, pos] = ones[rng.integers(5, 10, size=6)]                  # long runs (ZRL = 11111111001) + long codes
+        elif kind == 3:
+            blocks[b, 63] = 1023                                                # three ZRLs, then run 14 / size 10
+        else:
+            blocks[b, 1:1 + (b % 40)] = -1                                      # (zeros in the magnitude bits: 0xFF from codes only)
+    for i in range(info.n_comp):
+        L = info.layout[i]
+        n = L.blocks_w * L.blocks_h
+        blocks[L.coef_offset // 64:L.coef_offset // 64 + n, 0] = np.resize(np.array([1023, -1024, 1023, 0, 2047 - 1024], dtype=np.int16), n)
+    rec = blocks.reshape(-1)
+    jpg = hvc.jpeg_entropy_encode(info, rec)
+    scan = jpg[hvc.jpeg_read_header(jpg).ecs_offset:-2]
+    assert scan.count(b"\xff\x00") > nblk            # the case is what it claims to be
+    assert b"\xff\xff" not in scan                   # ... and every 0xFF is followed by its 0x00
+    _, got = hvc.jpeg_entropy_decode(jpg)
+    assert np.array_equal(got, rec)
+    assert np.array_equal(orc.Decoder(jpg).coef_record().astype(np.int16), rec)
