@@ -16,6 +16,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <vector>
 
@@ -682,7 +683,9 @@ static int walk_alone(Walk &w) {
 
 static int entropy_decode_impl(const uint8_t *data, size_t n, const hvc_jpeg_info *info, int16_t *coefs,
                                std::vector<hvc::WideDc> *wide) {
-    Walk w;
+    // (a walk carries its tables -- 112 KB: on the heap, the caller's thread may have a small stack)
+    const std::unique_ptr<Walk> wp(new Walk);
+    Walk &w = *wp;
     const int r = w.prepare(data, n, info, coefs, wide);
     return r ? r : w.done ? HVC_OK : walk_alone(w);
 }
@@ -709,7 +712,8 @@ static void entropy_decode_two_impl(const uint8_t *const data[2], const size_t n
         }
     } prof;
 #endif
-    Walk a, b;
+    const std::unique_ptr<Walk> ap(new Walk), bp(new Walk);
+    Walk &a = *ap, &b = *bp;
     st[0] = a.prepare(data[0], n[0], info[0], coefs[0], wide[0]);
     st[1] = b.prepare(data[1], n[1], info[1], coefs[1], wide[1]);
 #ifdef HVC_READER_PROFILE
@@ -723,8 +727,11 @@ static void entropy_decode_two_impl(const uint8_t *const data[2], const size_t n
     // both have a block in progress inside the hot loop; whoever ends one starts its next block and comes back
     if ((st[0] = a.begin_block()) || (st[1] = b.begin_block())) { // (the other one alone, from its first block)
         // restart whichever is intact from the top: nothing of it has been consumed beyond its first block's DC
-        if (!st[0]) { Walk a2; st[0] = a2.prepare(data[0], n[0], info[0], coefs[0], wide[0]); if (wide[0]) wide[0]->clear(); if (!st[0] && !a2.done) st[0] = walk_alone(a2); }
-        else if (!st[1]) { Walk b2; st[1] = b2.prepare(data[1], n[1], info[1], coefs[1], wide[1]); if (wide[1]) wide[1]->clear(); if (!st[1] && !b2.done) st[1] = walk_alone(b2); }
+        const int q = !st[0] ? 0 : !st[1] ? 1 : -1;
+        if (q >= 0) {
+            if (wide[q]) wide[q]->clear();
+            st[q] = entropy_decode_impl(data[q], n[q], info[q], coefs[q], wide[q]);
+        }
         return;
     }
     BitReader bra = a.br, brb = b.br;
