@@ -413,6 +413,15 @@ struct Walk {
 
     int prepare(const uint8_t *data, size_t n, const hvc_jpeg_info *info_, int16_t *coefs_, std::vector<hvc::WideDc> *wide_) {
         if (!data || !info_ || !coefs_) return HVC_E_INVALID_ARG;
+        // (a walk is reused by its thread: everything a previous file left behind starts over)
+        for (int i = 0; i < 4; i++) dc_pred[i] = 0, dc[i] = ac[i] = nullptr, part[i] = 0;
+        my = mx = bi = 0;
+        k = 64;
+        done = false;
+        dst = nullptr;
+        regular = true;
+        mcu.clear();
+        std::memset(cur, 0, 64 * sizeof(int16_t));
         info = info_;
         coefs = coefs_;
         stream_out = ((uintptr_t)coefs_ & 15) == 0;
@@ -681,11 +690,19 @@ static int walk_alone(Walk &w) {
 }
 } // namespace
 
+// A walk carries its tables -- 112 KB, not something for a caller's stack (the OCaml host's threads may have small
+// ones) -- and allocating it per file cost the batch pipeline's sixteen workers 2-3 % (and now and then far more, when the
+// allocator trimmed and re-grew its arenas): each thread keeps two, made on first use, gone with the thread.
+static Walk &thread_walk(int which) {
+    struct Two { Walk w[2]; }; // (one block, like the two locals they replace)
+    static thread_local std::unique_ptr<Two> t;
+    if (!t) t.reset(new Two);
+    return t->w[which];
+}
+
 static int entropy_decode_impl(const uint8_t *data, size_t n, const hvc_jpeg_info *info, int16_t *coefs,
                                std::vector<hvc::WideDc> *wide) {
-    // (a walk carries its tables -- 112 KB: on the heap, the caller's thread may have a small stack)
-    const std::unique_ptr<Walk> wp(new Walk);
-    Walk &w = *wp;
+    Walk &w = thread_walk(0);
     const int r = w.prepare(data, n, info, coefs, wide);
     return r ? r : w.done ? HVC_OK : walk_alone(w);
 }
@@ -712,8 +729,7 @@ static void entropy_decode_two_impl(const uint8_t *const data[2], const size_t n
         }
     } prof;
 #endif
-    const std::unique_ptr<Walk> ap(new Walk), bp(new Walk);
-    Walk &a = *ap, &b = *bp;
+    Walk &a = thread_walk(0), &b = thread_walk(1);
     st[0] = a.prepare(data[0], n[0], info[0], coefs[0], wide[0]);
     st[1] = b.prepare(data[1], n[1], info[1], coefs[1], wide[1]);
 #ifdef HVC_READER_PROFILE
@@ -727,7 +743,7 @@ static void entropy_decode_two_impl(const uint8_t *const data[2], const size_t n
     // both have a block in progress inside the hot loop; whoever ends one starts its next block and comes back
     if ((st[0] = a.begin_block()) || (st[1] = b.begin_block())) { // (the other one alone, from its first block)
         // restart whichever is intact from the top: nothing of it has been consumed beyond its first block's DC
-        const int q = !st[0] ? 0 : !st[1] ? 1 : -1;
+        const int q = !st[0] ? 0 : !st[1] ? 1 : -1; // (a and b are done with: entropy_decode_impl takes the first one over)
         if (q >= 0) {
             if (wide[q]) wide[q]->clear();
             st[q] = entropy_decode_impl(data[q], n[q], info[q], coefs[q], wide[q]);
