@@ -83,3 +83,32 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, (out.returncode, out.stderr)
     assert out.stdout.strip() == "%d symbols" % len(syms)
+
+
+def test_every_entry_point_refuses_null_arguments():
+    """Every int-returning function of include/hvc_jpeg.h called with nothing but zeros and null pointers (no context, no
+    buffers): an hvc_status comes back -- HVC_E_INVALID_ARG but for the two that have nothing to refuse -- and the process
+    is still there.  One child process for the whole sweep (a crash must not take the test runner along)."""
+    import subprocess
+    import sys
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "hvc_jpeg.h")).read(), flags=re.S)
+    protos = re.findall(r"HVC_API\s+int\s+(hvc_\w+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.S)
+    assert len(protos) >= 45
+    calls = [(name, 0 if args.strip() in ("", "void") else len(re.split(r",(?![^()]*\))", args))) for name, args in protos]
+    code = "\n".join([
+        "import ctypes as C, sys",
+        "sys.path.insert(0, %r)" % ROOT,
+        "import video_coding_amd as hvc",
+        "L = hvc.lib()",
+        "for name, n in %r:" % (calls,),
+        "    f = getattr(L, name); f.restype = C.c_int; f.argtypes = [C.c_void_p] * n",
+        "    print(name, f(*([None] * n)), flush=True)",
+        "print('SWEPT')"])
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    seen = dict(line.split() for line in r.stdout.splitlines() if line.startswith("hvc_"))
+    assert r.returncode == 0 and "SWEPT" in r.stdout, "crashed behind %s\n%s" % (list(seen)[-1:] or "the start", r.stderr[-2000:])
+    assert set(seen) == {name for name, _ in calls}
+    nothing_to_refuse = {"hvc_last_hip_error": "0",   # (no context: no error recorded)
+                         "hvc_compare_planes": "0"}   # (zero samples: the planes are equal)
+    for name, status in seen.items():
+        assert status == nothing_to_refuse.get(name, "-1"), (name, status)

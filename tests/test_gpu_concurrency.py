@@ -215,3 +215,41 @@ print("refusal ok")
     env = dict(os.environ, HVC_POOL_FAIL_AFTER="3")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "refusal ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_every_context_entry_point_refuses_null_buffers():
+    """The same sweep as tests/test_abi_symbols.py with a live context in front: every function that takes the context
+    called with it and otherwise nothing but zeros and null pointers -- a status comes back (never a positive one), the
+    process is still there, and the context then decodes a file like before.  In a child process."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "hvc_jpeg.h")).read(), flags=re.S)
+    protos = re.findall(r"HVC_API\s+int\s+(hvc_\w+)\s*\(\s*(?:const\s+)?hvc_ctx\s*\*\s*\w+\s*((?:,[^;]*?)?)\)\s*;", hdr, flags=re.S)
+    calls = [(name, len(re.split(r",(?![^()]*\))", rest)) - 1 if rest.strip() else 0) for name, rest in protos]
+    assert len(calls) >= 30
+    code = "\n".join([
+        "import ctypes as C, sys, numpy as np",
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)" % (root, os.path.join(root, "tests")),
+        "import video_coding_amd as hvc",
+        "from oracle import orc",
+        "ctx = hvc.Context(0); L = hvc.lib()",
+        "for name, n in %r:" % (calls,),
+        "    f = getattr(L, name); f.restype = C.c_int; f.argtypes = [C.c_void_p] * (n + 1)",
+        "    print(name, f(ctx._h, *([None] * n)), flush=True)",
+        "data = open(%r, 'rb').read()" % os.path.join(root, "tests", "golden", "Mouse480.jpg"),
+        "info, pixels = ctx.jpeg_decode(data)",
+        "d = orc.Decoder(data); d.decode()",
+        "assert all(np.array_equal(p, d.plane(i)) for i, p in enumerate(info.planes(pixels)))",
+        "print('SWEPT')"])
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    seen = dict(line.split() for line in r.stdout.splitlines() if line.startswith("hvc_"))
+    assert r.returncode == 0 and "SWEPT" in r.stdout, "failed behind %s\n%s" % (list(seen)[-1:] or "the start", r.stderr[-3000:])
+    assert set(seen) == {name for name, _ in calls}
+    assert all(int(s) <= 0 for s in seen.values()), seen
+    # what has something to refuse refuses it
+    for name in ("hvc_decode_frames", "hvc_encode_frames", "hvc_jpeg_decode", "hvc_jpeg_decode_batch", "hvc_jpeg_decode_batch_gpu",
+                 "hvc_jpeg_encode_batch", "hvc_huffman_encode_frames", "hvc_checksum_records"):  # (a copy of zero bytes is one)
+        assert int(seen[name]) < 0, (name, seen[name])
