@@ -148,6 +148,26 @@ struct Lut {
     std::vector<uint16_t> e; // (length << 8) | data ; 0 = no code; indexed by max_bits peeked bits (Tables.Lut)
     uint16_t fast[1 << FAST_BITS]; // the same entries for codes of <= FAST_BITS bits, indexed by FAST_BITS bits:
                                    // 2 KB, L1-resident; 0 = longer code (or none): look in e
+    // What the tables were built from last time, and whether that worked: a walk is reused by its thread, and the files of
+    // a batch -- or of a loop over single files -- mostly carry the same DHT segments (the 64 K-entry table of a 16-bit
+    // code is 128 KB to fill: most of what a small file's decode costs).
+    HuffSpec built_from;
+    int built = 0; // 0: nothing yet, 1: tables valid, -1: that specification is no usable code; for AC tables `+ 2`: pair / whole built too
+    bool same_spec(const HuffSpec &s) const {
+        return built != 0 && s.total == built_from.total && !std::memcmp(s.lengths, built_from.lengths, sizeof s.lengths) &&
+               !std::memcmp(s.values, built_from.values, sizeof(int) * (size_t)s.total);
+    }
+    // build() for a specification that may be the one the tables already hold; ac: the one-lookup tables too
+    bool build_for(const HuffSpec &s, bool ac_tables) {
+        if (same_spec(s)) return built > 0;
+        built_from = s;
+        built = build(s) ? 1 : -1;
+        if (built > 0) {
+            if (ac_tables) build_pair();
+            else build_whole_dc();
+        }
+        return built > 0;
+    }
     bool build(const HuffSpec &s) {
         std::memset(fast, 0, sizeof fast);
         int maxb = 0;
@@ -445,13 +465,11 @@ struct Walk {
                 if (aseg[j] == ai) ac[i] = ac[j];
             }
             if (!dc[i]) {
-                if (!dc_tab[i].build(h.dht[di].spec)) return HVC_E_BAD_JPEG;
-                dc_tab[i].build_whole_dc();
+                if (!dc_tab[i].build_for(h.dht[di].spec, false)) return HVC_E_BAD_JPEG;
                 dc[i] = &dc_tab[i];
             }
             if (!ac[i]) {
-                if (!ac_tab[i].build(h.dht[ai].spec)) return HVC_E_BAD_JPEG;
-                ac_tab[i].build_pair();
+                if (!ac_tab[i].build_for(h.dht[ai].spec, true)) return HVC_E_BAD_JPEG;
                 ac[i] = &ac_tab[i];
             }
         }
