@@ -223,8 +223,8 @@ struct Lut {
     // ... and the table the hot loop reads: ONE OR TWO symbols per lookup.  Where a second whole symbol (code + magnitude)
     // follows the first inside the FAST_BITS index, the entry carries both -- the dependency chain of the walk (shift,
     // load, shift) is then paid once for two symbols.  64-bit entry: byte 0 the bits consumed by all of it (0: the first
-    // symbol is not covered), byte 1 / byte 2 the index steps of the first / second symbol (second: 0 when there is
-    // none), byte 3 the bits of the first symbol alone (to step back when the first one completed the block and the
+    // symbol is not covered), byte 1 the index step of the first symbol, byte 2 the step of both together (= byte 1
+    // when there is no second), byte 3 the bits of the first symbol alone (to step back when the first one completed the block and the
     // "second" is the next block's), bits 32-47 / 48-63 the two coefficients (the second = the first when there is none:
     // the loop always stores twice, the second time over the first).  An end of block is never followed by a second symbol.
     uint64_t pair[1 << FAST_BITS];
@@ -245,7 +245,7 @@ struct Lut {
                         v2 = b >> 16;
                     }
                 }
-                o = (uint64_t)btot | (uint64_t)s1 << 8 | (uint64_t)s2 << 16 | (uint64_t)b1 << 24 | (uint64_t)(v1 & 0xffffu) << 32 |
+                o = (uint64_t)btot | (uint64_t)s1 << 8 | (uint64_t)(s1 + s2) << 16 | (uint64_t)b1 << 24 | (uint64_t)(v1 & 0xffffu) << 32 |
                     (uint64_t)(v2 & 0xffffu) << 48;
             }
             pair[w] = o;
@@ -619,11 +619,14 @@ struct Walk {
     }
 };
 
-// Up to four AC symbols of the block in progress, on a LOCAL copy of the walk's hot state (bit reader, index, block
-// and table pointers: they must live in registers -- through the Walk object every symbol paid loads and stores of
-// them).  One refill for the group; a symbol the one-lookup table does not cover is decoded by the two-step path
-// after a refill of its own and ends the group.  K becomes 64 at the end of the block; ERR receives the model's error.
-#define HVC_AC_ONE_(BR, K, BLK, ACW, ACF, ACT, AMAX, ERR)                                                            \
+// Up to four look-ups (one or two AC symbols each) of the block in progress, on a LOCAL copy of the walk's hot state (bit
+// reader, place in the block, table pointers: they must live in registers -- through the Walk object every symbol paid
+// loads and stores of them).  The place in the block is a POINTER, BP = the block + the index of the next coefficient, END
+// = the block + 64: a symbol's coefficient goes to BP[step - 1], the steps are added to BP, and BP >= END is the one
+// test that ends a block.  One refill for the group; a symbol the one-lookup table does not cover is decoded by the
+// two-step path after a refill of its own and ends the group.  BP becomes END at the end of the block; ERR receives the
+// model's error.
+#define HVC_AC_ONE_(BR, BP, END, ACW, ACF, ACT, AMAX, ERR)                                                           \
     {                                                                                                                \
         const uint64_t e_ = (ACW)[(BR).buf >> (64 - Lut::FAST_BITS)];                                                \
         const unsigned b_ = (unsigned)(e_ & 0xffu);                                                                  \
@@ -644,11 +647,11 @@ struct Walk {
                     (BR).cnt -= size_;                                                                               \
                 }                                                                                                    \
                 if (mag_ == 0 && run_ == 0) { /* decoder.ml:131-132 (EOB, or a zero-size code) */                   \
-                    (K) = 64;                                                                                        \
+                    (BP) = (END);                                                                                    \
                 } else {                                                                                             \
-                    (K) += run_;                                                                                     \
-                    if ((K) >= 64) (ERR) = HVC_E_BAD_JPEG; /* "coefficient index out of range" */                   \
-                    else (BLK)[(K)++] = (int16_t)mag_;                                                               \
+                    (BP) += run_;                                                                                    \
+                    if ((BP) >= (END)) (ERR) = HVC_E_BAD_JPEG; /* "coefficient index out of range" */               \
+                    else *(BP)++ = (int16_t)mag_;                                                                    \
                 }                                                                                                    \
             }                                                                                                        \
             break;                                                                                                   \
@@ -656,34 +659,34 @@ struct Walk {
         const uint64_t buf0_ = (BR).buf;                                                                             \
         (BR).buf <<= b_;                                                                                             \
         (BR).cnt -= (int)b_;                                                                                         \
-        const int k1_ = (K) + (int)((e_ >> 8) & 0xffu);  /* behind the first symbol */                               \
-        const int k2_ = k1_ + (int)((e_ >> 16) & 0xffu); /* behind the second one (= k1_ when there is none) */      \
-        (BLK)[k1_ - 1] = (int16_t)(e_ >> 32);            /* (past index 63: into the room behind the block) */       \
-        (BLK)[k2_ - 1] = (int16_t)(e_ >> 48);                                                                        \
-        (K) = k2_;                                                                                                   \
-        if (k2_ >= 64) { /* a last coefficient at index 63, an end of block, or an index out of range */            \
-            if (k1_ >= 64) {                                                                                         \
-                if (k1_ == 64) { /* the first symbol completed the block: what followed it is the next block's */   \
+        int16_t *const p1_ = (BP) + ((e_ >> 8) & 0xffu);  /* behind the first symbol */                              \
+        int16_t *const p2_ = (BP) + ((e_ >> 16) & 0xffu); /* behind the second one (= p1_ when there is none) */     \
+        p1_[-1] = (int16_t)(e_ >> 32);                    /* (past index 63: into the room behind the block) */      \
+        p2_[-1] = (int16_t)(e_ >> 48);                                                                               \
+        (BP) = p2_;                                                                                                  \
+        if (p2_ >= (END)) { /* a last coefficient at index 63, an end of block, or an index out of range */         \
+            if (p1_ >= (END)) {                                                                                      \
+                if (p1_ == (END)) { /* the first symbol completed the block: what followed it is the next block's */ \
                     const unsigned b1_ = (unsigned)((e_ >> 24) & 0xffu);                                             \
                     (BR).cnt += (int)(b_ - b1_);                                                                     \
                     (BR).buf = buf0_ << b1_;                                                                         \
-                } else if (k1_ < (int)Lut::WHOLE_EOB) {                                                              \
+                } else if (p1_ - (END) < (long)Lut::WHOLE_EOB - 64) {                                                \
                     (ERR) = HVC_E_BAD_JPEG; /* "coefficient index out of range" */                                  \
                 }                                                                                                    \
-            } else if (k2_ > 64 && k2_ < (int)Lut::WHOLE_EOB) {                                                      \
+            } else if (p2_ > (END) && p2_ - (END) < (long)Lut::WHOLE_EOB - 64) {                                     \
                 (ERR) = HVC_E_BAD_JPEG; /* "coefficient index out of range" */                                      \
             }                                                                                                        \
-            (K) = 64;                                                                                                \
+            (BP) = (END);                                                                                            \
             break;                                                                                                   \
         }                                                                                                            \
     }
-#define HVC_AC_GROUP(BR, K, BLK, ACW, ACF, ACT, AMAX, ERR)                                                           \
+#define HVC_AC_GROUP(BR, BP, END, ACW, ACF, ACT, AMAX, ERR)                                                          \
     do {                                                                                                             \
         (BR).refill();                                                                                               \
-        HVC_AC_ONE_(BR, K, BLK, ACW, ACF, ACT, AMAX, ERR)                                                            \
-        HVC_AC_ONE_(BR, K, BLK, ACW, ACF, ACT, AMAX, ERR)                                                            \
-        HVC_AC_ONE_(BR, K, BLK, ACW, ACF, ACT, AMAX, ERR)                                                            \
-        HVC_AC_ONE_(BR, K, BLK, ACW, ACF, ACT, AMAX, ERR)                                                            \
+        HVC_AC_ONE_(BR, BP, END, ACW, ACF, ACT, AMAX, ERR)                                                           \
+        HVC_AC_ONE_(BR, BP, END, ACW, ACF, ACT, AMAX, ERR)                                                           \
+        HVC_AC_ONE_(BR, BP, END, ACW, ACF, ACT, AMAX, ERR)                                                           \
+        HVC_AC_ONE_(BR, BP, END, ACW, ACF, ACT, AMAX, ERR)                                                           \
     } while (0)
 
 // the whole file, block after block
@@ -692,12 +695,12 @@ static int walk_alone(Walk &w) {
         int r = w.begin_block();
         if (r) return r;
         BitReader br = w.br;
-        int k = w.k, err = 0;
-        int16_t *const blk = w.cur;
+        int err = 0;
+        int16_t *bp = w.cur + w.k, *const end = w.cur + 64;
         const uint64_t *const acw = w.acw;
         const uint16_t *const acf = w.acf, *const act = w.act;
         const int amax = w.amax;
-        while (k < 64 && !err) HVC_AC_GROUP(br, k, blk, acw, acf, act, amax, err);
+        while (bp < end && !err) HVC_AC_GROUP(br, bp, end, acw, acf, act, amax, err);
         w.br = br;
         w.k = 64;
         if (err) return err;
@@ -769,48 +772,49 @@ static void entropy_decode_two_impl(const uint8_t *const data[2], const size_t n
         return;
     }
     BitReader bra = a.br, brb = b.br;
-    int ka = a.k, kb = b.k, ea = 0, eb = 0;
-    int16_t *const blka = a.cur, *const blkb = b.cur;
+    int ea = 0, eb = 0;
+    int16_t *bpa = a.cur + a.k, *bpb = b.cur + b.k, *const enda = a.cur + 64, *const endb = b.cur + 64;
     const uint64_t *acwa = a.acw, *acwb = b.acw;
     const uint16_t *acfa = a.acf, *acta = a.act, *acfb = b.acf, *actb = b.act;
     int amaxa = a.amax, amaxb = b.amax;
     bool alive_a = true, alive_b = true;
     while (alive_a && alive_b) {
-        while (ka < 64 && kb < 64 && !(ea | eb)) {
-            HVC_AC_GROUP(bra, ka, blka, acwa, acfa, acta, amaxa, ea);
-            HVC_AC_GROUP(brb, kb, blkb, acwb, acfb, actb, amaxb, eb);
+        while (bpa < enda && bpb < endb && !(ea | eb)) {
+            HVC_AC_GROUP(bra, bpa, enda, acwa, acfa, acta, amaxa, ea);
+            HVC_AC_GROUP(brb, bpb, endb, acwb, acfb, actb, amaxb, eb);
         }
-        if (ea || ka >= 64) { // A: error, or its block is complete
+        if (ea || bpa >= enda) { // A: error, or its block is complete
             a.br = bra;
             a.k = 64;
             if (ea) st[0] = ea;
             if (!ea && a.finished()) a.end_walk();
             if (ea || a.finished() || (st[0] = a.begin_block())) alive_a = false;
             else {
-                bra = a.br; ka = a.k; acwa = a.acw; acfa = a.acf; acta = a.act; amaxa = a.amax;
+                bra = a.br; bpa = a.cur + a.k; acwa = a.acw; acfa = a.acf; acta = a.act; amaxa = a.amax;
             }
         }
-        if (eb || kb >= 64) {
+        if (eb || bpb >= endb) {
             b.br = brb;
             b.k = 64;
             if (eb) st[1] = eb;
             if (!eb && b.finished()) b.end_walk();
             if (eb || b.finished() || (st[1] = b.begin_block())) alive_b = false;
             else {
-                brb = b.br; kb = b.k; acwb = b.acw; acfb = b.acf; actb = b.act; amaxb = b.amax;
+                brb = b.br; bpb = b.cur + b.k; acwb = b.acw; acfb = b.acf; actb = b.act; amaxb = b.amax;
             }
         }
     }
     // the survivor finishes alone: the block it has in progress first
-    auto finish = [](Walk &w, BitReader br, int k, int16_t *blk, int &status) {
+    auto finish = [](Walk &w, BitReader br, int16_t *bp, int &status) {
         int err = 0;
-        while (k < 64 && !err) HVC_AC_GROUP(br, k, blk, w.acw, w.acf, w.act, w.amax, err);
+        int16_t *const end = w.cur + 64;
+        while (bp < end && !err) HVC_AC_GROUP(br, bp, end, w.acw, w.acf, w.act, w.amax, err);
         w.br = br;
         w.k = 64;
         status = err ? err : walk_alone(w);
     };
-    if (alive_a) finish(a, bra, ka, blka, st[0]);
-    if (alive_b) finish(b, brb, kb, blkb, st[1]);
+    if (alive_a) finish(a, bra, bpa, st[0]);
+    if (alive_b) finish(b, brb, bpb, st[1]);
 }
 
 int hvc_jpeg_entropy_decode2(const uint8_t *jpeg_a, size_t n_a, const hvc_jpeg_info *info_a, int16_t *coefs_a, int *status_a,
