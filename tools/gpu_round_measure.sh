@@ -15,6 +15,7 @@ python bench.py --frames 4096 --steps 20 --no-cpu-baseline > gpurun_out/m_bench_
 python tools/bench_sustained.py > gpurun_out/m_sustained.json 2> /dev/null
 echo "bench done"
 python tools/bench_configs.py --config 3 --frames 1024 --threads 16 > gpurun_out/m_c3.json 2> gpurun_out/m_c3.err
+python tools/bench_configs.py --config 3 --frames 4096 --threads 16 > gpurun_out/m_c3_4096.json 2>> gpurun_out/m_c3.err
 python tools/bench_configs.py --config 4 > gpurun_out/m_c4.json 2> gpurun_out/m_c4.err
 python tools/bench_configs.py --config 5 > gpurun_out/m_c5.json 2> gpurun_out/m_c5.err
 python tools/bench_configs.py --config 6 > gpurun_out/m_c6.json 2> gpurun_out/m_c6.err
