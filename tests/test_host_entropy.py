@@ -512,3 +512,31 @@ def test_coder_output_full_of_ff_bytes(hvc, chroma, w, h):
     _, got = hvc.jpeg_entropy_decode(jpg)
     assert np.array_equal(got, rec)
     assert np.array_equal(orc.Decoder(jpg).coef_record().astype(np.int16), rec)
+
+
+def test_the_block_flush_without_avx512():
+    """A finished block leaves the reader's buffer with two 64-byte streaming stores where the CPU has AVX-512 and the
+    record is 64-byte aligned, with eight 16-byte ones elsewhere (HVC_NO_AVX512=1 chooses that form; the choice is made
+    once per process): the reader's tests again in a child process with the switch set -- and records that are only
+    16-byte / only 2-byte aligned in this one."""
+    import os
+    import subprocess
+    import sys
+    import video_coding_amd as m
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.environ.get("HVC_NO_AVX512") != "1":
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", os.path.join(root, "tests", "test_host_entropy.py"), "-k",
+                            "entropy_decode_equals_model or groups_of_four or two_files_in_turn or sampling_factors"],
+                           env=dict(os.environ, HVC_NO_AVX512="1"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:]
+    import ctypes as C
+    data = golden_bytes("Mouse480.jpg")
+    info, want = m.hvc.jpeg_entropy_decode(data)
+    for shift in (16, 2, 34):   # bytes off a 64-byte boundary
+        raw = np.zeros(info.coef_count * 2 + 128, dtype=np.uint8)
+        off = (-raw.ctypes.data) % 64 + shift
+        rec = raw[off:off + info.coef_count * 2].view(np.int16)
+        assert rec.ctypes.data % 64 == shift
+        assert m.hvc.lib().hvc_jpeg_entropy_decode(data, len(data), C.byref(info), rec.ctypes.data) == 0
+        assert np.array_equal(rec, want), shift
+        assert not raw[:off].any() and not raw[off + info.coef_count * 2:].any()
