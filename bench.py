@@ -178,6 +178,8 @@ def dist_init(world, backend, device=None):
     if use_group(world) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL on this driver (a rank started by
+        # another launcher than this file's own: the variable is normally exported already; never overridden)
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend, **kw)
     return dist
