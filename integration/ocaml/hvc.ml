@@ -250,6 +250,123 @@ let set_stream = foreign "hvc_set_stream" (ctx @-> ptr void @-> returning int)
 let reset_stream = foreign "hvc_reset_stream" (ctx @-> returning int)
 let synchronize = foreign "hvc_synchronize" ~release_runtime_lock:true (ctx @-> returning int)
 
+(* ---- the rest of include/hvc_jpeg.h, so that the binding names every entry point ---- *)
+
+(* const char *hvc_version(void); int hvc_last_hip_error(ctx) *)
+let version = foreign "hvc_version" (void @-> returning string)
+let last_hip_error = foreign "hvc_last_hip_error" (ctx @-> returning int)
+
+(* host threads of the batch pipelines: int hvc_host_threads(ctx, alive, ever_started); int hvc_host_threads_probe(threads);
+   int hvc_set_host_cpus(ctx, cpulist); int hvc_get_host_cpus(ctx, out, cap, n_cpus) *)
+let host_threads = foreign "hvc_host_threads" (ctx @-> ptr int @-> ptr uint64_t @-> returning int)
+let host_threads_probe = foreign "hvc_host_threads_probe" (int @-> returning int)
+let set_host_cpus = foreign "hvc_set_host_cpus" (ctx @-> string @-> returning int)
+let get_host_cpus = foreign "hvc_get_host_cpus" (ctx @-> ptr char @-> size_t @-> ptr int @-> returning int)
+
+(* timers, profiling, kernel choice: int hvc_timer_begin(ctx); int hvc_timer_end(ctx, ms); int hvc_set_profiling(ctx, enabled);
+   int hvc_last_kernel_ms(ctx, ms); int hvc_kernel_ms_history(ctx, ms, n); int hvc_set_decode_kernel(ctx, which);
+   int hvc_last_wide_blocks(ctx, count) *)
+let timer_begin = foreign "hvc_timer_begin" (ctx @-> returning int)
+let timer_end = foreign "hvc_timer_end" ~release_runtime_lock:true (ctx @-> ptr float @-> returning int)
+let set_profiling = foreign "hvc_set_profiling" (ctx @-> int @-> returning int)
+let last_kernel_ms = foreign "hvc_last_kernel_ms" (ctx @-> ptr float @-> returning int)
+let kernel_ms_history = foreign "hvc_kernel_ms_history" (ctx @-> ptr float @-> int @-> returning int)
+let set_decode_kernel = foreign "hvc_set_decode_kernel" (ctx @-> int @-> returning int)
+let last_wide_blocks = foreign "hvc_last_wide_blocks" (ctx @-> ptr uint64_t @-> returning int)
+
+(* int hvc_upsample420(ctx, src, cw, ch, src_stride, dst, dst_stride, n_planes, src_plane_stride, dst_plane_stride, where)
+   tools/src/planar_444.ml:82-103 *)
+let upsample420 =
+  foreign
+    "hvc_upsample420"
+    ~release_runtime_lock:true
+    (ctx @-> ptr char @-> int @-> int @-> size_t @-> ptr char @-> size_t @-> int @-> size_t @-> size_t @-> int
+    @-> returning int)
+;;
+
+(* int hvc_jpeg_entropy_decode2(jpeg_a, n_a, info_a, coefs_a, status_a, jpeg_b, n_b, info_b, coefs_b, status_b):
+   two files decoded in turn on the calling thread *)
+let jpeg_entropy_decode2 =
+  foreign
+    "hvc_jpeg_entropy_decode2"
+    ~release_runtime_lock:true
+    (string @-> size_t @-> ptr Jpeg_info.t @-> ptr int16_t @-> ptr int @-> string @-> size_t @-> ptr Jpeg_info.t
+    @-> ptr int16_t @-> ptr int @-> returning int)
+;;
+
+(* int hvc_jpeg_entropy_decode_gpu(ctx, jpegs, sizes, n_frames, coefs, coef_frame_stride, where, info, used_gpu) *)
+let jpeg_entropy_decode_gpu =
+  foreign
+    "hvc_jpeg_entropy_decode_gpu"
+    ~release_runtime_lock:true
+    (ctx @-> ptr string @-> ptr size_t @-> int @-> ptr int16_t @-> size_t @-> int @-> ptr Jpeg_info.t @-> ptr int
+    @-> returning int)
+;;
+
+(* int hvc_jpeg_decode_batch_yuv444(ctx, jpegs, sizes, n_frames, threads, frames_per_chunk, frames, frame_stride, where, stats) *)
+let jpeg_decode_batch_yuv444 =
+  foreign
+    "hvc_jpeg_decode_batch_yuv444"
+    ~release_runtime_lock:true
+    (ctx @-> ptr string @-> ptr size_t @-> int @-> int @-> int @-> ptr char @-> size_t @-> int
+    @-> ptr Batch_stats.t @-> returning int)
+;;
+
+(* the encoder's side: int hvc_jpeg_encoder_layout(width, height, chroma, quality, info); int hvc_jpeg_encoder_check(info);
+   int hvc_jpeg_header(info, out, cap, len); int hvc_jpeg_entropy_encode(info, coefs, out, cap, out_len)
+   encoder.ml:347-349, 371-418, 437-472, 127-193 *)
+let jpeg_encoder_layout =
+  foreign "hvc_jpeg_encoder_layout" (int @-> int @-> int @-> int @-> ptr Jpeg_info.t @-> returning int)
+;;
+
+let jpeg_encoder_check = foreign "hvc_jpeg_encoder_check" (ptr Jpeg_info.t @-> returning int)
+
+let jpeg_header =
+  foreign "hvc_jpeg_header" (ptr Jpeg_info.t @-> ptr char @-> size_t @-> ptr size_t @-> returning int)
+;;
+
+let jpeg_entropy_encode =
+  foreign
+    "hvc_jpeg_entropy_encode"
+    ~release_runtime_lock:true
+    (ptr Jpeg_info.t @-> ptr int16_t @-> ptr char @-> size_t @-> ptr size_t @-> returning int)
+;;
+
+(* int hvc_huffman_encode_frames(ctx, info, coefs, coef_frame_stride, n_frames, out, out_cap, offsets, where):
+   the GPU Huffman coder on device- or host-resident coefficient records *)
+let huffman_encode_frames =
+  foreign
+    "hvc_huffman_encode_frames"
+    ~release_runtime_lock:true
+    (ctx @-> ptr Jpeg_info.t @-> ptr int16_t @-> size_t @-> int @-> ptr char @-> size_t @-> ptr uint64_t @-> int
+    @-> returning int)
+;;
+
+(* int hvc_jpeg_encode_batch(ctx, frames, n_frames, width, height, chroma, quality, threads, frames_per_chunk, jpegs, caps,
+                             sizes, stats) and the same with the Huffman coder on the GPU      BASELINE config 5, files out *)
+let jpeg_encode_batch =
+  foreign
+    "hvc_jpeg_encode_batch"
+    ~release_runtime_lock:true
+    (ctx @-> ptr (ptr char) @-> int @-> int @-> int @-> int @-> int @-> int @-> int @-> ptr (ptr char) @-> ptr size_t
+    @-> ptr size_t @-> ptr Batch_stats.t @-> returning int)
+;;
+
+let jpeg_encode_batch_gpu =
+  foreign
+    "hvc_jpeg_encode_batch_gpu"
+    ~release_runtime_lock:true
+    (ctx @-> ptr (ptr char) @-> int @-> int @-> int @-> int @-> int @-> int @-> int @-> ptr (ptr char) @-> ptr size_t
+    @-> ptr size_t @-> ptr Batch_stats.t @-> returning int)
+;;
+
+(* device memory for callers that keep records resident: int hvc_device_alloc(ctx, bytes, out); int hvc_device_free(ctx, p);
+   int hvc_memcpy_h2d(ctx, dst, src, bytes); int hvc_memcpy_d2h(ctx, dst, src, bytes) *)
+let device_alloc = foreign "hvc_device_alloc" (ctx @-> size_t @-> ptr (ptr void) @-> returning int)
+let device_free = foreign "hvc_device_free" (ctx @-> ptr void @-> returning int)
+let memcpy_h2d = foreign "hvc_memcpy_h2d" ~release_runtime_lock:true (ctx @-> ptr void @-> ptr void @-> size_t @-> returning int)
+let memcpy_d2h = foreign "hvc_memcpy_d2h" ~release_runtime_lock:true (ctx @-> ptr void @-> ptr void @-> size_t @-> returning int)
+
 (* Plane.t (common/src/plane.ml:4-9) is a Base_bigstring = (char, int8_unsigned_elt, c_layout) Array1:
    its data pointer is passed zero-copy.  (Needs [Plane.plane : t -> Base_bigstring.t] exposed.) *)
 let plane_ptr (p : Hardcaml_video_common.Plane.t) =
