@@ -61,7 +61,8 @@ def test_patch_applies_to_the_reference(tmp_path):
     import shutil
     import subprocess
     import pytest
-    files = ["jpeg/model/src/decoder.ml", "jpeg/model/src/decoder.mli", "jpeg/model/src/dune", "common/src/plane.mli"]
+    files = ["jpeg/model/src/decoder.ml", "jpeg/model/src/decoder.mli", "jpeg/model/src/encoder.ml", "jpeg/model/src/encoder.mli",
+             "jpeg/model/src/dune", "common/src/plane.mli"]
     if not all(os.path.exists(os.path.join(REF, f)) for f in files):
         pytest.skip("the reference tree is not on this machine")
     for f in files:
@@ -75,6 +76,12 @@ def test_patch_applies_to_the_reference(tmp_path):
     for name in ("let decode_gpu ", "let decode_a_frame_gpu ", "module Gpu = struct", "?(decode_block = decode_block)"):
         assert name in ml, name
     assert "val decode_gpu : Hvc.ctx -> t -> unit" in mli and "val decode_a_frame_gpu" in mli
+    enc, enci = (tmp_path / "jpeg/model/src/encoder.ml").read_text(), (tmp_path / "jpeg/model/src/encoder.mli").read_text()
+    for name in ("let encode_seq_with ~encode_block (t : t) =", "let encode_seq (t : t) = encode_seq_with ~encode_block t",
+                 "let encode_seq_gpu (hvc : Hvc.ctx) (t : t) =", "let encode_420_gpu hvc ~frame ~quality ~writer ="):
+        assert name in enc, name
+    # the exported signature of encode_seq is the reference's own (an optional argument would not match it)
+    assert "val encode_seq : t -> Block.t Sequence.t" in enci and "val encode_seq_gpu : Hvc.ctx -> t -> Block.t Sequence.t" in enci
     assert "val plane : t -> Base_bigstring.t" in (tmp_path / "common/src/plane.mli").read_text()
     assert "ctypes.foreign" in (tmp_path / "jpeg/model/src/dune").read_text()
     # balanced: what the patch ADDS opens and closes its own brackets, comments and modules (a cheap stand-in for the
