@@ -16,10 +16,15 @@ sys.path.insert(0, os.path.join(_ROOT, 'tests'))
 import numpy as np
 import video_coding_amd as hvc
 from conftest import golden_bytes
-rng = np.random.Generator(np.random.PCG64(5))
+import argparse
+_ap = argparse.ArgumentParser()
+_ap.add_argument("--seed", type=int, default=5)
+_ap.add_argument("--scale", type=int, default=1, help="multiplies the number of cases of every part")
+_args = _ap.parse_args()
+rng = np.random.Generator(np.random.PCG64(_args.seed))
 base = [golden_bytes("mini.jpg"), golden_bytes("Mouse480.jpg")]
 ok = err = 0
-for it in range(6000):
+for it in range(6000 * _args.scale):
     b = bytearray(base[it & 1])
     mode = it % 5
     if mode == 4:   # truncation
@@ -40,7 +45,7 @@ print("decoded", ok, "rejected", err)
 # status and the record the single-file entry point gives it
 pair_ok = pair_err = 0
 whole = [hvc.hvc.jpeg_entropy_decode(b)[1] for b in base]
-for it in range(1500):
+for it in range(1500 * _args.scale):
     b = bytearray(base[it & 1])
     if it % 4 == 3:
         b = b[:int(rng.integers(2, len(b)))]
