@@ -512,7 +512,9 @@ static int create_code_table(const HuffSpec *s, Code *out) {
 /* tables.ml:478-502 Lut.create: (1 << max_bits) entries, None = length 0 */
 typedef struct { int max_bits; int *len; int *data; } Lut;
 
-static void lut_create(Lut *l, const Code *codes, int n) {
+/* 0, or -1 where the model raises: a specification whose codes do not fit the code space (more codes of some length
+ * than canonical assignment has room for) makes Lut.create index past its array -- "index out of bounds" */
+static int lut_create(Lut *l, const Code *codes, int n) {
     int max_bits = 0;
     for (int i = 0; i < n; i++) if (codes[i].length > max_bits) max_bits = codes[i].length;
     l->max_bits = max_bits;
@@ -522,11 +524,13 @@ static void lut_create(Lut *l, const Code *codes, int n) {
         int null_bits = max_bits - codes[i].length;
         int first = codes[i].bits << null_bits;
         int count = 1 << null_bits;
+        if (first < 0 || (i64)first + count > ((i64)1 << max_bits)) return -1;
         for (int k = first; k < first + count; k++) {
             l->len[k] = codes[i].length;
             l->data[k] = codes[i].data;
         }
     }
+    return 0;
 }
 static void lut_free(Lut *l) { free(l->len); free(l->data); l->len = l->data = NULL; }
 
@@ -622,6 +626,7 @@ typedef struct {
 #define ORC_E_PLANE_OOB (-11)
 #define ORC_E_NO_MARKER (-12)
 #define ORC_E_TOO_MANY (-13)
+#define ORC_E_LUT_OOB (-14) /* Lut.create raises: an over-subscribed Huffman table */
 
 /* decoder.ml:24-29 find_marker.  The OCaml loop never ends on a stream without
  * 0xff (get past the end raises in show only when n >= length); bounded here. */
@@ -780,6 +785,8 @@ ORC_API orc_decoder *orc_decoder_create(const uint8_t *jpg, size_t n, int *err) 
         if (h->frame.comp[i].h > max_h) max_h = h->frame.comp[i].h;
         if (h->frame.comp[i].v > max_v) max_v = h->frame.comp[i].v;
     }
+    /* (a frame whose components all have a zero sampling factor: Int.round_up ~to_multiple_of:0 raises in the model) */
+    if (max_h == 0 || max_v == 0) { *err = ORC_E_NO_FRAME_OR_SCAN; free(d); return NULL; }
     i64 rw = round_up(h->frame.width, max_h * 8), rh = round_up(h->frame.height, max_v * 8);
     d->ncomp = h->scan.ncomp;
     for (int i = 0; i < d->ncomp; i++) {
@@ -803,10 +810,10 @@ ORC_API orc_decoder *orc_decoder_create(const uint8_t *jpg, size_t n, int *err) 
         Code codes[256];
         int got = 0;
         for (int k = h->ndht - 1; k >= 0; k--)
-            if (h->dht[k].tclass == 0 && h->dht[k].id == c->scan.dc_sel) { int m = create_code_table(&h->dht[k].spec, codes); lut_create(&c->dc_tab, codes, m); got |= 1; break; }
+            if (h->dht[k].tclass == 0 && h->dht[k].id == c->scan.dc_sel) { int m = create_code_table(&h->dht[k].spec, codes); if (lut_create(&c->dc_tab, codes, m)) got |= 4; got |= 1; break; }
         for (int k = h->ndht - 1; k >= 0; k--)
-            if (h->dht[k].tclass == 1 && h->dht[k].id == c->scan.ac_sel) { int m = create_code_table(&h->dht[k].spec, codes); lut_create(&c->ac_tab, codes, m); got |= 2; break; }
-        if (got != 3) { *err = ORC_E_NO_HUFF; d->ncomp = i + 1; orc_decoder_destroy(d); return NULL; }
+            if (h->dht[k].tclass == 1 && h->dht[k].id == c->scan.ac_sel) { int m = create_code_table(&h->dht[k].spec, codes); if (lut_create(&c->ac_tab, codes, m)) got |= 4; got |= 2; break; }
+        if (got != 3) { *err = (got & 4) ? ORC_E_LUT_OOB : ORC_E_NO_HUFF; d->ncomp = i + 1; orc_decoder_destroy(d); return NULL; }
     }
     e = extract_ecs(&b, &d->ecs, &d->ecs_len);
     if (e) { *err = e; orc_decoder_destroy(d); return NULL; }
@@ -823,6 +830,11 @@ static int huffman_decode(Bits *bits, i64 *coefs, const Lut *dc_tab, const Lut *
     bits_advance(bits, dc_tab->len[code]);
     int cat = dc_tab->data[code];
     i64 dc = 0;
+    /* A DHT may name any byte as a DC category and the model reads that many magnitude bits without a check
+     * (decoder.ml:81-96).  Up to 32 this restatement follows it; beyond that the model computes 63-bit garbage (and
+     * from 63 bits on its shifts wrap), the product refuses the stream (include/hvc_jpeg.h), and so does this checker:
+     * nothing is compared there. */
+    if (cat > 32) return ORC_E_DC_CODE;
     if (cat != 0) { i64 v = bits_get(bits, cat); if (v < 0) return (int)v; dc = mag_prime(cat, v); }
     coefs[0] = dc;
     int cof_cnt = 1;
@@ -866,6 +878,7 @@ static int decode_block(orc_decoder *d, Component *c) {
 ORC_API int orc_decoder_next_block(orc_decoder *d) {
     if (d->done) return -1;
     const Component *c0 = &d->comp[0];
+    if (c0->component.h == 0 || c0->component.v == 0) return ORC_E_PLANE_OOB; /* (Division_by_zero in decode_seq :374-380) */
     int mbs_wide = c0->decoded_width / (8 * c0->component.h);
     int mbs_high = c0->decoded_height / (8 * c0->component.v);
     if (mbs_wide == 0 || mbs_high == 0) { d->done = 1; return -1; }

@@ -704,6 +704,95 @@ struct Walk {
         HVC_AC_ONE_(BR, BP, END, ACW, ACF, ACT, AMAX, ERR)                                                           \
     } while (0)
 
+// A segment of at most 32 bits (a file cut, or a stray marker, right behind the scan header).  Bitstream_reader.show raises
+// "out of bounds" when it is asked for as many bits as the whole segment has, or more (bitstream_reader.ml:31-33) -- a
+// test that says nothing about the position and that no real file meets; the windowed reader above does not make it.
+// Such a segment is decoded by the model's own steps instead (decoder.ml:89-140, one `show` per code over the table of
+// max_bits, one `get` per magnitude), each request held against the segment's length.
+static int walk_literal(Walk &w) {
+    const size_t length_in_bits = w.br.n * 8;
+    size_t pos = 0;
+    auto show = [&](int n, unsigned &v) -> bool { // false: the model raises
+        if ((size_t)n >= length_in_bits) return false;
+        v = 0;
+        for (int i = 0; i < n; i++) {
+            const size_t p = pos + (size_t)i;
+            const unsigned bit = (p >> 3) < w.br.n ? (w.br.p[p >> 3] >> (7 - (p & 7))) & 1u : 0u; // past the end: zeros
+            v = (v << 1) | bit;
+        }
+        return true;
+    };
+    while (!w.finished()) {
+        // the block's place: begin_block's first half
+        const Walk::McuBlock mb = w.mcu[(size_t)w.bi];
+        const int i = mb.comp;
+        if (!w.regular) {
+            const hvc_jpeg_component &c = w.info->comp[i];
+            const hvc_component &L = w.info->layout[i];
+            if (w.mx * c.hscale + mb.dx >= L.blocks_w || w.my * c.vscale + mb.dy >= L.blocks_h) return HVC_E_BAD_JPEG;
+        }
+        int16_t *const blk = w.coefs + w.part[i] + mb.off;
+        std::memset(blk, 0, 64 * sizeof(int16_t));
+        unsigned code = 0, bitsv = 0;
+        if (!show(w.dc[i]->max_bits, code)) return HVC_E_BAD_JPEG;
+        unsigned e = w.dc[i]->e[code];
+        if (!e) return HVC_E_BAD_JPEG; // "Can't find dc code"
+        pos += e >> 8;
+        const int cat = (int)(e & 0xff);
+        long long diff = 0;
+        if (cat) {
+            if (cat > 32) return HVC_E_BAD_JPEG; // (as begin_block)
+            if (!show(cat, bitsv)) return HVC_E_BAD_JPEG;
+            pos += (size_t)cat;
+            diff = ((bitsv >> (cat - 1)) & 1u) ? (long long)bitsv : (long long)bitsv - ((1ll << cat) - 1);
+        }
+        const long long dcv = diff + w.dc_pred[i];
+        w.dc_pred[i] = dcv;
+        if (dcv < -32768 || dcv > 32767) {
+            if (!w.wide) return HVC_E_RANGE;
+            try {
+                w.wide->push_back(hvc::WideDc{(uint32_t)((size_t)(blk - w.coefs) >> 6), dcv});
+            } catch (const std::bad_alloc &) {
+                return HVC_E_OUT_OF_MEMORY;
+            }
+            blk[0] = (int16_t)(dcv < 0 ? -32767 : 32767);
+        } else {
+            blk[0] = (int16_t)dcv;
+        }
+        for (int k = 1; k < 64;) {
+            if (!show(w.ac[i]->max_bits, code)) return HVC_E_BAD_JPEG;
+            e = w.ac[i]->e[code];
+            if (!e) return HVC_E_BAD_JPEG; // "Can't find ac code"
+            pos += e >> 8;
+            const int run = (int)((e >> 4) & 15), size = (int)(e & 15);
+            int mag = 0;
+            if (size) {
+                if (!show(size, bitsv)) return HVC_E_BAD_JPEG;
+                pos += (size_t)size;
+                mag = extend(size, bitsv);
+            }
+            if (mag == 0 && run == 0) break; // decoder.ml:131-132
+            k += run;
+            if (k >= 64) return HVC_E_BAD_JPEG; // "coefficient index out of range"
+            blk[k++] = (int16_t)mag;
+        }
+        // ... and its second half: on to the next block
+        if (++w.bi == (int)w.mcu.size()) {
+            w.bi = 0;
+            if (++w.mx == w.mbs_wide) {
+                w.mx = 0;
+                ++w.my;
+                w.row_parts();
+            } else {
+                for (int j = 0; j < w.info->n_comp; j++) w.part[j] += (size_t)w.info->comp[j].hscale * 64;
+            }
+        }
+    }
+    w.done = true;
+    return HVC_OK;
+}
+static bool needs_literal_walk(const Walk &w) { return w.br.n * 8 <= 32; }
+
 // the whole file, block after block
 static int walk_alone(Walk &w) {
     while (!w.finished()) {
@@ -740,7 +829,7 @@ static int entropy_decode_impl(const uint8_t *data, size_t n, const hvc_jpeg_inf
                                std::vector<hvc::WideDc> *wide) {
     Walk &w = thread_walk(0);
     const int r = w.prepare(data, n, info, coefs, wide);
-    return r ? r : w.done ? HVC_OK : walk_alone(w);
+    return r ? r : w.done ? HVC_OK : needs_literal_walk(w) ? walk_literal(w) : walk_alone(w);
 }
 
 int hvc_jpeg_entropy_decode(const uint8_t *data, size_t n, const hvc_jpeg_info *info, int16_t *coefs) try {
@@ -771,9 +860,10 @@ static void entropy_decode_two_impl(const uint8_t *const data[2], const size_t n
 #ifdef HVC_READER_PROFILE
     prof.t1 = std::chrono::steady_clock::now();
 #endif
-    if (st[0] || st[1] || a.done || b.done) { // one of them cannot start (or has nothing to do): the other runs alone
-        if (!st[0] && !a.done) st[0] = walk_alone(a);
-        if (!st[1] && !b.done) st[1] = walk_alone(b);
+    if (st[0] || st[1] || a.done || b.done || needs_literal_walk(a) || needs_literal_walk(b)) {
+        // one of them cannot start, has nothing to do or is too short for the windowed reader: each runs alone
+        if (!st[0] && !a.done) st[0] = needs_literal_walk(a) ? walk_literal(a) : walk_alone(a);
+        if (!st[1] && !b.done) st[1] = needs_literal_walk(b) ? walk_literal(b) : walk_alone(b);
         return;
     }
     // both have a block in progress inside the hot loop; whoever ends one starts its next block and comes back
@@ -1355,7 +1445,8 @@ static int prepare_gpu_decode_impl(const uint8_t *jpeg, size_t n, const ::hvc_jp
     }
     int per_mcu = 0;
     for (int i = 0; i < info->n_comp; i++) per_mcu += info->comp[i].hscale * info->comp[i].vscale;
-    gpu_ok = ok && info->n_comp <= 3 && per_mcu <= HVC_HD_MAX_MCU_BLOCKS && got < (1u << 28);
+    // (a segment of at most 32 bits: the host reader has the model's length test for those -- walk_literal)
+    gpu_ok = ok && info->n_comp <= 3 && per_mcu <= HVC_HD_MAX_MCU_BLOCKS && got < (1u << 28) && got * 8 > 32;
     return HVC_OK;
 }
 } // namespace hvc
