@@ -33,10 +33,11 @@
  *    tests/test_gpu_jpeg_api.py::test_dc_beyond_int16_decodes_like_the_model).  That includes DC categories of 17 to
  *    32 bits, which the model reads without complaint; a Huffman table announcing MORE than 32 magnitude bits for a
  *    DC symbol (the model would shift them through its 63-bit int) is refused as HVC_E_BAD_JPEG.
- *    Two more corners, both found by differential fuzzing against the model restatement: a frame component with a
- *    sampling factor of ZERO other than the first (the model decodes the other planes around an empty one and then
- *    cannot make a Frame.t of them; a zero factor in the first component, or in all, raises there) is refused at the
- *    header as HVC_E_BAD_JPEG; and an entropy-coded segment of at most 32 bits is decoded with
+ *    Two more corners, both found by differential fuzzing against the model restatement: a component that comes out
+ *    with ZERO width or height -- a sampling factor of zero other than the first component's, or a frame dimension of
+ *    zero: the model decodes the other planes around an empty one, or nothing at all, and then cannot make a Frame.t
+ *    of it (a zero factor in the first component, or in all, raises there) -- is refused at the header as
+ *    HVC_E_BAD_JPEG; and an entropy-coded segment of at most 32 bits is decoded with
  *    Bitstream_reader.show's own length test (bitstream_reader.ml:31-33: a request for as many bits as the whole
  *    segment has raises), so such a file is refused or decoded exactly where the model refuses or decodes it
  *    (tests/test_host_entropy.py::test_segments_of_a_few_bytes_raise_where_the_model_does,

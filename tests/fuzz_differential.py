@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the host front end (hvc_jpeg_read_header + hvc_jpeg_entropy_decode) against the model
+restatement (oracle/: which is why this script lives under tests/): mutated copies of the reference's two JPEG files --
+bytes anywhere, in the headers only, or around the start of the scan -- must be accepted by both with equal coefficient
+records, or refused by both, but for the kinds include/hvc_jpeg.h lists (a scan without a marker behind it, a DC outside
+int16, a component of zero size).  Anything else is printed and kept as /tmp/odd_<seed>_<n>.bin; exit code 1.
+
+    python tests/fuzz_differential.py SEED CASES {any|header|scanstart}
+
+(The test suite runs 1 200 cases of the `any` kind; round 3 ran 60 000 over the three kinds.)"""
+import os
+import sys
+_T = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, _T); sys.path.insert(0, os.path.dirname(_T))
+import numpy as np
+from conftest import golden_bytes
+import video_coding_amd as m
+from oracle import orc
+hvc=m.hvc
+seed=int(sys.argv[1]); N=int(sys.argv[2]); mode=sys.argv[3]
+rng = np.random.Generator(np.random.PCG64(seed))
+base=[golden_bytes("mini.jpg"),golden_bytes("Mouse480.jpg")]
+offs=[hvc.jpeg_read_header(b).ecs_offset for b in base]
+stats={}
+odd=[]
+for it in range(N):
+    k=it&1
+    data=bytearray(base[k])
+    nm=int(rng.integers(1,4))
+    for _ in range(nm):
+        if mode=='header': pos=int(rng.integers(2,offs[k]))
+        elif mode=='scanstart': pos=int(rng.integers(offs[k]-14,offs[k]+6))
+        else: pos=int(rng.integers(0,len(data)))
+        kind=int(rng.integers(0,4))
+        if kind==0: data[pos]=int(rng.integers(0,256))
+        elif kind==1: data[pos]^=1<<int(rng.integers(0,8))
+        elif kind==2: data[pos]=0xFF
+        else: data[pos]=0
+    data=bytes(data)
+    code=None
+    try:
+        info=hvc.jpeg_read_header(data)
+        if info.coef_count > 1<<24: continue
+        _,coefs=hvc.jpeg_entropy_decode(data,info)
+    except m.HvcError as e: code=e.code
+    try:
+        d=orc.Decoder(data); model=d.coef_record(); oerr=None
+    except ValueError as e: model=None; oerr=str(e)
+    if code is not None and model is None: key='both_reject'
+    elif code is not None:
+        factors=[(d.info(i)["decoded_width"],d.info(i)["decoded_height"]) for i in range(d.ncomp)]
+        if code==-5 and np.abs(model).max()>32767: key='dc_range'
+        elif code==-8 and any(0 in f for f in factors): key='zero_size'
+        else: key='HVC_REJECTS_MODEL_ACCEPTS'; odd.append((it,code,factors)); open('/tmp/odd_%d_%d.bin'%(seed,it),'wb').write(data)
+    elif model is None:
+        if '-12' in oerr: key='no_marker'
+        else: key='HVC_ACCEPTS_MODEL_REJECTS'; odd.append((it,oerr)); open('/tmp/odd_%d_%d.bin'%(seed,it),'wb').write(data)
+    else:
+        if np.array_equal(coefs,model.astype(np.int16)): key='agree'
+        else: key='MISMATCH'; odd.append((it,'coefs')); open('/tmp/odd_%d_%d.bin'%(seed,it),'wb').write(data)
+    stats[key]=stats.get(key,0)+1
+print(mode,seed,stats); print(odd[:20])
+sys.exit(1 if odd else 0)
