@@ -74,7 +74,7 @@ typedef enum hvc_status {
     HVC_E_NO_DEVICE = -2,    /* no usable gfx950 GPU / HIP runtime error at create */
     HVC_E_HIP = -3,          /* a HIP call failed; hvc_last_hip_error() has the code */
     HVC_E_ALIGNMENT = -4,    /* plane pointer/stride not 8-byte aligned, coefs not 16-byte aligned */
-    HVC_E_RANGE = -5,        /* quantiser entry 0, encoder output outside int16, or (record-returning entry points) a
+    HVC_E_RANGE = -5,        /* quantiser entry 0 on the ENCODER side (the model divides by it), encoder output outside int16, or (record-returning entry points) a
                                 decoded absolute DC outside int16 */
     HVC_E_OUT_OF_MEMORY = -6,
     HVC_E_TOO_LARGE = -7,    /* plane geometry beyond the kernel's index range */

@@ -322,6 +322,11 @@ static inline i64 quant_and_scale(i64 fdct, i64 qnt) {
 
 /* encoder.ml:81-90 + 92 + 103-108 for one block at (x_pos,y_pos) of a plane.
  * quant[] comes out in zig-zag order. */
+/* (a quantiser entry of zero: quant_and_scale raises Division_by_zero in the model; callers test with quant_table_divides) */
+static int quant_table_divides(const i64 *table) {
+    for (int i = 0; i < 64; i++) if (table[i] == 0) return 0;
+    return 1;
+}
 static void encode_block_stage(const uint8_t *plane, size_t stride, int x_pos, int y_pos,
                                const i64 *table, i64 *fdct, i64 *quant) {
     for (int y = 0; y < 8; y++)
@@ -340,6 +345,7 @@ ORC_API int orc_fdct_quant(const uint8_t *plane, size_t stride, size_t plane_str
     init_tables();
     i64 q[64], fd[64], qu[64];
     for (int i = 0; i < 64; i++) q[i] = qtab[i];
+    if (!quant_table_divides(q)) return -2; /* Division_by_zero */
     for (int p = 0; p < n_planes; p++) {
         const uint8_t *pl = plane + (size_t)p * plane_stride;
         for (int by = 0; by < bh; by++)
@@ -366,6 +372,7 @@ ORC_API int orc_encode_recon(const uint8_t *plane, size_t stride, size_t plane_s
     init_tables();
     i64 q[64], fd[64], qu[64], idct[64];
     for (int i = 0; i < 64; i++) q[i] = qtab[i];
+    if (!quant_table_divides(q)) return -2; /* Division_by_zero */
     for (int p = 0; p < n_planes; p++) {
         const uint8_t *pl = plane + (size_t)p * plane_stride;
         for (int by = 0; by < bh; by++)

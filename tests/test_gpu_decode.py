@@ -216,10 +216,8 @@ def test_errors(ctx):
     q = np.ones(64, dtype=np.uint16)
     c = np.zeros((1, 1, 64), dtype=np.int16)
     out = np.zeros((8, 8), dtype=np.uint8)
-    with pytest.raises(hvc.HvcError) as e:
-        q0 = q.copy(); q0[5] = 0
-        ctx.dequant_idct_recon(c, q0, 1, 1, 1, out)
-    assert e.value.code == -5
+    # a quantiser entry of zero: the decoder multiplies by it (decoder.ml:146 -- the model decodes such files), only the
+    # encoder, which divides, refuses it (test_quantiser_entries_of_zero)
     with pytest.raises(hvc.HvcError) as e:
         ctx.dequant_idct_recon(c, q, 1, 1, 1, out, stride=12)
     assert e.value.code == -4
@@ -484,3 +482,38 @@ print("split ok")
     env = dict(os.environ, HVC_LAUNCH_BYTES="150000")  # 69 KB a frame: two frames per launch
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "split ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_quantiser_entries_of_zero(ctx):
+    """A DQT may hold zeros (no encoder writes them; a mutated file does): `dequant.(i) <- coefs.(i) * qnt_tab.(i)`
+    (decoder.ml:146) makes the coefficient 0 and the model decodes the file -- so does the block stage, in its packed,
+    plain and int64 forms; the encoder's quantiser divides (encoder.ml:98-101: Division_by_zero) and refuses the table."""
+    import video_coding_amd as hvc
+    rng = np.random.Generator(np.random.PCG64(77))
+    bw, bh = 9, 5
+    for amp in (40, 2000):          # small coefficients (packed kernel) and large ones (fix-up path)
+        coefs = rng.integers(-amp, amp + 1, size=(bh, bw, 64)).astype(np.int16)
+        q = rng.integers(1, 60, size=64).astype(np.uint16)
+        q[[0, 3, 17, 63]] = 0
+        out = np.zeros((bh * 8, bw * 8), dtype=np.uint8)
+        ctx.dequant_idct_recon(coefs, q, bw, bh, 1, out)
+        want = orc.dequant_idct_recon(coefs, q, bw, bh)
+        assert np.array_equal(out, np.asarray(want).reshape(out.shape)), amp
+    # whole file: mini.jpg with zeros written into its chroma DQT
+    data = bytearray(golden_bytes("mini.jpg"))
+    i = data.index(b"\xff\xdb", data.index(b"\xff\xdb") + 2)
+    for k in (5, 9, 40, 64):
+        data[i + 4 + k] = 0
+    data = bytes(data)
+    info, pixels = ctx.jpeg_decode(data)
+    d = orc.Decoder(data)
+    d.decode()
+    for k, plane in enumerate(info.planes(pixels)):
+        assert np.array_equal(plane, d.plane(k)), k
+    # the encoder refuses
+    px = rng.integers(0, 256, size=(16, 16), dtype=np.uint8)
+    q0 = np.full(64, 7, dtype=np.uint16)
+    q0[9] = 0
+    with pytest.raises(hvc.HvcError) as e:
+        ctx.fdct_quant(px, q0, 2, 2, 1, np.zeros((2, 2, 64), dtype=np.int16))
+    assert e.value.code == -5

@@ -126,10 +126,14 @@ int make_layout(const hvc_component *comps, int n_comp, int n_qtabs, Layout &L) 
     return HVC_OK;
 }
 
-int check_qtabs(const uint16_t *qtabs, int n_qtabs) {
+// A quantiser entry of zero: the decoder multiplies by it (decoder.ml:146: the coefficient becomes 0, and the model
+// decodes files whose DQT holds zeros), the encoder divides by it (encoder.ml:98-101: Division_by_zero in the model,
+// HVC_E_RANGE here).
+int check_qtabs(const uint16_t *qtabs, int n_qtabs, bool divides) {
     if (!qtabs || n_qtabs < 1 || n_qtabs > HVC_MAX_QTABS) return HVC_E_INVALID_ARG;
-    for (int i = 0; i < n_qtabs * 64; i++)
-        if (qtabs[i] == 0) return HVC_E_RANGE;
+    if (divides)
+        for (int i = 0; i < n_qtabs * 64; i++)
+            if (qtabs[i] == 0) return HVC_E_RANGE;
     return HVC_OK;
 }
 
@@ -604,7 +608,7 @@ int decode_frames_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const u
                        const int16_t *dc_plane, size_t dc_fs, const std::vector<WideFix> *wide) {
     if (!c || !coefs || !pixels || n_frames < 0) return HVC_E_INVALID_ARG;
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
-    int r = check_qtabs(qtabs, n_qtabs);
+    int r = check_qtabs(qtabs, n_qtabs, false);
     if (r) return r;
     Layout L;
     r = make_layout(comps, n_comp, n_qtabs, L);
@@ -768,7 +772,7 @@ int decode_frames_yuv444_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, 
                               const std::vector<WideFix> *wide) {
     if (!c || !coefs || !frames || !comps || n_frames < 0) return HVC_E_INVALID_ARG;
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
-    int r = check_qtabs(qtabs, n_qtabs);
+    int r = check_qtabs(qtabs, n_qtabs, false);
     if (r) return r;
     // Yuv.assert_is_420 (tools/src/yuv.ml:104-116): wy = 2 wu, hy = 2 hu -- even luma size only
     if (n_comp != 3 || width < 2 || height < 2 || (width & 1) || (height & 1)) return HVC_E_INVALID_ARG;
@@ -1025,7 +1029,7 @@ int hvc_encode_frames(hvc_ctx *c, const uint8_t *pixels, size_t pixel_fs, const 
                       int where) try {
     if (!c || !coefs || !pixels || n_frames < 0) return HVC_E_INVALID_ARG;
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
-    int r = check_qtabs(qtabs, n_qtabs);
+    int r = check_qtabs(qtabs, n_qtabs, true);
     if (r) return r;
     // Encoder tables are 8-bit (Markers.Dqt element_precision = 8, encoder.ml:224-229;
     // Quant_tables.scale clips to 1..255, quant_tables.ml:139-147).
@@ -1137,7 +1141,7 @@ int hvc_encode_frames_recon(hvc_ctx *c, const uint8_t *pixels, size_t pixel_fs, 
     if (!c || !coefs || !pixels || n_frames < 0) return HVC_E_INVALID_ARG;
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
     Layout L;
-    int r = check_qtabs(qtabs, n_qtabs);
+    int r = check_qtabs(qtabs, n_qtabs, true);
     if (!r) r = make_layout(comps, n_comp, n_qtabs, L);
     if (r) return r;
     if (n_frames == 0) return HVC_OK;

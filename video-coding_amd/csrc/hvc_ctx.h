@@ -200,7 +200,7 @@ struct Layout {
     unsigned long long blocks_per_frame = 0;
 };
 int make_layout(const hvc_component *comps, int n_comp, int n_qtabs, Layout &L);
-int check_qtabs(const uint16_t *qtabs, int n_qtabs);
+int check_qtabs(const uint16_t *qtabs, int n_qtabs, bool divides); // divides: the encoder (an entry of zero is HVC_E_RANGE)
 
 // The batch pipelines' orchestrating thread waits most of the call (an upload's end, a chunk's kernels).
 // hipEventSynchronize spins -- also on an event created with hipEventBlockingSync, on this ROCm (measured: CPU time =
