@@ -126,3 +126,23 @@ def test_upsample_over_random_sizes(ctx):
         ctx.upsample420(src, cw, ch, dst, n_planes=n, src_plane_stride=cw * ch, dst_plane_stride=4 * cw * ch)
         for p in range(n):
             assert np.array_equal(dst[p], orc.supersample_hv2(src[p])), (it, p, cw, ch)
+
+
+def test_fused_444_over_random_even_sizes(ctx):
+    """hvc_decode_frames_yuv444 (block stage + crop + chroma upsample in one pass) at random even sizes -- tile seams, crops
+    inside block rows, byte-path widths -- random frame counts, padded frame strides, a share of blocks outside the proven
+    range (int64 fix-up + re-interpolation), host and device buffers, against decode -> crop -> supersample_hv2."""
+    from test_gpu_yuv444 import expected444, geometry420, make_record, run, tables
+    rng = np.random.Generator(np.random.PCG64(9))
+    for it in range(30):
+        width, height = 2 * int(rng.integers(1, 350)), 2 * int(rng.integers(1, 120))
+        planes, qt = geometry420(width, height), tables(int(rng.choice([10, 50, 75, 95])))
+        n = int(rng.integers(1, 4))
+        adversarial = float(rng.choice([0.0, 0.0, 0.02, 0.3]))
+        recs = [make_record(100 * it + f, planes, qt, adversarial) for f in range(n)]
+        fs = 3 * width * height + int(rng.integers(0, 3)) * 16
+        got = run(ctx, recs, planes, qt, width, height, bool(rng.integers(0, 2)), frame_stride=fs)
+        for f, rec in enumerate(recs):
+            want = expected444(rec, planes, qt, width, height)
+            assert np.array_equal(got[f][:want.size], want), (it, f, width, height, adversarial)
+            assert (got[f][want.size:] == 0xA5).all(), (it, "padding written")
