@@ -654,3 +654,26 @@ def test_tables_and_headers_the_model_raises_on(hvc):
     d = orc.Decoder(bytes(b))
     d.decode()
     assert d.info(0)["decoded_height"] == 0
+
+
+def test_a_callers_layout_with_unaligned_component_records(hvc):
+    """hvc_jpeg_entropy_decode takes the caller's hvc_jpeg_info: component records at offsets that are multiples of two
+    bytes only must decode (by the copying form of the block flush), not meet an aligned streaming store."""
+    import ctypes as C
+    import video_coding_amd as m
+    data = golden_bytes("Mouse480.jpg")
+    info, want = m.hvc.jpeg_entropy_decode(data)
+    for shift in (1, 4, 8, 33):
+        inf = m.hvc.jpeg_read_header(data)
+        at, offs = 0, []
+        for i in range(inf.n_comp):
+            at += shift
+            inf.layout[i].coef_offset = at
+            offs.append(at)
+            at += inf.layout[i].blocks_w * inf.layout[i].blocks_h * 64
+        rec = np.full(at + 64, 0x5A5A, dtype=np.int16)
+        assert m.hvc.lib().hvc_jpeg_entropy_decode(data, len(data), C.byref(inf), rec.ctypes.data) == 0
+        for i in range(inf.n_comp):
+            n = info.layout[i].blocks_w * info.layout[i].blocks_h * 64
+            assert np.array_equal(rec[offs[i]:offs[i] + n], want[info.layout[i].coef_offset:info.layout[i].coef_offset + n]), (shift, i)
+        assert (rec[:offs[0]] == 0x5A5A).all() and (rec[at:] == 0x5A5A).all()

@@ -457,7 +457,11 @@ struct Walk {
         info = info_;
         coefs = coefs_;
         static const bool have512 = __builtin_cpu_supports("avx512f") && !(std::getenv("HVC_NO_AVX512") && std::getenv("HVC_NO_AVX512")[0] == '1'); // (the switch: A/B)
-        stream_out = ((uintptr_t)coefs_ & 63) == 0 && have512 ? 2 : ((uintptr_t)coefs_ & 15) == 0 ? 1 : 0;
+        // how the blocks may leave: every block sits at coefs + a component's offset + a multiple of 128 bytes, so the
+        // record's address and the offsets (the caller's: not necessarily hvc_jpeg_read_header's) decide the alignment
+        uintptr_t align_bits = (uintptr_t)coefs_;
+        for (int i = 0; i < info_->n_comp && i < 4; i++) align_bits |= (uintptr_t)info_->layout[i].coef_offset * sizeof(int16_t);
+        stream_out = (align_bits & 63) == 0 && have512 ? 2 : (align_bits & 15) == 0 ? 1 : 0;
         wide = wide_;
         Header h;
         int r = parse_header(data, n, h);
