@@ -391,6 +391,24 @@ namespace hvc {
 size_t extract_ecs_to(const uint8_t *data, size_t n, size_t pos, uint8_t *dst, size_t cap);
 }
 namespace {
+// An hvc_jpeg_info is the caller's: hvc_jpeg_read_header / hvc_jpeg_encoder_layout filled it in, normally -- but nothing
+// keeps a caller from changing it, and the readers and coders index and divide by what it says.  What they rely on:
+// one to four components, sampling factors 1..15, planes of at least one block, and every component's record inside
+// the coef_count elements the caller's buffer is said to have.
+bool info_is_sane(const hvc_jpeg_info *info) {
+    if (info->n_comp < 1 || info->n_comp > 4) return false;
+    for (int i = 0; i < info->n_comp; i++) {
+        const hvc_jpeg_component &c = info->comp[i];
+        const hvc_component &L = info->layout[i];
+        if (c.hscale < 1 || c.hscale > 15 || c.vscale < 1 || c.vscale > 15) return false;
+        if (L.blocks_w < 1 || L.blocks_h < 1 || L.blocks_w > (1 << 20) || L.blocks_h > (1 << 20)) return false;
+        if (c.decoded_width < 0 || c.decoded_height < 0) return false;
+        const unsigned long long n = (unsigned long long)L.blocks_w * (unsigned long long)L.blocks_h * 64ull;
+        if (L.coef_offset > info->coef_count || n > info->coef_count - L.coef_offset) return false;
+    }
+    return true;
+}
+
 // a finished block leaves for the record and its buffer is cleared: two 64-byte loads, streaming stores and stores
 // where the CPU has them (six memory operations instead of twenty-four; the record's blocks are 128 bytes apart, so a
 // 64-byte aligned record makes every block's two halves whole cache lines)
@@ -444,7 +462,7 @@ struct Walk {
     bool done = false;
 
     int prepare(const uint8_t *data, size_t n, const hvc_jpeg_info *info_, int16_t *coefs_, std::vector<hvc::WideDc> *wide_) {
-        if (!data || !info_ || !coefs_) return HVC_E_INVALID_ARG;
+        if (!data || !info_ || !coefs_ || !info_is_sane(info_)) return HVC_E_INVALID_ARG;
         // (a walk is reused by its thread: everything a previous file left behind starts over)
         for (int i = 0; i < 4; i++) dc_pred[i] = 0, dc[i] = ac[i] = nullptr, part[i] = 0;
         my = mx = bi = 0;
@@ -944,9 +962,17 @@ int hvc_jpeg_entropy_decode2(const uint8_t *jpeg_a, size_t n_a, const hvc_jpeg_i
 // Decoder.crop / get_yuv_frame (decoder.ml:403-420): the actual_w x actual_h top-left part of every
 // padded plane, planes back to back (the layout Frame.output writes, common/src/frame.ml:66-70).
 int hvc_jpeg_get_yuv_frame(const hvc_jpeg_info *info, const uint8_t *pixels, uint8_t *out, size_t cap, size_t *out_len) try {
-    if (!info || !pixels || !out) return HVC_E_INVALID_ARG;
+    if (!info || !pixels || !out || info->n_comp < 1 || info->n_comp > 4) return HVC_E_INVALID_ARG;
     size_t need = 0;
-    for (int i = 0; i < info->n_comp; i++) need += (size_t)info->comp[i].actual_width * info->comp[i].actual_height;
+    for (int i = 0; i < info->n_comp; i++) { // (the caller's info: the crop must lie inside the plane it is cut from)
+        const hvc_jpeg_component &c = info->comp[i];
+        const hvc_component &L = info->layout[i];
+        if (c.actual_width < 0 || c.actual_height < 0 || c.actual_width > c.decoded_width || c.actual_height > c.decoded_height ||
+            L.stride < (size_t)c.decoded_width || L.plane_offset > info->pixel_bytes ||
+            (c.decoded_height > 0 && ((size_t)c.decoded_height - 1) * L.stride + (size_t)c.decoded_width > info->pixel_bytes - L.plane_offset))
+            return HVC_E_INVALID_ARG;
+        need += (size_t)c.actual_width * (size_t)c.actual_height;
+    }
     if (out_len) *out_len = need;
     if (need > cap) return HVC_E_INVALID_ARG;
     uint8_t *o = out;
@@ -1178,9 +1204,8 @@ int hvc_jpeg_encoder_layout(int width, int height, int chroma, int quality, hvc_
 // component per MCU; where that grid reaches past a component's plane the model raises
 // "[Plane.get] out of bounds" (plane.ml:43-50): 4:2:0 / 4:2:2 at width 16k + 1 (or height 16k + 1).
 int hvc_jpeg_encoder_check(const hvc_jpeg_info *info) try {
-    if (!info || info->n_comp != 3) return HVC_E_INVALID_ARG;
+    if (!info || info->n_comp != 3 || !info_is_sane(info)) return HVC_E_INVALID_ARG;
     const hvc_jpeg_component &c0 = info->comp[0];
-    if (c0.hscale < 1 || c0.vscale < 1) return HVC_E_INVALID_ARG;
     const int mbs_wide = c0.decoded_width / (8 * c0.hscale), mbs_high = c0.decoded_height / (8 * c0.vscale);
     for (int i = 0; i < 3; i++)
         if (mbs_wide * info->comp[i].hscale > info->layout[i].blocks_w ||
