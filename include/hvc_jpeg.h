@@ -31,17 +31,23 @@
  *    hvc_jpeg_decode_batch family) carry those blocks' true DCs on a side list through an int64 fix-up and give the
  *    model's pixels (tests/test_host_entropy.py::test_dc_beyond_int16_is_refused_not_wrapped,
  *    tests/test_gpu_jpeg_api.py::test_dc_beyond_int16_decodes_like_the_model).  That includes DC categories of 17 to
- *    32 bits, which the model reads without complaint; a Huffman table announcing MORE than 32 magnitude bits for a
- *    DC symbol (the model would shift them through its 63-bit int) is refused as HVC_E_BAD_JPEG.
- *    Two more corners, both found by differential fuzzing against the model restatement: a component that comes out
- *    with ZERO width or height -- a sampling factor of zero other than the first component's, or a frame dimension of
- *    zero: the model decodes the other planes around an empty one, or nothing at all, and then cannot make a Frame.t
- *    of it (a zero factor in the first component, or in all, raises there) -- is refused at the header as
- *    HVC_E_BAD_JPEG; and an entropy-coded segment of at most 32 bits is decoded with
+ *    62 bits, which the model reads without complaint (decoder.ml:81-96 asks no question of the table) and then carries
+ *    through its 63-bit arithmetic, wrap-around included: the int64 fix-up computes modulo 2^63 as OCaml does
+ *    (tests/test_gpu_jpeg_api.py::test_dc_categories_up_to_62_bits).  From 63 bits on, mag' (decoder.ml:73-79) shifts by
+ *    Sys.int_size or more, which OCaml leaves unspecified: there is no model result to match, HVC_E_BAD_JPEG.
+ *    A component that comes out with ZERO width or height -- a sampling factor of zero other than the first component's,
+ *    or a frame dimension of zero -- is the model's empty Plane.t: hvc_jpeg_read_header reports it (blocks_w or blocks_h
+ *    of 0), the readers walk the MCUs with no block for it, the block stage skips it, and hvc_jpeg_decode succeeds exactly
+ *    where Decoder.decode does; what the model then cannot do is make a Frame.t of such planes, and neither can
+ *    hvc_jpeg_get_yuv_frame (see there).  A zero factor in the FIRST component raises in decode_seq (Division_by_zero,
+ *    decoder.ml:377-382), in ALL components in init (Int.round_up to a multiple of 0): HVC_E_BAD_JPEG.
+ *    An entropy-coded segment of at most 32 bits is decoded with
  *    Bitstream_reader.show's own length test (bitstream_reader.ml:31-33: a request for as many bits as the whole
  *    segment has raises), so such a file is refused or decoded exactly where the model refuses or decodes it
  *    (tests/test_host_entropy.py::test_segments_of_a_few_bytes_raise_where_the_model_does,
- *    ::test_tables_and_headers_the_model_raises_on).
+ *    ::test_tables_and_headers_the_model_raises_on).  The one input left without a counterpart: a scan with no marker
+ *    behind it, on which the model's extract_entropy_coded_bits (decoder.ml:261-281) never returns; here the scan ends
+ *    with the file.
  *
  * Data layouts
  *  - coefficients: int16, [plane][blocks_h][blocks_w][64], each block in
@@ -165,7 +171,9 @@ HVC_API int hvc_dequant_idct_recon(hvc_ctx *ctx, const int16_t *coefs, size_t co
  * (Decoder.Component.t, decoder.ml:167-187; geometry of Decoder.init,
  * decoder.ml:304-345). */
 typedef struct hvc_component {
-    int blocks_w, blocks_h; /* decoded_width/8, decoded_height/8 */
+    int blocks_w, blocks_h; /* decoded_width/8, decoded_height/8.  0 x n or n x 0: the model's empty plane (a sampling
+                             * factor or frame dimension of zero, decoder.ml:304-345); the DECODING entry points skip such a
+                             * component as decode_seq does, the encoding ones refuse it (the model's encoder has none) */
     int qtab;               /* index into qtabs[] */
     int reserved;
     size_t coef_offset;     /* int16 elements from the frame's coefficient record */
@@ -245,6 +253,37 @@ HVC_API int hvc_upsample420(hvc_ctx *ctx, const uint8_t *src, int cw, int ch, si
                             uint8_t *dst, size_t dst_stride, int n_planes, size_t src_plane_stride,
                             size_t dst_plane_stride, int where);
 
+/* The rest of `oyuv convert` (tools/src/oconv.ml): the other resampling steps of Planar_444, plane by plane like
+ * hvc_upsample420 (n_planes planes, src_plane_stride / dst_plane_stride bytes apart, 0 = tight; host or device memory):
+ *   hvc_subsample420   Planar_444.subsample_hv2 over all rows (planar_444.ml:69-80, convert_to_420 :105-116):
+ *                      src sw x sh -> dst (sw / 2) x (sh / 2), dst[c, r] = (a + b + c + d + 2) >> 2 of the 2 x 2 samples
+ *   hvc_subsample422   Planar_444.subsample_h2 (planar_444.ml:18-23, convert_to_422 :35-44): src sw x sh -> dst (sw / 2) x sh
+ *   hvc_upsample422    Planar_444.supersample_h2 (planar_444.ml:25-33, convert_from_422 :55-67): src cw x h -> dst 2cw x h,
+ *                      dst[2c] = src[c], dst[2c + 1] = avg2 src[c] src[c + 1], the last column twice
+ *   hvc_crop_planes    Yuv.crop (tools/src/yuv.ml:42-62) of one plane: dst[c, r] = src[clamp (c + x_pos), clamp (r + y_pos)]
+ *                      -- a crop, an offset, and edge replication where the destination reaches past the source */
+HVC_API int hvc_subsample420(hvc_ctx *ctx, const uint8_t *src, int sw, int sh, size_t src_stride, uint8_t *dst,
+                             size_t dst_stride, int n_planes, size_t src_plane_stride, size_t dst_plane_stride, int where);
+HVC_API int hvc_subsample422(hvc_ctx *ctx, const uint8_t *src, int sw, int sh, size_t src_stride, uint8_t *dst,
+                             size_t dst_stride, int n_planes, size_t src_plane_stride, size_t dst_plane_stride, int where);
+HVC_API int hvc_upsample422(hvc_ctx *ctx, const uint8_t *src, int cw, int h, size_t src_stride, uint8_t *dst,
+                            size_t dst_stride, int n_planes, size_t src_plane_stride, size_t dst_plane_stride, int where);
+HVC_API int hvc_crop_planes(hvc_ctx *ctx, const uint8_t *src, int sw, int sh, size_t src_stride, int x_pos, int y_pos,
+                            uint8_t *dst, int dw, int dh, size_t dst_stride, int n_planes, size_t src_plane_stride,
+                            size_t dst_plane_stride, int where);
+
+/* Yuv_format.t (tools/src/yuv_format.ml): the planar formats by their usual number, the packed 4:2:2 ones by name */
+enum { HVC_YUV_420 = 420, HVC_YUV_422 = 422, HVC_YUV_444 = 444, HVC_YUV_YUY2 = 1, HVC_YUV_UYVY = 2, HVC_YUV_YVYU = 3 };
+/* bytes of one raw frame: Planar.create / Packed.create (yuv_format.ml:21-53: integer halves; packed = 2 * width * height) */
+HVC_API int hvc_yuv_frame_bytes(int format, int width, int height, size_t *bytes);
+/* Oconv.main's loop body (oconv.ml:111-133) for n_frames raw frames, back to back in `src` and `dst`:
+ *   Oconv.input   the source format to a 4:4:4 frame (Packed_422.convert_to_planar, Planar_444.convert_from_420 / _422)
+ *   Yuv.crop      ~x_pos:x_off ~y_pos:y_off into a dst_w x dst_h 4:4:4 frame (clamped source coordinates)
+ *   Oconv.output  the destination format (Planar_444.convert_to_420 / _422, Packed_422.convert_from_planar)
+ * HVC_E_INVALID_ARG where Yuv.assert_is_420 / _422 raise: an odd width for a subsampled format, an odd height for 4:2:0. */
+HVC_API int hvc_yuv_convert(hvc_ctx *ctx, const uint8_t *src, int src_format, int src_w, int src_h, int x_off, int y_off,
+                            uint8_t *dst, int dst_format, int dst_w, int dst_h, int n_frames, int where);
+
 /* ------------------------------------------------------------------------- */
 /* Host front end / back end around the block stage:
  * the callers and data formats either side of the hot path.  Host C++ only. */
@@ -279,9 +318,17 @@ HVC_API int hvc_jpeg_entropy_decode(const uint8_t *jpeg, size_t n, const hvc_jpe
 HVC_API int hvc_jpeg_entropy_decode2(const uint8_t *jpeg_a, size_t n_a, const hvc_jpeg_info *info_a, int16_t *coefs_a,
                                      int *status_a, const uint8_t *jpeg_b, size_t n_b, const hvc_jpeg_info *info_b,
                                      int16_t *coefs_b, int *status_b);
-/* Decoder.get_yuv_frame (decoder.ml:403-420): cropped planes back to back (Frame.output order). */
+/* Decoder.get_yuv_frame (decoder.ml:403-420): the crops of components 0, 1, 2 back to back (Frame.output order,
+ * common/src/frame.ml:66-70) -- where Frame.of_planes (frame.ml:42-61) makes a frame of them: three components at least,
+ * chroma planes of one size, and that size the luma plane's halved both ways, halved in width, or equal (C420 / C422 /
+ * C444 by integer halves).  HVC_E_BAD_JPEG where of_planes raises (4:1:1, 4:4:0, one or two components, an empty plane
+ * beside planes with samples); a fourth component is left out, as in the model.  *out_len: the bytes of the frame. */
 HVC_API int hvc_jpeg_get_yuv_frame(const hvc_jpeg_info *info, const uint8_t *pixels, uint8_t *out, size_t cap,
                                    size_t *out_len);
+/* Decoder.crop (decoder.ml:403-413) mapped over Decoder.get_decoded_planes (:399-401): EVERY component's crop back to
+ * back in scan order, whatever the sampling -- for the files whose planes Frame.of_planes has no name for. */
+HVC_API int hvc_jpeg_get_cropped_planes(const hvc_jpeg_info *info, const uint8_t *pixels, uint8_t *out, size_t cap,
+                                        size_t *out_len);
 /* Decoder.decode_a_frame minus the crop (decoder.ml:422-427): header, host entropy decode, GPU block
  * stage; `pixels` (host, info->pixel_bytes) receives the padded planes = get_decoded_planes. */
 HVC_API int hvc_jpeg_decode(hvc_ctx *ctx, const uint8_t *jpeg, size_t n, hvc_jpeg_info *info, uint8_t *pixels,

@@ -136,10 +136,17 @@ let jpeg_decode =
     (ctx @-> string @-> size_t @-> ptr Jpeg_info.t @-> ptr char @-> size_t @-> returning int)
 ;;
 
-(* int hvc_jpeg_get_yuv_frame(info, pixels, out, cap, out_len)               decoder.ml:403-420 *)
+(* int hvc_jpeg_get_yuv_frame(info, pixels, out, cap, out_len)               decoder.ml:403-420; Frame.of_planes' raises = HVC_E_BAD_JPEG *)
 let jpeg_get_yuv_frame =
   foreign
     "hvc_jpeg_get_yuv_frame"
+    (ptr Jpeg_info.t @-> ptr char @-> ptr char @-> size_t @-> ptr size_t @-> returning int)
+;;
+
+(* int hvc_jpeg_get_cropped_planes(info, pixels, out, cap, out_len)          decoder.ml:399-413: crop of every plane *)
+let jpeg_get_cropped_planes =
+  foreign
+    "hvc_jpeg_get_cropped_planes"
     (ptr Jpeg_info.t @-> ptr char @-> ptr char @-> size_t @-> ptr size_t @-> returning int)
 ;;
 
@@ -281,6 +288,58 @@ let upsample420 =
     "hvc_upsample420"
     ~release_runtime_lock:true
     (ctx @-> ptr char @-> int @-> int @-> size_t @-> ptr char @-> size_t @-> int @-> size_t @-> size_t @-> int
+    @-> returning int)
+;;
+
+(* the rest of `oyuv convert` (tools/src/oconv.ml), plane by plane like hvc_upsample420:
+   int hvc_subsample420(ctx, src, sw, sh, src_stride, dst, dst_stride, n_planes, src_plane_stride, dst_plane_stride, where)
+   tools/src/planar_444.ml:69-80, 105-116 *)
+let subsample420 =
+  foreign
+    "hvc_subsample420"
+    ~release_runtime_lock:true
+    (ctx @-> ptr char @-> int @-> int @-> size_t @-> ptr char @-> size_t @-> int @-> size_t @-> size_t @-> int
+    @-> returning int)
+;;
+
+(* int hvc_subsample422(...)   tools/src/planar_444.ml:18-23, 35-44 *)
+let subsample422 =
+  foreign
+    "hvc_subsample422"
+    ~release_runtime_lock:true
+    (ctx @-> ptr char @-> int @-> int @-> size_t @-> ptr char @-> size_t @-> int @-> size_t @-> size_t @-> int
+    @-> returning int)
+;;
+
+(* int hvc_upsample422(...)    tools/src/planar_444.ml:25-33, 55-67 *)
+let upsample422 =
+  foreign
+    "hvc_upsample422"
+    ~release_runtime_lock:true
+    (ctx @-> ptr char @-> int @-> int @-> size_t @-> ptr char @-> size_t @-> int @-> size_t @-> size_t @-> int
+    @-> returning int)
+;;
+
+(* int hvc_crop_planes(ctx, src, sw, sh, src_stride, x_pos, y_pos, dst, dw, dh, dst_stride, n_planes, src_plane_stride,
+   dst_plane_stride, where)   tools/src/yuv.ml:42-62 *)
+let crop_planes =
+  foreign
+    "hvc_crop_planes"
+    ~release_runtime_lock:true
+    (ctx @-> ptr char @-> int @-> int @-> size_t @-> int @-> int @-> ptr char @-> int @-> int @-> size_t @-> int
+    @-> size_t @-> size_t @-> int @-> returning int)
+;;
+
+(* int hvc_yuv_frame_bytes(format, width, height, bytes)   tools/src/yuv_format.ml:21-53 *)
+let yuv_frame_bytes = foreign "hvc_yuv_frame_bytes" (int @-> int @-> int @-> ptr size_t @-> returning int)
+
+(* int hvc_yuv_convert(ctx, src, src_format, src_w, src_h, x_off, y_off, dst, dst_format, dst_w, dst_h, n_frames, where)
+   tools/src/oconv.ml:111-133 *)
+let yuv_convert =
+  foreign
+    "hvc_yuv_convert"
+    ~release_runtime_lock:true
+    (ctx @-> ptr char @-> int @-> int @-> int @-> int @-> int @-> ptr char @-> int @-> int @-> int @-> int @-> int
     @-> returning int)
 ;;
 

@@ -4,7 +4,13 @@
  * A literal restatement, in plain C with 64-bit integers, of the software JPEG
  * model of hardcamls/video-coding (OCaml, `jpeg/model/src`, `common/src`,
  * `tools/src`).  OCaml `int` is 63-bit, so int64_t reproduces it exactly for
- * every value the model can reach from 16-bit coefficients (< 2^47).
+ * every value the model can reach from 16-bit coefficients (< 2^47).  Beyond
+ * that -- a Huffman table may give a DC symbol up to 62 magnitude bits, and the
+ * model reads them (decoder.ml:81-96) -- OCaml's ints wrap modulo 2^63 without
+ * a word: sums and products are kept modulo 2^64 here (-fwrapv, oracle/Makefile)
+ * and read as 63-bit numbers wherever the model looks at one (ocaml_int: the
+ * operand of `asr`, the compares of clip); tests/test_oracle_golden.py holds
+ * this against a big-integer restatement that wraps after every operation.
  *
  * Nothing in the product path (video-coding_amd/, libhvc_jpeg.so) includes,
  * links or calls this file.  Only tests/, __graft_entry__.smoke() and the
@@ -90,7 +96,9 @@ ORC_API void orc_quant_scale(const int *table, int q, int *out) {
 
 /* OCaml `asr` is an arithmetic shift (floor); `lsl` on a negative int is a
  * multiplication by 2^k, written as such here. */
-static inline i64 asr(i64 x, int k) { return x >> k; } /* gcc: arithmetic on signed */
+/* An OCaml int is 63 bits wide: what is kept here modulo 2^64, read as the model would read it. */
+static inline i64 ocaml_int(i64 x) { return (i64)((uint64_t)x << 1) >> 1; }
+static inline i64 asr(i64 x, int k) { return ocaml_int(x) >> k; } /* gcc: arithmetic on signed */
 
 /* dct.ml:11-54 */
 static void idct_row(i64 *block, int row) {
@@ -245,14 +253,14 @@ ORC_API void orc_fdct_8x8(i64 *block) {
 /* jpeg/model/src/decoder.ml:142-149                                          */
 ORC_API i64 orc_dequantize_dc_pred_and_inverse_zigzag(const i64 *qnt_tab, i64 dc_pred,
                                                       const i64 *coefs, i64 *dequant) {
-    i64 dc = coefs[0] + dc_pred;
+    i64 dc = ocaml_int(coefs[0] + dc_pred);
     dequant[0] = dc * qnt_tab[0];
     for (int i = 1; i < 64; i++) dequant[ZZ_INV[i]] = coefs[i] * qnt_tab[i];
     return dc;
 }
 
 /* decoder.ml:213 */
-static inline i64 clip_pix(i64 x) { return x < -128 ? -128 : (x > 127 ? 127 : x); }
+static inline i64 clip_pix(i64 x) { x = ocaml_int(x); return x < -128 ? -128 : (x > 127 ? 127 : x); }
 
 /* decoder.ml:215-224 : clip (mutating idct), +128, store at plane (x+i, y+j).
  * Plane is row-major u8 with `stride` bytes per row (common/src/plane.ml:45-61).
@@ -838,10 +846,11 @@ static int huffman_decode(Bits *bits, i64 *coefs, const Lut *dc_tab, const Lut *
     int cat = dc_tab->data[code];
     i64 dc = 0;
     /* A DHT may name any byte as a DC category and the model reads that many magnitude bits without a check
-     * (decoder.ml:81-96).  Up to 32 this restatement follows it; beyond that the model computes 63-bit garbage (and
-     * from 63 bits on its shifts wrap), the product refuses the stream (include/hvc_jpeg.h), and so does this checker:
-     * nothing is compared there. */
-    if (cat > 32) return ORC_E_DC_CODE;
+     * (decoder.ml:81-96).  Up to 62 everything in mag' is defined (`1 lsl (cat - 1)` and `-1 lsl cat` shift by less than
+     * Sys.int_size = 63) and this restatement follows; from 63 on OCaml leaves the shifts unspecified -- there is no
+     * model result, the product refuses the stream (include/hvc_jpeg.h), and so does this checker.  (A category of as
+     * many bits as the segment has, or more, raises in Bits.get either way.) */
+    if (cat > 62) return cat >= bits->length_in_bits ? ORC_E_BITS_OOB : ORC_E_DC_CODE;
     if (cat != 0) { i64 v = bits_get(bits, cat); if (v < 0) return (int)v; dc = mag_prime(cat, v); }
     coefs[0] = dc;
     int cof_cnt = 1;
@@ -977,6 +986,24 @@ ORC_API void orc_decoder_cropped_plane(const orc_decoder *d, int i, uint8_t *out
     const Component *c = &d->comp[i];
     for (int r = 0; r < c->actual_height; r++)
         memcpy(out + (size_t)r * c->actual_width, c->plane + (size_t)r * c->decoded_width, (size_t)c->actual_width);
+}
+
+/* decoder.ml:415-420 get_yuv_frame = Frame.of_planes ~y:(crop components.(0)) ~u:(crop components.(1)) ~v:(crop components.(2))
+ * with common/src/frame.ml:42-61 of_planes / infer_chroma_subsampling and :3-22 Chroma_subsampling.width / height.
+ * Returns 420 / 422 / 444, or < 0 where the model raises: components.(1) or .(2) missing (Invalid_argument "index out of
+ * bounds"), "Chroma planes must be same width and height", "Could not infer chroma subsampling". */
+#define ORC_E_FRAME_INDEX (-15)
+#define ORC_E_FRAME_CHROMA_SIZES (-16)
+#define ORC_E_FRAME_INFER (-17)
+ORC_API int orc_decoder_frame_of_planes(const orc_decoder *d) {
+    if (d->ncomp < 3) return ORC_E_FRAME_INDEX;
+    const Component *y = &d->comp[0], *u = &d->comp[1], *v = &d->comp[2];
+    if (u->actual_width != v->actual_width || u->actual_height != v->actual_height) return ORC_E_FRAME_CHROMA_SIZES;
+    /* check C420, then C422, then C444 (frame.ml:50-59) */
+    if (y->actual_width / 2 == u->actual_width && y->actual_height / 2 == u->actual_height) return 420;
+    if (y->actual_width / 2 == u->actual_width && y->actual_height == u->actual_height) return 422;
+    if (y->actual_width == u->actual_width && y->actual_height == u->actual_height) return 444;
+    return ORC_E_FRAME_INFER;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1289,6 +1316,40 @@ ORC_API void orc_crop_plane(const uint8_t *src, int sw, int sh, int x_pos, int y
             int col = c + x_pos; col = col < 0 ? 0 : (col >= sw ? sw - 1 : col);
             int row = r + y_pos; row = row < 0 ? 0 : (row >= sh ? sh - 1 : row);
             dst[r * dw + c] = src[row * sw + col];
+        }
+}
+
+/* tools/src/packed_422.ml:6-8 : byte offsets of Y, U, V inside a group of four bytes (two pixels); the second luma
+ * sample sits at yo + 2.  which: 1 = yuy2, 2 = uyvy, 3 = yvyu (the numbers of include/hvc_jpeg.h) */
+static void packed_fmt(int which, int *yo, int *uo, int *vo) {
+    if (which == 1) { *yo = 0; *uo = 1; *vo = 3; }
+    else if (which == 2) { *yo = 1; *uo = 0; *vo = 2; }
+    else { *yo = 0; *uo = 3; *vo = 1; }
+}
+/* :10-23 convert_to_planar : src is a plane of (2 w) x h bytes, dst a 4:2:2 frame of luma size w x h */
+ORC_API void orc_packed422_to_planar(int which, const uint8_t *src, int w, int h, uint8_t *y, uint8_t *u, uint8_t *v) {
+    int yo, uo, vo;
+    packed_fmt(which, &yo, &uo, &vo);
+    for (int row = 0; row < h; row++)
+        for (int col = 0; col < w / 2; col++) {
+            const uint8_t *p = src + (size_t)row * (2 * w) + col * 4;
+            y[(size_t)row * w + col * 2] = p[yo];
+            y[(size_t)row * w + col * 2 + 1] = p[yo + 2];
+            u[(size_t)row * (w / 2) + col] = p[uo];
+            v[(size_t)row * (w / 2) + col] = p[vo];
+        }
+}
+/* :33-46 convert_from_planar */
+ORC_API void orc_packed422_from_planar(int which, const uint8_t *y, const uint8_t *u, const uint8_t *v, int w, int h, uint8_t *dst) {
+    int yo, uo, vo;
+    packed_fmt(which, &yo, &uo, &vo);
+    for (int row = 0; row < h; row++)
+        for (int col = 0; col < w / 2; col++) {
+            uint8_t *p = dst + (size_t)row * (2 * w) + col * 4;
+            p[yo] = y[(size_t)row * w + col * 2];
+            p[yo + 2] = y[(size_t)row * w + col * 2 + 1];
+            p[uo] = u[(size_t)row * (w / 2) + col];
+            p[vo] = v[(size_t)row * (w / 2) + col];
         }
 }
 

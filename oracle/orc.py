@@ -40,7 +40,7 @@ def lib():
         L.orc_decoder_create.restype = C.c_void_p
         L.orc_decoder_create.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
         for f in ("orc_decoder_destroy", "orc_decoder_next_block", "orc_decoder_decode", "orc_decoder_ncomp",
-                  "orc_decoder_width", "orc_decoder_height"):
+                  "orc_decoder_width", "orc_decoder_height", "orc_decoder_frame_of_planes"):
             getattr(L, f).argtypes = [C.c_void_p]
         L.orc_decoder_destroy.restype = None
         L.orc_decoder_coef_record.argtypes = [C.c_void_p, C.c_void_p]
@@ -234,8 +234,22 @@ class Decoder:
         lib().orc_decoder_cropped_plane(self._d, i, _ptr(out))
         return out
 
-    def get_yuv_frame(self):
+    def cropped_planes(self):
+        """Array.map crop (get_decoded_planes t) (decoder.ml:399-413): every component's crop, whatever the sampling."""
         return [self.cropped_plane(i) for i in range(self.ncomp)]
+
+    def chroma_subsampling(self):
+        """Frame.infer_chroma_subsampling of the first three crops (frame.ml:42-61): 420 / 422 / 444; ValueError where
+        the model raises (fewer than three components, chroma planes of two sizes, sizes it has no name for)."""
+        r = lib().orc_decoder_frame_of_planes(self._d)
+        if r < 0:
+            raise ValueError("Frame.of_planes raises: %d" % r)
+        return r
+
+    def get_yuv_frame(self):
+        """Decoder.get_yuv_frame (decoder.ml:415-420): the crops of components 0, 1, 2 -- where Frame.of_planes takes them."""
+        self.chroma_subsampling()
+        return [self.cropped_plane(i) for i in range(3)]
 
 
 def decode_a_frame(data: bytes):
@@ -351,6 +365,57 @@ def crop_plane(src, dw, dh, x_pos=0, y_pos=0):
     dst = np.zeros((dh, dw), dtype=np.uint8)
     lib().orc_crop_plane(_ptr(src), src.shape[1], src.shape[0], x_pos, y_pos, _ptr(dst), dw, dh)
     return dst
+
+
+PACKED = {"YUY2": 1, "UYVY": 2, "YVYU": 3}
+
+
+def packed422_to_planar(which, src, w, h):
+    """Packed_422.convert_to_planar (tools/src/packed_422.ml:10-23): a (2 w) x h packed plane -> (y, u, v) of a 4:2:2 frame"""
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    y, u, v = np.zeros((h, w), np.uint8), np.zeros((h, w // 2), np.uint8), np.zeros((h, w // 2), np.uint8)
+    lib().orc_packed422_to_planar(C.c_int(which), _ptr(src), C.c_int(w), C.c_int(h), _ptr(y), _ptr(u), _ptr(v))
+    return y, u, v
+
+
+def packed422_from_planar(which, y, u, v):
+    """Packed_422.convert_from_planar (packed_422.ml:33-46)"""
+    y, u, v = (np.ascontiguousarray(p, dtype=np.uint8) for p in (y, u, v))
+    h, w = y.shape
+    dst = np.zeros((h, 2 * w), np.uint8)
+    lib().orc_packed422_from_planar(C.c_int(which), _ptr(y), _ptr(u), _ptr(v), C.c_int(w), C.c_int(h), _ptr(dst))
+    return dst
+
+
+def oconv_frame(raw, fmt_in, size_in, fmt_out, size_out, offset=(0, 0)):
+    """One pass of Oconv.main's loop (tools/src/oconv.ml:111-133) over one raw frame: Oconv.input (:12-28) into a 4:4:4
+    frame, Yuv.crop (tools/src/yuv.ml:42-62), Oconv.output (:38-51).  fmt: 420 / 422 / 444 or "YUY2" / "UYVY" / "YVYU".
+    ValueError where Yuv.assert_is_420 / _422 raise (yuv.ml:90-116)."""
+    def fits(fmt, w, h):
+        if fmt == 444:
+            return True
+        return w % 2 == 0 and (fmt != 420 or h % 2 == 0)
+    (w, h), (w2, h2) = size_in, size_out
+    if not fits(fmt_in, w, h) or not fits(fmt_out, w2, h2):
+        raise ValueError("Expecting a 4:2:x frame")
+    raw = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else raw
+    if fmt_in in PACKED:
+        y, u, v = packed422_to_planar(PACKED[fmt_in], raw[:2 * w * h].reshape(h, 2 * w), w, h)
+        u, v = supersample_h2(u), supersample_h2(v)
+    else:
+        y, u, v = split_yuv(raw, w, h, fmt_in)
+        if fmt_in == 420:
+            u, v = supersample_hv2(u), supersample_hv2(v)
+        elif fmt_in == 422:
+            u, v = supersample_h2(u), supersample_h2(v)
+    y, u, v = (crop_plane(p, w2, h2, offset[0], offset[1]) for p in (y, u, v))
+    if fmt_out in PACKED:
+        return packed422_from_planar(PACKED[fmt_out], y, subsample_h2(u, w2 // 2, h2), subsample_h2(v, w2 // 2, h2)).tobytes()
+    if fmt_out == 420:
+        u, v = subsample_hv2(u, w2 // 2, h2 // 2), subsample_hv2(v, w2 // 2, h2 // 2)
+    elif fmt_out == 422:
+        u, v = subsample_h2(u, w2 // 2, h2), subsample_h2(v, w2 // 2, h2)
+    return y.tobytes() + u.tobytes() + v.tobytes()
 
 
 def max_difference(a, b):

@@ -115,6 +115,16 @@ def g7_upsample():
     return {"source": "tools/src/planar_444.ml:139-249", "cases": out}
 
 
+def g7_packed422():
+    """tools/src/packed_422.ml:56-104 expect block: a 4x4 4:2:2 frame, its YUY2 packing, and the frame unpacked again."""
+    s = read("tools/src/packed_422.ml")
+    t = s[s.index('let%expect_test "planar <-> packed"'):]
+    rows = dump_planes(re.findall(r"\{\|(.*?)\|\}", t, re.S)[0])
+    assert [len(r) for r in rows] == [4] * 4 + [2] * 8 + [8] * 4 + [4] * 4 + [2] * 8
+    return {"source": "tools/src/packed_422.ml:56-104", "format": "yuy2", "frame": rows[:12], "packed": rows[12:16],
+            "unpacked": rows[16:]}
+
+
 def g8_header():
     """jpeg/model/test/test_encode_headers.ml:17-134: hexdump of write_headers
     c420 480x320 quality 20."""
@@ -189,7 +199,8 @@ def main():
     fixtures = {
         "g1_chen_dct.json": g1_chen(), "g2_mouse480_blocks.json": g2_mouse_blocks(),
         "g4_psnr_pins.json": g4_psnr(), "g5_quant_tables.json": g5_quant(),
-        "g7_upsample.json": g7_upsample(), "g8_header_c420_480x320_q20.json": g8_header(),
+        "g7_upsample.json": g7_upsample(), "g7_packed422.json": g7_packed422(),
+        "g8_header_c420_480x320_q20.json": g8_header(),
         "g8_codewords.json": g8_codewords(), "g8_rle.json": g8_rle(),
         "mouse480_header.json": mouse_header(),
     }

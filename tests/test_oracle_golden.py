@@ -187,3 +187,117 @@ def test_fdct_quant_batch_matches_encoder_coefs():
     for plane, q, c in ((y, ql, coefs[0]), (u, qc, coefs[1]), (v, qc, coefs[2])):
         got = orc.fdct_quant(plane, q, 8, 8).reshape(8, 8, 64)
         assert np.array_equal(got, c)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# OCaml's 63-bit ints.  No golden vector of the reference reaches them (nothing an encoder writes does); what is held here
+# is the restatement's ARITHMETIC: it keeps sums and products modulo 2^64 and reads them as 63-bit numbers at every `asr`
+# and compare (oracle/hvc_oracle.c ocaml_int) -- against the plain reading of the language: every operation on `int` is
+# taken modulo 2^63 (two's complement), written out below with Python's unbounded integers and a wrap after EVERY
+# operation, statement for statement from dct.ml:11-107 and decoder.ml:142-149, 213-224.
+
+def _w(x):
+    return ((x + (1 << 62)) % (1 << 63)) - (1 << 62)
+
+
+def _idct_1d_bigint(b, col):
+    W1, W2, W3, W5, W6, W7 = 2841, 2676, 2408, 1609, 1108, 565
+    add, sub, mul = (lambda a, c: _w(a + c)), (lambda a, c: _w(a - c)), (lambda a, c: _w(a * c))
+    asr = lambda a, k: a >> k                      # (on a value already in 63-bit range: floor, like OCaml's asr)
+    if col:
+        x0, x1 = add(mul(b[0], 256), 8192), mul(b[4], 256)      # lsl 8 = * 256 modulo 2^63
+        r, rs, s = 4, 3, 14
+    else:
+        x0, x1 = add(mul(b[0], 2048), 128), mul(b[4], 2048)
+        r, rs, s = 0, 0, 8
+    x2, x3, x4, x5, x6, x7 = b[6], b[2], b[1], b[7], b[5], b[3]
+    x8 = add(mul(W7, add(x4, x5)), r)
+    x4 = asr(add(x8, mul(W1 - W7, x4)), rs)
+    x5 = asr(sub(x8, mul(W1 + W7, x5)), rs)
+    x8 = add(mul(W3, add(x6, x7)), r)
+    x6 = asr(sub(x8, mul(W3 - W5, x6)), rs)
+    x7 = asr(sub(x8, mul(W3 + W5, x7)), rs)
+    x8 = add(x0, x1)
+    x0 = sub(x0, x1)
+    x1 = add(mul(W6, add(x3, x2)), r)
+    x2 = asr(sub(x1, mul(W2 + W6, x2)), rs)
+    x3 = asr(add(x1, mul(W2 - W6, x3)), rs)
+    x1 = add(x4, x6)
+    x4 = sub(x4, x6)
+    x6 = add(x5, x7)
+    x5 = sub(x5, x7)
+    x7 = add(x8, x3)
+    x8 = sub(x8, x3)
+    x3 = add(x0, x2)
+    x0 = sub(x0, x2)
+    x2n = asr(add(mul(181, add(x4, x5)), 128), 8)
+    x4n = asr(add(mul(181, sub(x4, x5)), 128), 8)
+    x2, x4 = x2n, x4n
+    return [asr(add(x7, x1), s), asr(add(x3, x2), s), asr(add(x0, x4), s), asr(add(x8, x6), s),
+            asr(sub(x8, x6), s), asr(sub(x0, x4), s), asr(sub(x3, x2), s), asr(sub(x7, x1), s)]
+
+
+def _decode_block_bigint(coefs_zz, q, dc_pred):
+    zi = list(orc.zigzag_inverse())
+    dc = _w(coefs_zz[0] + dc_pred)
+    deq = [0] * 64
+    deq[0] = _w(dc * q[0])
+    for i in range(1, 64):
+        deq[zi[i]] = _w(coefs_zz[i] * q[i])
+    v = list(deq)
+    for r in range(8):
+        v[8 * r:8 * r + 8] = _idct_1d_bigint(v[8 * r:8 * r + 8], False)
+    for c in range(8):
+        col = _idct_1d_bigint([v[c + 8 * k] for k in range(8)], True)
+        for k in range(8):
+            v[c + 8 * k] = col[k]
+    return dc, [max(-128, min(127, x)) + 128 for x in v]
+
+
+def test_the_restatement_wraps_like_63_bit_ocaml_ints():
+    rng = np.random.Generator(np.random.PCG64(63))
+    seen_wrap = 0
+    for case in range(300):
+        bits = [20, 33, 40, 47, 55, 61, 62][case % 7]
+        coefs = [0] * 64
+        coefs[0] = int(rng.integers(-(1 << 62), 1 << 62)) >> (62 - bits)
+        for k in rng.choice(np.arange(1, 64), size=int(rng.integers(0, 20)), replace=False):
+            coefs[int(k)] = int(rng.integers(-1023, 1024))
+        q = [int(x) for x in rng.integers(1, 65536 if case % 3 == 0 else 256, size=64)]
+        dc_pred = int(rng.integers(-(1 << 62), 1 << 62)) >> int(rng.integers(0, 40))
+        want_dc, want = _decode_block_bigint(coefs, q, dc_pred)
+        dc, _, _, recon = orc.decode_block_summary(np.array(coefs, dtype=np.int64), np.array(q, dtype=np.int64), dc_pred)
+        assert dc == want_dc, case
+        assert [int(x) for x in recon] == want, case
+        seen_wrap += abs(coefs[0] + dc_pred) >= (1 << 62) or abs(want_dc * q[0]) >= (1 << 62)
+    assert seen_wrap > 100      # (most of these cases really leave 63 bits)
+    # ... and on everything an encoder can write the wrap is the identity: the pinned vectors above are unchanged
+
+
+def test_g7_packed422_kat():
+    """tools/src/packed_422.ml:56-104: a 4 x 4 4:2:2 frame, packed as YUY2 and unpacked again"""
+    g = golden_json("g7_packed422.json")
+    A = lambda rows: np.array(rows, dtype=np.uint8)
+    y, u, v = A(g["frame"][0:4]), A(g["frame"][4:8]), A(g["frame"][8:12])
+    packed = orc.packed422_from_planar(orc.PACKED["YUY2"], y, u, v)
+    assert packed.tolist() == g["packed"]
+    y2, u2, v2 = orc.packed422_to_planar(orc.PACKED["YUY2"], packed, 4, 4)
+    assert y2.tolist() + u2.tolist() + v2.tolist() == g["unpacked"]
+    # the other two byte orders (packed_422.ml:6-8): the same samples at other places of each group of four bytes
+    for name, (yo, uo, vo) in (("UYVY", (1, 0, 2)), ("YVYU", (0, 3, 1))):
+        p = orc.packed422_from_planar(orc.PACKED[name], y, u, v).reshape(4, 2, 4)
+        assert np.array_equal(p[:, :, yo], y[:, 0::2]) and np.array_equal(p[:, :, yo + 2], y[:, 1::2])
+        assert np.array_equal(p[:, :, uo], u) and np.array_equal(p[:, :, vo], v)
+        back = orc.packed422_to_planar(orc.PACKED[name], p.reshape(4, 8), 4, 4)
+        assert all(np.array_equal(a, b) for a, b in zip(back, (y, u, v)))
+
+
+def test_oconv_reproduces_the_nonstandard_size_pin():
+    """test-nonstandard-sizes.t:3-15 -- `oyuv convert mini64x64.420 64x64 mini52x44.420 52x44`, then encode at quality
+    95, decode, PSNR against the converted file: G4's sixth triple through the restated Oconv pipeline in one piece"""
+    c = golden_json("g4_psnr_pins.json")["nonstandard"]
+    small = orc.oconv_frame(golden_bytes(c["file"]), 420, (64, 64), 420, (c["width"], c["height"]))
+    y, u, v = orc.split_yuv(small, c["width"], c["height"], 420)
+    jpg = orc.encode_yuv(y, u, v, c["width"], c["height"], 420, c["quality"])
+    got = orc.decode_a_frame(jpg)
+    assert [orc.ocaml_float_to_string(orc.psnr(a, b)) for a, b in zip((y, u, v), got)] == c["psnr"]

@@ -6,8 +6,9 @@
     python -m video_coding_amd oyuv compare {max-difference,mean-difference,mean-square-error,psnr}
                                             {y,u,v,yuv} FILE-1 FILE-2 WxH [-format 420]
                                                                                   tools/src/ocompare.ml:83-135
-    python -m video_coding_amd oyuv convert IN.yuv WxH OUT.yuv [-format 420] [-out-format 444]
-                                            (4:2:0 -> 4:4:4 at the same size only; tools/src/oconv.ml)
+    python -m video_coding_amd oyuv convert IN.yuv WxH OUT.yuv [W2xH2] [-frames A-B] [-format 420] [-out-format F]
+                                            [-src-offset X,Y]    formats 420 422 444 YUY2 UYVY YVYU
+                                                                                  tools/src/oconv.ml:58-133
 
 Every pixel goes through libhvc_jpeg.so on the GPU (there is no CPU path); output text matches the
 reference's (`print_s` of an int / a float), so jpeg/test/*.t expectations can be checked verbatim.
@@ -69,18 +70,70 @@ def oyuv_compare(a):
         print(show(fn(f1[i], f2[i])))
 
 
-def oyuv_convert(a):
-    w, h = a.size
-    if (a.format, a.out_format) != (420, 444) or (w & 1) or (h & 1):
-        raise SystemExit("only 4:2:0 -> 4:4:4 at an even size is implemented (Planar_444.convert_from_420)")
-    y, u, v = yuv.read_frame(a.infile, w, h, 420)
-    ctx = hvc.Context(a.device)
+def format_arg(s):
+    """Yuv_format.arg_type (tools/src/yuv_format.ml:66-77)"""
     try:
-        out = np.zeros((2, h, w), dtype=np.uint8)
-        ctx.upsample420(np.ascontiguousarray(np.stack([u, v])), w // 2, h // 2, out, n_planes=2)
-    finally:
-        ctx.close()
-    yuv.write_frame(a.outfile, [y, out[0], out[1]])
+        return hvc.YUV_FORMATS[s.upper()]
+    except KeyError:
+        raise argparse.ArgumentTypeError("Invalid YUV format")
+
+
+def _two(s):
+    """Offset.arg_type / Range.arg_type split on 'x', ',' and '-' (common/src/offset.ml:10-17, range.ml:10-19)"""
+    import re
+    return re.split("[x,-]", s)
+
+
+def range_arg(s):
+    """Range.arg_type: N = that frame, -B = 0 .. B, A-B (also AxB, A,B)"""
+    parts = _two(s)
+    try:
+        if len(parts) == 1:
+            return int(parts[0]), int(parts[0])
+        if len(parts) == 2:
+            return (0 if parts[0] == "" else int(parts[0])), int(parts[1])
+    except ValueError:
+        pass
+    raise argparse.ArgumentTypeError("Invalid frame size specified")   # (the reference's message, for both types)
+
+
+def offset_arg(s):
+    """Offset.arg_type: XxY, X,Y or X-Y (so no negative offsets on the command line, as in the reference)"""
+    parts = _two(s)
+    try:
+        if len(parts) == 2:
+            return int(parts[0]), int(parts[1])
+    except ValueError:
+        pass
+    raise argparse.ArgumentTypeError("Invalid frame size specified")
+
+
+def oyuv_convert(a):
+    """Oconv.main (tools/src/oconv.ml:111-133): skip frames.start frames, then convert frames start .. end; a short read
+    ends the run (Plane.End_of_image), whatever has been written stays"""
+    size_out = a.out_size or a.size
+    fmt_out = a.out_format if a.out_format is not None else a.format
+    n_in = hvc.yuv_frame_bytes(a.format, *a.size)
+    n_out = hvc.yuv_frame_bytes(fmt_out, *size_out)
+    first, last = a.frames
+    with (sys.stdin.buffer if a.infile == "-" else open(a.infile, "rb")) as f:
+        if first:
+            f.read(first * n_in) if a.infile == "-" else f.seek(first * n_in)
+        raw = f.read((last - first + 1) * n_in)
+    n = len(raw) // n_in   # (whole frames only: Oconv.input returns false on a short one)
+    out = np.zeros(n * n_out, dtype=np.uint8)
+    if n:
+        ctx = hvc.Context(a.device)
+        try:
+            ctx.yuv_convert(np.frombuffer(raw, dtype=np.uint8)[:n * n_in], a.format, a.size, out, fmt_out, size_out,
+                            offset=a.src_offset, n_frames=n)
+        finally:
+            ctx.close()
+    if a.outfile == "-":
+        sys.stdout.buffer.write(out.tobytes())
+    else:
+        with open(a.outfile, "wb") as f:
+            f.write(out.tobytes())
 
 
 def main(argv=None):
@@ -118,8 +171,11 @@ def main(argv=None):
     p.add_argument("infile")
     p.add_argument("size", type=size_arg)
     p.add_argument("outfile")
-    p.add_argument("-format", type=int, default=420, choices=[420, 422, 444])
-    p.add_argument("-out-format", dest="out_format", type=int, default=444, choices=[420, 422, 444])
+    p.add_argument("out_size", type=size_arg, nargs="?")
+    p.add_argument("-frames", type=range_arg, default=(0, 0))
+    p.add_argument("-format", type=format_arg, default=420)
+    p.add_argument("-out-format", dest="out_format", type=format_arg, default=None)
+    p.add_argument("-src-offset", dest="src_offset", type=offset_arg, default=(0, 0))
     p.set_defaults(fn=oyuv_convert)
 
     a = ap.parse_args(argv)

@@ -601,15 +601,35 @@ static int apply_wide_dc_444(hvc_ctx *c, const hvc::Decode444Params &P, const st
     return HVC_OK;
 }
 
+// A component without a block -- blocks_w or blocks_h of zero: what hvc_jpeg_read_header reports for a sampling factor of
+// zero or a frame without width or height, the model's empty Plane.t (decoder.ml:304-345) -- has no part in the block
+// stage: decode_seq never calls decode_block for it.  The decoding entry points drop such components from the list
+// they work on (the others keep their offsets); *n_kept == 0: nothing to decode at all.
+static int drop_empty_components(const hvc_component *comps, int n_comp, hvc_component *kept, int *n_kept) {
+    if (!comps || n_comp < 1 || n_comp > HVC_MAX_COMP) return HVC_E_INVALID_ARG;
+    *n_kept = 0;
+    for (int i = 0; i < n_comp; i++) {
+        if (comps[i].blocks_w < 0 || comps[i].blocks_h < 0) return HVC_E_INVALID_ARG;
+        if (comps[i].blocks_w > 0 && comps[i].blocks_h > 0) kept[(*n_kept)++] = comps[i];
+    }
+    return HVC_OK;
+}
+
 // dc_plane (device memory calls only, default kernels only): see hvc::DecodeParams::dc_plane
 // wide (device memory calls only): blocks to recompute with their true DC once the launches are enqueued
 int decode_frames_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const uint16_t *qtabs, int n_qtabs,
-                       const hvc_component *comps, int n_comp, int n_frames, uint8_t *pixels, size_t pixel_fs, int where,
+                       const hvc_component *comps_in, int n_comp_in, int n_frames, uint8_t *pixels, size_t pixel_fs, int where,
                        const int16_t *dc_plane, size_t dc_fs, const std::vector<WideFix> *wide) {
-    if (!c || !coefs || !pixels || n_frames < 0) return HVC_E_INVALID_ARG;
+    if (!c || n_frames < 0) return HVC_E_INVALID_ARG;
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
     int r = check_qtabs(qtabs, n_qtabs, false);
     if (r) return r;
+    hvc_component kept[HVC_MAX_COMP];
+    int n_comp = 0;
+    if ((r = drop_empty_components(comps_in, n_comp_in, kept, &n_comp))) return r;
+    if (n_comp == 0) return HVC_OK; // (no plane has a block: a record of no bytes)
+    const hvc_component *const comps = kept;
+    if (!coefs || !pixels) return HVC_E_INVALID_ARG;
     Layout L;
     r = make_layout(comps, n_comp, n_qtabs, L);
     if (r) return r;

@@ -69,6 +69,8 @@ int hvc_jpeg_decode_yuv444(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_i
         info->comp[1].vscale != 1 || info->comp[2].hscale != 1 || info->comp[2].vscale != 1)
         return HVC_E_INVALID_ARG;
     if (frame_cap < (size_t)3 * info->width * info->height) return HVC_E_INVALID_ARG;
+    if (info->width == 0 || info->height == 0) // a frame without a sample: the model decodes no block (decoder.ml:377-395)
+        return hvc_jpeg_entropy_decode(jpeg, n, info, nullptr); // and of_420 of empty planes is an empty frame; the tables are still looked up
     int on_gpu = 0;
     const size_t fb = (size_t)3 * info->width * info->height;
     AfterReader after;
@@ -109,10 +111,10 @@ int hvc_jpeg_decode_yuv444(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_i
 } HVC_ABI_CATCH
 
 int hvc_jpeg_decode(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_info *info, uint8_t *pixels, size_t pixel_cap) try {
-    if (!c || !jpeg || !info || !pixels) return HVC_E_INVALID_ARG;
+    if (!c || !jpeg || !info) return HVC_E_INVALID_ARG;
     int r = hvc_jpeg_read_header(jpeg, n, info);
     if (r) return r;
-    if (pixel_cap < info->pixel_bytes) return HVC_E_INVALID_ARG;
+    if (pixel_cap < info->pixel_bytes || (!pixels && info->pixel_bytes)) return HVC_E_INVALID_ARG; // (planes without a sample need no memory)
     int on_gpu = 0;
     AfterReader after;
     // coefficient record on the device: ALL components' block stage there in one launch, one download -- enqueued
@@ -230,6 +232,15 @@ int decode_batch_impl(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *siz
     if (yuv444 && (!is_420_scan(info0) || (info0.width & 1) || (info0.height & 1))) return HVC_E_INVALID_ARG;
     const size_t out_bytes = yuv444 ? (size_t)3 * info0.width * info0.height : info0.pixel_bytes; // per frame
     if (pixel_fs < out_bytes || (!yuv444 && (pixel_fs & 7))) return HVC_E_INVALID_ARG;
+    if (info0.coef_count == 0) { // frames without a block (a width or height of zero): nothing to upload, nothing to launch --
+        for (int f = 0; f < n_frames; f++) { // every file is still read as the model reads it (headers, tables)
+            hvc_jpeg_info fi;
+            if ((r = hvc_jpeg_read_header(jpegs[f], sizes[f], &fi))) return r;
+            if (fi.n_comp != info0.n_comp || fi.coef_count != 0 || std::memcmp(fi.layout, info0.layout, sizeof fi.layout)) return HVC_E_INVALID_ARG;
+            if ((r = hvc_jpeg_entropy_decode(jpegs[f], sizes[f], &fi, nullptr))) return r;
+        }
+        return HVC_OK;
+    }
     if (threads < 1) threads = 1;
     if (threads > 256) threads = 256;
     if (frames_per_chunk < 1) frames_per_chunk = 32;

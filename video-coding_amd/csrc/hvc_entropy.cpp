@@ -306,6 +306,17 @@ struct BitReader {
 inline int extend(int cat, unsigned code) {
     return (code & (1u << (cat - 1))) ? (int)code : (int)code - (int)((1u << cat) - 1);
 }
+// ... for the categories no JPEG has but a DHT may name (decoder.ml:81-96 reads `cat` bits for whatever the table says): up
+// to 62 bits everything in mag' is defined -- `1 lsl (cat - 1)`, `-1 lsl cat` stay below OCaml's Sys.int_size = 63.
+inline long long extend_wide(int cat, unsigned long long code) {
+    return ((code >> (cat - 1)) & 1ull) ? (long long)code : (long long)(code - ((1ull << cat) - 1ull));
+}
+// OCaml's int is 63 bits wide and wraps without a word (decoder.ml:143 `coefs.(0) + dc_pred`): the sum modulo 2^64,
+// read as a 63-bit two's complement number.
+inline long long add63(long long a, long long b) {
+    return (long long)(((unsigned long long)a + (unsigned long long)b) << 1) >> 1;
+}
+const int HVC_MAX_DC_CAT = 62; // beyond: OCaml leaves the shifts of mag' unspecified (a count >= Sys.int_size); refused
 
 } // namespace
 
@@ -346,8 +357,10 @@ int hvc_jpeg_read_header(const uint8_t *data, size_t n, hvc_jpeg_info *info) try
         c.decoded_height = (int)(rh * h.cv[f] / max_v);
         c.actual_width = h.width * h.ch[f] / max_h;
         c.actual_height = h.height * h.cv[f] / max_v;
-        if (c.decoded_width < 8 || c.decoded_height < 8 || (c.decoded_width & 7) || (c.decoded_height & 7))
-            return HVC_E_BAD_JPEG;
+        // (multiples of 8 by construction.  ZERO where the component's sampling factor is zero, or the frame's width or
+        // height is: Decoder.init builds an empty plane there -- Plane.create ~width:0 -- and decode_seq walks the MCUs with
+        // no block for it, decoder.ml:304-345, 362-395; what cannot be made of such planes is a Frame.t: hvc_jpeg_get_yuv_frame)
+        if (c.decoded_width < 0 || c.decoded_height < 0 || (c.decoded_width & 7) || (c.decoded_height & 7)) return HVC_E_BAD_JPEG;
         // find_quant_table (decoder.ml:232-236): newest table with that id
         int qi = -1;
         for (int k = (int)h.dqt.size() - 1; k >= 0; k--)
@@ -394,14 +407,16 @@ namespace {
 // An hvc_jpeg_info is the caller's: hvc_jpeg_read_header / hvc_jpeg_encoder_layout filled it in, normally -- but nothing
 // keeps a caller from changing it, and the readers and coders index and divide by what it says.  What they rely on:
 // one to four components, sampling factors 1..15, planes of at least one block, and every component's record inside
-// the coef_count elements the caller's buffer is said to have.
-bool info_is_sane(const hvc_jpeg_info *info) {
+// the coef_count elements the caller's buffer is said to have.  The readers (allow_empty) also take what the model's
+// decoder takes: a sampling factor of zero and a plane without blocks (Decoder.init, decoder.ml:304-345).
+bool info_is_sane(const hvc_jpeg_info *info, bool allow_empty = false) {
     if (info->n_comp < 1 || info->n_comp > 4) return false;
+    const int lo = allow_empty ? 0 : 1;
     for (int i = 0; i < info->n_comp; i++) {
         const hvc_jpeg_component &c = info->comp[i];
         const hvc_component &L = info->layout[i];
-        if (c.hscale < 1 || c.hscale > 15 || c.vscale < 1 || c.vscale > 15) return false;
-        if (L.blocks_w < 1 || L.blocks_h < 1 || L.blocks_w > (1 << 20) || L.blocks_h > (1 << 20)) return false;
+        if (c.hscale < lo || c.hscale > 15 || c.vscale < lo || c.vscale > 15) return false;
+        if (L.blocks_w < lo || L.blocks_h < lo || L.blocks_w > (1 << 20) || L.blocks_h > (1 << 20)) return false;
         if (c.decoded_width < 0 || c.decoded_height < 0) return false;
         const unsigned long long n = (unsigned long long)L.blocks_w * (unsigned long long)L.blocks_h * 64ull;
         if (L.coef_offset > info->coef_count || n > info->coef_count - L.coef_offset) return false;
@@ -462,7 +477,8 @@ struct Walk {
     bool done = false;
 
     int prepare(const uint8_t *data, size_t n, const hvc_jpeg_info *info_, int16_t *coefs_, std::vector<hvc::WideDc> *wide_) {
-        if (!data || !info_ || !coefs_ || !info_is_sane(info_)) return HVC_E_INVALID_ARG;
+        if (!data || !info_ || !info_is_sane(info_, true)) return HVC_E_INVALID_ARG;
+        if (!coefs_ && info_->coef_count) return HVC_E_INVALID_ARG; // (a record without a block needs no memory)
         // (a walk is reused by its thread: everything a previous file left behind starts over)
         for (int i = 0; i < 4; i++) dc_pred[i] = 0, dc[i] = ac[i] = nullptr, part[i] = 0;
         my = mx = bi = 0;
@@ -517,6 +533,8 @@ struct Walk {
         std::memset(ecs.data() + got, 0, room - got); // zero padding: see BitReader
         br = BitReader{ecs.data(), got};
         const hvc_jpeg_component &c0 = info->comp[0];
+        // decode_seq divides by the FIRST component's factors (decoder.ml:377-382): Division_by_zero there
+        if (c0.hscale == 0 || c0.vscale == 0) return HVC_E_BAD_JPEG;
         mbs_wide = c0.decoded_width / (8 * c0.hscale);
         mbs_high = c0.decoded_height / (8 * c0.vscale);
         done = mbs_wide <= 0 || mbs_high <= 0 || info->n_comp <= 0;
@@ -582,16 +600,21 @@ struct Walk {
         const int cat = e & 0xff;
         if (cat > 16) {
             // No JPEG has DC categories above 11 (baseline) / 16; the model, though, reads `cat`
-            // magnitude bits for whatever the table says (decoder.ml:81-96: no check).  Up to 32 bits
+            // magnitude bits for whatever the table says (decoder.ml:81-96: no check).  Up to 62 bits
             // this reader follows it -- such a difference never fits the int16 record (|d| >= 65536),
-            // so only the wide-DC mode goes on -- beyond that the stream is refused.
-            if (cat > 32) return HVC_E_BAD_JPEG;
+            // so only the wide-DC mode goes on -- beyond that OCaml itself leaves the result open.
+            if (cat > HVC_MAX_DC_CAT) return HVC_E_BAD_JPEG;
             if (!wide) return HVC_E_RANGE;
-            br.refill();
-            const unsigned code = (unsigned)(br.buf >> (64 - cat));
-            diff = ((code >> (cat - 1)) & 1u) ? (long long)code : (long long)code - ((1ll << cat) - 1);
-            br.buf <<= cat;
-            br.cnt -= cat;
+            unsigned long long code = 0;
+            for (int left = cat; left > 0;) { // (the window holds 32 bits and more after a refill)
+                const int take = left > 32 ? 32 : left;
+                br.refill();
+                code = (code << take) | (br.buf >> (64 - take));
+                br.buf <<= take;
+                br.cnt -= take;
+                left -= take;
+            }
+            diff = extend_wide(cat, code);
         } else if (cat) { // code + magnitude <= 32 bits: still inside the window
             diff = extend(cat, (unsigned)(br.buf >> (64 - cat)));
             br.buf <<= cat;
@@ -601,7 +624,7 @@ struct Walk {
     }
 
     inline int finish_begin(int i, long long diff) {
-        const long long dcv = diff + dc_pred[i];
+        const long long dcv = add63(diff, dc_pred[i]);
         dc_pred[i] = dcv;
         if (dcv < -32768 || dcv > 32767) {
             if (!wide) return HVC_E_RANGE;
@@ -735,7 +758,7 @@ static int walk_literal(Walk &w) {
     const size_t length_in_bits = w.br.n * 8;
     size_t pos = 0;
     auto show = [&](int n, unsigned &v) -> bool { // false: the model raises
-        if ((size_t)n >= length_in_bits) return false;
+        if ((size_t)n >= length_in_bits) return false; // (so n < 32 from here on: the segment has at most 32 bits)
         v = 0;
         for (int i = 0; i < n; i++) {
             const size_t p = pos + (size_t)i;
@@ -763,12 +786,11 @@ static int walk_literal(Walk &w) {
         const int cat = (int)(e & 0xff);
         long long diff = 0;
         if (cat) {
-            if (cat > 32) return HVC_E_BAD_JPEG; // (as begin_block)
-            if (!show(cat, bitsv)) return HVC_E_BAD_JPEG;
+            if (!show(cat, bitsv)) return HVC_E_BAD_JPEG; // (every category of 32 bits and more ends here: Bits.get raises)
             pos += (size_t)cat;
-            diff = ((bitsv >> (cat - 1)) & 1u) ? (long long)bitsv : (long long)bitsv - ((1ll << cat) - 1);
+            diff = extend_wide(cat, bitsv);
         }
-        const long long dcv = diff + w.dc_pred[i];
+        const long long dcv = add63(diff, w.dc_pred[i]);
         w.dc_pred[i] = dcv;
         if (dcv < -32768 || dcv > 32767) {
             if (!w.wide) return HVC_E_RANGE;
@@ -959,30 +981,63 @@ int hvc_jpeg_entropy_decode2(const uint8_t *jpeg_a, size_t n_a, const hvc_jpeg_i
     return HVC_OK;
 } HVC_ABI_CATCH
 
-// Decoder.crop / get_yuv_frame (decoder.ml:403-420): the actual_w x actual_h top-left part of every
-// padded plane, planes back to back (the layout Frame.output writes, common/src/frame.ml:66-70).
-int hvc_jpeg_get_yuv_frame(const hvc_jpeg_info *info, const uint8_t *pixels, uint8_t *out, size_t cap, size_t *out_len) try {
-    if (!info || !pixels || !out || info->n_comp < 1 || info->n_comp > 4) return HVC_E_INVALID_ARG;
-    size_t need = 0;
-    for (int i = 0; i < info->n_comp; i++) { // (the caller's info: the crop must lie inside the plane it is cut from)
+// Decoder.crop (decoder.ml:403-413) of the first `n_planes` components: the actual_w x actual_h top-left part of each
+// padded plane, planes back to back.  (the caller's info: every crop must lie inside the plane it is cut from)
+static bool crops_are_inside(const hvc_jpeg_info *info) {
+    for (int i = 0; i < info->n_comp; i++) {
         const hvc_jpeg_component &c = info->comp[i];
         const hvc_component &L = info->layout[i];
         if (c.actual_width < 0 || c.actual_height < 0 || c.actual_width > c.decoded_width || c.actual_height > c.decoded_height ||
             L.stride < (size_t)c.decoded_width || L.plane_offset > info->pixel_bytes ||
-            (c.decoded_height > 0 && ((size_t)c.decoded_height - 1) * L.stride + (size_t)c.decoded_width > info->pixel_bytes - L.plane_offset))
-            return HVC_E_INVALID_ARG;
-        need += (size_t)c.actual_width * (size_t)c.actual_height;
+            (c.decoded_height > 0 && c.decoded_width > 0 &&
+             ((size_t)c.decoded_height - 1) * L.stride + (size_t)c.decoded_width > info->pixel_bytes - L.plane_offset))
+            return false;
     }
+    return true;
+}
+static int crop_planes(const hvc_jpeg_info *info, int n_planes, const uint8_t *pixels, uint8_t *out, size_t cap, size_t *out_len) {
+    size_t need = 0;
+    for (int i = 0; i < n_planes; i++) need += (size_t)info->comp[i].actual_width * (size_t)info->comp[i].actual_height;
     if (out_len) *out_len = need;
     if (need > cap) return HVC_E_INVALID_ARG;
+    if (need && (!pixels || !out)) return HVC_E_INVALID_ARG; // (planes without a sample need no memory)
     uint8_t *o = out;
-    for (int i = 0; i < info->n_comp; i++) {
+    for (int i = 0; i < n_planes; i++) {
         const hvc_jpeg_component &c = info->comp[i];
+        if (c.actual_width == 0) continue;
         const uint8_t *p = pixels + info->layout[i].plane_offset;
         for (int y = 0; y < c.actual_height; y++, o += c.actual_width)
             std::memcpy(o, p + (size_t)y * info->layout[i].stride, (size_t)c.actual_width);
     }
     return HVC_OK;
+}
+
+// Decoder.get_yuv_frame (decoder.ml:415-420) = Frame.of_planes of the crops of components 0, 1 and 2 -- and of_planes
+// (common/src/frame.ml:42-61) makes a Frame.t only of planes it can name: `components.(1)` / `.(2)` must exist (Invalid_argument
+// otherwise), the chroma planes must be of one size ("Chroma planes must be same width and height") and that size must be
+// the luma plane's halved both ways, halved in width, or the same (C420 / C422 / C444, tried in this order, integer
+// halves; "Could not infer chroma subsampling").  Everything else the model has decoded -- 4:1:1, 4:4:0, one or two
+// components, a plane without samples beside planes with -- it cannot hand out as a frame: HVC_E_BAD_JPEG, the model's raise.
+// A fourth component is decoded and left out, as there.  Output: the three crops back to back (Frame.output order, frame.ml:66-70).
+int hvc_jpeg_get_yuv_frame(const hvc_jpeg_info *info, const uint8_t *pixels, uint8_t *out, size_t cap, size_t *out_len) try {
+    if (!info || info->n_comp < 1 || info->n_comp > 4 || !crops_are_inside(info)) return HVC_E_INVALID_ARG;
+    if (out_len) *out_len = 0;
+    if (info->n_comp < 3) return HVC_E_BAD_JPEG;
+    const hvc_jpeg_component &y = info->comp[0], &u = info->comp[1], &v = info->comp[2];
+    if (u.actual_width != v.actual_width || u.actual_height != v.actual_height) return HVC_E_BAD_JPEG;
+    const bool c420 = y.actual_width / 2 == u.actual_width && y.actual_height / 2 == u.actual_height;
+    const bool c422 = y.actual_width / 2 == u.actual_width && y.actual_height == u.actual_height;
+    const bool c444 = y.actual_width == u.actual_width && y.actual_height == u.actual_height;
+    if (!c420 && !c422 && !c444) return HVC_E_BAD_JPEG;
+    return crop_planes(info, 3, pixels, out, cap, out_len);
+} HVC_ABI_CATCH
+
+// Array.map crop over Decoder.get_decoded_planes (decoder.ml:399-413): EVERY component's crop, back to back in scan order,
+// whatever the sampling -- what a caller takes where Frame.of_planes has no name for the planes (4:1:1, 4:4:0, grey, four
+// components).  For a frame get_yuv_frame accepts, the same bytes (plus the fourth component's, if there is one).
+int hvc_jpeg_get_cropped_planes(const hvc_jpeg_info *info, const uint8_t *pixels, uint8_t *out, size_t cap, size_t *out_len) try {
+    if (!info || info->n_comp < 1 || info->n_comp > 4 || !crops_are_inside(info)) return HVC_E_INVALID_ARG;
+    return crop_planes(info, info->n_comp, pixels, out, cap, out_len);
 } HVC_ABI_CATCH
 
 } // extern "C"
@@ -1473,9 +1528,13 @@ static int prepare_gpu_decode_impl(const uint8_t *jpeg, size_t n, const ::hvc_jp
         ok = ok && got != SIZE_MAX;
     }
     int per_mcu = 0;
-    for (int i = 0; i < info->n_comp; i++) per_mcu += info->comp[i].hscale * info->comp[i].vscale;
+    bool empty_plane = info->coef_count == 0; // (the model's empty planes: the host reader walks around them)
+    for (int i = 0; i < info->n_comp; i++) {
+        per_mcu += info->comp[i].hscale * info->comp[i].vscale;
+        empty_plane |= info->comp[i].hscale < 1 || info->comp[i].vscale < 1;
+    }
     // (a segment of at most 32 bits: the host reader has the model's length test for those -- walk_literal)
-    gpu_ok = ok && info->n_comp <= 3 && per_mcu <= HVC_HD_MAX_MCU_BLOCKS && got < (1u << 28) && got * 8 > 32;
+    gpu_ok = ok && !empty_plane && info->n_comp <= 3 && per_mcu <= HVC_HD_MAX_MCU_BLOCKS && got < (1u << 28) && got * 8 > 32;
     return HVC_OK;
 }
 } // namespace hvc

@@ -178,25 +178,35 @@ __device__ __forceinline__ unsigned ashr14_sat_pack4(int a, int b, int c, int d)
     return r;
 }
 
-// The same pass in int64, literally as the model writes it (dct.ml:11-98).
+// The same pass as the model writes it (dct.ml:11-98), in the model's arithmetic: OCaml's int is a 63-bit two's
+// complement number that wraps without a word.  Sums and products are kept modulo 2^64 (unsigned: congruent modulo
+// 2^63 to the model's values), and a value is brought to its 63-bit reading where the model LOOKS at it: the operand of
+// an `asr`, the compare of clip.  For everything 16-bit coefficients and 16-bit tables can reach (< 2^47) the reading is
+// the identity; it matters for the DC values a table with 33...62-bit categories produces (include/hvc_jpeg.h).
+__device__ __forceinline__ int64_t ocaml_int(uint64_t x) { return (int64_t)(x << 1) >> 1; }
+template <int S>
+__device__ __forceinline__ uint64_t asr63(uint64_t x) { return S ? (uint64_t)(ocaml_int(x) >> S) : x; }
+
 template <bool COL>
 __device__ __forceinline__ void idct_1d_wide(int64_t *b, int s) {
-    int64_t x0 = COL ? b[0] * 256 + 8192 : b[0] * 2048 + 128;
-    int64_t x1 = COL ? b[4 * s] * 256 : b[4 * s] * 2048;
-    int64_t x2 = b[6 * s], x3 = b[2 * s], x4 = b[1 * s], x5 = b[7 * s], x6 = b[5 * s], x7 = b[3 * s];
-    constexpr int64_t R = COL ? 4 : 0;
+    typedef uint64_t u64;
+    constexpr u64 w1 = (u64)W1, w2 = (u64)W2, w3 = (u64)W3, w5 = (u64)W5, w6 = (u64)W6, w7 = (u64)W7;
+    u64 x0 = COL ? (u64)b[0] * 256u + 8192u : (u64)b[0] * 2048u + 128u;
+    u64 x1 = COL ? (u64)b[4 * s] * 256u : (u64)b[4 * s] * 2048u;
+    u64 x2 = (u64)b[6 * s], x3 = (u64)b[2 * s], x4 = (u64)b[1 * s], x5 = (u64)b[7 * s], x6 = (u64)b[5 * s], x7 = (u64)b[3 * s];
+    constexpr u64 R = COL ? 4 : 0;
     constexpr int RS = COL ? 3 : 0;
-    int64_t x8 = W7 * (x4 + x5) + R;
-    x4 = (x8 + (W1 - W7) * x4) >> RS;
-    x5 = (x8 - (W1 + W7) * x5) >> RS;
-    x8 = W3 * (x6 + x7) + R;
-    x6 = (x8 - (W3 - W5) * x6) >> RS;
-    x7 = (x8 - (W3 + W5) * x7) >> RS;
+    u64 x8 = w7 * (x4 + x5) + R;
+    x4 = asr63<RS>(x8 + (w1 - w7) * x4);
+    x5 = asr63<RS>(x8 - (w1 + w7) * x5);
+    x8 = w3 * (x6 + x7) + R;
+    x6 = asr63<RS>(x8 - (w3 - w5) * x6);
+    x7 = asr63<RS>(x8 - (w3 + w5) * x7);
     x8 = x0 + x1;
     x0 = x0 - x1;
-    x1 = W6 * (x3 + x2) + R;
-    x2 = (x1 - (W2 + W6) * x2) >> RS;
-    x3 = (x1 + (W2 - W6) * x3) >> RS;
+    x1 = w6 * (x3 + x2) + R;
+    x2 = asr63<RS>(x1 - (w2 + w6) * x2);
+    x3 = asr63<RS>(x1 + (w2 - w6) * x3);
     x1 = x4 + x6;
     x4 = x4 - x6;
     x6 = x5 + x7;
@@ -205,19 +215,21 @@ __device__ __forceinline__ void idct_1d_wide(int64_t *b, int s) {
     x8 = x8 - x3;
     x3 = x0 + x2;
     x0 = x0 - x2;
-    int64_t ys = x4 + x5, yd = x4 - x5;
-    x2 = (181 * ys + 128) >> 8;
-    x4 = (181 * yd + 128) >> 8;
+    const u64 ys = x4 + x5, yd = x4 - x5;
+    x2 = asr63<8>(181u * ys + 128u);
+    x4 = asr63<8>(181u * yd + 128u);
     constexpr int S = COL ? 14 : 8;
-    b[0] = (x7 + x1) >> S;
-    b[1 * s] = (x3 + x2) >> S;
-    b[2 * s] = (x0 + x4) >> S;
-    b[3 * s] = (x8 + x6) >> S;
-    b[4 * s] = (x8 - x6) >> S;
-    b[5 * s] = (x0 - x4) >> S;
-    b[6 * s] = (x3 - x2) >> S;
-    b[7 * s] = (x7 - x1) >> S;
+    b[0] = (int64_t)asr63<S>(x7 + x1);
+    b[1 * s] = (int64_t)asr63<S>(x3 + x2);
+    b[2 * s] = (int64_t)asr63<S>(x0 + x4);
+    b[3 * s] = (int64_t)asr63<S>(x8 + x6);
+    b[4 * s] = (int64_t)asr63<S>(x8 - x6);
+    b[5 * s] = (int64_t)asr63<S>(x0 - x4);
+    b[6 * s] = (int64_t)asr63<S>(x3 - x2);
+    b[7 * s] = (int64_t)asr63<S>(x7 - x1);
 }
+// decoder.ml:142-149 `coefs.(i) * qnt_tab.(i)` in the same arithmetic (the factors: an int16 or a 63-bit DC, a 16-bit entry)
+__device__ __forceinline__ int64_t mul63(int64_t a, int64_t b) { return (int64_t)((uint64_t)a * (uint64_t)b); }
 
 // ---------------------------------------------------------------------------
 // Work decomposition shared by the fast and the wide kernel.
@@ -810,7 +822,7 @@ __global__ __launch_bounds__(64) void k_decode_wide(DecodeParams P, const unsign
         for (int k = 0; k < 64; k++) v[ZI[k]] = (int64_t)cf[k] * (int64_t)q[k];
         if (P.dc_plane) // the DC lives in the compact array (DecodeParams::dc_plane)
             v[0] = (int64_t)P.dc_plane[(size_t)frame * P.dc_fs + ((br.coef_idx - (size_t)frame * P.coef_fs) >> 6)] * (int64_t)q[0];
-        if (dc_list) v[0] = (int64_t)dc_list[i] * (int64_t)q[0];
+        if (dc_list) v[0] = mul63((int64_t)dc_list[i], (int64_t)q[0]);
         for (int r = 0; r < 8; r++) idct_1d_wide<false>(v + r * 8, 1);
         for (int c = 0; c < 8; c++) idct_1d_wide<true>(v + c, 8);
         for (int j = 0; j < 8; j++)
@@ -1077,7 +1089,7 @@ __global__ __launch_bounds__(64) void k_decode_wide_444(Decode444Params P, const
         const int16_t *cf = P.coefs + frame * P.coef_fs + in_frame;
         for (int k = 0; k < 64; k++) v[ZI[k]] = (int64_t)cf[k] * (int64_t)q[k];
         if (P.dc_plane) v[0] = (int64_t)P.dc_plane[frame * P.dc_fs + (in_frame >> 6)] * (int64_t)q[0];
-        if (dc_list) v[0] = (int64_t)dc_list[i] * (int64_t)q[0];
+        if (dc_list) v[0] = mul63((int64_t)dc_list[i], (int64_t)q[0]);
         for (int rr = 0; rr < 8; rr++) idct_1d_wide<false>(v + rr * 8, 1);
         for (int c = 0; c < 8; c++) idct_1d_wide<true>(v + c, 8);
         uint8_t *plane = P.out + frame * P.out_fs + K.out_off;

@@ -22,7 +22,8 @@ SYMBOLS = [
     "hvc_jpeg_decode_batch", "hvc_quant_table", "hvc_jpeg_encoder_layout", "hvc_jpeg_entropy_encode",
     "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444", "hvc_jpeg_decode_yuv444", "hvc_compare_planes", "hvc_jpeg_encode_batch", "hvc_jpeg_decode_batch_yuv444", "hvc_jpeg_encoder_check", "hvc_huffman_encode_frames", "hvc_jpeg_header", "hvc_jpeg_encode_batch_gpu", "hvc_jpeg_entropy_decode_gpu", "hvc_jpeg_decode_batch_gpu",
     "hvc_checksum_records", "hvc_encode_frames_recon", "hvc_set_host_cpus", "hvc_get_host_cpus",
-    "hvc_host_threads", "hvc_host_threads_probe", "hvc_jpeg_entropy_decode2",
+    "hvc_host_threads", "hvc_host_threads_probe", "hvc_jpeg_entropy_decode2", "hvc_jpeg_get_cropped_planes",
+    "hvc_subsample420", "hvc_subsample422", "hvc_upsample422", "hvc_crop_planes", "hvc_yuv_frame_bytes", "hvc_yuv_convert",
 ]
 
 
@@ -120,10 +121,16 @@ def lib():
             L.hvc_fdct_quant.argtypes = [vp, vp, sz, sz, vp, i, i, i, vp, sz, i]
             L.hvc_encode_frames.argtypes = [vp, vp, sz, vp, i, C.POINTER(Component), i, i, vp, sz, i]
             L.hvc_upsample420.argtypes = [vp, vp, i, i, sz, vp, sz, i, sz, sz, i]
+            for f in ("hvc_subsample420", "hvc_subsample422", "hvc_upsample422"):
+                getattr(L, f).argtypes = [vp, vp, i, i, sz, vp, sz, i, sz, sz, i]
+            L.hvc_crop_planes.argtypes = [vp, vp, i, i, sz, i, i, vp, i, i, sz, i, sz, sz, i]
+            L.hvc_yuv_frame_bytes.argtypes = [i, i, i, C.POINTER(sz)]
+            L.hvc_yuv_convert.argtypes = [vp, vp, i, i, i, i, i, vp, i, i, i, i, i]
         ip = C.POINTER(JpegInfo)
         L.hvc_jpeg_read_header.argtypes = [vp, sz, ip]
         L.hvc_jpeg_entropy_decode.argtypes = [vp, sz, ip, vp]
         L.hvc_jpeg_get_yuv_frame.argtypes = [ip, vp, vp, sz, C.POINTER(sz)]
+        L.hvc_jpeg_get_cropped_planes.argtypes = [ip, vp, vp, sz, C.POINTER(sz)]
         L.hvc_jpeg_entropy_decode2.argtypes = [vp, sz, ip, vp, C.POINTER(i), vp, sz, ip, vp, C.POINTER(i)]
         L.hvc_jpeg_decode.argtypes = [vp, vp, sz, ip, vp, sz]
         L.hvc_jpeg_decode_yuv444.argtypes = [vp, vp, sz, ip, vp, sz]
@@ -220,12 +227,33 @@ def jpeg_entropy_decode2(data_a: bytes, data_b: bytes):
 
 
 def jpeg_get_yuv_frame(info, pixels):
+    """Decoder.get_yuv_frame: the crops of components 0, 1, 2 back to back -- HvcError(HVC_E_BAD_JPEG) where the model's
+    Frame.of_planes raises (fewer than three components, planes it cannot name as 4:2:0 / 4:2:2 / 4:4:4)."""
+    pixels = np.ascontiguousarray(pixels, dtype=np.uint8)
+    need = sum(info.comp[i].actual_width * info.comp[i].actual_height for i in range(min(info.n_comp, 3)))
+    out = np.empty(need, dtype=np.uint8)
+    n = C.c_size_t()
+    _chk(lib().hvc_jpeg_get_yuv_frame(C.byref(info), pixels.ctypes.data, out.ctypes.data, need, C.byref(n)))
+    return out[:n.value]
+
+
+def jpeg_get_cropped_planes(info, pixels):
+    """Decoder.crop over every decoded plane, back to back in scan order, whatever the sampling."""
     pixels = np.ascontiguousarray(pixels, dtype=np.uint8)
     need = sum(info.comp[i].actual_width * info.comp[i].actual_height for i in range(info.n_comp))
     out = np.empty(need, dtype=np.uint8)
     n = C.c_size_t()
-    _chk(lib().hvc_jpeg_get_yuv_frame(C.byref(info), pixels.ctypes.data, out.ctypes.data, need, C.byref(n)))
+    _chk(lib().hvc_jpeg_get_cropped_planes(C.byref(info), pixels.ctypes.data, out.ctypes.data, need, C.byref(n)))
     return out
+
+
+YUV_FORMATS = {"420": 420, "422": 422, "444": 444, "YUY2": 1, "UYVY": 2, "YVYU": 3}   # Yuv_format.arg_type (yuv_format.ml:66-77)
+
+
+def yuv_frame_bytes(fmt, width, height):
+    n = C.c_size_t()
+    _chk(lib().hvc_yuv_frame_bytes(fmt, width, height, C.byref(n)), "hvc_yuv_frame_bytes")
+    return n.value
 
 
 def quant_table(chroma_table, quality):
@@ -546,3 +574,39 @@ class Context:
         assert w1 == w2
         _chk(lib().hvc_upsample420(self._h, sa, cw, ch, src_stride or cw, da, dst_stride or 2 * cw, n_planes,
                                    src_plane_stride, dst_plane_stride, w1))
+
+    def _plane_op(self, name, src, sw, sh, dst, dw, n_planes, src_stride, dst_stride, src_plane_stride, dst_plane_stride):
+        sa, w1 = _addr(src)
+        da, w2 = _addr(dst)
+        assert w1 == w2
+        _chk(getattr(lib(), name)(self._h, sa, sw, sh, src_stride or sw, da, dst_stride or dw, n_planes, src_plane_stride,
+                                  dst_plane_stride, w1), name)
+
+    def subsample420(self, src, sw, sh, dst, n_planes=1, src_stride=None, dst_stride=None, src_plane_stride=0, dst_plane_stride=0):
+        """Planar_444.subsample_hv2: sw x sh -> (sw // 2) x (sh // 2)"""
+        self._plane_op("hvc_subsample420", src, sw, sh, dst, sw // 2, n_planes, src_stride, dst_stride, src_plane_stride, dst_plane_stride)
+
+    def subsample422(self, src, sw, sh, dst, n_planes=1, src_stride=None, dst_stride=None, src_plane_stride=0, dst_plane_stride=0):
+        """Planar_444.subsample_h2: sw x sh -> (sw // 2) x sh"""
+        self._plane_op("hvc_subsample422", src, sw, sh, dst, sw // 2, n_planes, src_stride, dst_stride, src_plane_stride, dst_plane_stride)
+
+    def upsample422(self, src, cw, h, dst, n_planes=1, src_stride=None, dst_stride=None, src_plane_stride=0, dst_plane_stride=0):
+        """Planar_444.supersample_h2: cw x h -> 2cw x h"""
+        self._plane_op("hvc_upsample422", src, cw, h, dst, 2 * cw, n_planes, src_stride, dst_stride, src_plane_stride, dst_plane_stride)
+
+    def crop_planes(self, src, sw, sh, x_pos, y_pos, dst, dw, dh, n_planes=1, src_stride=None, dst_stride=None,
+                    src_plane_stride=0, dst_plane_stride=0):
+        """Yuv.crop of one plane (clamped source coordinates)"""
+        sa, w1 = _addr(src)
+        da, w2 = _addr(dst)
+        assert w1 == w2
+        _chk(lib().hvc_crop_planes(self._h, sa, sw, sh, src_stride or sw, x_pos, y_pos, da, dw, dh, dst_stride or dw, n_planes,
+                                   src_plane_stride, dst_plane_stride, w1), "hvc_crop_planes")
+
+    def yuv_convert(self, src, src_format, src_size, dst, dst_format, dst_size, offset=(0, 0), n_frames=1):
+        """Oconv.main's loop body: n_frames raw frames of src_format / src_size -> dst_format / dst_size"""
+        sa, w1 = _addr(src)
+        da, w2 = _addr(dst)
+        assert w1 == w2
+        _chk(lib().hvc_yuv_convert(self._h, sa, src_format, src_size[0], src_size[1], offset[0], offset[1], da, dst_format,
+                                   dst_size[0], dst_size[1], n_frames, w1), "hvc_yuv_convert")
