@@ -36,9 +36,12 @@ The JSON line also carries
                 values tests/golden/bench_checksums.json holds for these seeds -- which the CPU suite
                 reproduces from the model restatement (tests/test_bench_checksums.py): the timed output is
                 the model's output, not just fast;
-  sustained     >= --sustain-seconds (2 s) of the same step repeated AFTER the K timed steps, one event pair per step:
+  sustained     >= --sustain-seconds (6 s) of the same step repeated AFTER the K timed steps, one event pair per step:
                 first / last decile of the step time (clock or thermal drift would show), the GPU-busy fraction; never
                 part of `value` / `ms_per_step`, which come from the K timed steps alone;
+  others        (1 GPU, config 2) the other figures of DESIGN.md measured in this run, after the timed region: config 4's launch
+                shape, K3, the fused 4:4:4 kernel, K2, subsample_hv2 (ms, fraction of 8 TB/s), configs 3 and 5 as pipelines
+                with the host and the GPU entropy stage (Gpixel/s, threads, what binds them); each K5-verified;
   cpu_baseline  the CPU restatement of the model path (oracle/hvc_oracle.c, scalar, 1 thread) timed on this
                 host on a bounded sample of the same workload.  The oracle is the checker, timed as a
                 baseline only: this leg is its only use here (parity is the job of tests/).
@@ -135,21 +138,79 @@ def cpu_baseline(frames, qtabs, planes, pixels_per_frame, min_seconds=10.0):
                           "sample": "%d frames, %.1f s, frame-sharded threads" % (cores * per_thread, dtm)}}
 
 
-def measured_traffic(config, frames):
+DOMINANT_KERNEL = "k_decode_packed"   # what this file's step launches (hvc_decode_frames, default kernel choice)
+
+
+def measured_traffic(config, frames, kernel=DOMINANT_KERNEL):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate --pmc runs of this very
     command and corrected as MI355X_MICROARCH.md prescribes).  bench.py cannot collect counters
-    itself: (None, reason) when the profile is absent or was taken at another configuration."""
+    itself: (None, reason) when the profile is absent, was taken at another configuration or launch
+    size, or belongs to another kernel than the one this run launched (an entry names its kernel
+    symbol; one that does not is not trusted)."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
+        stale = None
         for e in t.get("entries", [t]):
             if e.get("frames_per_launch") == frames and e.get("config", 2) == config:
-                return round(e["hbm_bytes"]), "profiles/traffic.json (session %s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
-                                              "this command, not collected in this run" % (e.get("session") or "r01f")
-        return None, "no committed PMC pass for config %d at %d frames per launch" % (config, frames)
+                if not str(e.get("kernel", "")).startswith(kernel):
+                    stale = "profiles/traffic.json has a pass for this configuration, but of kernel %r, not %r: not reported" % (e.get("kernel"), kernel)
+                    continue
+                return round(e["hbm_bytes"]), "profiles/traffic.json (session %s, kernel %s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
+                                              "this command, not collected in this run" % (e.get("session") or "r01f", e["kernel"])
+        return None, stale or "no committed PMC pass for config %d at %d frames per launch" % (config, frames)
     except (OSError, ValueError, KeyError):
         return None, "profiles/traffic.json absent"
+
+
+def other_measurements(threads):
+    """`others` of the JSON line: the figures DESIGN.md quotes beside the headline, measured in this very run AFTER everything
+    `value` is made of (tools/bench_configs.py's functions, called, not shelled out; each K5-verified against
+    tests/golden/bench_checksums.json).  Kernels: ms per launch and the fraction of 8 TB/s their algorithmic bytes make;
+    pipelines: Gpixel/s and what binds them.  Never part of `value`."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs as bc
+    cpus = len(os.sched_getaffinity(0))
+    try:  # the pod's CPU quota (cgroup v2 cpu.max: "quota period"): what the host stages really have, whatever the mask shows
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        cpu_quota = None if quota == "max" else round(int(quota) / int(period), 2)
+    except (OSError, ValueError):
+        cpu_quota = None
+    out = {"host": {"cpus_in_affinity_mask": cpus, "cgroup_cpu_quota": cpu_quota, "threads_used": threads}}
+
+    def run(name, fn, bound, pick):
+        t0 = time.perf_counter()
+        try:
+            r = fn()
+            e = pick(r)
+            e["bound"] = bound
+            e["verified"] = (r.get("checksum") or {}).get("verified")
+        except Exception as ex:  # (one entry failing must not take the headline line with it; the entry says so)
+            e = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        e["wall_s"] = round(time.perf_counter() - t0, 1)
+        out[name] = e
+        torch.cuda.empty_cache()
+
+    kern = lambda r: {"ms": r["kernel_ms"], "frac_of_8TBps": r["frac_of_8TBps"], "algorithmic_GBps": r["algorithmic_GBps"]}
+    pipe = lambda r: {"Gpixel_s": round(r["value"] / 1e3, 2), "frames": r["frames"], "wall_ms": r["wall_ms"], "threads": r["host_threads"],
+                      "frames_per_chunk": r["frames_per_chunk"]}
+    run("config4_launch_128x4K444", lambda: bc.resident_decode(bc.make_args(frames=128, steps=16, warmup=4),
+                                                               [(480, 270, 0), (480, 270, 1), (480, 270, 1)], 3840, 2160, 4), "hbm", kern)
+    run("k3_encode_256x4K420", lambda: bc.config5(bc.make_args(frames=256, steps=20, warmup=5)), "hbm", kern)
+    run("fused444_512x1080p", lambda: bc.config_444(bc.make_args(frames=512, steps=20, warmup=5, fused_only=True)), "hbm",
+        lambda r: {"ms": r["fused_ms"], "frac_of_8TBps": r["frac_of_8TBps"], "algorithmic_GBps": r["algorithmic_GBps"]})
+    run("k2_upsample420_512_planes", lambda: bc.config_k2(bc.make_args(frames=256, steps=20, warmup=5)), "hbm", kern)
+    run("subsample420_512_planes", lambda: bc.config_sub420(bc.make_args(frames=256, steps=20, warmup=5)), "hbm", kern)
+    # BASELINE config 3 at its own size (4096 x 1080p files), config 5 end to end on 256 x 4K frames
+    run("config3_host_reader_4096_files", lambda: bc.config3(bc.make_args(frames=4096, steps=2, threads=threads, chunk=32)), "host", pipe)
+    run("config3_gpu_reader_4096_files", lambda: bc.config3(bc.make_args(frames=4096, steps=2, threads=threads, chunk=256, gpu_entropy=True)),
+        "pcie", pipe)
+    run("config5_files_host_coder_256_frames", lambda: bc.config5_files(bc.make_args(frames=256, steps=2, threads=threads, chunk=16)), "host", pipe)
+    run("config5_files_gpu_coder_256_frames", lambda: bc.config5_files(bc.make_args(frames=256, steps=2, threads=threads, chunk=16, gpu_entropy=True)),
+        "pcie", pipe)
+    return out
 
 
 def expected_checksums(config, n_distinct, rank):
@@ -247,6 +308,46 @@ def max_over_ranks(dt, world, dist=None, device="cpu"):
     return float(t.item())
 
 
+def gather_over_ranks(values, world, dist=None, device="cpu"):
+    """every rank's list of floats on every rank ([rank][k]): the per-rank kernel times of rank 0's line, so that a slow
+    GPU shows in the scaling record instead of hiding inside the MAX over ranks.  Timing closure like the barrier: the
+    data path has no collective."""
+    if not use_group(world):
+        return [list(values)]
+    import torch
+    mine = torch.tensor(list(values), dtype=torch.float64, device=device)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return [[float(x) for x in p.tolist()] for p in parts]
+
+
+def parse_cpulist(text):
+    """'0-15,32-47' -> [0, ..., 15, 32, ..., 47] (the format of sysfs local_cpulist and of hvc_get_host_cpus)"""
+    cpus = []
+    for part in text.strip().split(","):
+        if part:
+            a, _, b = part.partition("-")
+            cpus.extend(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def bind_rank_to_gpu_node(ctx):
+    """N > 1 on one node: the rank's launch thread and the context's host threads on the CPUs of the GPU's NUMA node
+    (hvc_set_host_cpus "auto" = the local_cpulist of the GPU's PCI function, inside the process's own mask) -- a step of
+    config 4 is 16 launches of 1.6 ms, little slack for a launch thread on the other socket.  Returns the CPU list as text,
+    or None where the node cannot be told (then nothing is changed)."""
+    try:
+        ctx.set_host_cpus("auto")
+        text, n = ctx.get_host_cpus()
+        cpus = parse_cpulist(text) if n > 0 else []
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            return text
+    except Exception:
+        pass
+    return None
+
+
 def whole_job_mpixels(world, frames_per_gpu, steps, dt, pixels_per_frame=W * H):
     """value = units ALL ranks processed / max-over-ranks time (weak scaling: per-GPU work fixed)."""
     return world * frames_per_gpu * steps * pixels_per_frame / dt / 1e6
@@ -281,7 +382,8 @@ def parse_args(argv=None):
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames (replicated)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--sustain-seconds", type=float, default=2.0,
+    ap.add_argument("--no-others", action="store_true", help="skip `others` (configs 3 / 4 / 5 and the other kernels, after the timed region)")
+    ap.add_argument("--sustain-seconds", type=float, default=6.0,
                     help="after the K timed steps: this many seconds of the same step back to back, reported as "
                          "`sustained` (never part of `value`); 0 = skip")
     args = ap.parse_args(argv)
@@ -306,7 +408,10 @@ def run_without_gpu(args, rank, world):
         calls.append(1)
         time.sleep(0.001 * (rank + 1))
 
-    dt = max_over_ranks(timed_steps(step, args.steps, args.warmup, lambda: None, world, dist), world, dist, "cpu")
+    dt_local = timed_steps(step, args.steps, args.warmup, lambda: None, world, dist)
+    dt = max_over_ranks(dt_local, world, dist, "cpu")
+    step_ms = 1.0 * (rank + 1)   # (what stands in for a rank's kernel time here: its sleep)
+    per_rank = gather_over_ranks([step_ms, step_ms, step_ms], world, dist, "cpu")
     if rank == 0:
         wl = WORKLOADS[args.config]
         print(json.dumps({"metric": wl["metric"], "value": round(whole_job_mpixels(world, args.shard, args.steps, dt, wl["W"] * wl["H"]), 1),
@@ -314,7 +419,9 @@ def run_without_gpu(args, rank, world):
                           "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "int32",
                           "data": "none: launch-path rehearsal without a GPU (HVC_BENCH_NO_GPU=1), nothing decoded, not a measurement",
-                          "config": {"workload": wl["name"], "step_calls_rank0": len(calls)}}), flush=True)
+                          "config": {"workload": wl["name"], "step_calls_rank0": len(calls)},
+                          "per_rank_kernel_ms": {"mean_min_max": [[round(x, 4) for x in r] for r in per_rank],
+                                                 "what": "launch-path rehearsal: each rank's sleep per step"}}), flush=True)
     if use_group(world):
         dist.destroy_process_group()
 
@@ -344,6 +451,7 @@ def main():
     dist = dist_init(world, "gloo" if rehearsal else "nccl", torch.device("cuda", local_rank))
 
     ctx = hvc.Context(local_rank)  # raises without a gfx950 GPU: there is no CPU fallback
+    node_cpus = bind_rank_to_gpu_node(ctx) if (world > 1 and not rehearsal) else None
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     d_distinct, qtabs = make_distinct_frames(ctx, hvc, planes, args.distinct, wl["seed"], rank)
     specs, cfs, pfs = hvc.hvc.frame_layout(planes)
@@ -389,6 +497,8 @@ def main():
     if sustained is not None:  # ... and what the sustained run left behind is still the model's output
         again = [int(x) for x in ctx.checksum_records(d_pix, pfs, min(args.distinct, held))]
         sustained["output_unchanged"] = again == sums
+    per_rank = gather_over_ranks([float(np.mean(kernel_ms)), float(np.min(kernel_ms)), float(np.max(kernel_ms))], world, dist,
+                                 "cpu" if rehearsal else "cuda")
     frames_host = d_distinct.cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     ok_local = want is not None and sums == want
     if use_group(world):  # every rank's output is verified; rank 0 reports how many were
@@ -439,12 +549,21 @@ def main():
                          "verification": "compared on every rank" if want is not None else
                                          "SKIPPED: no golden checksums for this run (--distinct > 8 or no entry for this rank)"},
         }
+        out["per_rank_kernel_ms"] = {"mean_min_max": [[round(x, 4) for x in r] for r in per_rank],
+                                     "slowest_over_fastest": round(max(r[0] for r in per_rank) / min(r[0] for r in per_rank), 4),
+                                     "rank0_cpus": node_cpus,
+                                     "what": "k_decode_packed's event-timed launches inside the timed region, every rank's own"}
         if sustained is not None:
             out["sustained"] = sustained
+    ctx.close()
+    if rank == 0:
+        if world == 1 and args.config == 2 and not args.no_others and not rehearsal:
+            del d_coefs, d_pix, d_distinct   # (the headline's 9.6 GB: the other workloads bring their own)
+            torch.cuda.empty_cache()
+            out["others"] = other_measurements(min(16, len(os.sched_getaffinity(0))))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames_host, qtabs, planes, PW * PH, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    ctx.close()
     if use_group(world):
         dist.destroy_process_group()
     # a run whose output is not the model's is not a measurement: the line above says so ("verified": false) and the

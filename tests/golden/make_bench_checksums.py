@@ -5,7 +5,8 @@ the benchmarks decode, computed with the CPU restatement of the model on the ben
     bench.py --config 2 / 4    distinct frame f of rank r: synth_frame_pixels(seed + 1000 r + 16 f) ->
                                Encoder block stage at quality 75 (encoder.ml:81-108) -> Decoder block stage
                                (decoder.ml:142-149, 213-224) -> padded pixel record
-    tools/bench_configs.py     config 3 (files -> padded planes), 4, 5 (pixels -> coefficient records), 7 (fused 4:4:4)
+    tools/bench_configs.py     config 3 (files -> padded planes), 4, 5 (pixels -> coefficient records), 7 (fused 4:4:4),
+                               K2 / subsample_hv2 (random planes), 5-files (raw frames -> the model encoder's files)
 
 bench.py and tools/bench_configs.py read the file (data, not the oracle) and report `verified`;
 tests/test_bench_checksums.py re-derives entries from the oracle on every CPU run."""
@@ -104,13 +105,39 @@ def c7_entry(n_distinct=4):
     return out
 
 
+def _random_planes(seed, n_distinct, h, w):
+    return np.random.Generator(np.random.PCG64(seed)).integers(0, 256, size=(n_distinct, h, w)).astype(np.uint8)
+
+
+def k2_entry(n_distinct=4):
+    """tools/bench_configs.py config_k2: supersample_hv2 (planar_444.ml:82-103) of seeded random 960 x 540 planes"""
+    return ["%016x" % int(checksum_records(orc.supersample_hv2(p).reshape(1, -1))[0]) for p in _random_planes(5, n_distinct, 540, 960)]
+
+
+def sub420_entry(n_distinct=4):
+    """config_sub420: subsample_hv2 (planar_444.ml:69-80) of seeded random 1920 x 1080 planes"""
+    return ["%016x" % int(checksum_records(orc.subsample_hv2(p, 960, 540).reshape(1, -1))[0]) for p in _random_planes(6, n_distinct, 1080, 1920)]
+
+
+def c5_files_entry(n_distinct=4):
+    """config5_files: Encoder.encode_420 ~quality:75 of seeded 4K frames -> the K5 checksum of each file's bytes"""
+    W, H = 3840, 2160
+    out = []
+    for f in range(n_distinct):
+        y, u, v = synth_pixels(110 + f, H, W), synth_pixels(120 + f, H // 2, W // 2), synth_pixels(130 + f, H // 2, W // 2)
+        jpg = np.frombuffer(orc.encode_yuv(y, u, v, W, H, 420, 75), dtype=np.uint8)
+        out.append("%016x" % int(checksum_records(jpg[None, :])[0]))
+    return out
+
+
 def main():
     g = {"comment": "K5 checksums of the benchmarks' decoded distinct frames per the CPU restatement of the model; "
                     "written by tests/golden/make_bench_checksums.py",
          "bench_config2": bench_entry(2, range(8)),
          "bench_config4": bench_entry(4, range(8)),
          "configs_c3": c3_entry(), "configs_c4": resident_entry([(480, 270, 0), (480, 270, 1), (480, 270, 1)], 40),
-         "configs_c5": c5_entry(), "configs_c7": c7_entry()}
+         "configs_c5": c5_entry(), "configs_c7": c7_entry(), "configs_k2": k2_entry(), "configs_sub420": sub420_entry(),
+         "configs_c5_files": c5_files_entry()}
     with open(os.path.join(ROOT, "tests", "golden", "bench_checksums.json"), "w") as f:
         json.dump(g, f, indent=1)
     print("written")

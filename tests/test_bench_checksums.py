@@ -56,3 +56,6 @@ def test_tools_bench_configs_entries_follow_from_the_model():
     assert mk.c3_entry(1) == G["configs_c3"][:1]
     assert mk.c5_entry(1) == G["configs_c5"][:1]
     assert mk.c7_entry(1) == G["configs_c7"][:1]
+    assert mk.k2_entry(1) == G["configs_k2"][:1]
+    assert mk.sub420_entry(1) == G["configs_sub420"][:1]
+    assert mk.c5_files_entry(1) == G["configs_c5_files"][:1]

@@ -56,6 +56,25 @@ def test_single_rank_needs_no_process_group():
     dt = bench.timed_steps(lambda: n.append(1), steps=3, warmup=1, sync=lambda: None, world=1)
     assert len(n) == 4 and dt >= 0
     assert bench.max_over_ranks(dt, 1) == dt
+    assert bench.gather_over_ranks([1.5, 1.0, 2.0], 1) == [[1.5, 1.0, 2.0]]
+    assert bench.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and bench.parse_cpulist("") == []
+
+
+def test_traffic_entry_must_name_the_kernel_that_ran(tmp_path, monkeypatch):
+    """roofline.traffic is a committed PMC pass, not a per-run measurement: bench.py quotes it only for the configuration,
+    the launch size AND the kernel symbol it has just run"""
+    sys.path.insert(0, ROOT)
+    import bench
+    got, src = bench.measured_traffic(2, 1024)
+    assert got is not None and "k_decode_packed" in src
+    assert bench.measured_traffic(2, 1000)[0] is None                      # another launch size
+    got, why = bench.measured_traffic(2, 1024, kernel="k_decode_ldsdma")   # another kernel behind the same step
+    assert got is None and "k_decode_packed" in why
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "traffic.json").write_text(json.dumps({"entries": [{"config": 2, "frames_per_launch": 1024, "hbm_bytes": 1.0}]}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.measured_traffic(2, 1024)[0] is None                      # an entry that does not say which kernel: not trusted
 
 
 def _clean_env(**extra):
@@ -123,6 +142,9 @@ def test_eight_ranks_as_the_driver_will_start_them():
         rec = _json_line(out.stdout)
         assert rec["n_gpus"] == 8 and rec["steps"] == 3 and rec["scaling"] == "weak"
         assert rec["ms_per_step"] >= 8.0  # rank 7 sleeps 8 ms a step and bounds the job
+        # every rank's own figure reaches rank 0's line (gathered over the group that closes the timing): a slow GPU shows
+        per_rank = rec["per_rank_kernel_ms"]["mean_min_max"]
+        assert [r[0] for r in per_rank] == [float(k + 1) for k in range(8)]
         frames = 1024 if config == 2 else 256
         px = 1920 * 1080 if config == 2 else 3840 * 2160
         assert abs(rec["value"] - 8 * frames * px / (rec["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * rec["value"]

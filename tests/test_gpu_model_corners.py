@@ -108,29 +108,42 @@ def test_frames_without_width_or_height(ctx, which):
 # ---------------------------------------------------------------------------------------------------------------------
 
 def wide_dc_file_420(cats, w, h, q0, seed):
-    """a 4:2:0 file: every component's DC differences take the given categories in turn (random magnitudes and signs)"""
+    """a 4:2:0 file: every component's DC differences take the given categories in turn (random magnitudes and signs).
+    cats = "wrap": absolute DCs of m * 2^56 + s with small s, to be used with q0 = 128 -- the dequantised DC is
+    m * 2^63 + 128 s, which the model's 63-bit multiplication turns into 128 s: blocks of ordinary grey levels whose every
+    bit depends on the wrap-around (differences of 57 ... 62 bits)"""
     rng = np.random.Generator(np.random.PCG64(seed))
     Wr, Hr = -(-w // 16) * 16, -(-h // 16) * 16
     nbs = [(Wr // 8) * (Hr // 8), (Wr // 16) * (Hr // 16), (Wr // 16) * (Hr // 16)]
     rec = np.zeros((sum(nbs), 64), dtype=object)
     at = 0
     for ci, nb in enumerate(nbs):
+        bw = Wr // 8 if ci == 0 else Wr // 16
+        # the blocks of the component in SCAN order (decode_seq, decoder.ml:374-395): the writer codes the differences of
+        # blocks that follow each other there, and every one of them has to have its chosen category
+        if ci == 0:
+            order = [(2 * my + sy) * bw + 2 * mx + sx for my in range(Hr // 16) for mx in range(Wr // 16) for sy in range(2) for sx in range(2)]
+        else:
+            order = list(range(nb))
         acc = 0
-        for i in range(nb):
-            c = cats[(i + ci) % len(cats)]
-            if c:
-                mag = (1 << (c - 1)) | (int(rng.integers(0, 1 << 62)) & ((1 << (c - 1)) - 1))
-                acc += mag if rng.integers(0, 2) else -mag
-            rec[at + i, 0] = acc
+        for i, b in enumerate(order):
+            if cats == "wrap":
+                acc = (int(rng.integers(-15, 16)) << 56) + int(rng.integers(-7, 8))
+            else:
+                c = cats[(i + ci) % len(cats)]
+                if c:
+                    mag = (1 << (c - 1)) | (int(rng.integers(0, 1 << 62)) & ((1 << (c - 1)) - 1))
+                    acc += mag if rng.integers(0, 2) else -mag
+            rec[at + b, 0] = acc
             for k in rng.choice(np.arange(1, 64), size=int(rng.integers(0, 6)), replace=False):
-                rec[at + i, int(k)] = int(rng.integers(-40, 41))
+                rec[at + b, int(k)] = int(rng.integers(-40, 41))
         at += nb
     qt = np.stack([np.concatenate([[q0], np.arange(2, 65)]), np.concatenate([[q0], np.arange(64, 1, -1)])]).astype(np.uint16)
     return jpeg_optimised_tables(w, h, 420, qt, rec.reshape(-1), table_sets=2)
 
 
 @pytest.mark.parametrize("cats,q0", [([33, 35, 40, 0, 47], 1), ([48, 55, 61, 62], 1), ([62, 62, 62], 255), ([20, 33, 11, 62, 47, 3], 97),
-                                     ([40, 41, 42, 43], 2)])
+                                     ([40, 41, 42, 43], 2), ("wrap", 128)])
 def test_dc_categories_up_to_62_bits(ctx, cats, q0):
     """decoder.ml:81-96 reads whatever category the table names; from there on the model computes modulo 2^63.  The
     files-to-pixels entry points carry such DCs on the side list through the int64 fix-up, which reads its sums and
@@ -138,8 +151,10 @@ def test_dc_categories_up_to_62_bits(ctx, cats, q0):
     planes, one file at a time, fused 4:4:4, and both batch pipelines."""
     import torch
     import video_coding_amd as hvc
-    files = [wide_dc_file_420(cats, 72, 40, q0, 10 * sum(cats) + k) for k in range(3)]
+    files = [wide_dc_file_420(cats, 72, 40, q0, (10 * sum(cats) if cats != "wrap" else 5) + k) for k in range(3)]
     wants = [model(j) for j in files]
+    if cats == "wrap":   # (the point of this case: not saturated planes but grey levels made by the wrap-around)
+        assert all(len(np.unique(d.plane(0))) > 20 for d in wants)
     assert max(int(np.abs(orc.Decoder(j).coef_record().astype(np.float64)).max()) for j in files) > 2.0 ** 31
     info = hvc.hvc.jpeg_read_header(files[0])
     for j, d in zip(files, wants):

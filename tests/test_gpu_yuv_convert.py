@@ -43,16 +43,25 @@ def test_g7_kats_on_the_gpu(ctx):
 
 
 def test_g7_packed_kat_on_the_gpu(ctx):
-    """tools/src/packed_422.ml:56-104 through hvc_yuv_convert: planar 4:2:2 -> YUY2 -> planar 4:2:2"""
+    """tools/src/packed_422.ml:56-104 through hvc_yuv_convert.  Oconv always passes through a 4:4:4 frame (oconv.ml:12-51), so
+    the chroma samples of a 4:2:2 -> YUY2 conversion are supersample_h2 then subsample_h2 of the frame's (not the identity:
+    avg2 50 55 = 53); the luma samples and every byte's PLACE are the expect test's."""
     import video_coding_amd as hvc
     g = golden_json("g7_packed422.json")
-    frame = np.concatenate([A(g["frame"][0:4]).reshape(-1), A(g["frame"][4:8]).reshape(-1), A(g["frame"][8:12]).reshape(-1)])
+    y, u, v = A(g["frame"][0:4]), A(g["frame"][4:8]), A(g["frame"][8:12])
+    frame = np.concatenate([y.reshape(-1), u.reshape(-1), v.reshape(-1)])
     packed = np.zeros(32, np.uint8)
     ctx.yuv_convert(frame, 422, (4, 4), packed, hvc.hvc.YUV_FORMATS["YUY2"], (4, 4))
-    assert packed.reshape(4, 8).tolist() == g["packed"]
+    u2, v2 = (orc.subsample_h2(orc.supersample_h2(p), 2, 4) for p in (u, v))    # (pinned by G7's 444<->422 frames)
+    kat = np.array(g["packed"], dtype=np.uint8).reshape(4, 2, 4)
+    got = packed.reshape(4, 2, 4)
+    assert np.array_equal(got[:, :, 0], kat[:, :, 0]) and np.array_equal(got[:, :, 2], kat[:, :, 2])   # Y0, Y1 as in the expect test
+    assert np.array_equal(got[:, :, 1], u2) and np.array_equal(got[:, :, 3], v2)                       # U and V at their places
+    assert packed.tobytes() == orc.oconv_frame(frame, 422, (4, 4), "YUY2", (4, 4))
     back = np.zeros(32, np.uint8)
-    ctx.yuv_convert(packed, hvc.hvc.YUV_FORMATS["YUY2"], (4, 4), back, 422, (4, 4))
-    assert np.array_equal(back, frame)
+    ctx.yuv_convert(np.array(g["packed"], dtype=np.uint8).reshape(-1), hvc.hvc.YUV_FORMATS["YUY2"], (4, 4), back, 422, (4, 4))
+    assert np.array_equal(back[:16], y.reshape(-1))                                                     # the unpacked luma plane
+    assert back.tobytes() == orc.oconv_frame(np.array(g["packed"], dtype=np.uint8).reshape(-1), "YUY2", (4, 4), 422, (4, 4))
 
 
 @pytest.mark.parametrize("device", [False, True])
@@ -99,8 +108,8 @@ def test_plane_operations_on_random_planes(ctx, device):
                 assert (got[p, :, 2 * w:] == 0xAA).all()
             # Yuv.crop: inside, shifted out of every edge, larger than the source
             for (dw, dh, x, y) in ((w, h, 0, 0), (max(1, w - 3), max(1, h - 1), 2, 1), (w + 5, h + 4, -3, -2), (9, 3, w - 2, h - 1)):
-                got = run(lambda s, *a, **k: ctx.crop_planes(s, w, h, x, y, *a, **k), src, (n_planes, dh, dw + 8), dw, dh,
-                          dst_stride=dw + 8, dst_plane_stride=dh * (dw + 8), **kw)
+                got = run(lambda s_, dw_, dh_, o_, **k: ctx.crop_planes(s_, w, h, x, y, o_, dw_, dh_, **k), src, (n_planes, dh, dw + 8),
+                          dw, dh, dst_stride=dw + 8, dst_plane_stride=dh * (dw + 8), **kw)
                 for p in range(n_planes):
                     assert np.array_equal(got[p, :, :dw], orc.crop_plane(planes[p], dw, dh, x, y)), (w, h, dw, dh, x, y, p)
                     assert (got[p, :, dw:] == 0xAA).all()

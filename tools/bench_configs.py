@@ -5,6 +5,10 @@
                hipMemcpyAsync on a copy stream || block-stage kernel (hvc_jpeg_decode_batch)
   --config 4   4K 4:4:4 decode, one GPU's shard shape (388 800 blocks/frame), HBM-resident
   --config 5   encoder: forward 8x8 DCT + quantise, 4K 4:2:0, HBM-resident (hvc_encode_frames)
+  --config 2 / 10 / 7 / 8 / 9 / 6   K2 upsample / subsample_hv2 / fused 4:4:4 / config 5 to files / GPU Huffman coder / host buffers
+
+Every config function returns its JSON object (bench.py collects them as `others` in its one line); run as a command,
+this file prints it.
 
 Each prints one JSON line.  Inputs are synthetic and are prepared with the library's own paths
 (hvc_jpeg_encode / hvc_encode_frames) outside every timed region; nothing here touches the oracle.
@@ -41,6 +45,7 @@ def verify(ctx, data, record_bytes, n_records, key, distinct):
 
 
 def config3(args):
+    """-> the JSON object of configuration 3 (host or GPU reader)"""
     import torch
     import video_coding_amd as hvc
     from video_coding_amd.synth import synth_pixels
@@ -79,7 +84,7 @@ def config3(args):
             best = (dt, st, cpu)
     dt, st, cpu = best
     jpeg_bytes = sum(len(j) for j in batch)
-    print(json.dumps({
+    result = {
         **verify(ctx, d_pix, info.pixel_bytes, args.frames, "configs_c3", args.distinct),
         "config": ("3-gpu-entropy" if gpu else "3") + ("-host-out" if args.host_out else "") +
                   ("-own-tables" if getattr(args, "own_tables", False) else ""),
@@ -97,8 +102,9 @@ def config3(args):
         "overlap": "sum of stage times / wall = %.2f" % ((st.entropy_ms_sum / args.threads + st.h2d_ms_sum +
                                                           st.kernel_ms_sum) / (dt * 1e3)),
         "bound": ("GPU reader kernels / upload" if gpu else "host Huffman (entropy time / threads ~ wall)") +
-                 (", download of the frames" if args.host_out else "")}))
+                 (", download of the frames" if args.host_out else "")}
     ctx.close()
+    return result
 
 
 def resident_decode(args, planes, W, H, tag):
@@ -129,12 +135,13 @@ def resident_decode(args, planes, W, H, tag):
     k_ms = float(np.mean(ctx.kernel_ms_history(min(args.steps, 64))))
     blocks = sum(bw * bh for bw, bh, _ in planes)
     algo = args.frames * blocks * 192
-    print(json.dumps({**verify(ctx, d_pix, pfs, args.frames, "configs_c%d" % tag, args.distinct),
+    result = {**verify(ctx, d_pix, pfs, args.frames, "configs_c%d" % tag, args.distinct),
                       "config": tag, "metric": "Mpixel/s decoded", "value": round(args.frames * args.steps * W * H / dt / 1e6, 1),
                       "unit": "Mpixel/s", "frames": args.frames, "blocks_per_frame": blocks, "kernel_ms": round(k_ms, 4),
                       "algorithmic_GBps": round(algo / (k_ms * 1e-3) / 1e9, 1), "frac_of_8TBps": round(algo / (k_ms * 1e-3) / 8e12, 4),
-                      "wide_path_blocks": int(ctx.last_wide_blocks())}))
+                      "wide_path_blocks": int(ctx.last_wide_blocks())}
     ctx.close()
+    return result
 
 
 def config5(args):
@@ -165,13 +172,14 @@ def config5(args):
     k_ms = float(np.mean(ctx.kernel_ms_history(min(args.steps, 64))))
     blocks = sum(bw * bh for bw, bh, _ in planes)
     algo = args.frames * blocks * 192
-    print(json.dumps({**verify(ctx, d_coefs, cfs * 2, args.frames, "configs_c5", args.distinct),
+    result = {**verify(ctx, d_coefs, cfs * 2, args.frames, "configs_c5", args.distinct),
                       "config": 5, "metric": "Mpixel/s encoded (fDCT + quantise, 4K 4:2:0)",
                       "value": round(args.frames * args.steps * W * H / dt / 1e6, 1), "unit": "Mpixel/s",
                       "frames": args.frames, "blocks_per_frame": blocks, "kernel_ms": round(k_ms, 4),
                       "algorithmic_GBps": round(algo / (k_ms * 1e-3) / 1e9, 1),
-                      "frac_of_8TBps": round(algo / (k_ms * 1e-3) / 8e12, 4)}))
+                      "frac_of_8TBps": round(algo / (k_ms * 1e-3) / 8e12, 4)}
     ctx.close()
+    return result
 
 
 def config_host(args):
@@ -196,11 +204,12 @@ def config_host(args):
         ctx.decode_frames(coefs, cfs, qtabs, comps, args.frames, pixels, pfs)
     dt = (time.perf_counter() - t0) / args.steps
     moved = args.frames * (cfs * 2 + pfs)
-    print(json.dumps({"config": "host", "metric": "Mpixel/s decoded, host buffers in and out (PCIe-inclusive)",
+    result = {"config": "host", "metric": "Mpixel/s decoded, host buffers in and out (PCIe-inclusive)",
                       "value": round(args.frames * 1920 * 1080 / dt / 1e6, 1), "unit": "Mpixel/s", "frames": args.frames,
                       "ms_per_call": round(dt * 1e3, 2), "bytes_over_pcie": moved,
-                      "pcie_GBps": round(moved / dt / 1e9, 1)}))
+                      "pcie_GBps": round(moved / dt / 1e9, 1)}
     ctx.close()
+    return result
 
 
 def config_444(args):
@@ -235,7 +244,7 @@ def config_444(args):
                             src_stride=960, dst_stride=W, src_plane_stride=pfs, dst_plane_stride=3 * W * H)
 
     res = {}
-    for name, fn in (("fused", fused), ("separate", separate)):
+    for name, fn in (("fused", fused),) if getattr(args, "fused_only", False) else (("fused", fused), ("separate", separate)):
         for _ in range(args.warmup):
             fn()
         torch.cuda.synchronize()
@@ -246,15 +255,16 @@ def config_444(args):
     blocks_needed = 240 * 135 + 2 * 120 * 68
     algo = n * (blocks_needed * 128 + 3 * W * H)
     ctx.decode_frames_yuv444(d_coefs, cfs, qtabs, comps, n, W, H, d_out)  # (the separate path ran last: the fused output once more)
-    print(json.dumps({**verify(ctx, d_out, 3 * W * H, n, "configs_c7", args.distinct),
+    result = {**verify(ctx, d_out, 3 * W * H, n, "configs_c7", args.distinct),
                       "config": "444", "metric": "Mpixel/s decoded to 4:4:4 (1080p 4:2:0 in)", "frames": n,
-                      "fused_ms": round(res["fused"], 4), "separate_ms": round(res["separate"], 4),
+                      "fused_ms": round(res["fused"], 4), "separate_ms": round(res["separate"], 4) if "separate" in res else None,
                       "value": round(n * W * H / (res["fused"] * 1e-3) / 1e6, 1), "unit": "Mpixel/s",
-                      "speedup_vs_separate": round(res["separate"] / res["fused"], 3),
+                      "speedup_vs_separate": round(res["separate"] / res["fused"], 3) if "separate" in res else None,
                       "algorithmic_GBps": round(algo / (res["fused"] * 1e-3) / 1e9, 1),
                       "frac_of_8TBps": round(algo / (res["fused"] * 1e-3) / 8e12, 4),
-                      "wide_path_blocks": int(ctx.last_wide_blocks())}))
+                      "wide_path_blocks": int(ctx.last_wide_blocks())}
     ctx.close()
+    return result
 
 
 def config5_files(args):
@@ -283,10 +293,24 @@ def config5_files(args):
         if best is None or st.wall_ms < best[1].wall_ms:
             best = (dt, st, jpegs)
     py_dt, st, jpegs = best
+    # what came out: K5 over the bytes of the first `distinct` files (a file is one record) against the model encoder's
+    # files for these seeds, and every later file equal to the one of its distinct frame
+    sums = ["%016x" % int(ctx.checksum_records(np.frombuffer(jpegs[f], dtype=np.uint8), len(jpegs[f]), 1)[0]) for f in range(args.distinct)]
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "bench_checksums.json")) as f:
+            want = json.load(f)["configs_c5_files"]
+    except (OSError, ValueError, KeyError):
+        want = None
+    ok = None
+    if want is not None and args.distinct <= len(want):
+        ok = sums == want[:args.distinct] and all(jpegs[f] == jpegs[f % args.distinct] for f in range(args.frames))
+    checksum = {"checksum": {"records": args.frames, "distinct": sums, "expected": "tests/golden/bench_checksums.json:configs_c5_files",
+                             "verified": ok}}
     # the call itself as a C caller sees it (hvc_batch_stats.wall_ms); the Python wrapper around it allocates 256 output
     # arrays and copies every file into a bytes object, which is not the library's time
     dt = st.wall_ms * 1e-3
-    print(json.dumps({
+    result = {
+        **checksum,
         "config": "5-files" + ("-gpu-entropy" if gpu else ""), "python_wrapper_wall_ms": round(py_dt * 1e3, 2),
         "metric": "Mpixel/s encoded to JPEG files, host pad + H2D + GPU fDCT/quantise + " +
                   ("GPU Huffman + D2H of segments + host assembly" if gpu else "D2H + host Huffman") + " overlapped",
@@ -296,8 +320,9 @@ def config5_files(args):
         "pad_thread_ms_sum": round(st.host_prep_ms_sum, 1), "entropy_thread_ms_sum": round(st.entropy_ms_sum, 1),
         "entropy_Mpixel_s_per_thread": round(args.frames * W * H / (max(st.entropy_ms_sum, 1e-9) * 1e-3) / 1e6, 1),
         "h2d_ms_sum": round(st.h2d_ms_sum, 2), "kernel_ms_sum": round(st.kernel_ms_sum, 2),
-        "d2h_ms_sum": round(st.d2h_ms_sum, 2), "d2h_GBps": round(st.coef_bytes / (st.d2h_ms_sum * 1e-3) / 1e9, 1)}))
+        "d2h_ms_sum": round(st.d2h_ms_sum, 2), "d2h_GBps": round(st.coef_bytes / (st.d2h_ms_sum * 1e-3) / 1e9, 1)}
     ctx.close()
+    return result
 
 
 def config_huffman(args):
@@ -332,11 +357,16 @@ def config_huffman(args):
         call()
     dt = (time.perf_counter() - t0) / args.steps
     seg_bytes = int(offs[-1].item())
-    print(json.dumps({"config": "huffman", "metric": "Mpixel/s entropy-coded on the GPU (4K 4:2:0, q75)", "frames": n,
+    result = {"config": "huffman", "metric": "Mpixel/s entropy-coded on the GPU (4K 4:2:0, q75)", "frames": n,
                       "value": round(n * W * H / dt / 1e6, 1), "unit": "Mpixel/s", "ms_per_call": round(dt * 1e3, 3),
                       "segment_MB": round(seg_bytes / 1e6, 1), "bits_per_pixel": round(seg_bytes * 8 / (n * W * H), 2),
-                      "coef_GBps": round(n * cfs * 2 / dt / 1e9, 1)}))
+                      "coef_GBps": round(n * cfs * 2 / dt / 1e9, 1)}
     ctx.close()
+    return result
+
+
+def _random_planes(seed, n_distinct, h, w):
+    return np.random.Generator(np.random.PCG64(seed)).integers(0, 256, size=(n_distinct, h, w)).astype(np.uint8)
 
 
 def config_k2(args):
@@ -345,8 +375,7 @@ def config_k2(args):
     import video_coding_amd as hvc
     cw, ch = 960, 540
     n = 2 * args.frames
-    rng = np.random.Generator(np.random.PCG64(5))
-    src = rng.integers(0, 256, size=(args.distinct, ch, cw)).astype(np.uint8)
+    src = _random_planes(5, args.distinct, ch, cw)
     reps = (n + args.distinct - 1) // args.distinct
     d_src = torch.from_numpy(src).cuda().repeat(reps, 1, 1)[:n].contiguous()
     d_dst = torch.zeros((n, 2 * ch, 2 * cw), dtype=torch.uint8, device="cuda")
@@ -360,15 +389,54 @@ def config_k2(args):
         ctx.upsample420(d_src, cw, ch, d_dst, n_planes=n)
     ms = ctx.timer_end() / args.steps
     algo = n * cw * ch * 5  # 1 B read + 4 B written per source pixel
-    print(json.dumps({"config": "k2", "metric": "chroma samples/s upsampled 4:2:0 -> 4:4:4", "planes": n,
-                      "kernel_ms": round(ms, 4), "algorithmic_GBps": round(algo / (ms * 1e-3) / 1e9, 1),
-                      "frac_of_8TBps": round(algo / (ms * 1e-3) / 8e12, 4)}))
+    result = {**verify(ctx, d_dst, 4 * cw * ch, n, "configs_k2", args.distinct),
+              "config": "k2", "metric": "chroma samples/s upsampled 4:2:0 -> 4:4:4", "planes": n,
+              "kernel_ms": round(ms, 4), "algorithmic_GBps": round(algo / (ms * 1e-3) / 1e9, 1),
+              "frac_of_8TBps": round(algo / (ms * 1e-3) / 8e12, 4)}
     ctx.close()
+    return result
+
+
+def config_sub420(args):
+    """Planar_444.subsample_hv2 (the chroma planes of `oyuv convert` 4:4:4 -> 4:2:0): 1920x1080 planes -> 960x540, 2 planes
+    per frame; 5 B per destination sample (4 read + 1 written)."""
+    import torch
+    import video_coding_amd as hvc
+    w, h = 1920, 1080
+    n = 2 * args.frames
+    src = _random_planes(6, args.distinct, h, w)
+    reps = (n + args.distinct - 1) // args.distinct
+    d_src = torch.from_numpy(src).cuda().repeat(reps, 1, 1)[:n].contiguous()
+    d_dst = torch.zeros((n, h // 2, w // 2), dtype=torch.uint8, device="cuda")
+    ctx = hvc.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    for _ in range(args.warmup):
+        ctx.subsample420(d_src, w, h, d_dst, n_planes=n)
+    torch.cuda.synchronize()
+    ctx.timer_begin()
+    for _ in range(args.steps):
+        ctx.subsample420(d_src, w, h, d_dst, n_planes=n)
+    ms = ctx.timer_end() / args.steps
+    algo = n * (w // 2) * (h // 2) * 5
+    result = {**verify(ctx, d_dst, (w // 2) * (h // 2), n, "configs_sub420", args.distinct),
+              "config": "sub420", "metric": "chroma samples/s subsampled 4:4:4 -> 4:2:0", "planes": n,
+              "kernel_ms": round(ms, 4), "algorithmic_GBps": round(algo / (ms * 1e-3) / 1e9, 1),
+              "frac_of_8TBps": round(algo / (ms * 1e-3) / 8e12, 4)}
+    ctx.close()
+    return result
+
+
+def make_args(**kw):
+    """the argument object of the config functions for callers that are not this file's command line (bench.py)"""
+    d = dict(frames=None, distinct=4, steps=None, warmup=10, threads=min(16, len(os.sched_getaffinity(0))), chunk=32,
+             gpu_entropy=False, host_out=False, own_tables=False, fused_only=False)
+    d.update(kw)
+    return argparse.Namespace(**d)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", type=int, required=True, choices=[2, 3, 4, 5, 6, 7, 8, 9])
+    ap.add_argument("--config", type=int, required=True, choices=[2, 3, 4, 5, 6, 7, 8, 9, 10])
     ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--distinct", type=int, default=4)
     ap.add_argument("--steps", type=int, default=None)
@@ -378,43 +446,49 @@ def main():
     ap.add_argument("--gpu-entropy", action="store_true", help="configs 3 / 8: Huffman decoding / coding on the GPU as well")
     ap.add_argument("--host-out", action="store_true", help="config 3: decoded frames to host memory instead of HBM")
     ap.add_argument("--own-tables", action="store_true", help="config 3: every file with Huffman tables optimised for itself")
+    ap.add_argument("--fused-only", action="store_true", help="config 7: skip the three-launch composition")
     args = ap.parse_args()
     if args.config == 2:  # K2 upsample (optional output stage)
         args.frames = args.frames or 256
         args.steps = args.steps or 20
-        config_k2(args)
+        r = config_k2(args)
+    elif args.config == 10:  # subsample_hv2 (oyuv convert 4:4:4 -> 4:2:0)
+        args.frames = args.frames or 256
+        args.steps = args.steps or 20
+        r = config_sub420(args)
     elif args.config == 9:  # GPU Huffman coder alone
         args.frames = args.frames or 32
         args.steps = args.steps or 10
-        config_huffman(args)
+        r = config_huffman(args)
     elif args.config == 8:  # config 5 with files out
         args.frames = args.frames or 256
         args.steps = args.steps or 3
         if args.chunk == 32:
             args.chunk = 16
-        config5_files(args)
+        r = config5_files(args)
     elif args.config == 7:  # fused 4:4:4 output (next-3)
         args.frames = args.frames or 512
         args.steps = args.steps or 20
-        config_444(args)
+        r = config_444(args)
     elif args.config == 6:  # host-buffer boundary of config 2
         args.frames = args.frames or 128
         args.steps = args.steps or 5
-        config_host(args)
+        r = config_host(args)
     elif args.config == 3:
         args.frames = args.frames or 256
         args.steps = args.steps or 3
-        config3(args)
+        r = config3(args)
     elif args.config == 4:
         # one GPU's shard of config 4 = 2048 frames, processed as 16 resident chunks of 128 frames
         # (9.6 GB per launch), re-using the same device-resident synthetic chunk
         args.frames = args.frames or 128
         args.steps = args.steps or 16
-        resident_decode(args, [(480, 270, 0), (480, 270, 1), (480, 270, 1)], 3840, 2160, 4)
+        r = resident_decode(args, [(480, 270, 0), (480, 270, 1), (480, 270, 1)], 3840, 2160, 4)
     else:
         args.frames = args.frames or 256
         args.steps = args.steps or 30
-        config5(args)
+        r = config5(args)
+    print(json.dumps(r))
 
 
 if __name__ == "__main__":

@@ -26,8 +26,12 @@ def main(d):
     if tr:
         print("\n## --kernel-trace --stats  (durations in ns)")
         print("%-60s %8s %14s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
-        for name, calls, total, avg, pct in q(tr[0], "select name,total_calls,total_duration,average,percentage from top_kernels"):
-            print("%-60s %8d %14.0f %12.1f %7.2f" % (name[:60], calls, total * 1e3 if total < 1e6 else total, avg * 1e3 if avg < 1e5 else avg, pct))
+        # (from the dispatch table itself, in ns: the database's top_kernels view reports its totals in another unit than
+        # its averages, which round 3's summaries printed side by side as if they were one -- VERDICT r3)
+        rows = q(tr[0], "select name, count(*), sum(duration), avg(duration) from kernels group by name order by sum(duration) desc")
+        grand = float(sum(r[2] for r in rows)) or 1.0
+        for name, calls, total, avg in rows:
+            print("%-60s %8d %14.0f %12.1f %7.2f" % (name[:60], calls, total, avg, 100.0 * total / grand))
         # the dominant hvc kernel: average over all dispatches and over the timed ones only (the first
         # `warmup` launches of a bench run are the untimed warm-ups, still off the sustained clock)
         dom = q(tr[0], "select name from top_kernels where name like '%hvc::%' order by total_duration desc limit 1")
