@@ -311,6 +311,16 @@ HVC_API int hvc_jpeg_read_header(const uint8_t *jpeg, size_t n, hvc_jpeg_info *i
 /* The Huffman + DC-prediction half of Decoder.decode in decode_seq order (decoder.ml:118-140, 143,
  * 261-281, 362-395) into one frame's coefficient record (host memory, info->coef_count int16). */
 HVC_API int hvc_jpeg_entropy_decode(const uint8_t *jpeg, size_t n, const hvc_jpeg_info *info, int16_t *coefs);
+/* An EXTENSION, off unless asked for: restart intervals (DRI + RSTn markers, ITU-T T.81 B.2.4.4, E.2.4).  The model parses
+ * DRI and never looks at it again; its entropy-coded segment ends at the first RSTn as at any marker (decoder.ml:56-59,
+ * 261-281), so it decodes the first interval and reads zeros from there on -- and so does every entry point of this library
+ * by default (model parity).  hvc_jpeg_entropy_decode_restart is hvc_jpeg_entropy_decode with the markers honoured: every
+ * interval's bytes behind its RSTn, DC predictors back to zero at each (SURVEY.md 8f next-1's named extension);
+ * hvc_set_restart_markers(ctx, 1) makes the context's file-level entry points (hvc_jpeg_decode, hvc_jpeg_decode_yuv444, the
+ * batch pipelines, hvc_jpeg_entropy_decode_gpu) do the same: such files are read by the host reader.  A file without DRI
+ * decodes the same either way. */
+HVC_API int hvc_jpeg_entropy_decode_restart(const uint8_t *jpeg, size_t n, const hvc_jpeg_info *info, int16_t *coefs);
+HVC_API int hvc_set_restart_markers(hvc_ctx *ctx, int honour);
 /* The same for TWO files on the calling thread, their symbols decoded in turn: a file is one stream and its symbols one
  * dependency chain (shift, table load, shift), two files are two chains the core overlaps -- 1.07x (Zen 5) to 1.3x (Golden
  * Cove) the files per second per thread on the bench's content (what the batch pipelines' workers do).  *status_a / *status_b receive

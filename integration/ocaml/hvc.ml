@@ -343,6 +343,17 @@ let yuv_convert =
     @-> returning int)
 ;;
 
+(* an extension beyond the model (off by default): restart intervals honoured
+   int hvc_jpeg_entropy_decode_restart(jpeg, n, info, coefs);  int hvc_set_restart_markers(ctx, honour) *)
+let jpeg_entropy_decode_restart =
+  foreign
+    "hvc_jpeg_entropy_decode_restart"
+    ~release_runtime_lock:true
+    (string @-> size_t @-> ptr Jpeg_info.t @-> ptr int16_t @-> returning int)
+;;
+
+let set_restart_markers = foreign "hvc_set_restart_markers" (ctx @-> int @-> returning int)
+
 (* int hvc_jpeg_entropy_decode2(jpeg_a, n_a, info_a, coefs_a, status_a, jpeg_b, n_b, info_b, coefs_b, status_b):
    two files decoded in turn on the calling thread *)
 let jpeg_entropy_decode2 =

@@ -90,3 +90,39 @@ for it in range(300):
     except hvc.HvcError:
         enc_err += 1
 print("encoded", enc_ok, "refused", enc_err)
+# round 4: the reader with restart intervals honoured (the opt-in extension) on mutated files that carry DRI / RSTn, files with
+# an empty plane, files whose tables name DC categories of up to 62 bits -- decoded or refused, never a memory error
+sys.path.insert(0, os.path.join(_ROOT, 'tools'))
+from jpeg_opt_writer import jpeg_optimised_tables
+qt = np.stack([np.arange(1, 65), np.arange(64, 0, -1)]).astype(np.uint16)
+seeds = []
+for sampling, w, h, ri in (([(2, 2), (1, 1), (1, 1)], 96, 64, 2), ([(1, 1)] * 3, 40, 24, 1), ([(2, 1), (1, 1), (0, 1)], 64, 32, 3),
+                           ([(2, 2), (0, 0), (1, 1)], 48, 48, 0)):
+    mh, mv = max(s[0] for s in sampling), max(s[1] for s in sampling)
+    Wr, Hr = -(-w // (8 * mh)) * 8 * mh, -(-h // (8 * mv)) * 8 * mv
+    nblk = sum((Wr * sh // mh // 8) * (Hr * sv // mv // 8) for sh, sv in sampling)
+    rec = np.zeros((nblk, 64), dtype=object)
+    rec[:, 0] = [int(x) for x in rng.integers(-500, 501, size=nblk)]
+    if ri == 0:
+        rec[::7, 0] = [int(x) << 40 for x in rng.integers(-100, 101, size=len(rec[::7]))]    # (categories of 40-odd bits: HVC_E_RANGE at best)
+    rec[:, 1:4] = rng.integers(-30, 31, size=(nblk, 3))
+    seeds.append(jpeg_optimised_tables(w, h, sampling, qt, rec.reshape(-1), table_sets=1, restart_interval=ri))
+r_ok = r_err = 0
+for it in range(4000 * _args.scale):
+    b = bytearray(seeds[it % len(seeds)])
+    if it % 5 == 4:
+        b = b[:int(rng.integers(2, len(b)))] + b"\xff\xd9"
+    else:
+        for _ in range(int(rng.integers(0, 5))):
+            pos = int(rng.integers(0, len(b)))
+            b[pos] = int(rng.choice([int(rng.integers(0, 256)), 0xFF, 0xD0 + int(rng.integers(0, 8)), 0]))
+    b = bytes(b)
+    for restart in (False, True):
+        try:
+            info = hvc.hvc.jpeg_read_header(b)
+            if info.coef_count > 1 << 24: continue
+            hvc.hvc.jpeg_entropy_decode(b, info, restart_markers=restart)
+            r_ok += 1
+        except hvc.HvcError:
+            r_err += 1
+print("restart intervals / empty planes / wide categories: decoded", r_ok, "rejected", r_err)

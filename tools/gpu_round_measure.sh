@@ -1,6 +1,8 @@
 #!/bin/bash
 # One GPU session that produces every number DESIGN.md quotes (run via gpurun from the repo root):
-#   gpurun_out/m_*.json  bench lines, gpurun_out/prof_<tag>_*/ rocprofv3 databases -> gpurun_out/<tag>_*_rocprofv3.txt
+#   gpurun_out/m_*.json  bench lines, gpurun_out/prof_<tag>_*/ rocprofv3 databases -> gpurun_out/<tag>_*_rocprofv3.txt;
+#   at the end of part a everything m_* becomes <tag>_lines.jsonl (every JSON line, tagged with its command's name),
+#   <tag>_stderr.txt and <tag>_<name>.txt (tools/consolidate_session.py): what goes to profiles/
 set -e
 TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -21,6 +23,7 @@ python tools/bench_configs.py --config 5 > gpurun_out/m_c5.json 2> gpurun_out/m_
 python tools/bench_configs.py --config 6 > gpurun_out/m_c6.json 2> gpurun_out/m_c6.err
 python tools/bench_configs.py --config 7 > gpurun_out/m_c7.json 2> gpurun_out/m_c7.err
 python tools/bench_configs.py --config 2 > gpurun_out/m_k2.json 2> gpurun_out/m_k2.err
+python tools/bench_configs.py --config 10 > gpurun_out/m_sub420.json 2> gpurun_out/m_sub420.err
 python tools/bench_configs.py --config 8 > gpurun_out/m_c5_files.json 2> gpurun_out/m_c5_files.err
 HVC_DECODE_KERNEL=q16 python bench.py --no-cpu-baseline > gpurun_out/m_bench_q16.json 2> gpurun_out/m_bench_q16.err
 # the file-level pipelines with the entropy stages on the GPU, the GPU Huffman coder alone, one file at a time
@@ -55,7 +58,7 @@ echo "reader chunk done"
 /tmp/mem_ubench3 > gpurun_out/m_mem_ubench3.txt 2>&1 || true
 # the ceilings by bytes per lane (the block kernels move 192 - 384 B per lane: their ceiling is not the 16-B-per-lane one),
 # and the kernels' real / ideal load and store halves
-for u in inflight_ubench shape_ubench k1_ubench; do
+for u in inflight_ubench shape_ubench k1_ubench k1_dma_ubench; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/$u tools/ubench/$u.hip 2> /dev/null && /tmp/$u > gpurun_out/m_$u.txt 2>&1 || true
 done
 # every kernel against the memory ceiling of its own access shape (traffic-only measurement build)
@@ -72,6 +75,7 @@ if [ -f build/variants/libhvc_traffic.so ]; then
     done; } > gpurun_out/m_shape_ceilings.txt 2> /dev/null
 fi
 echo "ceilings done"
+python tools/consolidate_session.py gpurun_out m ${TAG}
 fi
 if [ "$PART" = "a" ]; then exit 0; fi
 bash tools/gpu_profile.sh ${TAG}_decode

@@ -93,12 +93,14 @@ def long_prefixes(bits, huffval):
     return out
 
 
-def jpeg_optimised_tables(w, h, chroma, qtabs, coefs, table_sets=2, ac_shape=None, stats=None):
+def jpeg_optimised_tables(w, h, chroma, qtabs, coefs, table_sets=2, ac_shape=None, stats=None, restart_interval=0):
     """coefs: one frame's coefficient record in the C ABI's layout (int16, component planes back to back,
     zig-zag, DC absolute) for a w x h frame of the given sampling (the encoder's geometry, encoder.ml:437-472)
     -> a baseline JPEG whose Huffman tables are the optimal ones FOR THIS FILE (table_sets = 2: luma / chroma
     pairs as every common encoder writes them; 3: one pair per component; 1: one pair for all)."""
     # (ac_shape / stats: below)
+    # restart_interval = Ri > 0: a DRI segment, and behind every Ri MCUs (but the last) the bits are padded with ones to a
+    # byte, an RSTm marker (m = 0 ... 7 in turn) follows and the DC predictors start again at zero (ITU-T T.81 E.1.4, B.2.4.4)
     # chroma may also be a list of (h, v) sampling factors, one per component (1..4 components, any factors 1..4): the
     # DECODER's geometry then (Decoder.init, decoder.ml:294-345: every plane = the frame rounded up to whole MCUs, scaled
     # by the component's share of the largest factors) -- samplings the model's encoder never writes but its decoder reads
@@ -120,10 +122,15 @@ def jpeg_optimised_tables(w, h, chroma, qtabs, coefs, table_sets=2, ac_shape=Non
     assert coefs.size == at, (coefs.size, at)
     tset = {1: [0] * len(comps), 2: [0] + [1] * (len(comps) - 1), 3: list(range(len(comps)))}[table_sets]
     # pass 1: symbols in scan order (decode_seq order, decoder.ml:374-395)
-    syms = []  # (table set, is_ac, symbol, extra value, extra bits)
+    syms = []  # (table set, is_ac, symbol, extra value, extra bits); (-1, m, ...) = the marker RSTm
     pred = [0] * len(comps)
+    n_mcu, mcus = (Hr // (8 * vs)) * (Wr // (8 * hs)), 0
     for my in range(Hr // (8 * vs)):
         for mx in range(Wr // (8 * hs)):
+            if restart_interval and mcus and mcus % restart_interval == 0:
+                syms.append((-1, (mcus // restart_interval - 1) % 8, 0, 0, 0))
+                pred = [0] * len(comps)
+            mcus += 1
             for ci, (_, hh, vv, _) in enumerate(comps):
                 bw = dims[ci][0]
                 for sy in range(vv):
@@ -149,7 +156,8 @@ def jpeg_optimised_tables(w, h, chroma, qtabs, coefs, table_sets=2, ac_shape=Non
     n_sets = max(tset) + 1
     freq = [[[0] * 256 for _ in range(2)] for _ in range(n_sets)]
     for ts, ac, sym, _, _ in syms:
-        freq[ts][ac][sym] += 1
+        if ts >= 0:
+            freq[ts][ac][sym] += 1
     # ac_shape = "many_prefixes": see _many_prefix_lengths (tests of the GPU reader's overflow search); stats (a dict)
     # receives, per table set, how many coded AC symbols sit under a prefix beyond the eighth
     specs = [[_many_prefix_lengths(freq[ts][ac]) if (ac and ac_shape == "many_prefixes") else _optimal_lengths(freq[ts][ac])
@@ -166,6 +174,15 @@ def jpeg_optimised_tables(w, h, chroma, qtabs, coefs, table_sets=2, ac_shape=Non
     # pass 2: the bits
     acc, nb, out = 0, 0, bytearray()
     for ts, ac, sym, extra, eb in syms:
+        if ts < 0:  # RSTm: pad to a byte with ones, then the marker
+            if nb:
+                byte = ((acc << (8 - nb)) | ((1 << (8 - nb)) - 1)) & 0xFF
+                out.append(byte)
+                if byte == 0xFF:
+                    out.append(0)
+            acc, nb = 0, 0
+            out += bytes([0xFF, 0xD0 + ac])
+            continue
         c, ln = codes[ts][ac][sym]
         acc = (acc << (ln + eb)) | (c << eb) | extra
         nb += ln + eb
@@ -192,6 +209,8 @@ def jpeg_optimised_tables(w, h, chroma, qtabs, coefs, table_sets=2, ac_shape=Non
         for ac in range(2):
             bits, vals = specs[ts][ac]
             hdr += seg(0xC4, bytes([(ac << 4) | ts]) + bytes(bits[1:17]) + bytes(vals))
+    if restart_interval:
+        hdr += seg(0xDD, int(restart_interval).to_bytes(2, "big"))
     hdr += seg(0xDA, bytes([len(comps)]) + b"".join(bytes([cid, (tset[i] << 4) | tset[i]]) for i, (cid, _, _, _) in enumerate(comps)) +
                bytes([0, 63, 0]))
     return bytes(hdr) + bytes(out) + b"\xff\xd9"

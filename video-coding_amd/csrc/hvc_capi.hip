@@ -400,6 +400,12 @@ int hvc_set_decode_kernel(hvc_ctx *c, int which) try {
     return HVC_OK;
 } HVC_ABI_CATCH
 
+int hvc_set_restart_markers(hvc_ctx *c, int honour) try {
+    if (!c) return HVC_E_INVALID_ARG;
+    c->honour_restart = honour != 0;
+    return HVC_OK;
+} HVC_ABI_CATCH
+
 int hvc_set_profiling(hvc_ctx *c, int enabled) try {
     if (!c) return HVC_E_INVALID_ARG;
     c->profiling = enabled != 0;

@@ -62,6 +62,7 @@ static int decode_one_with_wide_dc(hvc_ctx *c, const hvc_jpeg_info *info, const 
 int hvc_jpeg_decode_yuv444(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_info *info, uint8_t *frame,
                            size_t frame_cap) try {
     if (!c || !jpeg || !info || !frame) return HVC_E_INVALID_ARG;
+    hvc::RestartScope honour(c->honour_restart); // (hvc_set_restart_markers; off = the model's behaviour)
     int r = hvc_jpeg_read_header(jpeg, n, info);
     if (r) return r;
     // a 4:2:0 scan: Y 2x2, Cb / Cr 1x1 (Frame.infer_chroma_subsampling, common/src/frame.ml:42-61)
@@ -112,6 +113,7 @@ int hvc_jpeg_decode_yuv444(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_i
 
 int hvc_jpeg_decode(hvc_ctx *c, const uint8_t *jpeg, size_t n, hvc_jpeg_info *info, uint8_t *pixels, size_t pixel_cap) try {
     if (!c || !jpeg || !info) return HVC_E_INVALID_ARG;
+    hvc::RestartScope honour(c->honour_restart); // (hvc_set_restart_markers; off = the model's behaviour)
     int r = hvc_jpeg_read_header(jpeg, n, info);
     if (r) return r;
     if (pixel_cap < info->pixel_bytes || (!pixels && info->pixel_bytes)) return HVC_E_INVALID_ARG; // (planes without a sample need no memory)
@@ -226,6 +228,7 @@ int decode_batch_impl(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *siz
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (n_frames == 0) return HVC_OK;
+    hvc::RestartScope honour(c->honour_restart);
     hvc_jpeg_info info0;
     int r = hvc_jpeg_read_header(jpegs[0], sizes[0], &info0);
     if (r) return r;
@@ -300,6 +303,7 @@ int decode_batch_impl(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *siz
     std::atomic<long long> entropy_ns{0};
     auto worker_body = [&]() {
         if (!pin_to_ctx_cpus(c)) error.store(HVC_E_INVALID_ARG); // hvc_set_host_cpus
+        hvc::RestartScope honour(c->honour_restart); // (a pool thread reads the files: the flag is its own)
         // Frames are taken TWO at a time and decoded symbol by symbol in turn (hvc::entropy_decode_wide2): one stream is
         // one dependency chain, two streams are two chains the core overlaps -- 1.4x the frames per second per thread.
         std::vector<hvc::WideDc> wide2[2];

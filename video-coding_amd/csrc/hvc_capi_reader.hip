@@ -374,6 +374,7 @@ int hvc_jpeg_entropy_decode_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const s
                                 size_t coef_fs, int where, hvc_jpeg_info *info, int *used_gpu) try {
     if (!c || !jpegs || !sizes || !coefs || !info || n_frames < 1) return HVC_E_INVALID_ARG;
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
+    hvc::RestartScope honour(c->honour_restart);
     int r = hvc_jpeg_read_header(jpegs[0], sizes[0], info);
     if (r) return r;
     if ((n_frames > 1 && coef_fs < info->coef_count) || (coef_fs & 7)) return HVC_E_INVALID_ARG;
@@ -433,6 +434,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (n_frames == 0) return HVC_OK;
+    hvc::RestartScope honour(c->honour_restart);
     auto host_pipeline = [&]() {
         return decode_batch_impl(c, jpegs, sizes, n_frames, threads, frames_per_chunk, pixels, pixel_fs, where, stats, yuv444);
     };
@@ -601,6 +603,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     auto worker_body = [&]() {
         hvc::HdTables t;
         if (!pin_to_ctx_cpus(c)) error.store(HVC_E_INVALID_ARG); // hvc_set_host_cpus
+        hvc::RestartScope honour(c->honour_restart);
         for (;;) {
             const int f = next_frame.fetch_add(1);
             if (f >= n_frames || error.load()) return;

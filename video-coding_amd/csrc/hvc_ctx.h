@@ -43,6 +43,7 @@ struct hvc_ctx {
     hipEvent_t k0[HVC_PROF_RING] = {}, k1[HVC_PROF_RING] = {};
     unsigned long long k_calls = 0;
     bool profiling = false;
+    bool honour_restart = false; // hvc_set_restart_markers: restart intervals honoured by the file-level entry points (an extension)
     int decode_kernel = 0; // hvc_set_decode_kernel: 0 packed (default), 1 unpacked int32, 2 int64 for every block, 3 q16
     unsigned *d_fix_count = nullptr; // two counters, used alternately (see k_decode_wide); behind them (+ 8 bytes) the 64-bit
                                      // total of the last call's fix-up blocks over all its launches (hvc_last_wide_blocks)

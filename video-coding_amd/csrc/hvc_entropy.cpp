@@ -29,6 +29,13 @@
 #include "hvc_kernels.h"
 #include "hvc_pool.h"
 
+namespace hvc {
+// Restart intervals (DRI / RSTn, ITU-T T.81 B.2.4.4 and E.2.4) -- BEYOND the model, which parses DRI and then cuts the scan at
+// the first RSTn like at any marker (decoder.ml:56-59, 261-281).  Honoured only where the caller has asked for it
+// (hvc_set_restart_markers, hvc_jpeg_entropy_decode_restart): the flag of the thread that reads the file.
+thread_local bool tl_honour_restart = false;
+} // namespace hvc
+
 namespace {
 
 using hvc::HVC_ZF;
@@ -58,6 +65,7 @@ struct Header {
     std::vector<DqtSeg> dqt; // in file order; lookups take the LAST match like the model's cons-list
     std::vector<DhtSeg> dht;
     bool have_frame = false, have_scan = false;
+    int restart_interval = 0; // DRI (markers.ml:186-197): the model parses it and never looks at it again
     size_t ecs_pos = 0; // byte position right after the SOS header
 };
 
@@ -122,9 +130,9 @@ int parse_header(const uint8_t *data, size_t n, Header &h) {
             for (int i = 0; i < total; i++) s.spec.values[i] = r.get8();
             s.spec.total = total;
             h.dht.push_back(s);
-        } else if (mc == 0xdd) { // DRI: parsed and ignored, like the model (decoder.ml:56-59)
+        } else if (mc == 0xdd) { // DRI: parsed and ignored, like the model (decoder.ml:56-59) -- unless the caller opts in
             (void)r.get16();
-            (void)r.get16();
+            h.restart_interval = r.get16();
         } else if (mc == 0xd8) { // SOI
         } else if ((mc >= 0xe0 && mc <= 0xef) || mc == 0xfe) { // APPn / COM: skip (decoder.ml:31-34)
             // Bits.show 16 then advance len*8: the length field itself is part of the skipped bytes
@@ -404,6 +412,35 @@ namespace hvc {
 size_t extract_ecs_to(const uint8_t *data, size_t n, size_t pos, uint8_t *dst, size_t cap);
 }
 namespace {
+// The entropy-coded segment THROUGH its RSTn markers: every interval unstuffed and appended, `starts` = where each begins in
+// `out`; ends at the first marker that is not RSTn (0xFF fill bytes in front of a marker are skipped, T.81 B.1.1.2).
+void extract_ecs_restart(const uint8_t *data, size_t n, size_t pos, std::vector<uint8_t> &out, std::vector<size_t> &starts, size_t pad) {
+    out.clear();
+    starts.clear();
+    starts.push_back(0);
+    out.reserve((n > pos ? n - pos : 0) + pad);
+    while (pos < n) {
+        const uint8_t *ff = (const uint8_t *)std::memchr(data + pos, 0xff, n - pos);
+        const size_t stop = ff ? (size_t)(ff - data) : n;
+        out.insert(out.end(), data + pos, data + stop);
+        if (!ff) break;
+        const int next = stop + 1 < n ? data[stop + 1] : -1;
+        if (next == 0x00) {
+            out.push_back(0xff);
+            pos = stop + 2;
+        } else if (next == 0xff) {
+            pos = stop + 1; // a fill byte
+        } else if (next >= 0xd0 && next <= 0xd7) {
+            starts.push_back(out.size());
+            pos = stop + 2;
+        } else {
+            break;
+        }
+    }
+    starts.push_back(out.size()); // (one past the last interval: lengths by difference)
+    out.resize(out.size() + pad, 0);
+}
+
 // An hvc_jpeg_info is the caller's: hvc_jpeg_read_header / hvc_jpeg_encoder_layout filled it in, normally -- but nothing
 // keeps a caller from changing it, and the readers and coders index and divide by what it says.  What they rely on:
 // one to four components, sampling factors 1..15, planes of at least one block, and every component's record inside
@@ -445,6 +482,12 @@ struct Walk {
                                               // components that name the same DHT segment share one table (Cb and Cr
                                               // do in every file an encoder writes: 12 KB less for the L1 to hold)
     std::vector<uint8_t> ecs;
+    // restart intervals, where the caller has opted in (else rst_interval = 0 and nothing below is looked at): MCUs per
+    // interval, where each interval's bytes begin in `ecs`, the interval in progress, MCUs begun, the MCU the next one starts at
+    int rst_interval = 0;
+    std::vector<size_t> rst_start;
+    size_t rst_k = 0;
+    long long mcus_begun = 0, rst_at = 0;
     BitReader br{nullptr, 0};
     long long dc_pred[4] = {0, 0, 0, 0}; // (the model's 63-bit ints: 67 M blocks of +-65535 stay far inside)
     int mbs_wide = 0, mbs_high = 0;
@@ -527,11 +570,20 @@ struct Walk {
         // extract_entropy_coded_bits (decoder.ml:261-281): up to the first marker, 0xff00 -> 0xff.  (A missing EOI just
         // ends the segment: the model would spin on zero bytes there.)
         const size_t pos = h.ecs_pos, room = (n > pos ? n - pos : 0) + 16 + BitReader::PAD;
+        rst_interval = hvc::tl_honour_restart ? h.restart_interval : 0;
+        rst_k = 0;
+        mcus_begun = 0;
+        rst_at = rst_interval;
+        if (rst_interval) { // (opt-in, beyond the model)
+            extract_ecs_restart(data, n, pos, ecs, rst_start, 16 + BitReader::PAD);
+            br = BitReader{ecs.data(), rst_start[1] - rst_start[0]};
+        } else {
         ecs.resize(room);
         size_t got = hvc::extract_ecs_to(data, n, pos, ecs.data(), room - BitReader::PAD);
         if (got == SIZE_MAX) return HVC_E_BAD_JPEG; // (cannot happen: unstuffing only ever shortens)
         std::memset(ecs.data() + got, 0, room - got); // zero padding: see BitReader
         br = BitReader{ecs.data(), got};
+        }
         const hvc_jpeg_component &c0 = info->comp[0];
         // decode_seq divides by the FIRST component's factors (decoder.ml:377-382): Division_by_zero there
         if (c0.hscale == 0 || c0.vscale == 0) return HVC_E_BAD_JPEG;
@@ -568,6 +620,14 @@ struct Walk {
     // over the record instead of a 6 MB memset that has left the cache by the time the block comes up), the DC symbol;
     // then the position moves on
     int begin_block() {
+        if (rst_interval && bi == 0 && mcus_begun == rst_at) { // the first block of an MCU that opens a restart interval:
+            rst_at += rst_interval;                          // byte-aligned data behind the RSTn marker, predictors at zero (T.81 E.2.4)
+            rst_k++;
+            const size_t last = rst_start.size() - 1; // (a stream with fewer markers than its DRI promises: zeros from its end on)
+            const size_t at = rst_k < last ? rst_start[rst_k] : rst_start[last], end = rst_k < last ? rst_start[rst_k + 1] : rst_start[last];
+            br = BitReader{ecs.data() + at, end - at};
+            for (int j = 0; j < 4; j++) dc_pred[j] = 0;
+        }
         const McuBlock mb = mcu[(size_t)bi];
         const int i = mb.comp;
         if (!regular) {
@@ -644,6 +704,7 @@ struct Walk {
         amax = ac[i]->max_bits;
         if (++bi == (int)mcu.size()) {
             bi = 0;
+            ++mcus_begun;
             if (++mx == mbs_wide) {
                 mx = 0;
                 ++my;
@@ -835,7 +896,7 @@ static int walk_literal(Walk &w) {
     w.done = true;
     return HVC_OK;
 }
-static bool needs_literal_walk(const Walk &w) { return w.br.n * 8 <= 32; }
+static bool needs_literal_walk(const Walk &w) { return !w.rst_interval && w.br.n * 8 <= 32; } // (the model's own test: not with restart intervals)
 
 // the whole file, block after block
 static int walk_alone(Walk &w) {
@@ -877,6 +938,12 @@ static int entropy_decode_impl(const uint8_t *data, size_t n, const hvc_jpeg_inf
 }
 
 int hvc_jpeg_entropy_decode(const uint8_t *data, size_t n, const hvc_jpeg_info *info, int16_t *coefs) try {
+    return entropy_decode_impl(data, n, info, coefs, nullptr);
+} HVC_ABI_CATCH
+
+// The same with restart intervals honoured (an extension: not the model's behaviour, see hvc::tl_honour_restart)
+int hvc_jpeg_entropy_decode_restart(const uint8_t *data, size_t n, const hvc_jpeg_info *info, int16_t *coefs) try {
+    hvc::RestartScope honour(true);
     return entropy_decode_impl(data, n, info, coefs, nullptr);
 } HVC_ABI_CATCH
 
@@ -1534,6 +1601,7 @@ static int prepare_gpu_decode_impl(const uint8_t *jpeg, size_t n, const ::hvc_jp
         empty_plane |= info->comp[i].hscale < 1 || info->comp[i].vscale < 1;
     }
     // (a segment of at most 32 bits: the host reader has the model's length test for those -- walk_literal)
+    if (tl_honour_restart && h.restart_interval > 0) ok = false; // restart intervals (opt-in): the host reader's
     gpu_ok = ok && !empty_plane && info->n_comp <= 3 && per_mcu <= HVC_HD_MAX_MCU_BLOCKS && got < (1u << 28) && got * 8 > 32;
     return HVC_OK;
 }

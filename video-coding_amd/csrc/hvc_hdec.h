@@ -168,6 +168,13 @@ struct WideDc {
 };
 // hvc_jpeg_entropy_decode that goes on where that one answers HVC_E_RANGE: such blocks are listed in `wide` (the
 // file-level decode entry points then recompute them in int64 with their true DC, as the model does)
+// restart intervals honoured by the host reader on this thread (opt-in, beyond the model: hvc_entropy.cpp)
+extern thread_local bool tl_honour_restart;
+struct RestartScope {
+    bool prev;
+    explicit RestartScope(bool on) : prev(tl_honour_restart) { tl_honour_restart = on; }
+    ~RestartScope() { tl_honour_restart = prev; }
+};
 int entropy_decode_wide(const uint8_t *data, size_t n, const ::hvc_jpeg_info *info, int16_t *coefs, std::vector<WideDc> &wide);
 // the same for two files at once on one thread, their symbols decoded in turn (two dependency chains for the core to
 // overlap); st[i] = what entropy_decode_wide would have returned for file i

@@ -161,7 +161,11 @@ __global__ __launch_bounds__(256) void k_pack422(PackedOp P) { // convert_from_p
     b[P.yo + 2] = P.cy[f + (size_t)row * P.w + 2 * col + 1];
     b[P.uo] = P.cu[f + (size_t)row * pairs + col];
     b[P.vo] = P.cv[f + (size_t)row * pairs + col];
-    *reinterpret_cast<unsigned *>(d) = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24); // (4 col into rows of 2 w bytes: aligned when the frames are)
+    if (((uintptr_t)d & 3) == 0) { // (4 col into rows of 2 w bytes: aligned whenever the caller's frames are)
+        *reinterpret_cast<unsigned *>(d) = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+    } else {
+        for (int k = 0; k < 4; k++) d[k] = (uint8_t)b[k];
+    }
 }
 
 enum OpKind { OP_SUB420, OP_SUB422, OP_UP422, OP_CROP };

@@ -23,6 +23,7 @@ SYMBOLS = [
     "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444", "hvc_jpeg_decode_yuv444", "hvc_compare_planes", "hvc_jpeg_encode_batch", "hvc_jpeg_decode_batch_yuv444", "hvc_jpeg_encoder_check", "hvc_huffman_encode_frames", "hvc_jpeg_header", "hvc_jpeg_encode_batch_gpu", "hvc_jpeg_entropy_decode_gpu", "hvc_jpeg_decode_batch_gpu",
     "hvc_checksum_records", "hvc_encode_frames_recon", "hvc_set_host_cpus", "hvc_get_host_cpus",
     "hvc_host_threads", "hvc_host_threads_probe", "hvc_jpeg_entropy_decode2", "hvc_jpeg_get_cropped_planes",
+    "hvc_jpeg_entropy_decode_restart", "hvc_set_restart_markers",
     "hvc_subsample420", "hvc_subsample422", "hvc_upsample422", "hvc_crop_planes", "hvc_yuv_frame_bytes", "hvc_yuv_convert",
 ]
 
@@ -121,7 +122,8 @@ def lib():
             L.hvc_fdct_quant.argtypes = [vp, vp, sz, sz, vp, i, i, i, vp, sz, i]
             L.hvc_encode_frames.argtypes = [vp, vp, sz, vp, i, C.POINTER(Component), i, i, vp, sz, i]
             L.hvc_upsample420.argtypes = [vp, vp, i, i, sz, vp, sz, i, sz, sz, i]
-            for f in ("hvc_subsample420", "hvc_subsample422", "hvc_upsample422"):
+            for f in ("hvc_jpeg_entropy_decode_restart", "hvc_set_restart_markers",
+    "hvc_subsample420", "hvc_subsample422", "hvc_upsample422"):
                 getattr(L, f).argtypes = [vp, vp, i, i, sz, vp, sz, i, sz, sz, i]
             L.hvc_crop_planes.argtypes = [vp, vp, i, i, sz, i, i, vp, i, i, sz, i, sz, sz, i]
             L.hvc_yuv_frame_bytes.argtypes = [i, i, i, C.POINTER(sz)]
@@ -129,6 +131,8 @@ def lib():
         ip = C.POINTER(JpegInfo)
         L.hvc_jpeg_read_header.argtypes = [vp, sz, ip]
         L.hvc_jpeg_entropy_decode.argtypes = [vp, sz, ip, vp]
+        L.hvc_jpeg_entropy_decode_restart.argtypes = [vp, sz, ip, vp]
+        L.hvc_set_restart_markers.argtypes = [vp, i]
         L.hvc_jpeg_get_yuv_frame.argtypes = [ip, vp, vp, sz, C.POINTER(sz)]
         L.hvc_jpeg_get_cropped_planes.argtypes = [ip, vp, vp, sz, C.POINTER(sz)]
         L.hvc_jpeg_entropy_decode2.argtypes = [vp, sz, ip, vp, C.POINTER(i), vp, sz, ip, vp, C.POINTER(i)]
@@ -208,11 +212,13 @@ def jpeg_read_header(data: bytes):
     return info
 
 
-def jpeg_entropy_decode(data: bytes, info=None):
-    """Huffman + DC prediction of one frame -> (info, int16 coefficient record)"""
+def jpeg_entropy_decode(data: bytes, info=None, restart_markers=False):
+    """Huffman + DC prediction of one frame -> (info, int16 coefficient record).  restart_markers: the extension
+    hvc_jpeg_entropy_decode_restart (DRI / RSTn honoured; off = the model's behaviour)"""
     info = info or jpeg_read_header(data)
     coefs = np.empty(info.coef_count, dtype=np.int16)
-    _chk(lib().hvc_jpeg_entropy_decode(data, len(data), C.byref(info), coefs.ctypes.data), "hvc_jpeg_entropy_decode")
+    fn = "hvc_jpeg_entropy_decode_restart" if restart_markers else "hvc_jpeg_entropy_decode"
+    _chk(getattr(lib(), fn)(data, len(data), C.byref(info), coefs.ctypes.data), fn)
     return info, coefs
 
 
@@ -351,6 +357,10 @@ class Context:
         ms = C.c_float()
         _chk(lib().hvc_timer_end(self._h, C.byref(ms)))
         return ms.value
+
+    def set_restart_markers(self, honour=True):
+        """the extension: the context's file-level entry points honour DRI / RSTn (default off = the model's behaviour)"""
+        _chk(lib().hvc_set_restart_markers(self._h, 1 if honour else 0), "hvc_set_restart_markers")
 
     def set_decode_kernel(self, which):
         """0 packed (default) | 1 unpacked int32 | 2 int64 for every block -- identical output"""
