@@ -7,8 +7,10 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 40 --warmup 10 --no-cpu-baseline $@"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python3 $ROOT/bench.py $ARGS > $OUT/trace_bench.log 2>&1
+ARGS="--steps 40 --warmup 10 --no-cpu-baseline --no-others --sustain-seconds 2 $@"   # (the profile is of the headline step alone)
+# the kernel trace is of the command exactly as the driver runs it (`python bench.py`, or with the caller's arguments): the
+# dominant kernel's average over its TIMED dispatches (tools/rocpd_summary.py) is what bench.py's own event time must agree with
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python3 $ROOT/bench.py "$@" > $OUT/trace_bench.log 2>&1
 # PMC passes (own runs; no trace domains)
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python3 $ROOT/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- python3 $ROOT/bench.py $ARGS > $OUT/pmc_write.log 2>&1

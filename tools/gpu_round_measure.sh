@@ -61,19 +61,7 @@ echo "reader chunk done"
 for u in inflight_ubench shape_ubench k1_ubench k1_dma_ubench; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/$u tools/ubench/$u.hip 2> /dev/null && /tmp/$u > gpurun_out/m_$u.txt 2>&1 || true
 done
-# every kernel against the memory ceiling of its own access shape (traffic-only measurement build)
-if [ -f build/variants/libhvc_traffic.so ]; then
-  T=$ROOT/build/variants/libhvc_traffic.so
-  { echo "# shipped library, then the traffic-only build (same loads / stores / LDS exchanges, no arithmetic), same box, same session"
-    for rep in 1 2; do
-      echo -n "K1 shipped      "; python bench.py --steps 40 --no-cpu-baseline | grep -o '"frac": [0-9.]*\|"kernel_ms": [0-9.]*' | paste - -
-      echo -n "K1 traffic-only "; HVC_JPEG_LIB=$T python bench.py --steps 40 --no-cpu-baseline | grep -o '"frac": [0-9.]*\|"kernel_ms": [0-9.]*' | paste - -
-      echo -n "K3 shipped      "; python tools/bench_configs.py --config 5 | grep -o '"kernel_ms": [0-9.]*\|"frac_of_8TBps": [0-9.]*' | paste - -
-      echo -n "K3 traffic-only "; HVC_JPEG_LIB=$T python tools/bench_configs.py --config 5 | grep -o '"kernel_ms": [0-9.]*\|"frac_of_8TBps": [0-9.]*' | paste - -
-      echo -n "444 shipped      "; python tools/bench_configs.py --config 7 | grep -o '"fused_ms": [0-9.]*\|"frac_of_8TBps": [0-9.]*' | paste - -
-      echo -n "444 traffic-only "; HVC_JPEG_LIB=$T python tools/bench_configs.py --config 7 | grep -o '"fused_ms": [0-9.]*\|"frac_of_8TBps": [0-9.]*' | paste - -
-    done; } > gpurun_out/m_shape_ceilings.txt 2> /dev/null
-fi
+bash tools/gpu_shape_ceilings.sh > gpurun_out/m_shape_ceilings.txt 2> /dev/null || true
 echo "ceilings done"
 python tools/consolidate_session.py gpurun_out m ${TAG}
 fi

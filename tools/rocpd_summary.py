@@ -57,7 +57,7 @@ def main(d):
         if dom and timed:  # bench.py: setup + warm-up, then exactly K timed steps, then the `sustained` run
             t = ds[WARMUP:WARMUP + timed]
             if t:
-                print("dominant kernel, the %d TIMED dispatches (after %d of setup / warm-up; %d more belong to the sustained run): avg %.1f ns"
+                print("dominant kernel, the %d TIMED dispatches (after %d of setup / warm-up; %d more belong to the sustained run and to `others`): avg %.1f ns"
                       % (len(t), WARMUP, max(0, len(ds) - WARMUP - timed), sum(t) / len(t)))
         # The trace's vgpr_count column is HALF the kernel's register allocation (rounded up to the granule of 8) on gfx950:
         # k_decode_packed 60 for the 116 of its code object (-> 120), k_decode_wide 108 for 216, k_decode_444 40 for 76
