@@ -2,7 +2,7 @@
 # closing session of a round on the final code: the whole GPU suite, smoke(), and the randomised differential sweeps
 # (GPU Huffman reader and both file-level pipelines against the host reader), each into gpurun_out/${TAG}_*.
 set -e
-TAG=${1:-r03z}
+TAG=${1:-r04z}
 mkdir -p gpurun_out
 timeout -k 10 1000 python -m pytest tests -m gpu -q -x > gpurun_out/${TAG}_pytest.log 2>&1 || { tail -40 gpurun_out/${TAG}_pytest.log; exit 1; }
 tail -3 gpurun_out/${TAG}_pytest.log

@@ -27,7 +27,7 @@ def main():
     import torch
     rng = np.random.Generator(np.random.PCG64(args.seed))
     ctx = hvc.Context(0)
-    bad = odd = own_batches = odd_samplings = 0
+    bad = odd = own_batches = odd_samplings = empty_planes = restart_batches = 0
     for case in range(args.cases):
         w = int(rng.integers(1, 30)) * 16
         h = int(rng.integers(1, 20)) * 16
@@ -42,6 +42,11 @@ def main():
         if rng.integers(0, 4) == 0:     # a quarter of the batches: sampling factors the encoder never writes (any factors 1..4,
             ncomp = int(rng.integers(1, 5))  # one to four components), random sparse coefficient records
             sampling = [(int(rng.integers(1, 5)), int(rng.integers(1, 5))) for _ in range(ncomp)]
+            if ncomp > 1 and rng.integers(0, 3) == 0:   # ... a component without blocks (a factor of zero, never the first one's):
+                k = int(rng.integers(1, ncomp))          # the model's empty plane -- both pipelines walk around it
+                sampling[k] = (0, sampling[k][1]) if rng.integers(0, 2) else (sampling[k][0], 0)
+                empty_planes += 1
+            restart = int(rng.integers(1, 9)) if rng.integers(0, 3) == 0 else 0   # restart intervals, honoured on request (the extension)
             mh, mv = max(a for a, _ in sampling), max(b for _, b in sampling)
             Wr, Hr = -(-w // (8 * mh)) * 8 * mh, -(-h // (8 * mv)) * 8 * mv
             nblk = sum((Wr * a // mh // 8) * (Hr * b // mv // 8) for a, b in sampling)
@@ -52,8 +57,11 @@ def main():
                 blocks[:, 0] = rng.integers(-200, 201, size=nblk)
                 dense = rng.random((nblk, 63)) < rng.choice([0.02, 0.1, 0.4])
                 blocks[:, 1:][dense] = rng.integers(-50, 51, size=int(dense.sum()))
-                files.append(jpeg_optimised_tables(w, h, sampling, qt, blocks.reshape(-1), min(len(sampling), int(rng.integers(1, 4)))))
+                files.append(jpeg_optimised_tables(w, h, sampling, qt, blocks.reshape(-1), min(len(sampling), int(rng.integers(1, 4))) if not any(0 in f for f in sampling) else 1,
+                                                   restart_interval=restart))
             odd_samplings += 1
+            restart_batches += restart > 0
+            ctx.set_restart_markers(restart > 0 and bool(rng.integers(0, 2)))   # (off: the model's reading of the marked files)
         own = int(rng.integers(0, 3)) if sampling is None else 0   # a third of the batches: some or all files re-written with their own optimised Huffman
         if own == 1:                    # tables (1, 2 or 3 table sets): the GPU pipeline's per-frame-table mode
             qt = np.stack([hvc.hvc.quant_table(0, q), hvc.hvc.quant_table(1, q)])
@@ -92,6 +100,7 @@ def main():
             gerr = None
         except hvc.HvcError as e:
             gerr = e.code
+        ctx.set_restart_markers(False)
         if err != gerr:
             bad += 1
             print("ERROR CODES DIFFER", case, err, gerr, file=sys.stderr)
@@ -103,7 +112,8 @@ def main():
             bad += 1
             print("MISMATCH", case, (w, h, q, n, chunk, threads, host_out, yuv444), file=sys.stderr)
     print({"cases": args.cases, "batches_with_truncated_files": odd, "batches_with_per_file_tables": own_batches,
-           "batches_with_unusual_samplings": odd_samplings, "mismatches": bad})
+           "batches_with_unusual_samplings": odd_samplings, "with_an_empty_plane": empty_planes, "with_restart_markers": restart_batches,
+           "mismatches": bad})
     ctx.close()
     sys.exit(1 if bad else 0)
 
