@@ -397,3 +397,35 @@ def test_q16_exchange_step_is_covered_by_the_packed_proof():
     # the kernel uses the packed kernel's thresholds, not its own
     q16 = src[src.index("void k_decode_q16("):src.index("// K1 wide: int64")]
     assert "P.ethr_packed[br.qtab]" in q16 and "GUARD_RE" in q16 and "GUARD_Y" in q16
+
+
+def test_xcd_work_is_a_permutation_of_the_grid():
+    """csrc/hvc_kernels.hip xcd_work: workgroup id = y * tiles + x -> ((k / R) * 8 + id % 8) * R + k % R with k = id / 8, inside
+    the whole groups of 8 R workgroups; frame = umulhi(linear, ceil(2^32 / tiles)).  Replayed here with the kernel's own
+    integer steps: every (frame, tile) of the grid is taken exactly once, for the benches' grids and for awkward ones, and
+    the reciprocal is exact wherever xcd_map_for lets the mapping on (tiles * tiles * frames < 2^32).  (That the kernels
+    really cover every tile is what the GPU parity tests at full size see: a tile nobody took would stay zero.)"""
+    import numpy as np
+
+    def mapped(per, n, sh):
+        magic = ((1 << 32) + per - 1) // per
+        group, total = 8 << sh, per * n
+        full = total - total % group
+        ids = np.arange(total, dtype=np.uint64)
+        k = ids >> np.uint64(3)
+        lin = ((((k >> np.uint64(sh)) << np.uint64(3)) + (ids & np.uint64(7))) << np.uint64(sh)) + (k & np.uint64((1 << sh) - 1))
+        lin = np.where(ids < full, lin, ids)
+        frame = (lin * np.uint64(magic)) >> np.uint64(32)
+        assert np.array_equal(frame, lin // np.uint64(per))            # the reciprocal is exact on this grid
+        return lin
+
+    for per, n in ((192, 1024), (1521, 128), (192, 7), (5, 3), (761, 256), (192, 9), (3, 1000), (64, 64)):
+        assert per * per * n < 1 << 32
+        for sh in (0, 3, 4, 5, 6, 9):
+            lin = mapped(per, n, sh)
+            assert np.array_equal(np.sort(lin), np.arange(per * n, dtype=np.uint64)), (per, n, sh)
+    # what it is for: inside a whole group, the workgroups with id % 8 == x (one XCD's) take runs of R consecutive positions
+    lin = mapped(192, 1024, 5)
+    for xcd in range(8):
+        mine = lin[xcd::8][:96]
+        assert np.array_equal(mine[:32], np.arange(32) + xcd * 32) and np.array_equal(mine[32:64], np.arange(32) + 256 + xcd * 32)

@@ -24,7 +24,7 @@ struct P {
     const uint4 *coefs;
     unsigned char *pixels;
     size_t coef_fs, pixel_fs; // in uint4 / bytes
-    int n_comp, work, tiles, frames, contiguous;
+    int n_comp, work, tiles, frames, contiguous, run;
     unsigned tiles_magic;
     Comp comp[3];
 };
@@ -40,9 +40,24 @@ __device__ __forceinline__ unsigned churn(const uint4 (&r)[8], int work) {
 }
 
 // the reference shape: k_decode_packed's loads and stores, one block per lane, one tile per workgroup
+// p.contiguous (re-used as the XCD mapping of this kernel): 0 = workgroup (x, y) takes tile x of frame y, consecutive tiles on
+// consecutive XCDs (the dispatcher deals workgroups round-robin over the 8 XCDs); 1 = every XCD sweeps its own contiguous
+// eighth of the batch; 2 = every XCD takes whole frames in turn (frame = 8 * k + xcd)
 __global__ __launch_bounds__(256) void k1_ref(P p) {
     extern __shared__ unsigned char dyn_lds[];
-    const int lane = threadIdx.x, tile = blockIdx.x;
+    const int lane = threadIdx.x;
+    unsigned id = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned total = gridDim.x * gridDim.y;
+    if (p.contiguous == 1) id = (id & 7u) * (total >> 3) + (id >> 3);
+    else if (p.contiguous == 2) {
+        const unsigned xcd = id & 7u, k = id >> 3, per = gridDim.x; // k-th workgroup of this XCD: tile k % per of its (k / per)-th frame
+        id = ((k / per) * 8u + xcd) * per + k % per;
+    } else if (p.contiguous == 3) { // runs of p.run consecutive tiles per XCD (p.run divides the total / 8)
+        const unsigned xcd = id & 7u, k = id >> 3, per = (unsigned)p.run;
+        id = ((k / per) * 8u + xcd) * per + k % per;
+    }
+    const unsigned frame_y = id / gridDim.x;
+    const int tile = (int)(id - frame_y * gridDim.x);
     int c = 0;
 #pragma unroll
     for (int i = 1; i < 3; i++)
@@ -52,12 +67,12 @@ __global__ __launch_bounds__(256) void k1_ref(P p) {
     const bool active = b < K.nblk;
     b = active ? b : K.nblk - 1;
     const unsigned by = __umulhi((unsigned)b, K.magic), bx = (unsigned)b - by * (unsigned)K.bw;
-    const uint4 *src = p.coefs + (size_t)blockIdx.y * p.coef_fs + K.coef_off + (size_t)b * 8;
+    const uint4 *src = p.coefs + (size_t)frame_y * p.coef_fs + K.coef_off + (size_t)b * 8;
     uint4 r[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) r[j] = src[j];
     const unsigned acc = churn(r, p.work);
-    unsigned char *dst = p.pixels + (size_t)blockIdx.y * p.pixel_fs + K.plane_off + (size_t)by * 8 * K.stride + (size_t)bx * 8;
+    unsigned char *dst = p.pixels + (size_t)frame_y * p.pixel_fs + K.plane_off + (size_t)by * 8 * K.stride + (size_t)bx * 8;
     if (active) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -264,6 +279,7 @@ static Variant variant(const char *name) {
 int main(int argc, char **argv) {
     const int frames = argc > 1 ? atoi(argv[1]) : 1024;
     const int passes = argc > 2 ? atoi(argv[2]) : 3;
+    const bool only_ref = argc > 3; // a third argument: the block-per-lane shape's XCD mappings alone
     P p;
     size_t blocks;
     geometry(p, nullptr, nullptr, blocks);
@@ -313,11 +329,19 @@ int main(int argc, char **argv) {
             if (!contiguous) for (int wg : {8, 4}) {
                 const unsigned lds = wg >= 8 ? 0u : (unsigned)(160 * 1024 / wg - 1024) & ~255u;
                 CHECK(hipFuncSetAttribute((const void *)k1_ref, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-                const double t = timeit([&] { hipLaunchKernelGGL(k1_ref, dim3(p.tiles, frames), dim3(256), lds, 0, pr); }, reps);
-                snprintf(name, sizeof name, "block per lane (K1's shape), %d VALU, %d workgroups per CU", work, wg);
-                report(name, t, "");
+                for (int xcd : {2, 1008, 1012, 1016, 1024, 1032, 1064, 1128, 1256, 1512, 0}) { // (0 last: the plain mapping leaves the reference output for the variants below)
+                    P px = pr;
+                    px.contiguous = xcd >= 1000 ? 3 : xcd;
+                    px.run = xcd >= 1000 ? (xcd == 3072 ? 1536 : xcd - 1000) : 0;
+                    CHECK(hipMemsetAsync(out_ref, 0, n_out));
+                    const double t = timeit([&] { hipLaunchKernelGGL(k1_ref, dim3(p.tiles, frames), dim3(256), lds, 0, px); }, reps);
+                    snprintf(name, sizeof name, "block per lane (K1's shape), %d VALU, %d workgroups per CU%s", work, wg,
+                             xcd == 1 ? ", every XCD its own eighth of the batch" : xcd == 2 ? ", every XCD whole frames in turn" : "");
+                    if (xcd >= 1000) snprintf(name + strlen(name), sizeof name - strlen(name), ", every XCD runs of %d tiles", px.run);
+                    report(name, t, "");
+                }
             }
-            for (const Variant &v : variants) {
+            if (!only_ref) for (const Variant &v : variants) {
                 P pv = pr;
                 pv.pixels = out;
                 CHECK(hipFuncSetAttribute(v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds));

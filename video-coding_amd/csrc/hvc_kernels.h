@@ -3,6 +3,7 @@
 #define HVC_KERNELS_H
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -61,13 +62,16 @@ struct DecodeParams {
     // launches, each with its own counter): the first launch of a call stores, the others add (stream order, no memset)
     unsigned long long *wide_total;
     int wide_first;
+    int xcd_map;      // > 0: workgroups -> (frame, tile) by xcd_work(): every XCD takes runs of 2^(xcd_map - 1) tiles; 0: as dispatched
+    unsigned xcd_magic; // ceil(2^32 / tiles per frame)
 };
 
 struct EncodeParams {
     const uint8_t *pixels;
     int16_t *coefs;
     size_t coef_fs, pixel_fs;
-    int n_frames, n_comp, tiles_per_frame, pad;
+    int n_frames, n_comp, tiles_per_frame, xcd_map;
+    unsigned xcd_magic, pad;
     CompK comp[HVC_MAX_COMP];
     float qrcp[HVC_MAX_QTABS * 64];   // fl((1 + 2^-16) / (4*q)), zig-zag order (kernarg segment)
 };
@@ -75,8 +79,9 @@ struct EncodeParams {
 struct UpsampleParams {
     const uint8_t *src;
     uint8_t *dst;
-    int cw, ch, n_planes, pad;
+    int cw, ch, n_planes, xcd_map;
     size_t src_stride, dst_stride, src_ps, dst_ps;
+    unsigned xcd_magic, pad;
 };
 
 // One plane of a 4:2:0 coefficient record decoded straight to a tight 4:4:4 frame
@@ -121,7 +126,55 @@ struct Decode444Params {
     size_t dc_fs;
     unsigned long long *wide_total; // as in DecodeParams
     int wide_first;
+    int xcd_map;                    // as in DecodeParams
+    unsigned xcd_magic;
 };
+
+// HVC_XCD_RUN in the environment (A/B switch): 0 = workgroups as dispatched; R = runs of R tiles per XCD (a power of two).
+// Default: 16 for the block-per-lane kernels (K1, K3, K2), 64 for the fused 4:4:4 kernel, whose tiles are two or four times as
+// large and mix 2:1 with 1:2 traffic (HVC_XCD_RUN_444 overrides that one) -- each the best of 16 / 32 / 64 in same-box A/Bs.
+inline int xcd_map_run(bool fused = false) {
+    static const int run = [] { const char *v = getenv("HVC_XCD_RUN"); return v ? atoi(v) : -1; }();
+    static const int run444 = [] { const char *v = getenv("HVC_XCD_RUN_444"); return v ? atoi(v) : -1; }();
+    if (fused) return run444 >= 0 ? run444 : run >= 0 ? run : 64;
+    return run >= 0 ? run : 16;
+}
+// Workgroup -> (frame, tile).  The dispatcher deals a grid's workgroups round-robin over the 8 XCDs in linear order (x
+// fastest, then y): taken as they come, consecutive tiles land behind eight different L2s and eight interleaved request
+// streams sweep every stretch of memory.  Instead every XCD takes RUNS of R = 2^(map - 1) consecutive tiles of the batch's
+// linear (frame, tile) order: workgroup id = y * tiles + x has XCD id % 8 and is that XCD's k-th (k = id / 8); it takes
+// position k % R of the XCD's (k / R)-th run, and the runs of the eight XCDs interleave: linear = ((k / R) * 8 + xcd) * R +
+// k % R.  A permutation of [0, full) where full = the workgroups in whole groups of 8 R (the rest stay as dispatched), so
+// every (frame, tile) still has exactly one workgroup.  frame = linear / tiles by a host-made reciprocal (magic = ceil(2^32 /
+// tiles), exact while linear * tiles < 2^32: the host leaves the mapping off otherwise).  Scalar arithmetic only.
+// Measured on K1's traffic shape (tools/ubench/k1_dma_ubench.hip, profiles/r04h - r04k_*): runs of 16 - 64 tiles +2 ... +3.4
+// points of the HBM peak over the plain order on two boxes, whole frames per XCD +1.3 ... +2.6, runs of 4 or of 12 / 24 / 48
+// tiles little or nothing; in the kernels (same box, alternating): DESIGN.md section 5.
+#ifdef __HIPCC__
+__device__ __forceinline__ void xcd_work(int map, unsigned magic, unsigned &frame, unsigned &tile) {
+    frame = blockIdx.y;
+    tile = blockIdx.x;
+    if (map > 0) {
+        const unsigned per = gridDim.x, id = frame * per + tile, sh = (unsigned)map - 1u;
+        const unsigned group = 8u << sh, total = per * gridDim.y;
+        if (id < total - total % group) {
+            const unsigned k = id >> 3;
+            const unsigned lin = ((((k >> sh) << 3) + (id & 7u)) << sh) + (k & ((1u << sh) - 1u));
+            frame = __umulhi(lin, magic);
+            tile = lin - frame * per;
+        }
+    }
+}
+#endif
+// host side: the reciprocal, and whether the mapping may be used for a grid of `per` x `n` workgroups (0 = off)
+inline int xcd_map_for(unsigned per, unsigned n, unsigned &magic, bool fused = false) {
+    magic = per > 1 ? (unsigned)(((1ull << 32) + per - 1) / per) : 0u;
+    const int run = xcd_map_run(fused);
+    if (run <= 0 || per <= 1 || (unsigned long long)per * n * per >= (1ull << 32)) return 0;
+    int sh = 0;
+    while ((1 << (sh + 1)) <= run) sh++;
+    return sh + 1;
+}
 
 // k0/k1 (optional): events recorded right before / after the dominant kernel.
 // wide_only: every block through the int64 kernel (tables with entries > 255).

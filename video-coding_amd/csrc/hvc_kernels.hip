@@ -562,13 +562,15 @@ template <bool DCP>
 __global__ __launch_bounds__(HVC_PACKED_LB) void k_decode_packed(DecodeParams P) {
     BlockRef br;
     const int lane = threadIdx.x;
-    const bool active = locate(P, blockIdx.y, blockIdx.x, lane, br);
+    unsigned wframe, wtile;
+    xcd_work(P.xcd_map, P.xcd_magic, wframe, wtile);
+    const bool active = locate(P, (int)wframe, (int)wtile, lane, br);
     const uint4 *src = reinterpret_cast<const uint4 *>(P.coefs + br.coef_idx);
     const unsigned *__restrict__ qp = P.qpair + br.qtab * 32; // wave-uniform, kernarg segment
     PackedGuard g;
     unsigned out[8][2];
     int16_t dcv = 0;
-    if (DCP) dcv = P.dc_plane[(size_t)blockIdx.y * P.dc_fs + ((br.coef_idx - (size_t)blockIdx.y * P.coef_fs) >> 6)];
+    if (DCP) dcv = P.dc_plane[(size_t)wframe * P.dc_fs + ((br.coef_idx - (size_t)wframe * P.coef_fs) >> 6)];
 #if HVC_TRAFFIC_ONLY == 2 // whole-line loads where all 64 blocks of the wavefront exist (they are contiguous then)
     const bool hvc_full = __ballot(active) == ~0ull;
     const int hvc_src_stride = hvc_full ? 64 : 1;
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(HVC_PACKED_LB) void k_decode_packed(DecodeParams P)
         base = __shfl(base, 0);
         if (flag) {
             unsigned idx = base + (unsigned)__popcll(m & ((1ull << wl) - 1ull));
-            P.fix_list[idx] = ((unsigned)blockIdx.y * (unsigned)P.tiles_per_frame + blockIdx.x) * HVC_TILE + lane;
+            P.fix_list[idx] = (wframe * (unsigned)P.tiles_per_frame + wtile) * HVC_TILE + lane;
         }
     }
 }
@@ -970,18 +972,20 @@ __global__ __launch_bounds__(HVC_TILE * NW, 4 / NW) HVC_444_ATTR void k_decode_4
     constexpr int WGS = HVC_TILE * NW, TW = HVC_444_TILE_BW * NW;
     __shared__ uint4 edge[WGS]; // per lane: first row (x, y) and first column (z, w) of its chroma block
     const int lane = threadIdx.x;
-    const int tile = (int)blockIdx.x + P.tile0;        // (tile0 = y_tiles when the luma planes went through k_decode_packed)
+    unsigned wframe, wtile;
+    xcd_work(P.xcd_map, P.xcd_magic, wframe, wtile);
+    const int tile = (int)wtile + P.tile0;             // (tile0 = y_tiles when the luma planes went through k_decode_packed)
     const bool chroma = tile >= P.y_tiles;             // workgroup-uniform
     if (P.skip && P.skip == (chroma ? 2 : 1)) return;  // (measurements: one half of the kernel alone)
     const Ref444 r = locate444(P, tile, lane, WGS, TW);
     const Plane444K &K = P.pl[r.p];
     const size_t in_frame = K.coef_off + ((size_t)r.by * K.bw + r.bx) * 64; // the block's place in the frame record
-    const uint4 *src = reinterpret_cast<const uint4 *>(P.coefs + (size_t)blockIdx.y * P.coef_fs + in_frame);
+    const uint4 *src = reinterpret_cast<const uint4 *>(P.coefs + (size_t)wframe * P.coef_fs + in_frame);
     const unsigned *__restrict__ qp = P.qpair + K.qtab * 32;
     PackedGuard g;
     unsigned out[8][2];
     int16_t dcv = 0;
-    if (DCP) dcv = P.dc_plane[(size_t)blockIdx.y * P.dc_fs + (in_frame >> 6)];
+    if (DCP) dcv = P.dc_plane[(size_t)wframe * P.dc_fs + (in_frame >> 6)];
 #if HVC_TRAFFIC_ONLY == 2
     const int hvc_src_stride = 1; // (the fused kernel keeps its load shape)
 #endif
@@ -989,7 +993,7 @@ __global__ __launch_bounds__(HVC_TILE * NW, 4 / NW) HVC_444_ATTR void k_decode_4
     const bool bad = packed_guard_failed(g, P.ethr_packed[K.qtab]);
 
     const size_t W = (size_t)P.width;
-    uint8_t *plane = P.out + (size_t)blockIdx.y * P.out_fs + K.out_off;
+    uint8_t *plane = P.out + (size_t)wframe * P.out_fs + K.out_off;
     const int lasty = K.ah - 1 - r.by * 8; // last block row that is inside the crop (>= 0 for active lanes)
     if (!chroma) {
         if (r.active && !bad) {
@@ -1053,7 +1057,7 @@ __global__ __launch_bounds__(HVC_TILE * NW, 4 / NW) HVC_444_ATTR void k_decode_4
         base = __shfl(base, 0);
         if (flag) {
             unsigned idx = base + (unsigned)__popcll(m & ((1ull << wl) - 1ull));
-            P.fix_list[idx] = ((unsigned)blockIdx.y * (unsigned)P.tiles_per_frame + (unsigned)tile) * WGS + lane;
+            P.fix_list[idx] = (wframe * (unsigned)P.tiles_per_frame + (unsigned)tile) * WGS + lane;
         }
     }
 }
@@ -1315,7 +1319,9 @@ __device__ __forceinline__ int quant1(int f, float r) {
 __global__ __launch_bounds__(HVC_ENCODE_LB) HVC_ENCODE_ATTR void k_encode(EncodeParams P) {
     BlockRef br;
     const int lane = threadIdx.x;
-    const bool active = locate(P, blockIdx.y, blockIdx.x, lane, br);
+    unsigned wframe, wtile;
+    xcd_work(P.xcd_map, P.xcd_magic, wframe, wtile);
+    const bool active = locate(P, (int)wframe, (int)wtile, lane, br);
     const uint8_t *pix = P.pixels + br.pix_idx;
     // 8 rows x 8 B per lane; a wave's row loads are 512 contiguous bytes of a pixel row.
     unsigned px[8][2];
@@ -1466,11 +1472,13 @@ __global__ __launch_bounds__(256) void k_upsample420(UpsampleParams P) {
 __global__ __launch_bounds__(256) void k_upsample420_x8(UpsampleParams P) {
     const int groups = P.cw >> 3;
     const long long total = (long long)groups * P.ch;
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    unsigned wplane, wtile;
+    xcd_work(P.xcd_map, P.xcd_magic, wplane, wtile);
+    const long long t = (long long)wtile * 256 + threadIdx.x;
     if (t >= total) return;
     const int row = (int)(t / groups), g = (int)(t % groups);
-    const uint8_t *src = P.src + (size_t)blockIdx.y * P.src_ps;
-    uint8_t *dst = P.dst + (size_t)blockIdx.y * P.dst_ps;
+    const uint8_t *src = P.src + (size_t)wplane * P.src_ps;
+    uint8_t *dst = P.dst + (size_t)wplane * P.dst_ps;
     const int row2 = min(P.ch - 1, row + 1); // :86
     const uint8_t *s1 = src + (size_t)row * P.src_stride + 8 * g;
     const uint8_t *s2 = src + (size_t)row2 * P.src_stride + 8 * g;
@@ -1562,6 +1570,7 @@ hipError_t launch_checksum(const uint8_t *data, size_t record_bytes, size_t reco
     return hipGetLastError();
 }
 
+
 hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0, hipEvent_t k1) {
     if (P.n_frames <= 0 || P.tiles_per_frame <= 0) return hipSuccess;
     hipError_t e;
@@ -1581,10 +1590,14 @@ hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0, hi
         hipLaunchKernelGGL(k_decode_q16, grid, dim3(HVC_TILE), 0, s, P);
     else if (sel == 1)
         hipLaunchKernelGGL(k_decode_fast, grid, dim3(HVC_TILE), 0, s, P);
-    else if (P.dc_plane)
-        hipLaunchKernelGGL(k_decode_packed<true>, grid, dim3(HVC_TILE), 0, s, P);
-    else
-        hipLaunchKernelGGL(k_decode_packed<false>, grid, dim3(HVC_TILE), 0, s, P);
+    else {
+        DecodeParams Q = P;
+        Q.xcd_map = xcd_map_for(grid.x, grid.y, Q.xcd_magic); // (xcd_work: every XCD takes runs of consecutive tiles)
+        if (P.dc_plane)
+            hipLaunchKernelGGL(k_decode_packed<true>, grid, dim3(HVC_TILE), 0, s, Q);
+        else
+            hipLaunchKernelGGL(k_decode_packed<false>, grid, dim3(HVC_TILE), 0, s, Q);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (k1 && (e = hipEventRecord(k1, s)) != hipSuccess) return e;
@@ -1677,6 +1690,7 @@ hipError_t launch_decode_444(const Decode444Params &P, bool wide_only, hipStream
     static const int only = [] { const char *v = getenv("HVC_444_ONLY"); return !v ? 0 : v[0] == 'l' ? 2 : v[0] == 'c' ? 1 : 0; }();
     Decode444Params Q = P;
     Q.skip = only;
+    Q.xcd_map = xcd_map_for((unsigned)(P.tiles_per_frame - P.tile0), (unsigned)P.n_frames, Q.xcd_magic, true);
     // HVC_444_LDS_PAD=bytes (experiments): dynamic LDS nobody uses, to hold the kernel to fewer workgroups per CU
     static const unsigned pad = [] { const char *v = getenv("HVC_444_LDS_PAD"); return v ? (unsigned)atoi(v) : 0u; }();
     if (!aligned && P.nw != 1) return hipErrorInvalidValue; // (plan_decode_444 was told otherwise)
@@ -1711,7 +1725,9 @@ hipError_t launch_encode(const EncodeParams &P, hipStream_t s, hipEvent_t k0, hi
     dim3 grid((unsigned)P.tiles_per_frame, (unsigned)P.n_frames, 1);
     if (k0 && (e = hipEventRecord(k0, s)) != hipSuccess) return e;
     static const unsigned pad = [] { const char *v = getenv("HVC_ENC_LDS_PAD"); return v ? (unsigned)atoi(v) : 0u; }(); // experiments
-    hipLaunchKernelGGL(k_encode, grid, dim3(HVC_TILE), pad, s, P);
+    EncodeParams Q = P;
+    Q.xcd_map = xcd_map_for(grid.x, grid.y, Q.xcd_magic);
+    hipLaunchKernelGGL(k_encode, grid, dim3(HVC_TILE), pad, s, Q);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (k1 && (e = hipEventRecord(k1, s)) != hipSuccess) return e;
@@ -1728,8 +1744,10 @@ hipError_t launch_upsample420(const UpsampleParams &P, hipStream_t s) {
                     (P.dst_ps % 16 == 0) && ((uintptr_t)P.src % 8 == 0) && ((uintptr_t)P.dst % 16 == 0);
     if (x8) {
         const long long n8 = (long long)(P.cw >> 3) * P.ch;
+        UpsampleParams Q = P;
+        Q.xcd_map = xcd_map_for((unsigned)((n8 + 255) / 256), (unsigned)P.n_planes, Q.xcd_magic);
         hipLaunchKernelGGL(k_upsample420_x8, dim3((unsigned)((n8 + 255) / 256), (unsigned)P.n_planes, 1), dim3(256), 0,
-                           s, P);
+                           s, Q);
     } else if (vec)
         hipLaunchKernelGGL(k_upsample420<true>, grid, dim3(256), 0, s, P);
     else

@@ -16,7 +16,9 @@ struct PlaneOp {
     uint8_t *dst;
     int sw, sh, dw, dh;   // source / destination plane size in samples
     int x_pos, y_pos;     // Yuv.crop only
-    int vec, pad;         // bases, strides and plane strides allow the 16 / 8-byte forms
+    int vec;              // bases, strides and plane strides allow the 16 / 8-byte forms
+    int xcd_map;          // workgroup -> (plane, piece of the plane) by hvc::xcd_work (runs of pieces per XCD), 0 = as dispatched
+    unsigned xcd_magic, pad;
     size_t src_stride, dst_stride, src_ps, dst_ps;
 };
 
@@ -33,12 +35,14 @@ __device__ __forceinline__ unsigned avg2x4(unsigned a, unsigned b) { // (a + b +
 // Planar_444.subsample_hv2 (planar_444.ml:69-80): dst[col, row] = avg4 of the 2 x 2 source samples; dst = (sw / 2) x (sh / 2)
 __global__ __launch_bounds__(256) void k_subsample420(PlaneOp P) {
     const unsigned groups = (unsigned)(P.dw + 7) >> 3;
-    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    unsigned wplane, wpiece;
+    hvc::xcd_work(P.xcd_map, P.xcd_magic, wplane, wpiece);
+    const unsigned t = wpiece * 256u + threadIdx.x;
     if (t >= groups * (unsigned)P.dh) return;
     const unsigned row = t / groups, g = t - row * groups;
-    const uint8_t *s0 = P.src + (size_t)blockIdx.y * P.src_ps + (size_t)(2 * row) * P.src_stride + 16 * g;
+    const uint8_t *s0 = P.src + (size_t)wplane * P.src_ps + (size_t)(2 * row) * P.src_stride + 16 * g;
     const uint8_t *s1 = s0 + P.src_stride;
-    uint8_t *d = P.dst + (size_t)blockIdx.y * P.dst_ps + (size_t)row * P.dst_stride + 8 * g;
+    uint8_t *d = P.dst + (size_t)wplane * P.dst_ps + (size_t)row * P.dst_stride + 8 * g;
     if (P.vec && (int)(8 * g + 8) <= P.dw) {
         const u4v a = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(s0));
         const u4v b = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(s1));
@@ -57,11 +61,13 @@ __global__ __launch_bounds__(256) void k_subsample420(PlaneOp P) {
 // Planar_444.subsample_h2 (planar_444.ml:18-23): dst[col, row] = avg2 src[2 col, row] src[2 col + 1, row]; dst = (sw / 2) x sh
 __global__ __launch_bounds__(256) void k_subsample422(PlaneOp P) {
     const unsigned groups = (unsigned)(P.dw + 7) >> 3;
-    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    unsigned wplane, wpiece;
+    hvc::xcd_work(P.xcd_map, P.xcd_magic, wplane, wpiece);
+    const unsigned t = wpiece * 256u + threadIdx.x;
     if (t >= groups * (unsigned)P.dh) return;
     const unsigned row = t / groups, g = t - row * groups;
-    const uint8_t *s0 = P.src + (size_t)blockIdx.y * P.src_ps + (size_t)row * P.src_stride + 16 * g;
-    uint8_t *d = P.dst + (size_t)blockIdx.y * P.dst_ps + (size_t)row * P.dst_stride + 8 * g;
+    const uint8_t *s0 = P.src + (size_t)wplane * P.src_ps + (size_t)row * P.src_stride + 16 * g;
+    uint8_t *d = P.dst + (size_t)wplane * P.dst_ps + (size_t)row * P.dst_stride + 8 * g;
     if (P.vec && (int)(8 * g + 8) <= P.dw) {
         const u4v a = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(s0));
         const unsigned r0 = ((pairsum(a.x) + 0x00010001u) >> 1) & 0x00ff00ffu, r1 = ((pairsum(a.y) + 0x00010001u) >> 1) & 0x00ff00ffu;
@@ -77,11 +83,13 @@ __global__ __launch_bounds__(256) void k_subsample422(PlaneOp P) {
 // column twice (avg2 a a = a: the right neighbour of the last column is the column itself); dst = (2 sw) x sh
 __global__ __launch_bounds__(256) void k_upsample422(PlaneOp P) {
     const unsigned groups = (unsigned)(P.sw + 7) >> 3;
-    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    unsigned wplane, wpiece;
+    hvc::xcd_work(P.xcd_map, P.xcd_magic, wplane, wpiece);
+    const unsigned t = wpiece * 256u + threadIdx.x;
     if (t >= groups * (unsigned)P.sh) return;
     const unsigned row = t / groups, g = t - row * groups;
-    const uint8_t *s = P.src + (size_t)blockIdx.y * P.src_ps + (size_t)row * P.src_stride + 8 * g;
-    uint8_t *d = P.dst + (size_t)blockIdx.y * P.dst_ps + (size_t)row * P.dst_stride + 16 * g;
+    const uint8_t *s = P.src + (size_t)wplane * P.src_ps + (size_t)row * P.src_stride + 8 * g;
+    uint8_t *d = P.dst + (size_t)wplane * P.dst_ps + (size_t)row * P.dst_stride + 16 * g;
     if (P.vec && (int)(8 * g + 8) <= P.sw) {
         const u2v a = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(s));
         const unsigned next = (int)(8 * g + 8) < P.sw ? s[8] : (a.y >> 24);
@@ -106,13 +114,15 @@ __global__ __launch_bounds__(256) void k_upsample422(PlaneOp P) {
 // Yuv.crop (tools/src/yuv.ml:42-62) of one plane: dst[col, row] = src[clamp (col + x_pos), clamp (row + y_pos)]
 __global__ __launch_bounds__(256) void k_crop(PlaneOp P) {
     const unsigned groups = (unsigned)(P.dw + 7) >> 3;
-    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    unsigned wplane, wpiece;
+    hvc::xcd_work(P.xcd_map, P.xcd_magic, wplane, wpiece);
+    const unsigned t = wpiece * 256u + threadIdx.x;
     if (t >= groups * (unsigned)P.dh) return;
     const unsigned row = t / groups, g = t - row * groups;
     int sr = (int)row + P.y_pos;
     sr = sr < 0 ? 0 : sr >= P.sh ? P.sh - 1 : sr;
-    const uint8_t *s = P.src + (size_t)blockIdx.y * P.src_ps + (size_t)sr * P.src_stride;
-    uint8_t *d = P.dst + (size_t)blockIdx.y * P.dst_ps + (size_t)row * P.dst_stride + 8 * g;
+    const uint8_t *s = P.src + (size_t)wplane * P.src_ps + (size_t)sr * P.src_stride;
+    uint8_t *d = P.dst + (size_t)wplane * P.dst_ps + (size_t)row * P.dst_stride + 8 * g;
     unsigned b[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -180,6 +190,7 @@ hipError_t launch_plane_op(OpKind kind, PlaneOp P, int n_planes, hipStream_t s) 
     P.vec = kind == OP_CROP ? ((uintptr_t)P.dst % 8 == 0 && P.dst_stride % 8 == 0 && P.dst_ps % 8 == 0)
                             : ((uintptr_t)P.src % sa == 0 && P.src_stride % sa == 0 && P.src_ps % sa == 0 &&
                                (uintptr_t)P.dst % da == 0 && P.dst_stride % da == 0 && P.dst_ps % da == 0);
+    P.xcd_map = hvc::xcd_map_for(grid.x, grid.y, P.xcd_magic);
     switch (kind) {
     case OP_SUB420: hipLaunchKernelGGL(k_subsample420, grid, dim3(256), 0, s, P); break;
     case OP_SUB422: hipLaunchKernelGGL(k_subsample422, grid, dim3(256), 0, s, P); break;
