@@ -12,10 +12,20 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
 // workgroup g reads the R * 4 KiB at in + g * R * 256 pieces and writes the W * 4 KiB at out + g * W * 256 pieces;
 // instruction j of a wave covers one contiguous KiB
+// sh >= 0 (round 4): the workgroups do not take their regions in dispatch order (consecutive regions behind eight different
+// XCDs' L2s) but every XCD takes runs of 2^sh consecutive regions (csrc/hvc_kernels.h xcd_work)
 template <int R, int W>
-__global__ __launch_bounds__(256) void k(const u4v *__restrict__ in, u4v *__restrict__ out, size_t groups) {
+__global__ __launch_bounds__(256) void k(const u4v *__restrict__ in, u4v *__restrict__ out, size_t groups, int sh) {
     extern __shared__ unsigned char dyn_lds[];
-    const size_t g = blockIdx.x;
+    unsigned id = blockIdx.x;
+    if (sh >= 0) {
+        const unsigned group = 8u << sh, total = gridDim.x;
+        if (id < total - total % group) {
+            const unsigned kk = id >> 3;
+            id = ((((kk >> sh) << 3) + (id & 7u)) << sh) + (kk & ((1u << sh) - 1u));
+        }
+    }
+    const size_t g = id;
     if (g >= groups) return;
     const int lane = threadIdx.x, wv = lane >> 6, l = lane & 63;
     const u4v *src = in + (g * 4 + wv) * (size_t)(R * 64) + l;
@@ -52,20 +62,28 @@ double timeit(F launch, int reps) {
 static const size_t TOTAL = 9600ull * 1000000ull;
 static u4v *A, *B;
 
+static int g_run_kib = 0; // 0: as dispatched; else every XCD takes runs of about this many KiB of the INPUT stream
 template <int R, int W>
 void run(bool pr) {
     const size_t groups = TOTAL / ((size_t)(R + W) * 4096);
+    int sh = -1;
+    if (g_run_kib) { // a workgroup reads R * 4 KiB
+        sh = 0;
+        while ((size_t)(2 << sh) * R * 4 <= (size_t)g_run_kib) sh++;
+    }
     CHECK(hipFuncSetAttribute((const void *)k<R, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     if (pr) printf("%2d x 16 B in, %2d x 16 B out per lane:", R, W);
     for (int wg : {8, 6, 4, 3, 2}) {
         const unsigned lds = wg >= 8 ? 0u : (unsigned)(160 * 1024 / wg - 1024) & ~255u;
-        const double ms = timeit([&] { hipLaunchKernelGGL((k<R, W>), dim3((unsigned)groups), dim3(256), lds, 0, A, B, groups); }, 15);
+        const double ms = timeit([&] { hipLaunchKernelGGL((k<R, W>), dim3((unsigned)groups), dim3(256), lds, 0, A, B, groups, sh); }, 15);
         if (pr) printf("  %d wg/CU %5.1f %%", wg, (double)groups * (R + W) * 4096 / (ms * 1e-3) / 8e12 * 100);
     }
     if (pr) printf("   (%d KiB of loads in flight per CU at 8 wg/CU)\n", 32 * R);
 }
 
-int main() {
+int main(int argc, char **argv) {
+    g_run_kib = argc > 1 ? atoi(argv[1]) : 0;
+    if (g_run_kib) printf("every XCD takes runs of about %d KiB of the input stream\n", g_run_kib);
     CHECK(hipMalloc(&A, TOTAL));
     CHECK(hipMalloc(&B, TOTAL));
     CHECK(hipMemset(A, 1, TOTAL));

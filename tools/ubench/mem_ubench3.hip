@@ -15,9 +15,22 @@
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
 // thread t of the grid reads R pieces in[j * n + t] and writes W pieces out[j * n + t] (n = threads in the grid)
+// g_sh >= 0: the workgroups are not taken in dispatch order (consecutive 4 KiB pieces behind eight different XCDs' L2s) but
+// every XCD takes runs of 2^g_sh consecutive pieces (csrc/hvc_kernels.h xcd_work, round 4)
+__device__ __forceinline__ unsigned piece_of(int sh) {
+    unsigned id = blockIdx.x;
+    if (sh >= 0) {
+        const unsigned group = 8u << sh, total = gridDim.x;
+        if (id < total - total % group) {
+            const unsigned k = id >> 3;
+            id = ((((k >> sh) << 3) + (id & 7u)) << sh) + (k & ((1u << sh) - 1u));
+        }
+    }
+    return id;
+}
 template <int R, int W, bool NT>
-__global__ __launch_bounds__(256) void mix(const u4v *__restrict__ in, u4v *__restrict__ out, size_t n, unsigned *sink) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void mix(const u4v *__restrict__ in, u4v *__restrict__ out, size_t n, unsigned *sink, int sh) {
+    const size_t t = (size_t)piece_of(sh) * 256 + threadIdx.x;
     if (t >= n) return;
     u4v acc = {1u, 2u, 3u, 4u};
 #pragma unroll
@@ -51,10 +64,11 @@ double timeit(F launch, int reps) {
 }
 
 static bool g_print = false;
+static int g_sh = -1;
 template <int R, int W, bool NT>
 void run(const char *name, const u4v *in, u4v *out, size_t total_bytes, unsigned *sink) {
     const size_t n = total_bytes / 16 / (R + W);
-    const double ms = timeit([&] { hipLaunchKernelGGL((mix<R, W, NT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, in, out, n, sink); }, 20);
+    const double ms = timeit([&] { hipLaunchKernelGGL((mix<R, W, NT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, in, out, n, sink, g_sh); }, 20);
     if (!g_print) return; // first pass: warm-up
     printf("%-44s %2d:%-2d %8.4f ms %8.1f GB/s  (%.1f %% of 8 TB/s)\n", name, R, W, ms, (double)n * 16 * (R + W) / (ms * 1e-3) / 1e9,
            (double)n * 16 * (R + W) / (ms * 1e-3) / 8e12 * 100);
@@ -69,9 +83,12 @@ int main(int argc, char **argv) {
     CHECK(hipMalloc(&sink, 4));
     CHECK(hipMemset(in, 1, total));
     CHECK(hipMemset(out, 0, total));
-    for (int rep = 0; rep < 2; rep++) {
-        g_print = rep == 1;
+    for (int rep = 0; rep < 6; rep++) {
+        g_print = rep >= 1;
+        const int shs[6] = {-1, -1, 4, 6, 7, 9}; // as dispatched (twice: the first pass warms up), then runs of 16 / 64 / 128 / 512 pieces of 4 KiB
+        g_sh = shs[rep];
         if (rep == 1) printf("bytes per launch %.1f GB\n", total / 1e9);
+        if (rep >= 2) printf("-- every XCD takes runs of %d consecutive 4 KiB pieces of each stream\n", 1 << g_sh);
         run<1, 0, false>("pure read", in, out, total, sink);
         run<0, 1, false>("pure write, plain stores", in, out, total, sink);
         run<0, 1, true>("pure write, nt stores", in, out, total, sink);
