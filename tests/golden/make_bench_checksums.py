@@ -6,7 +6,7 @@ the benchmarks decode, computed with the CPU restatement of the model on the ben
                                Encoder block stage at quality 75 (encoder.ml:81-108) -> Decoder block stage
                                (decoder.ml:142-149, 213-224) -> padded pixel record
     tools/bench_configs.py     config 3 (files -> padded planes), 4, 5 (pixels -> coefficient records), 7 (fused 4:4:4),
-                               K2 / subsample_hv2 (random planes), 5-files (raw frames -> the model encoder's files)
+                               K2 / subsample_hv2 (random planes), 5-files (raw frames -> the model encoder's files), 11 (oyuv convert passes)
 
 bench.py and tools/bench_configs.py read the file (data, not the oracle) and report `verified`;
 tests/test_bench_checksums.py re-derives entries from the oracle on every CPU run."""
@@ -130,6 +130,24 @@ def c5_files_entry(n_distinct=4):
     return out
 
 
+def convert_entries(n_distinct=4, only=None):
+    """config_convert: every pass of tools/bench_configs.py CONVERT_PASSES, one Oconv.main pass (oconv.ml:111-133) per
+    seeded raw frame"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs as bc
+    out = {}
+    for i, (key, fi, si, fo, so, off) in enumerate(bc.CONVERT_PASSES):
+        if only is not None and key not in only:
+            continue
+        fmt = lambda f: f if f in orc.PACKED else int(f)
+        in_fs = si[0] * si[1] * {"420": 3, "444": 6}.get(fi, 4) // 2  # (4:2:2, planar or packed: 2 bytes per pixel)
+        frames = bc.convert_input(i, n_distinct, in_fs)
+        out["configs_convert_" + key] = [
+            "%016x" % int(checksum_records(np.frombuffer(orc.oconv_frame(fr, fmt(fi), si, fmt(fo), so, off), dtype=np.uint8)[None, :])[0])
+            for fr in frames]
+    return out
+
+
 def main():
     g = {"comment": "K5 checksums of the benchmarks' decoded distinct frames per the CPU restatement of the model; "
                     "written by tests/golden/make_bench_checksums.py",
@@ -137,7 +155,7 @@ def main():
          "bench_config4": bench_entry(4, range(8)),
          "configs_c3": c3_entry(), "configs_c4": resident_entry([(480, 270, 0), (480, 270, 1), (480, 270, 1)], 40),
          "configs_c5": c5_entry(), "configs_c7": c7_entry(), "configs_k2": k2_entry(), "configs_sub420": sub420_entry(),
-         "configs_c5_files": c5_files_entry()}
+         "configs_c5_files": c5_files_entry(), **convert_entries()}
     with open(os.path.join(ROOT, "tests", "golden", "bench_checksums.json"), "w") as f:
         json.dump(g, f, indent=1)
     print("written")

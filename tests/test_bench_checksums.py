@@ -59,3 +59,6 @@ def test_tools_bench_configs_entries_follow_from_the_model():
     assert mk.k2_entry(1) == G["configs_k2"][:1]
     assert mk.sub420_entry(1) == G["configs_sub420"][:1]
     assert mk.c5_files_entry(1) == G["configs_c5_files"][:1]
+    for key, sums in mk.convert_entries(1, only=("420_to_uyvy", "420_crop_720p")).items():
+        assert sums == G[key][:1]
+    assert sum(k.startswith("configs_convert_") for k in G) == 5

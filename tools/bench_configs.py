@@ -6,6 +6,7 @@
   --config 4   4K 4:4:4 decode, one GPU's shard shape (388 800 blocks/frame), HBM-resident
   --config 5   encoder: forward 8x8 DCT + quantise, 4K 4:2:0, HBM-resident (hvc_encode_frames)
   --config 2 / 10 / 7 / 8 / 9 / 6   K2 upsample / subsample_hv2 / fused 4:4:4 / config 5 to files / GPU Huffman coder / host buffers
+  --config 11  whole `oyuv convert` passes (hvc_yuv_convert) on 1080p frames
 
 Every config function returns its JSON object (bench.py collects them as `others` in its one line); run as a command,
 this file prints it.
@@ -426,6 +427,54 @@ def config_sub420(args):
     return result
 
 
+# the passes of config 11: (key, input format, input size, output format, output size, offset) -- 1080p frames
+CONVERT_PASSES = [("420_to_444", "420", (1920, 1080), "444", (1920, 1080), (0, 0)),
+                  ("444_to_420", "444", (1920, 1080), "420", (1920, 1080), (0, 0)),
+                  ("420_to_uyvy", "420", (1920, 1080), "UYVY", (1920, 1080), (0, 0)),
+                  ("yuy2_to_420", "YUY2", (1920, 1080), "420", (1920, 1080), (0, 0)),
+                  ("420_crop_720p", "420", (1920, 1080), "420", (1280, 720), (320, 180))]
+
+
+def convert_input(key_index, n_distinct, frame_bytes):
+    """the seeded raw frames of pass number key_index (tests/golden/make_bench_checksums.py makes the same ones)"""
+    return np.random.Generator(np.random.PCG64(200 + key_index)).integers(0, 256, size=(n_distinct, frame_bytes)).astype(np.uint8)
+
+
+def config_convert(args):
+    """`oyuv convert` (Oconv.main, oconv.ml:111-133) on whole raw frames resident in HBM, hvc_yuv_convert: every pass's
+    frames per second and its bytes in + bytes out per second (the passes go through a full-size 4:4:4 frame as the
+    reference's do, so this rate is end to end, not a kernel's)."""
+    import torch
+    import video_coding_amd as hvc
+    ctx = hvc.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    passes = []
+    for i, (key, fi, si, fo, so, off) in enumerate(CONVERT_PASSES):
+        fin, fout = hvc.YUV_FORMATS[fi], hvc.YUV_FORMATS[fo]
+        in_fs, out_fs = hvc.yuv_frame_bytes(fin, *si), hvc.yuv_frame_bytes(fout, *so)
+        src = convert_input(i, args.distinct, in_fs)
+        reps = (args.frames + args.distinct - 1) // args.distinct
+        d_src = torch.from_numpy(src).cuda().repeat(reps, 1)[:args.frames].contiguous()
+        d_dst = torch.zeros((args.frames, out_fs), dtype=torch.uint8, device="cuda")
+        for _ in range(args.warmup):
+            ctx.yuv_convert(d_src, fin, si, d_dst, fout, so, off, n_frames=args.frames)
+        torch.cuda.synchronize()
+        ctx.timer_begin()
+        for _ in range(args.steps):
+            ctx.yuv_convert(d_src, fin, si, d_dst, fout, so, off, n_frames=args.frames)
+        ms = ctx.timer_end() / args.steps
+        v = verify(ctx, d_dst, out_fs, args.frames, "configs_convert_" + key, args.distinct)
+        passes.append({"pass": key, "ms": round(ms, 4), "frames_per_s": round(args.frames / (ms * 1e-3), 1),
+                       "in_plus_out_GBps": round(args.frames * (in_fs + out_fs) / (ms * 1e-3) / 1e9, 1),
+                       "verified": v["checksum"]["verified"]})
+        del d_src, d_dst
+    ctx.close()
+    oks = [q["verified"] for q in passes]
+    return {"config": "convert", "metric": "oyuv convert passes, 1080p frames resident in HBM", "frames": args.frames,
+            "passes": passes, "checksum": {"verified": None if None in oks else all(oks),
+                                           "expected": "tests/golden/bench_checksums.json:configs_convert_*"}}
+
+
 def make_args(**kw):
     """the argument object of the config functions for callers that are not this file's command line (bench.py)"""
     d = dict(frames=None, distinct=4, steps=None, warmup=10, threads=min(16, len(os.sched_getaffinity(0))), chunk=32,
@@ -436,7 +485,7 @@ def make_args(**kw):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", type=int, required=True, choices=[2, 3, 4, 5, 6, 7, 8, 9, 10])
+    ap.add_argument("--config", type=int, required=True, choices=[2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
     ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--distinct", type=int, default=4)
     ap.add_argument("--steps", type=int, default=None)
@@ -456,6 +505,10 @@ def main():
         args.frames = args.frames or 256
         args.steps = args.steps or 20
         r = config_sub420(args)
+    elif args.config == 11:  # whole `oyuv convert` passes
+        args.frames = args.frames or 256
+        args.steps = args.steps or 10
+        r = config_convert(args)
     elif args.config == 9:  # GPU Huffman coder alone
         args.frames = args.frames or 32
         args.steps = args.steps or 10

@@ -10,4 +10,4 @@ There is no CPU fallback: loading fails loudly when the library is missing and
 hvc.Context() raises when no gfx950 GPU is usable.
 """
 from . import hvc  # noqa: F401
-from .hvc import Component, Context, HvcError, build, lib  # noqa: F401
+from .hvc import YUV_FORMATS, Component, Context, HvcError, build, lib, yuv_frame_bytes  # noqa: F401

@@ -1221,6 +1221,9 @@ __device__ __forceinline__ int vmad24(int k, int x, int acc) {
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "s"(k), "v"(x), "v"(acc));
     return d;
 }
+// (Round 4 tried the rotations as one v_dot2_i32_i16 per output on int16 operand pairs packed once per pair: 80 VALU
+// instructions per block fewer (1062 -> 982) and 72 VGPRs -- and 0.3 - 0.7 points SLOWER than this form on the same box,
+// three alternations: profiles/r04q_k3_dot2_ab.txt.  K3 does not wait for its VALU.)
 __device__ __forceinline__ int c4(int f, int g) { return vmul24(362, f + g) >> 9; }
 __device__ __forceinline__ int c4m(int f, int g) { return vmul24(362, f - g) >> 9; }
 __device__ __forceinline__ int c62(int f, int g) { return vmad24(473, g, vmul24(196, f)) >> 9; }
@@ -1591,12 +1594,13 @@ hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0, hi
     else if (sel == 1)
         hipLaunchKernelGGL(k_decode_fast, grid, dim3(HVC_TILE), 0, s, P);
     else {
+        static const unsigned pad = [] { const char *v = getenv("HVC_DEC_LDS_PAD"); return v ? (unsigned)atoi(v) : 0u; }(); // experiments: unused LDS caps the workgroups per CU
         DecodeParams Q = P;
         Q.xcd_map = xcd_map_for(grid.x, grid.y, Q.xcd_magic); // (xcd_work: every XCD takes runs of consecutive tiles)
         if (P.dc_plane)
-            hipLaunchKernelGGL(k_decode_packed<true>, grid, dim3(HVC_TILE), 0, s, Q);
+            hipLaunchKernelGGL(k_decode_packed<true>, grid, dim3(HVC_TILE), pad, s, Q);
         else
-            hipLaunchKernelGGL(k_decode_packed<false>, grid, dim3(HVC_TILE), 0, s, Q);
+            hipLaunchKernelGGL(k_decode_packed<false>, grid, dim3(HVC_TILE), pad, s, Q);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -123,6 +123,13 @@ __global__ __launch_bounds__(256) void k_crop(PlaneOp P) {
     sr = sr < 0 ? 0 : sr >= P.sh ? P.sh - 1 : sr;
     const uint8_t *s = P.src + (size_t)wplane * P.src_ps + (size_t)sr * P.src_stride;
     uint8_t *d = P.dst + (size_t)wplane * P.dst_ps + (size_t)row * P.dst_stride + 8 * g;
+    const int c0 = (int)(8 * g) + P.x_pos;
+    if (P.vec && (int)(8 * g + 8) <= P.dw && c0 >= 0 && c0 + 8 <= P.sw) { // no column clamps: 8 bytes at once, from any alignment
+        u2v w;
+        __builtin_memcpy(&w, s + c0, 8);
+        *reinterpret_cast<u2v *>(d) = w;
+        return;
+    }
     unsigned b[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -144,38 +151,95 @@ struct PackedOp {
     uint8_t *packed_out;
     uint8_t *y, *u, *v;            // planar 4:2:2: w x h, (w / 2) x h, (w / 2) x h, tight
     const uint8_t *cy, *cu, *cv;   // the same planes as a source
-    int w, h, yo, uo, vo, pad;
+    int w, h, yo, uo, vo;
+    int vec;                       // bases and strides allow the lane's 16 / 8 / 4 / 4-byte pieces
+    unsigned sel_y, sel_u, sel_v;  // v_perm_b32 selectors: two packed dwords -> 4 luma / 2 + 2 chroma samples
+    unsigned sel_out[2];           //                        {luma dword, (u, v)} -> the packed dword of an even / odd pair
+    int xcd_map;                   // hvc::xcd_work
+    unsigned xcd_magic, pad;
     size_t packed_fs, planar_fs;   // bytes from frame to frame
+    size_t luma_fs;                // ... of the luma plane, which may live in another array than the chroma planes
 };
+// One lane moves four pairs of pixels: 16 packed bytes <-> 8 luma + 4 + 4 chroma samples; a wave's pieces are contiguous
+// runs of a row in all four arrays.  The byte shuffles are v_perm_b32 with selectors the host makes from (yo, uo, vo).
 __global__ __launch_bounds__(256) void k_unpack422(PackedOp P) { // convert_to_planar :10-23
-    const unsigned pairs = (unsigned)P.w >> 1;
-    const unsigned t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= pairs * (unsigned)P.h) return;
-    const unsigned row = t / pairs, col = t - row * pairs;
-    const uint8_t *s = P.packed_in + (size_t)blockIdx.y * P.packed_fs + (size_t)row * 2 * P.w + 4 * col;
-    const size_t f = (size_t)blockIdx.y * P.planar_fs;
-    P.y[f + (size_t)row * P.w + 2 * col] = s[P.yo];
-    P.y[f + (size_t)row * P.w + 2 * col + 1] = s[P.yo + 2];
-    P.u[f + (size_t)row * pairs + col] = s[P.uo];
-    P.v[f + (size_t)row * pairs + col] = s[P.vo];
+    const unsigned pairs = (unsigned)P.w >> 1, groups = (pairs + 3) >> 2;
+    unsigned wframe, wpiece;
+    hvc::xcd_work(P.xcd_map, P.xcd_magic, wframe, wpiece);
+    const unsigned t = wpiece * 256u + threadIdx.x;
+    if (t >= groups * (unsigned)P.h) return;
+    const unsigned row = t / groups, g = t - row * groups;
+    const uint8_t *s = P.packed_in + (size_t)wframe * P.packed_fs + (size_t)row * 2 * P.w + 16 * g;
+    const size_t f = (size_t)wframe * P.planar_fs;
+    uint8_t *y = P.y + (size_t)wframe * P.luma_fs + (size_t)row * P.w + 8 * g, *u = P.u + f + (size_t)row * pairs + 4 * g,
+            *v = P.v + f + (size_t)row * pairs + 4 * g;
+    if (P.vec && 4 * g + 4 <= pairs) {
+        const u4v d = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(s));
+        const u2v yy = {__builtin_amdgcn_perm(d.y, d.x, P.sel_y), __builtin_amdgcn_perm(d.w, d.z, P.sel_y)};
+        const unsigned u01 = __builtin_amdgcn_perm(d.y, d.x, P.sel_u), u23 = __builtin_amdgcn_perm(d.w, d.z, P.sel_u);
+        const unsigned v01 = __builtin_amdgcn_perm(d.y, d.x, P.sel_v), v23 = __builtin_amdgcn_perm(d.w, d.z, P.sel_v);
+        __builtin_nontemporal_store(yy, reinterpret_cast<u2v *>(y));
+        __builtin_nontemporal_store(__builtin_amdgcn_perm(u23, u01, 0x05040100u), reinterpret_cast<unsigned *>(u));
+        __builtin_nontemporal_store(__builtin_amdgcn_perm(v23, v01, 0x05040100u), reinterpret_cast<unsigned *>(v));
+        return;
+    }
+    for (unsigned k = 0; k < 4 && 4 * g + k < pairs; k++) {
+        y[2 * k] = s[4 * k + P.yo];
+        y[2 * k + 1] = s[4 * k + P.yo + 2];
+        u[k] = s[4 * k + P.uo];
+        v[k] = s[4 * k + P.vo];
+    }
 }
 __global__ __launch_bounds__(256) void k_pack422(PackedOp P) { // convert_from_planar :33-46
-    const unsigned pairs = (unsigned)P.w >> 1;
-    const unsigned t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= pairs * (unsigned)P.h) return;
-    const unsigned row = t / pairs, col = t - row * pairs;
-    uint8_t *d = P.packed_out + (size_t)blockIdx.y * P.packed_fs + (size_t)row * 2 * P.w + 4 * col;
-    const size_t f = (size_t)blockIdx.y * P.planar_fs;
-    unsigned b[4] = {0, 0, 0, 0};
-    b[P.yo] = P.cy[f + (size_t)row * P.w + 2 * col];
-    b[P.yo + 2] = P.cy[f + (size_t)row * P.w + 2 * col + 1];
-    b[P.uo] = P.cu[f + (size_t)row * pairs + col];
-    b[P.vo] = P.cv[f + (size_t)row * pairs + col];
-    if (((uintptr_t)d & 3) == 0) { // (4 col into rows of 2 w bytes: aligned whenever the caller's frames are)
-        *reinterpret_cast<unsigned *>(d) = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-    } else {
-        for (int k = 0; k < 4; k++) d[k] = (uint8_t)b[k];
+    const unsigned pairs = (unsigned)P.w >> 1, groups = (pairs + 3) >> 2;
+    unsigned wframe, wpiece;
+    hvc::xcd_work(P.xcd_map, P.xcd_magic, wframe, wpiece);
+    const unsigned t = wpiece * 256u + threadIdx.x;
+    if (t >= groups * (unsigned)P.h) return;
+    const unsigned row = t / groups, g = t - row * groups;
+    uint8_t *d = P.packed_out + (size_t)wframe * P.packed_fs + (size_t)row * 2 * P.w + 16 * g;
+    const size_t f = (size_t)wframe * P.planar_fs;
+    const uint8_t *y = P.cy + (size_t)wframe * P.luma_fs + (size_t)row * P.w + 8 * g, *u = P.cu + f + (size_t)row * pairs + 4 * g,
+                  *v = P.cv + f + (size_t)row * pairs + 4 * g;
+    if (P.vec && 4 * g + 4 <= pairs) {
+        const u2v yy = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(y));
+        const unsigned uu = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(u));
+        const unsigned vv = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(v));
+        u4v o; // pair j: the lane's luma bytes 2 j, 2 j + 1 and its chroma bytes j
+        o.x = __builtin_amdgcn_perm(yy.x, __builtin_amdgcn_perm(uu, vv, 0x0c0c0004u), P.sel_out[0]);
+        o.y = __builtin_amdgcn_perm(yy.x, __builtin_amdgcn_perm(uu, vv, 0x0c0c0105u), P.sel_out[1]);
+        o.z = __builtin_amdgcn_perm(yy.y, __builtin_amdgcn_perm(uu, vv, 0x0c0c0206u), P.sel_out[0]);
+        o.w = __builtin_amdgcn_perm(yy.y, __builtin_amdgcn_perm(uu, vv, 0x0c0c0307u), P.sel_out[1]);
+        __builtin_nontemporal_store(o, reinterpret_cast<u4v *>(d));
+        return;
     }
+    for (unsigned k = 0; k < 4 && 4 * g + k < pairs; k++) {
+        d[4 * k + P.yo] = y[2 * k];
+        d[4 * k + P.yo + 2] = y[2 * k + 1];
+        d[4 * k + P.uo] = u[k];
+        d[4 * k + P.vo] = v[k];
+    }
+}
+
+// the launch of either: selectors, alignment, grid
+template <class K>
+hipError_t launch_packed_op(K kernel, PackedOp P, int n_frames, hipStream_t s) {
+    const unsigned long long lanes = (unsigned long long)(((P.w >> 1) + 3) >> 2) * (unsigned long long)P.h;
+    if (n_frames <= 0 || lanes == 0) return hipSuccess;
+    const dim3 grid((unsigned)((lanes + 255) / 256), (unsigned)n_frames, 1);
+    const unsigned yo = (unsigned)P.yo, uo = (unsigned)P.uo, vo = (unsigned)P.vo;
+    P.sel_y = ((4 + yo + 2) << 24) | ((4 + yo) << 16) | ((yo + 2) << 8) | yo;
+    P.sel_u = 0x0c0c0000u | ((4 + uo) << 8) | uo;
+    P.sel_v = 0x0c0c0000u | ((4 + vo) << 8) | vo;
+    for (unsigned h = 0; h < 2; h++) // S0 = the luma dword (selector bytes 4 .. 7), S1 = (u, v) in bytes 0, 1
+        P.sel_out[h] = ((4 + 2 * h) << (8 * yo)) | ((4 + 2 * h + 1) << (8 * (yo + 2))) | (0u << (8 * uo)) | (1u << (8 * vo));
+    const uintptr_t pk = (uintptr_t)(P.packed_in ? P.packed_in : P.packed_out), py = (uintptr_t)(P.cy ? P.cy : P.y),
+                    pu = (uintptr_t)(P.cu ? P.cu : P.u), pv = (uintptr_t)(P.cv ? P.cv : P.v);
+    P.vec = P.w % 8 == 0 && pk % 16 == 0 && py % 8 == 0 && pu % 4 == 0 && pv % 4 == 0 && P.packed_fs % 16 == 0 && P.planar_fs % 4 == 0 &&
+            P.luma_fs % 8 == 0;
+    P.xcd_map = hvc::xcd_map_for(grid.x, grid.y, P.xcd_magic);
+    hipLaunchKernelGGL(kernel, grid, dim3(256), 0, s, P);
+    return hipGetLastError();
 }
 
 enum OpKind { OP_SUB420, OP_SUB422, OP_UP422, OP_CROP };
@@ -332,16 +396,30 @@ int hvc_yuv_convert(hvc_ctx *c, const uint8_t *src, int src_format, int src_w, i
     if ((r = grow(c, &c->d_aux2, &c->aux2_cap, b_fs * (size_t)n_frames))) return r;
     uint8_t *const A = (uint8_t *)c->d_aux, *const B = (uint8_t *)c->d_aux2;
     hipStream_t st = c->stream;
-    auto op = [&](OpKind kind, const uint8_t *s, int sw, int sh, size_t s_fs, uint8_t *d, int dw, int dh, size_t d_fs) -> hipError_t {
+    auto op = [&](OpKind kind, const uint8_t *s, int sw, int sh, size_t s_fs, uint8_t *d, int dw, int dh, size_t d_fs,
+                  size_t s_stride = 0) -> hipError_t { // (s_stride: the source is a window of wider rows)
         PlaneOp P;
         std::memset(&P, 0, sizeof P);
         P.src = s, P.dst = d, P.sw = sw, P.sh = sh, P.dw = dw, P.dh = dh, P.x_pos = x_off, P.y_pos = y_off;
-        P.src_stride = (size_t)sw, P.dst_stride = (size_t)dw, P.src_ps = s_fs, P.dst_ps = d_fs;
+        P.src_stride = s_stride ? s_stride : (size_t)sw, P.dst_stride = (size_t)dw, P.src_ps = s_fs, P.dst_ps = d_fs;
         return launch_plane_op(kind, P, n_frames, st);
     };
     auto copy_plane = [&](const uint8_t *s, size_t s_fs, uint8_t *d, size_t d_fs, size_t bytes) -> hipError_t { // Plane.blit per frame
         return hipMemcpy2DAsync(d, d_fs, s, s_fs, bytes, (size_t)n_frames, hipMemcpyDeviceToDevice, st);
     };
+
+    // where the output's planes live (known first: an input stage whose result IS the output writes it there)
+    const bool same = dst_w == src_w && dst_h == src_h && x_off == 0 && y_off == 0; // the crop is the identity
+    int dcw, dch;
+    chroma_size(dst_format, dst_w, dst_h, dcw, dch);
+    const bool packed_out = is_packed(dst_format);
+    uint8_t *const oy = packed_out ? B + 3 * dp : d_dst; // the output's planar luma plane
+    const size_t o_fs = packed_out ? b_fs : out_fs;
+    uint8_t *const ou = oy + dp, *const ov = ou + (size_t)dcw * dch;
+    const int out_planar = packed_out ? HVC_YUV_422 : dst_format;
+    const int in_planar = is_packed(src_format) ? HVC_YUV_422 : src_format;
+    const bool direct = same && out_planar == HVC_YUV_444 && in_planar != HVC_YUV_444; // the input stage's full-size chroma planes ARE the output's
+    const bool luma_direct = same && is_packed(src_format) && !packed_out; // ... and the unpacked luma plane is
 
     // ---- Oconv.input (oconv.ml:12-28): the frame as three full-size planes
     Planes in;
@@ -353,12 +431,10 @@ int hvc_yuv_convert(hvc_ctx *c, const uint8_t *src, int src_format, int src_w, i
     if (is_packed(src_format)) { // Packed_422.convert_to_planar into the scratch's first part
         PackedOp K;
         std::memset(&K, 0, sizeof K);
-        K.packed_in = d_src, K.y = A, K.u = A + sp, K.v = A + sp + sp / 2, K.w = src_w, K.h = src_h;
+        K.packed_in = d_src, K.y = luma_direct ? oy : A, K.u = A + sp, K.v = A + sp + sp / 2, K.w = src_w, K.h = src_h;
         packed_offsets(src_format, K.yo, K.uo, K.vo);
-        K.packed_fs = in_fs, K.planar_fs = a_fs;
-        const unsigned long long lanes = (unsigned long long)(src_w / 2) * src_h;
-        hipLaunchKernelGGL(k_unpack422, dim3((unsigned)((lanes + 255) / 256), (unsigned)n_frames, 1), dim3(256), 0, st, K);
-        HIPCHK(c, hipGetLastError());
+        K.packed_fs = in_fs, K.planar_fs = a_fs, K.luma_fs = luma_direct ? o_fs : a_fs;
+        HIPCHK(c, launch_packed_op(k_unpack422, K, n_frames, st));
         py = A, pu = A + sp, pv = A + sp + sp / 2, p_fs = a_fs, planar = HVC_YUV_422;
     }
     in.p[0] = py, in.w[0] = src_w, in.h[0] = src_h, in.fs[0] = p_fs;
@@ -366,40 +442,41 @@ int hvc_yuv_convert(hvc_ctx *c, const uint8_t *src, int src_format, int src_w, i
     if (planar == HVC_YUV_444) {
         in.p[1] = pu, in.p[2] = pv, in.fs[1] = in.fs[2] = p_fs;
     } else {
-        uint8_t *const up[2] = {A + 2 * sp, A + 3 * sp};
+        uint8_t *const up[2] = {direct ? ou : A + 2 * sp, direct ? ov : A + 3 * sp};
+        const size_t up_fs = direct ? o_fs : a_fs;
         const uint8_t *const cp[2] = {pu, pv};
         for (int k = 0; k < 2; k++) {
             if (planar == HVC_YUV_420) { // Planar_444.convert_from_420 :122-131 (K2)
                 hvc::UpsampleParams U;
                 std::memset(&U, 0, sizeof U);
                 U.src = cp[k], U.dst = up[k], U.cw = src_w / 2, U.ch = src_h / 2, U.n_planes = n_frames;
-                U.src_stride = (size_t)(src_w / 2), U.dst_stride = (size_t)src_w, U.src_ps = p_fs, U.dst_ps = a_fs;
+                U.src_stride = (size_t)(src_w / 2), U.dst_stride = (size_t)src_w, U.src_ps = p_fs, U.dst_ps = up_fs;
                 HIPCHK(c, hvc::launch_upsample420(U, st));
             } else { // convert_from_422 :55-67
-                HIPCHK(c, op(OP_UP422, cp[k], src_w / 2, src_h, p_fs, up[k], src_w, src_h, a_fs));
+                HIPCHK(c, op(OP_UP422, cp[k], src_w / 2, src_h, p_fs, up[k], src_w, src_h, up_fs));
             }
-            in.p[k + 1] = up[k], in.fs[k + 1] = a_fs;
+            in.p[k + 1] = up[k], in.fs[k + 1] = up_fs;
         }
     }
 
     // ---- Yuv.crop (yuv.ml:42-62) and Oconv.output (oconv.ml:38-51)
-    const bool same = dst_w == src_w && dst_h == src_h && x_off == 0 && y_off == 0; // the crop is the identity
-    int dcw, dch;
-    chroma_size(dst_format, dst_w, dst_h, dcw, dch);
-    const bool packed_out = is_packed(dst_format);
-    uint8_t *const oy = packed_out ? B + 3 * dp : d_dst; // where the output's planar luma plane lives
-    const size_t o_fs = packed_out ? b_fs : out_fs;
-    uint8_t *const ou = oy + dp, *const ov = ou + (size_t)dcw * dch;
     // luma: straight to its place
-    if (same) HIPCHK(c, copy_plane(in.p[0], in.fs[0], oy, o_fs, dp));
+    const bool luma_in_place = same && packed_out; // the packing kernel reads the input's luma plane where it is
+    if (luma_direct || luma_in_place) {
+    } else if (same) HIPCHK(c, copy_plane(in.p[0], in.fs[0], oy, o_fs, dp));
     else HIPCHK(c, op(OP_CROP, in.p[0], src_w, src_h, in.fs[0], oy, dst_w, dst_h, o_fs));
-    // chroma: full size after the crop, then the output's sampling
-    const int out_planar = packed_out ? HVC_YUV_422 : dst_format;
-    for (int k = 1; k < 3; k++) {
+    // chroma: full size after the crop, then the output's sampling.  A crop window that lies inside the source (nothing to
+    // clamp) and keeps the 16-byte pieces of the sub-sampling kernels aligned is not materialised: the kernels read the window
+    // in place, with the source's row stride.
+    const bool window = !same && out_planar != HVC_YUV_444 && x_off >= 0 && y_off >= 0 && x_off + dst_w <= src_w &&
+                        y_off + dst_h <= src_h && x_off % 16 == 0 && src_w % 16 == 0;
+    for (int k = 1; k < 3 && !direct; k++) {
         uint8_t *const od = k == 1 ? ou : ov;
         const uint8_t *full = in.p[k];
-        size_t full_fs = in.fs[k];
-        if (!same) {
+        size_t full_fs = in.fs[k], full_stride = 0;
+        if (window) {
+            full += (size_t)y_off * src_w + x_off, full_stride = (size_t)src_w;
+        } else if (!same) {
             uint8_t *const cropped = out_planar == HVC_YUV_444 ? od : B + (size_t)(k - 1) * dp;
             HIPCHK(c, op(OP_CROP, in.p[k], src_w, src_h, in.fs[k], cropped, dst_w, dst_h, out_planar == HVC_YUV_444 ? o_fs : b_fs));
             full = cropped, full_fs = out_planar == HVC_YUV_444 ? o_fs : b_fs;
@@ -407,20 +484,18 @@ int hvc_yuv_convert(hvc_ctx *c, const uint8_t *src, int src_format, int src_w, i
         if (out_planar == HVC_YUV_444) {
             if (same) HIPCHK(c, copy_plane(full, full_fs, od, o_fs, dp));
         } else if (out_planar == HVC_YUV_420) { // convert_to_420 :105-116
-            HIPCHK(c, op(OP_SUB420, full, dst_w, dst_h, full_fs, od, dst_w / 2, dst_h / 2, o_fs));
+            HIPCHK(c, op(OP_SUB420, full, dst_w, dst_h, full_fs, od, dst_w / 2, dst_h / 2, o_fs, full_stride));
         } else { // convert_to_422 :35-44
-            HIPCHK(c, op(OP_SUB422, full, dst_w, dst_h, full_fs, od, dst_w / 2, dst_h, o_fs));
+            HIPCHK(c, op(OP_SUB422, full, dst_w, dst_h, full_fs, od, dst_w / 2, dst_h, o_fs, full_stride));
         }
     }
     if (packed_out) { // Packed_422.convert_from_planar
         PackedOp K;
         std::memset(&K, 0, sizeof K);
-        K.packed_out = d_dst, K.cy = oy, K.cu = ou, K.cv = ov, K.w = dst_w, K.h = dst_h;
+        K.packed_out = d_dst, K.cy = luma_in_place ? in.p[0] : oy, K.cu = ou, K.cv = ov, K.w = dst_w, K.h = dst_h;
         packed_offsets(dst_format, K.yo, K.uo, K.vo);
-        K.packed_fs = out_fs, K.planar_fs = b_fs;
-        const unsigned long long lanes = (unsigned long long)(dst_w / 2) * dst_h;
-        hipLaunchKernelGGL(k_pack422, dim3((unsigned)((lanes + 255) / 256), (unsigned)n_frames, 1), dim3(256), 0, st, K);
-        HIPCHK(c, hipGetLastError());
+        K.packed_fs = out_fs, K.planar_fs = b_fs, K.luma_fs = luma_in_place ? in.fs[0] : b_fs;
+        HIPCHK(c, launch_packed_op(k_pack422, K, n_frames, st));
     }
     if (where == HVC_MEM_HOST) {
         HIPCHK(c, hipMemcpyAsync(dst, d_dst, out_fs * (size_t)n_frames, hipMemcpyDeviceToHost, st));
