@@ -196,13 +196,13 @@ def other_measurements(threads):
     kern = lambda r: {"ms": r["kernel_ms"], "frac_of_8TBps": r["frac_of_8TBps"], "algorithmic_GBps": r["algorithmic_GBps"]}
     pipe = lambda r: {"Gpixel_s": round(r["value"] / 1e3, 2), "frames": r["frames"], "wall_ms": r["wall_ms"], "threads": r["host_threads"],
                       "frames_per_chunk": r["frames_per_chunk"]}
-    run("config4_launch_128x4K444", lambda: bc.resident_decode(bc.make_args(frames=128, steps=16, warmup=4),
+    run("config4_launch_128x4K444", lambda: bc.resident_decode(bc.make_args(frames=128, steps=32, warmup=16),
                                                                [(480, 270, 0), (480, 270, 1), (480, 270, 1)], 3840, 2160, 4), "hbm", kern)
-    run("k3_encode_256x4K420", lambda: bc.config5(bc.make_args(frames=256, steps=20, warmup=5)), "hbm", kern)
-    run("fused444_512x1080p", lambda: bc.config_444(bc.make_args(frames=512, steps=20, warmup=5, fused_only=True)), "hbm",
+    run("k3_encode_256x4K420", lambda: bc.config5(bc.make_args(frames=256, steps=40, warmup=20)), "hbm", kern)
+    run("fused444_512x1080p", lambda: bc.config_444(bc.make_args(frames=512, steps=40, warmup=20, fused_only=True)), "hbm",
         lambda r: {"ms": r["fused_ms"], "frac_of_8TBps": r["frac_of_8TBps"], "algorithmic_GBps": r["algorithmic_GBps"]})
-    run("k2_upsample420_512_planes", lambda: bc.config_k2(bc.make_args(frames=256, steps=20, warmup=5)), "hbm", kern)
-    run("subsample420_512_planes", lambda: bc.config_sub420(bc.make_args(frames=256, steps=20, warmup=5)), "hbm", kern)
+    run("k2_upsample420_512_planes", lambda: bc.config_k2(bc.make_args(frames=256, steps=100, warmup=50)), "hbm", kern)
+    run("subsample420_512_planes", lambda: bc.config_sub420(bc.make_args(frames=256, steps=100, warmup=50)), "hbm", kern)
     # BASELINE config 3 at its own size (4096 x 1080p files), config 5 end to end on 256 x 4K frames
     run("config3_host_reader_4096_files", lambda: bc.config3(bc.make_args(frames=4096, steps=2, threads=threads, chunk=32)), "host", pipe)
     run("config3_gpu_reader_4096_files", lambda: bc.config3(bc.make_args(frames=4096, steps=2, threads=threads, chunk=256, gpu_entropy=True)),
