@@ -317,8 +317,10 @@ HVC_API int hvc_jpeg_entropy_decode(const uint8_t *jpeg, size_t n, const hvc_jpe
  * by default (model parity).  hvc_jpeg_entropy_decode_restart is hvc_jpeg_entropy_decode with the markers honoured: every
  * interval's bytes behind its RSTn, DC predictors back to zero at each (SURVEY.md 8f next-1's named extension);
  * hvc_set_restart_markers(ctx, 1) makes the context's file-level entry points (hvc_jpeg_decode, hvc_jpeg_decode_yuv444, the
- * batch pipelines, hvc_jpeg_entropy_decode_gpu) do the same: such files are read by the host reader.  A file without DRI
- * decodes the same either way. */
+ * batch pipelines, hvc_jpeg_entropy_decode_gpu) do the same -- the host reader by walking from interval to interval, the GPU
+ * reader by taking every interval as a stream of its own (an RSTn is a synchronisation point known in advance: a byte
+ * boundary, the first block of an MCU, predictors at zero); files of one batch whose DRI differs from the first file's, or
+ * whose markers are not the ones their DRI promises, are the host reader's.  A file without DRI decodes the same either way. */
 HVC_API int hvc_jpeg_entropy_decode_restart(const uint8_t *jpeg, size_t n, const hvc_jpeg_info *info, int16_t *coefs);
 HVC_API int hvc_set_restart_markers(hvc_ctx *ctx, int honour);
 /* The same for TWO files on the calling thread, their symbols decoded in turn: a file is one stream and its symbols one

@@ -46,7 +46,7 @@ def main():
                 k = int(rng.integers(1, ncomp))          # the model's empty plane -- both pipelines walk around it
                 sampling[k] = (0, sampling[k][1]) if rng.integers(0, 2) else (sampling[k][0], 0)
                 empty_planes += 1
-            restart = int(rng.integers(1, 9)) if rng.integers(0, 3) == 0 else 0   # restart intervals, honoured on request (the extension)
+            restart = int(rng.integers(1, 9)) if rng.integers(0, 2) == 0 else 0   # restart intervals, honoured on request (the extension)
             mh, mv = max(a for a, _ in sampling), max(b for _, b in sampling)
             Wr, Hr = -(-w // (8 * mh)) * 8 * mh, -(-h // (8 * mv)) * 8 * mv
             nblk = sum((Wr * a // mh // 8) * (Hr * b // mv // 8) for a, b in sampling)

@@ -162,19 +162,45 @@ int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *si
     // the batch and which one every frame uses.  One set that fits two slots = the fast LDS-table kernels; anything
     // else = per-frame tables in device memory (PF mode, hvc_hdec.h).
     std::vector<hvc::HdTables> sets;
-    std::vector<unsigned> tabset_of((size_t)n_frames, 0u);
+    hvc::HdParams P;
+    if (!gd_geometry(info0, P)) return HVC_OK;
+    // Restart intervals honoured (hvc_set_restart_markers) and the first file's scan has more than one: every interval of
+    // every file is a reader frame of its own (hvc_hdec.h HdParams::rst_*) -- `units` below; else a unit is a file.
+    unsigned rst = 0, ipf = 1;
+    if (hvc::tl_honour_restart) {
+        rst = hvc::restart_interval_of(jpegs[0], sizes[0]);
+        const unsigned long long mcus = (unsigned long long)P.mbs_wide * (unsigned long long)P.mbs_high;
+        if (rst && mcus > rst) {
+            const unsigned long long q = (mcus + rst - 1) / rst;
+            if (q * (unsigned long long)n_frames > 65535ull) return HVC_OK; // (the launches' grids: the host reader's)
+            ipf = (unsigned)q;
+            P.rst_mcus = rst;
+            P.rst_ipf = ipf;
+            P.blocks_per_frame = rst * (unsigned)P.blocks_per_mcu; // (< the file's blocks: no overflow)
+        }
+    }
+    const size_t units = (size_t)n_frames * ipf;
+    std::vector<unsigned> tabset_of;
     // The segments go straight from the files into ONE pinned buffer (unstuffed on the way) and from there to the
     // device: laid out by an upper bound of every segment's length -- its file's -- so that the places are known before
     // the files are read.  (Through per-file vectors, a pageable batch buffer and the runtime's own staging the bytes of
     // a 1 MB file were copied three times before the copy engine saw them: 0.15 of the call's 1.0 ms.)
     const unsigned SB = HVC_HD_SUBSEQ_BITS / 8;
-    std::vector<unsigned> ecs_off((size_t)n_frames), sub_off((size_t)n_frames + 1);
+    std::vector<unsigned> ecs_off, sub_off, file_off, uoff, ulen; // (per unit; file_off: per file)
     size_t bytes = 0, subs = 0;
     try {
+        tabset_of.assign(units, 0u);
+        ecs_off.resize(units);
+        sub_off.resize(units + 1);
+        file_off.resize((size_t)n_frames);
+        uoff.resize(ipf);
+        ulen.resize(ipf);
         for (int f = 0; f < n_frames; f++) {
             const size_t nsub_most = (sizes[f] + SB - 1) / SB + 1; // an entropy-coded segment is shorter than its file
-            ecs_off[(size_t)f] = (unsigned)bytes;
-            bytes += nsub_most * SB + 16; // SB = 128: every frame starts on a 16-byte boundary, 16 zero bytes of overshoot
+            file_off[(size_t)f] = (unsigned)bytes;
+            // SB = 128: every frame starts on a 16-byte boundary, 16 zero bytes of overshoot; every interval has a slot of
+            // its own (hvc::hd_unit_slot: at most 2 SB + 16 bytes more than its bytes)
+            bytes += ipf > 1 ? nsub_most * SB + (size_t)ipf * (2 * SB + 16) : nsub_most * SB + 16;
             if (bytes >= (1ull << 31)) return HVC_OK;
         }
     } catch (const std::bad_alloc &) {
@@ -203,13 +229,28 @@ int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *si
             bool ok = false;
             const size_t room = (sizes[f] + SB - 1) / SB * SB; // (the frame's slot without its extra subsequence and overshoot)
             size_t got = 0;
-            r = hvc::prepare_gpu_decode_to(jpegs[f], sizes[f], &fi, t, h_ecs + ecs_off[(size_t)f], room, &got, ok);
-            if (r) return r;
-            if (!ok) return HVC_OK;
-            const size_t nsub = (got + SB - 1) / SB + 1; // one extra: the reader sees zeros past the end
-            std::memset(h_ecs + ecs_off[(size_t)f] + got, 0, nsub * SB + 16 - got); // (the buffer is reused from call to call)
-            sub_off[(size_t)f] = (unsigned)subs;
-            subs += nsub;
+            uint8_t *const fdst = h_ecs + file_off[(size_t)f];
+            if (ipf > 1) { // its intervals, each in a slot of its own (zeros behind the bytes: written with them)
+                hvc::RstUnits ru{rst, ipf, uoff.data(), ulen.data()};
+                r = hvc::prepare_gpu_decode_to(jpegs[f], sizes[f], &fi, t, fdst, room + (size_t)ipf * (2 * SB + 16), &got, ok, &ru);
+                if (r) return r;
+                if (!ok) return HVC_OK;
+                for (unsigned q = 0; q < ipf; q++) {
+                    const size_t u = (size_t)f * ipf + q;
+                    ecs_off[u] = file_off[(size_t)f] + uoff[q];
+                    sub_off[u] = (unsigned)subs;
+                    subs += (ulen[q] + SB - 1) / SB + 1;
+                }
+            } else {
+                r = hvc::prepare_gpu_decode_to(jpegs[f], sizes[f], &fi, t, fdst, room, &got, ok);
+                if (r) return r;
+                if (!ok) return HVC_OK;
+                const size_t nsub = (got + SB - 1) / SB + 1; // one extra: the reader sees zeros past the end
+                std::memset(fdst + got, 0, nsub * SB + 16 - got); // (the buffer is reused from call to call)
+                ecs_off[(size_t)f] = file_off[(size_t)f];
+                sub_off[(size_t)f] = (unsigned)subs;
+                subs += nsub;
+            }
             if (subs >= (1ull << 31)) return HVC_OK;
             size_t k = sets.size(); // newest first: files of one source tend to come in runs
             while (k > 0 && std::memcmp(&sets[k - 1], &t, sizeof t)) k--;
@@ -217,36 +258,40 @@ int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *si
                 sets.push_back(t);
                 k = sets.size();
             }
-            tabset_of[(size_t)f] = (unsigned)(k - 1);
+            for (unsigned q = 0; q < ipf; q++) tabset_of[(size_t)f * ipf + q] = (unsigned)(k - 1);
         }
     } catch (const std::bad_alloc &) {
         return HVC_E_OUT_OF_MEMORY;
     }
     clk.mark("headers+unstuff");
     const hvc::HdTables &tables0 = sets[0];
-    hvc::HdParams P;
-    if (!gd_geometry(info0, P)) return HVC_OK;
-    P.n_frames = n_frames;
-    sub_off[(size_t)n_frames] = (unsigned)subs;
+    const size_t nU = units; // the reader's frames: files, or their restart intervals
+    P.n_frames = (int)nU;
+    sub_off[nU] = (unsigned)subs;
     P.total_sub = (unsigned)subs;
     // the index arrays: [ecs_off n][sub_off n + 1] travel; [frame_of subs] is filled on the device from sub_off,
     // [frame_blocks n][changed, status] are written there
-    const size_t meta_words = (size_t)n_frames + ((size_t)n_frames + 1) + subs + (size_t)n_frames + 2;
-    std::vector<unsigned> h_meta((size_t)2 * n_frames + 1);
-    for (int f = 0; f < n_frames; f++) {
-        h_meta[(size_t)f] = ecs_off[(size_t)f];
-        h_meta[(size_t)n_frames + (size_t)f] = sub_off[(size_t)f];
+    const size_t meta_words = nU + (nU + 1) + subs + nU + 2;
+    std::vector<unsigned> h_meta;
+    try {
+        h_meta.resize(2 * nU + 1);
+    } catch (const std::bad_alloc &) {
+        return HVC_E_OUT_OF_MEMORY;
     }
-    h_meta[(size_t)2 * n_frames] = sub_off[(size_t)n_frames];
+    for (size_t f = 0; f < nU; f++) {
+        h_meta[f] = ecs_off[f];
+        h_meta[nU + f] = sub_off[f];
+    }
+    h_meta[2 * nU] = sub_off[nU];
     int r;
     if ((r = grow(c, &c->gd_ecs, &c->gd_ecs_cap, bytes + HVC_HD_ECS_SLACK))) return r;
     if ((r = grow(c, &c->gd_meta, &c->gd_meta_cap, meta_words * sizeof(unsigned) + 64))) return r;
     if ((r = grow(c, &c->gd_state, &c->gd_state_cap, HVC_HD_STATE_BYTES(subs)))) return r;
-    if ((r = grow(c, &c->gd_dcd, &c->gd_dcd_cap, (size_t)n_frames * P.blocks_per_frame * sizeof(int16_t)))) return r;
+    if ((r = grow(c, &c->gd_dcd, &c->gd_dcd_cap, nU * P.blocks_per_frame * sizeof(int16_t)))) return r;
     P.dcd = (int16_t *)c->gd_dcd;
     unsigned *m = (unsigned *)c->gd_meta;
-    unsigned *d_ecs_off = m, *d_sub_off = m + n_frames, *d_frame_of = d_sub_off + n_frames + 1;
-    unsigned *d_frame_blocks = d_frame_of + subs, *d_flags = d_frame_blocks + n_frames;
+    unsigned *d_ecs_off = m, *d_sub_off = m + nU, *d_frame_of = d_sub_off + nU + 1;
+    unsigned *d_frame_blocks = d_frame_of + subs, *d_flags = d_frame_blocks + nU;
     hipStream_t st = c->stream;
     // From here on copies out of this function's own vectors (h_meta, ftabs, tabset_of) and out of the reused pinned
     // buffer are in flight: EVERY way out of the function waits for the stream first (the early returns included).
@@ -277,18 +322,18 @@ int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *si
         }
         for (size_t k = 0; k < sets.size(); k++) hvc::make_frame_tabs(sets[k], P.n_comp, ftabs[k]);
         const size_t tb = sets.size() * sizeof(hvc::HdFrameTabs);
-        if ((r = grow(c, &c->gd_ftabs, &c->gd_ftabs_cap, tb + (size_t)n_frames * sizeof(unsigned)))) return r;
+        if ((r = grow(c, &c->gd_ftabs, &c->gd_ftabs_cap, tb + nU * sizeof(unsigned)))) return r;
         HIPCHK(c, hipMemcpyAsync(c->gd_ftabs, ftabs.data(), tb, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync((char *)c->gd_ftabs + tb, tabset_of.data(), (size_t)n_frames * sizeof(unsigned), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync((char *)c->gd_ftabs + tb, tabset_of.data(), nU * sizeof(unsigned), hipMemcpyHostToDevice, st));
         P.tables = nullptr;
         P.spec = nullptr;
         P.ftabs = (const hvc::HdFrameTabs *)c->gd_ftabs;
         P.tabset_of = (const unsigned *)((char *)c->gd_ftabs + tb);
         P.selmask = gd_component_selmask(P);
-        if (gd_lists_per_frame(P.total_sub, n_frames)) {
-            if ((r = grow(c, &c->gd_fcnt, &c->gd_fcnt_cap, (size_t)HVC_HD_LIST_N * (size_t)n_frames * sizeof(unsigned)))) return r;
+        if (gd_lists_per_frame(P.total_sub, (int)nU)) {
+            if ((r = grow(c, &c->gd_fcnt, &c->gd_fcnt_cap, (size_t)HVC_HD_LIST_N * nU * sizeof(unsigned)))) return r;
             P.list_fn = (unsigned *)c->gd_fcnt; // work lists per frame (k_hd_sync_pf)
-            for (int f = 0; f < n_frames; f++) P.max_frame_sub = std::max(P.max_frame_sub, sub_off[(size_t)f + 1] - sub_off[(size_t)f]);
+            for (size_t f = 0; f < nU; f++) P.max_frame_sub = std::max(P.max_frame_sub, sub_off[f + 1] - sub_off[f]);
         }
     }
     P.ecs = (const uint8_t *)c->gd_ecs;
@@ -446,12 +491,41 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     if (pixel_fs < out_bytes || (!yuv444 && (pixel_fs & 7))) return HVC_E_INVALID_ARG;
     hvc::HdParams G;
     hvc::HdTables tables0;
+    const unsigned SB = HVC_HD_SUBSEQ_BITS / 8;
+    // Restart intervals honoured (hvc_set_restart_markers) and the first file's scan has more than one: every interval of
+    // every file is a reader frame of its own (hvc_hdec.h HdParams::rst_*), ipf of them per file; else ipf = 1, frame = file.
+    unsigned rst = 0, ipf = 1;
     {
-        std::vector<uint8_t> tmp;
+        const bool geo = gd_geometry(info0, G);
+        if (geo && hvc::tl_honour_restart) {
+            rst = hvc::restart_interval_of(jpegs[0], sizes[0]);
+            const unsigned long long mcus = (unsigned long long)G.mbs_wide * (unsigned long long)G.mbs_high;
+            if (rst && mcus > rst) {
+                const unsigned long long q = (mcus + rst - 1) / rst;
+                if (q > 4096) return host_pipeline(); // (intervals of a few MCUs: half of every frame's subsequences would be padding)
+                ipf = (unsigned)q;
+                G.rst_mcus = rst;
+                G.rst_ipf = ipf;
+                G.blocks_per_frame = rst * (unsigned)G.blocks_per_mcu;
+            }
+        }
         bool ok = false;
-        r = hvc::prepare_gpu_decode(jpegs[0], sizes[0], &info0, tables0, tmp, ok);
+        try {
+            if (ipf > 1) {
+                std::vector<uint8_t> tmp(sizes[0] + (size_t)ipf * (2 * SB + 16) + SB);
+                std::vector<unsigned> uo(ipf), ul(ipf);
+                hvc::RstUnits ru{rst, ipf, uo.data(), ul.data()};
+                size_t got = 0;
+                r = hvc::prepare_gpu_decode_to(jpegs[0], sizes[0], &info0, tables0, tmp.data(), tmp.size(), &got, ok, &ru);
+            } else {
+                std::vector<uint8_t> tmp;
+                r = hvc::prepare_gpu_decode(jpegs[0], sizes[0], &info0, tables0, tmp, ok);
+            }
+        } catch (const std::bad_alloc &) {
+            return HVC_E_OUT_OF_MEMORY;
+        }
         if (r) return r;
-        if (!ok || !gd_geometry(info0, G)) return host_pipeline();
+        if (!ok || !geo) return host_pipeline();
     }
     if (threads < 1) threads = 1;
     if (threads > 256) threads = 256;
@@ -459,20 +533,23 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     // (measured: 256 files best in chunks of 64, 1024 and more in chunks of 256)
     if (frames_per_chunk < 1) frames_per_chunk = n_frames / 4 < 64 ? 64 : n_frames / 4 > 256 ? 256 : n_frames / 4;
     if (frames_per_chunk > n_frames) frames_per_chunk = n_frames;
+    if ((unsigned long long)frames_per_chunk * ipf > 65535ull) frames_per_chunk = (int)(65535u / ipf); // (the reader's grids: frames per launch)
     const int C = frames_per_chunk, NB = hvc_ctx::RING;
+    const size_t CU = (size_t)C * ipf; // reader frames of a full chunk
     const int n_chunks = (n_frames + C - 1) / C;
     size_t max_file = 0;
     for (int f = 0; f < n_frames; f++) {
         if (!jpegs[f]) return HVC_E_INVALID_ARG;
         max_file = sizes[f] > max_file ? sizes[f] : max_file;
     }
-    const unsigned SB = HVC_HD_SUBSEQ_BITS / 8;
-    const size_t nsub_max = (max_file + SB - 1) / SB + 1;  // an entropy-coded segment is shorter than its file
-    const size_t R = nsub_max * SB + 16;                   // bytes per frame in the segment ring (16-byte multiple)
+    // an entropy-coded segment is shorter than its file; every frame has one subsequence of zeros behind its bytes and 16
+    // bytes of overshoot, its bytes start on a subsequence boundary (intervals: hvc::hd_unit_slot for each)
+    const size_t nsub_max = ipf > 1 ? (max_file + SB - 1) / SB + 2 * (size_t)ipf : (max_file + SB - 1) / SB + 1;
+    const size_t R = ipf > 1 ? (max_file + SB - 1) / SB * SB + (size_t)ipf * (2 * SB + 16) : nsub_max * SB + 16; // bytes per FILE in the segment ring (16-byte multiple)
     if ((size_t)C * nsub_max >= (1ull << 31) || (size_t)C * R >= (1ull << 31)) return host_pipeline();
     const size_t ecs_bytes = (size_t)C * R;
     // index arrays of a chunk: [ecs_off C][sub_off C + 1][tabset_of C][frame_of C * nsub_max][frame_blocks C][changed, status]
-    const size_t meta_words = (size_t)C + ((size_t)C + 1) + (size_t)C + (size_t)C * nsub_max + (size_t)C + 2;
+    const size_t meta_words = CU + (CU + 1) + CU + (size_t)C * nsub_max + CU + 2; // (C -> CU: per reader frame)
     const size_t meta_bytes = meta_words * sizeof(unsigned);
     const size_t ftabs_bytes = ((size_t)C + 1) * sizeof(hvc::HdFrameTabs); // record 0: the first file's tables, 1 + f: frame f's own
     const size_t coef_chunk = info0.coef_count * sizeof(int16_t) * (size_t)C;
@@ -564,8 +641,8 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     constexpr int NRD = HVC_NRD; // reader streams in use (round 1: 1: 71 Gpixel/s on config 3, 2: 77, 3: 79 with half as much scratch again)
     const size_t state_bytes = (HVC_HD_STATE_BYTES((size_t)C * nsub_max) + 255) & ~(size_t)255;
     if ((r = grow(c, &c->gd_state, &c->gd_state_cap, NRD * state_bytes))) return r;
-    if ((r = grow(c, &c->gd_fcnt, &c->gd_fcnt_cap, (size_t)NRD * HVC_HD_LIST_N * (size_t)C * sizeof(unsigned)))) return r;
-    const size_t dcd_elems = ((size_t)C * G.blocks_per_frame + 127) & ~(size_t)127;
+    if ((r = grow(c, &c->gd_fcnt, &c->gd_fcnt_cap, (size_t)NRD * HVC_HD_LIST_N * CU * sizeof(unsigned)))) return r;
+    const size_t dcd_elems = (CU * G.blocks_per_frame + 127) & ~(size_t)127;
     if ((r = grow(c, &c->gd_dcd, &c->gd_dcd_cap, NRD * dcd_elems * sizeof(int16_t)))) return r;
     // The DC values go from the reader's DC pass to the block stage through a compact array, one per ring slot (a
     // chunk's block stage may still read it while the next chunk's DC pass runs), instead of 2 bytes into each
@@ -598,6 +675,15 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
     std::vector<char> chunk_host((size_t)n_chunks, 0), skipped((size_t)n_chunks, 0);
     std::vector<int> done_in_chunk((size_t)n_chunks, 0);
     std::vector<unsigned> ecs_size((size_t)n_frames, 0);
+    std::vector<unsigned> unit_off, unit_len; // restart intervals: [file][interval] place inside the file's ring region, bytes
+    if (ipf > 1) {
+        try {
+            unit_off.resize((size_t)n_frames * ipf);
+            unit_len.resize((size_t)n_frames * ipf);
+        } catch (const std::bad_alloc &) {
+            return HVC_E_OUT_OF_MEMORY;
+        }
+    }
     int released_upto = NB - 1;
     std::atomic<long long> prep_ns{0};
     auto worker_body = [&]() {
@@ -621,7 +707,12 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
             bool ok = false;
             uint8_t *dst = (uint8_t *)c->gp_h_ecs[slot] + (size_t)(f - k * C) * R; // unstuffed straight into the pinned slot
             size_t got = 0;
-            if (!e) e = hvc::prepare_gpu_decode_to(jpegs[f], sizes[f], &fi, t, dst, (nsub_max - 1) * SB, &got, ok);
+            if (!e && ipf > 1) { // (every interval's slot is zero-filled behind its bytes as it is written)
+                hvc::RstUnits ru{rst, ipf, unit_off.data() + (size_t)f * ipf, unit_len.data() + (size_t)f * ipf};
+                e = hvc::prepare_gpu_decode_to(jpegs[f], sizes[f], &fi, t, dst, R, &got, ok, &ru);
+            } else if (!e) {
+                e = hvc::prepare_gpu_decode_to(jpegs[f], sizes[f], &fi, t, dst, (nsub_max - 1) * SB, &got, ok);
+            }
             const bool own_tables = !e && ok && std::memcmp(&t, &tables0, sizeof t) != 0;
             const bool unfit = !e && (!ok || (own_tables && !pf_fits) || (!pf_fits && ok && hvc::tables_use_overflow(t, info0.n_comp)));
             if (own_tables && !unfit) { // its own Huffman tables: a record of its own
@@ -629,8 +720,10 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
                 frame_pf[(size_t)f] = 1;
             }
             if (!e && !unfit) {
-                const size_t used = ((got + SB - 1) / SB + 1) * SB + 16; // this frame's subsequences + overshoot
-                std::memset(dst + got, 0, used - got);
+                if (ipf == 1) {
+                    const size_t used = ((got + SB - 1) / SB + 1) * SB + 16; // this frame's subsequences + overshoot
+                    std::memset(dst + got, 0, used - got);
+                }
                 ecs_size[(size_t)f] = (unsigned)got;
             }
             prep_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
@@ -770,39 +863,43 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         }
         // the chunk's index arrays
         unsigned *hm = (unsigned *)c->gp_h_meta[slot];
-        unsigned *h_ecs_off = hm, *h_sub_off = hm + C, *h_tabset_of = h_sub_off + C + 1; // (frame_of: filled on the GPU)
+        unsigned *h_ecs_off = hm, *h_sub_off = hm + CU, *h_tabset_of = h_sub_off + CU + 1; // (frame_of: filled on the GPU)
         unsigned subs = 0;
         bool pf = !uniform_ok;
         for (int f = 0; f < cnt; f++) {
-            const unsigned nsub = (ecs_size[(size_t)(first + f)] + SB - 1) / SB + 1;
-            h_tabset_of[f] = frame_pf[(size_t)(first + f)] ? 1u + (unsigned)f : 0u;
             pf |= frame_pf[(size_t)(first + f)] != 0;
-            h_ecs_off[f] = (unsigned)((size_t)f * R);
-            h_sub_off[f] = subs;
-            subs += nsub;
             ecs_total += ecs_size[(size_t)(first + f)];
+            for (unsigned q = 0; q < ipf; q++) { // the file's reader frames: itself, or its restart intervals
+                const size_t u = (size_t)f * ipf + q, g = (size_t)(first + f) * ipf + q;
+                const unsigned bytes = ipf > 1 ? unit_len[g] : ecs_size[(size_t)(first + f)];
+                h_tabset_of[u] = frame_pf[(size_t)(first + f)] ? 1u + (unsigned)f : 0u;
+                h_ecs_off[u] = (unsigned)((size_t)f * R + (ipf > 1 ? unit_off[g] : 0u));
+                h_sub_off[u] = subs;
+                subs += (bytes + SB - 1) / SB + 1;
+            }
         }
-        h_sub_off[cnt] = subs;
+        const size_t nu = (size_t)cnt * ipf;
+        h_sub_off[nu] = subs;
         unsigned *dm = (unsigned *)c->gp_d_meta[slot];
         hvc::HdParams P = G;
-        P.n_frames = cnt;
+        P.n_frames = (int)nu;
         P.total_sub = subs;
         P.ecs = (const uint8_t *)c->gp_d_ecs[slot];
         P.ecs_off = dm;
-        P.sub_off = dm + C;
-        P.frame_of = dm + C + C + 1 + C;
+        P.sub_off = dm + CU;
+        P.frame_of = dm + CU + CU + 1 + CU;
         if (pf) {
             P.tables = nullptr;
             P.spec = nullptr;
             P.ftabs = (const hvc::HdFrameTabs *)c->gp_d_ftabs[slot];
-            P.tabset_of = dm + C + C + 1;
+            P.tabset_of = dm + CU + CU + 1;
             P.selmask = comp_selmask;
-            if (gd_lists_per_frame(subs, cnt)) {
-                P.list_fn = (unsigned *)c->gd_fcnt + (size_t)(k % NRD) * HVC_HD_LIST_N * (size_t)C; // work lists per frame (k_hd_sync_pf)
+            if (gd_lists_per_frame(subs, (int)nu)) {
+                P.list_fn = (unsigned *)c->gd_fcnt + (size_t)(k % NRD) * HVC_HD_LIST_N * CU; // work lists per frame (k_hd_sync_pf)
                 P.max_frame_sub = (unsigned)nsub_max;
             }
         }
-        P.frame_blocks = dm + (meta_words - 2 - C);
+        P.frame_blocks = dm + (meta_words - 2 - CU);
         P.changed = dm + (meta_words - 2);
         P.status = dm + (meta_words - 1);
         P.coefs = (int16_t *)c->d_ring[slot];
@@ -816,7 +913,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
         if (he == hipSuccess)
             he = hipMemcpyAsync(c->gp_d_ecs[slot], c->gp_h_ecs[slot], (size_t)cnt * R, hipMemcpyHostToDevice, c->copy_stream);
         if (he == hipSuccess)
-            he = hipMemcpyAsync(dm, hm, ((size_t)3 * C + 1) * sizeof(unsigned), hipMemcpyHostToDevice, c->copy_stream);
+            he = hipMemcpyAsync(dm, hm, (3 * CU + 1) * sizeof(unsigned), hipMemcpyHostToDevice, c->copy_stream);
         if (he == hipSuccess && pf) // the tables of the chunk's frames (36 KB a frame against ~1 MB of segment)
             he = hipMemcpyAsync(c->gp_d_ftabs[slot], c->gp_h_ftabs[slot], ((size_t)cnt + 1) * sizeof(hvc::HdFrameTabs),
                                 hipMemcpyHostToDevice, c->copy_stream);

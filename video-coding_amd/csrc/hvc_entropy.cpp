@@ -412,13 +412,21 @@ namespace hvc {
 size_t extract_ecs_to(const uint8_t *data, size_t n, size_t pos, uint8_t *dst, size_t cap);
 }
 namespace {
-// The entropy-coded segment THROUGH its RSTn markers: every interval unstuffed and appended, `starts` = where each begins in
-// `out`; ends at the first marker that is not RSTn (0xFF fill bytes in front of a marker are skipped, T.81 B.1.1.2).
-void extract_ecs_restart(const uint8_t *data, size_t n, size_t pos, std::vector<uint8_t> &out, std::vector<size_t> &starts, size_t pad) {
+// The entropy-coded segment THROUGH its RSTn markers: every interval unstuffed and appended with `pad` zero bytes behind it
+// (past its end an interval reads as zero bits, like a segment past its end: bitstream_reader.ml:19-22 -- and what the GPU
+// reader's intervals see behind theirs); starts[k] / lens[k] = where interval k begins in `out` and how long it is; ends at
+// the first marker that is not RSTn (0xFF fill bytes in front of a marker are skipped, T.81 B.1.1.2).
+void extract_ecs_restart(const uint8_t *data, size_t n, size_t pos, std::vector<uint8_t> &out, std::vector<size_t> &starts,
+                         std::vector<size_t> &lens, size_t pad) {
     out.clear();
     starts.clear();
+    lens.clear();
     starts.push_back(0);
     out.reserve((n > pos ? n - pos : 0) + pad);
+    auto close = [&]() {
+        lens.push_back(out.size() - starts.back());
+        out.resize(out.size() + pad, 0);
+    };
     while (pos < n) {
         const uint8_t *ff = (const uint8_t *)std::memchr(data + pos, 0xff, n - pos);
         const size_t stop = ff ? (size_t)(ff - data) : n;
@@ -431,14 +439,16 @@ void extract_ecs_restart(const uint8_t *data, size_t n, size_t pos, std::vector<
         } else if (next == 0xff) {
             pos = stop + 1; // a fill byte
         } else if (next >= 0xd0 && next <= 0xd7) {
+            close();
             starts.push_back(out.size());
             pos = stop + 2;
         } else {
             break;
         }
     }
-    starts.push_back(out.size()); // (one past the last interval: lengths by difference)
-    out.resize(out.size() + pad, 0);
+    close();
+    starts.push_back(out.size() - pad); // (a stream with fewer markers than its DRI promises: intervals of no bytes = zeros)
+    lens.push_back(0);
 }
 
 // An hvc_jpeg_info is the caller's: hvc_jpeg_read_header / hvc_jpeg_encoder_layout filled it in, normally -- but nothing
@@ -485,7 +495,7 @@ struct Walk {
     // restart intervals, where the caller has opted in (else rst_interval = 0 and nothing below is looked at): MCUs per
     // interval, where each interval's bytes begin in `ecs`, the interval in progress, MCUs begun, the MCU the next one starts at
     int rst_interval = 0;
-    std::vector<size_t> rst_start;
+    std::vector<size_t> rst_start, rst_len;
     size_t rst_k = 0;
     long long mcus_begun = 0, rst_at = 0;
     BitReader br{nullptr, 0};
@@ -575,8 +585,8 @@ struct Walk {
         mcus_begun = 0;
         rst_at = rst_interval;
         if (rst_interval) { // (opt-in, beyond the model)
-            extract_ecs_restart(data, n, pos, ecs, rst_start, 16 + BitReader::PAD);
-            br = BitReader{ecs.data(), rst_start[1] - rst_start[0]};
+            extract_ecs_restart(data, n, pos, ecs, rst_start, rst_len, 16 + BitReader::PAD);
+            br = BitReader{ecs.data(), rst_len[0]};
         } else {
         ecs.resize(room);
         size_t got = hvc::extract_ecs_to(data, n, pos, ecs.data(), room - BitReader::PAD);
@@ -624,8 +634,8 @@ struct Walk {
             rst_at += rst_interval;                          // byte-aligned data behind the RSTn marker, predictors at zero (T.81 E.2.4)
             rst_k++;
             const size_t last = rst_start.size() - 1; // (a stream with fewer markers than its DRI promises: zeros from its end on)
-            const size_t at = rst_k < last ? rst_start[rst_k] : rst_start[last], end = rst_k < last ? rst_start[rst_k + 1] : rst_start[last];
-            br = BitReader{ecs.data() + at, end - at};
+            const size_t q = (size_t)rst_k < last ? (size_t)rst_k : last;
+            br = BitReader{ecs.data() + rst_start[q], rst_len[q]};
             for (int j = 0; j < 4; j++) dc_pred[j] = 0;
         }
         const McuBlock mb = mcu[(size_t)bi];
@@ -1514,17 +1524,64 @@ static void extract_ecs(const uint8_t *data, size_t n, size_t pos, std::vector<u
 }
 
 static int prepare_gpu_decode_impl(const uint8_t *jpeg, size_t n, const ::hvc_jpeg_info *info, HdTables &t,
-                                   std::vector<uint8_t> *ecs, uint8_t *dst, size_t cap, size_t *ecs_size, bool &gpu_ok);
+                                   std::vector<uint8_t> *ecs, uint8_t *dst, size_t cap, size_t *ecs_size, bool &gpu_ok, RstUnits *units = nullptr);
 int prepare_gpu_decode(const uint8_t *jpeg, size_t n, const ::hvc_jpeg_info *info, HdTables &t, std::vector<uint8_t> &ecs,
                        bool &gpu_ok) {
     return prepare_gpu_decode_impl(jpeg, n, info, t, &ecs, nullptr, 0, nullptr, gpu_ok);
 }
 int prepare_gpu_decode_to(const uint8_t *jpeg, size_t n, const ::hvc_jpeg_info *info, HdTables &t, uint8_t *dst, size_t cap,
-                          size_t *ecs_size, bool &gpu_ok) {
-    return prepare_gpu_decode_impl(jpeg, n, info, t, nullptr, dst, cap, ecs_size, gpu_ok);
+                          size_t *ecs_size, bool &gpu_ok, RstUnits *units) {
+    return prepare_gpu_decode_impl(jpeg, n, info, t, nullptr, dst, cap, ecs_size, gpu_ok, units);
+}
+unsigned restart_interval_of(const uint8_t *jpeg, size_t n) {
+    Header h;
+    return parse_header(jpeg, n, h) ? 0u : (unsigned)h.restart_interval;
+}
+// Restart mode: every interval unstuffed into its own slot of dst -- interval k at off[k] (a multiple of 16), len[k] bytes,
+// zeros behind it to the end of its slot, hd_unit_slot(len[k]) bytes.  Follows extract_ecs_restart marker for marker.
+// Returns the number of intervals found, or SIZE_MAX when there are more than `most` or dst is too small.
+static size_t extract_ecs_units_to(const uint8_t *data, size_t n, size_t pos, uint8_t *dst, size_t cap, unsigned most, unsigned *off,
+                                   unsigned *len, size_t *total) {
+    size_t at = 0, out = 0, k = 0; // the open interval's slot starts at `at`, `out` bytes of it are written
+    *total = 0;
+    auto close = [&]() -> bool {
+        const size_t slot = hd_unit_slot(out);
+        if (k >= most || slot > cap - at) return false; // (the bytes themselves fitted: checked as they were written)
+        std::memset(dst + at + out, 0, slot - out);
+        off[k] = (unsigned)at;
+        len[k] = (unsigned)out;
+        *total += out;
+        k++;
+        at += slot;
+        out = 0;
+        return true;
+    };
+    while (pos < n) {
+        const uint8_t *ff = (const uint8_t *)std::memchr(data + pos, 0xff, n - pos);
+        const size_t stop = ff ? (size_t)(ff - data) : n;
+        if (at > cap || stop - pos > cap - at - out) return SIZE_MAX;
+        std::memcpy(dst + at + out, data + pos, stop - pos);
+        out += stop - pos;
+        if (!ff) break;
+        const int next = stop + 1 < n ? data[stop + 1] : -1;
+        if (next == 0x00) {
+            if (out >= cap - at) return SIZE_MAX;
+            dst[at + out++] = 0xff;
+            pos = stop + 2;
+        } else if (next == 0xff) {
+            pos = stop + 1;
+        } else if (next >= 0xd0 && next <= 0xd7) {
+            if (!close()) return SIZE_MAX;
+            pos = stop + 2;
+        } else {
+            break;
+        }
+    }
+    if (at > cap || !close()) return SIZE_MAX;
+    return k;
 }
 static int prepare_gpu_decode_impl(const uint8_t *jpeg, size_t n, const ::hvc_jpeg_info *info, HdTables &t,
-                                   std::vector<uint8_t> *ecs, uint8_t *dst, size_t cap, size_t *ecs_size, bool &gpu_ok) {
+                                   std::vector<uint8_t> *ecs, uint8_t *dst, size_t cap, size_t *ecs_size, bool &gpu_ok, RstUnits *units) {
     gpu_ok = false;
     Header h;
     int r = parse_header(jpeg, n, h);
@@ -1585,8 +1642,31 @@ static int prepare_gpu_decode_impl(const uint8_t *jpeg, size_t n, const ::hvc_jp
             ok = ok && fill(h.dht[ai].spec, t.ac[i], t.ovf_ac[i]);
         }
     }
+    // Restart intervals honoured (opt-in) and the scan has more than one: every interval is a unit of its own for the GPU
+    // reader (hvc_hdec.h HdParams::rst_*) -- for a caller that lays units out; any other leaves the file to the host reader.
+    // (One interval = no marker is expected: the plain segment, which ends at the first marker whatever it is.)
+    unsigned long long mcus = 0;
+    if (info->n_comp > 0 && info->comp[0].hscale > 0 && info->comp[0].vscale > 0)
+        mcus = (unsigned long long)(info->comp[0].decoded_width / (8 * info->comp[0].hscale)) *
+               (unsigned long long)(info->comp[0].decoded_height / (8 * info->comp[0].vscale));
+    const bool rst_multi = tl_honour_restart && h.restart_interval > 0 && mcus > (unsigned long long)h.restart_interval;
     size_t got;
-    if (ecs) {
+    if (rst_multi) {
+        const unsigned long long ipf = (mcus + (unsigned)h.restart_interval - 1) / (unsigned)h.restart_interval;
+        got = 0;
+        if (ecs_size) *ecs_size = 0;
+        if (!units || ecs || !dst || units->ipf != ipf || units->interval != (unsigned)h.restart_interval) {
+            ok = false;
+        } else {
+            const size_t found = extract_ecs_units_to(jpeg, n, h.ecs_pos, dst, cap, units->ipf, units->off, units->len, &got);
+            ok = ok && found == units->ipf; // (fewer or more markers than the DRI promises: the host reader's)
+            if (ecs_size) *ecs_size = got;
+        }
+    } else if (units) { // (a batch laid out for intervals, a file without them)
+        ok = false;
+        got = 0;
+        if (ecs_size) *ecs_size = 0;
+    } else if (ecs) {
         extract_ecs(jpeg, n, h.ecs_pos, *ecs);
         got = ecs->size();
     } else {
@@ -1601,7 +1681,6 @@ static int prepare_gpu_decode_impl(const uint8_t *jpeg, size_t n, const ::hvc_jp
         empty_plane |= info->comp[i].hscale < 1 || info->comp[i].vscale < 1;
     }
     // (a segment of at most 32 bits: the host reader has the model's length test for those -- walk_literal)
-    if (tl_honour_restart && h.restart_interval > 0) ok = false; // restart intervals (opt-in): the host reader's
     gpu_ok = ok && !empty_plane && info->n_comp <= 3 && per_mcu <= HVC_HD_MAX_MCU_BLOCKS && got < (1u << 28) && got * 8 > 32;
     return HVC_OK;
 }

@@ -115,7 +115,13 @@ struct HdParams {
     int n_frames;
     unsigned total_sub;
     int n_comp, blocks_per_mcu, mbs_wide, mbs_high;
-    unsigned blocks_per_frame;
+    unsigned blocks_per_frame; // blocks a frame can have (restart mode: rst_mcus MCUs' worth -- the capacity of dcd's rows)
+    // Restart intervals (opt-in, beyond the model: include/hvc_jpeg.h hvc_set_restart_markers): every interval of a file is a
+    // FRAME of its own to the reader -- its bytes start on a subsequence boundary, its first subsequence has the true start
+    // (block 0 of an MCU, DC predictors at zero), nothing synchronises or sums across its ends.  Frame f = interval
+    // f % rst_ipf of file f / rst_ipf: its blocks are the MCUs [k rst_mcus, (k + 1) rst_mcus) of the file's scan (the last
+    // interval of a file may have fewer) and land in the FILE's coefficient record.  rst_ipf <= 1: off, frame = file.
+    unsigned rst_mcus, rst_ipf;
     HdComp comp[4];
     unsigned char b2comp[HVC_HD_MAX_MCU_BLOCKS];
     int16_t *coefs;
@@ -148,15 +154,27 @@ void hd_stats_read(unsigned long long out[4]); // experiments (tools/exp_hd_stat
 hipError_t launch_hd_frame_of(const HdParams &P, hipStream_t s); // fills P.frame_of from P.sub_off (callers that do not upload it)
 hipError_t launch_hd_finish(const HdParams &P, int rounds_done, hipStream_t s); // count scan, write pass, DC pass
 bool hd_write2_fits(const HdParams &P); // the fast write pass can address these records (PF mode needs it)
+inline unsigned hd_files(const HdParams &P) { return P.rst_ipf > 1 ? ((unsigned)P.n_frames + P.rst_ipf - 1) / P.rst_ipf : (unsigned)P.n_frames; }
 
 // hvc_entropy.cpp: header parse + table preparation + unstuffing for one file
 // returns HVC_OK, or an hvc_status the host decoder would also return at this stage;
 // gpu_ok = false when the stream needs the host decoder (tables that are no prefix code, > 16 blocks per MCU)
 int prepare_gpu_decode(const uint8_t *jpeg, size_t n, const ::hvc_jpeg_info *info, HdTables &t, std::vector<uint8_t> &ecs,
                        bool &gpu_ok);
-// the same, unstuffing straight into dst[0, cap) (a pinned ring slot); a segment that does not fit clears gpu_ok
+// the same, unstuffing straight into dst[0, cap) (a pinned ring slot); a segment that does not fit clears gpu_ok.
+// units (restart intervals honoured on this thread, the file's DRI = units->interval and its scan holds units->ipf > 1 of
+// them): interval k goes to dst + off[k], len[k] bytes and zeros behind them to the end of its slot, hd_unit_slot(len[k]);
+// *ecs_size = the bytes of all intervals.  A file with restart intervals and no `units` (or other numbers) clears gpu_ok.
+struct RstUnits {
+    unsigned interval, ipf;
+    unsigned *off, *len; // [ipf]
+};
+// a reader frame's bytes in the segment buffer: its subsequences, one more of zeros (the reader sees zeros past the end)
+// and 16 bytes of overshoot -- a multiple of 16
+inline size_t hd_unit_slot(size_t len) { return ((len + HVC_HD_SUBSEQ_BITS / 8 - 1) / (HVC_HD_SUBSEQ_BITS / 8) + 1) * (HVC_HD_SUBSEQ_BITS / 8) + 16; }
 int prepare_gpu_decode_to(const uint8_t *jpeg, size_t n, const ::hvc_jpeg_info *info, HdTables &t, uint8_t *dst, size_t cap,
-                          size_t *ecs_size, bool &gpu_ok);
+                          size_t *ecs_size, bool &gpu_ok, RstUnits *units = nullptr);
+unsigned restart_interval_of(const uint8_t *jpeg, size_t n); // the file's DRI (0: none, or no header that parses)
 
 
 // A block whose absolute DC (decoder.ml:143, a 63-bit sum in the model) does not fit the int16 coefficient record:

@@ -50,6 +50,22 @@ __device__ __forceinline__ unsigned long long pack_state(unsigned p, int k, int 
     return (unsigned long long)p | ((unsigned long long)(unsigned)k << 32) | ((unsigned long long)(unsigned)b << 40);
 }
 
+// Frame f of the reader as a place in the batch's records (HdParams::rst_*): the file whose record its blocks go to, the
+// first of the file's MCUs it holds, how many blocks it has.  Without restart intervals: the frame itself, 0, all.
+struct FrameRef {
+    unsigned file, mcu0, need;
+};
+__device__ __forceinline__ FrameRef frame_ref(const HdParams &P, unsigned f) {
+    FrameRef r{f, 0u, P.blocks_per_frame};
+    if (P.rst_ipf > 1u) {
+        r.file = f / P.rst_ipf;
+        r.mcu0 = (f - r.file * P.rst_ipf) * P.rst_mcus;
+        const unsigned left = (unsigned)P.mbs_wide * (unsigned)P.mbs_high - r.mcu0; // (>= 1: rst_ipf = ceil(MCUs / rst_mcus))
+        r.need = (left < P.rst_mcus ? left : P.rst_mcus) * (unsigned)P.blocks_per_mcu;
+    }
+    return r;
+}
+
 // A lane's bits come straight from global memory, one (byte-swapped) dword per 32 bits consumed, requested
 // two refills ahead -- a dozen symbols -- so their latency is covered.  (A first version staged each lane's
 // 144 bytes in LDS: 38 KB per workgroup, which held the kernel at 2 waves per SIMD; without it LDS holds only
@@ -99,7 +115,7 @@ __device__ __forceinline__ void load_geo(const HdParams &P, HdGeo &G) {
 template <bool WRITE>
 __device__ __forceinline__ void walk(const HdParams &P, const HdGeo &G, const HdTables &T, const unsigned *slot, unsigned base, unsigned limit,
                                      unsigned &p, int &k, int &b, unsigned &nb, unsigned first_block, int16_t *rec,
-                                     unsigned &err, int16_t *lb = nullptr) {
+                                     unsigned &err, int16_t *lb = nullptr, unsigned mcu0 = 0u, unsigned need = 0u) {
     // WRITE: lb = this lane's 64-coefficient LDS buffer (zeroed).  Coefficients are assembled there and
     // leave as whole 128-byte blocks (eight 16-byte stores); storing them one by one -- 2 bytes at random
     // places of a record that is not in any cache -- made the write pass cost as much as all the
@@ -113,7 +129,7 @@ __device__ __forceinline__ void walk(const HdParams &P, const HdGeo &G, const Hd
     // position of the current block: MCU coordinates advance by counting, no divisions inside the loop
     unsigned mx = 0, my = 0;
     if (WRITE) {
-        const unsigned mcu = first_block / (unsigned)B;
+        const unsigned mcu = first_block / (unsigned)B + mcu0;
         my = mcu / (unsigned)P.mbs_wide;
         mx = mcu - my * (unsigned)P.mbs_wide;
     }
@@ -122,7 +138,7 @@ __device__ __forceinline__ void walk(const HdParams &P, const HdGeo &G, const Hd
         return rec + G.coef_off[comp] +
                ((size_t)(my * (unsigned)G.v[comp] + G.b2sy[bb]) * (unsigned)G.bw[comp] + (size_t)(mx * (unsigned)G.h[comp] + G.b2sx[bb])) * 64;
     };
-    bool live = WRITE && bi < P.blocks_per_frame; // this block's coefficients are stored (and its errors count)
+    bool live = WRITE && bi < need; // this block's coefficients are stored (and its errors count)
     if (live) blk = block_ptr(b);
     // The serial chain per symbol is what bounds the whole decoder, so it is kept short: a 64-bit
     // MSB-aligned window in registers (refilled a dword at a time from the lane's LDS slot, the next
@@ -221,7 +237,7 @@ __device__ __forceinline__ void walk(const HdParams &P, const HdGeo &G, const Hd
                     my++;
                 }
             }
-            live = WRITE && bi < P.blocks_per_frame;
+            live = WRITE && bi < need;
             if (live) blk = block_ptr(b);
         }
     }
@@ -717,7 +733,7 @@ __global__ __launch_bounds__(1024) void k_hd_scan(HdParams P) {
     }
     if (lane == 0) {
         P.frame_blocks[frame] = carry_s;
-        if (carry_s < P.blocks_per_frame) atomicOr(P.status, 4u); // the stream ends before the frame does
+        if (carry_s < frame_ref(P, (unsigned)frame).need) atomicOr(P.status, 4u); // the stream ends before the frame does
     }
 }
 
@@ -745,7 +761,8 @@ __global__ __launch_bounds__(256) void k_hd_write(HdParams P, int final_round) {
     if (hd_unsettled(P, final_round)) return;
     if (!valid) return;
     const unsigned first_block = P.nblk[i];
-    if (first_block >= P.blocks_per_frame) return; // past the last coded block: the model never reads this far
+    const FrameRef R = frame_ref(P, f);
+    if (first_block >= R.need) return; // past the last coded block: the model never reads this far
     const unsigned long long st = P.start_used[i];
     unsigned p = (unsigned)st;
     int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
@@ -755,8 +772,8 @@ __global__ __launch_bounds__(256) void k_hd_write(HdParams P, int final_round) {
         return;
     }
     const unsigned base = j * (unsigned)S;
-    walk<true>(P, G, T, slot, base, base + (unsigned)S, p, k, b, nb, first_block, P.coefs + (size_t)f * P.coef_fs, err,
-               reinterpret_cast<int16_t *>(lbuf + threadIdx.x * 8));
+    walk<true>(P, G, T, slot, base, base + (unsigned)S, p, k, b, nb, first_block, P.coefs + (size_t)R.file * P.coef_fs, err,
+               reinterpret_cast<int16_t *>(lbuf + threadIdx.x * 8), R.mcu0, R.need);
     // the exit the synchronisation launches recorded for this subsequence must be the one this walk arrives at
     const unsigned long long *fin = (final_round & 1) ? P.exit_a : P.exit_b; // launch final_round - 1 wrote it
     if (pack_state(p, k, b) != fin[i]) err |= 8u;
@@ -865,7 +882,8 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
     const int B = P.blocks_per_mcu;
     const unsigned base = j * (unsigned)S, limit = base + (unsigned)S, hard = limit + (unsigned)(WR_EXTRA * S);
     unsigned bi = valid ? P.nblk[i] : 0xffffffffu; // the block this subsequence starts in
-    bool act = valid && bi < P.blocks_per_frame;   // past the last coded block: the model never reads this far
+    const FrameRef R = frame_ref(P, f);
+    bool act = valid && bi < R.need;   // past the last coded block: the model never reads this far
     const unsigned long long st = act ? P.start_used[i] : 0ull;
     const unsigned p0 = act ? (unsigned)st : base;
     int k = (int)((st >> 32) & 0xffu), b = (int)((st >> 40) & 0xffu);
@@ -877,10 +895,10 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
         act = false;
     }
     bool live = act && k == 0;
-    const unsigned mcu = (act ? bi : 0u) / (unsigned)B;
+    const unsigned mcu = (act ? bi : 0u) / (unsigned)B + R.mcu0;
     unsigned my = mcu / (unsigned)P.mbs_wide, mx = mcu - my * (unsigned)P.mbs_wide; // advance by counting
     // 16-byte units from P.coefs: records are multiples of 8 coefficients apart, planes of 64 (launch_hd_finish checks the range)
-    const unsigned frame_unit0 = (unsigned)(((size_t)f * P.coef_fs) >> 3);
+    const unsigned frame_unit0 = (unsigned)(((size_t)R.file * P.coef_fs) >> 3);
     auto block_no = [&](int bb) -> unsigned {
         const int comp = G.b2comp[bb];
         return frame_unit0 + (G.coef_off[comp] >> 3) +
@@ -1011,7 +1029,7 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
                 k = 0;
                 b = b + 1 == B ? 0 : b + 1;
                 bi++;
-                live = bi < P.blocks_per_frame;
+                live = bi < R.need;
                 bt = tvb + ((selmask >> (2 * b)) & 3u) * (2 * SPEC_T);
                 bt_ac = bt + SPEC_T;
                 if (b == 0) { // next MCU
@@ -1050,8 +1068,9 @@ __global__ __launch_bounds__(1024) void k_hd_dc(HdParams P, int final_round) {
     if (comp >= P.n_comp || hd_unsettled(P, final_round)) return; // (not settled: the write pass stored nothing)
     const HdComp &C = P.comp[comp];
     const int hv = C.h * C.v;
-    const unsigned n = (unsigned)P.mbs_wide * (unsigned)P.mbs_high * (unsigned)hv;
-    int16_t *rec = P.coefs + (size_t)frame * P.coef_fs + C.coef_off;
+    const FrameRef R = frame_ref(P, (unsigned)frame);
+    const unsigned n = R.need / (unsigned)P.blocks_per_mcu * (unsigned)hv; // the component's blocks in this frame
+    int16_t *rec = P.coefs + (size_t)R.file * P.coef_fs + C.coef_off;
     // k_hd_write2 leaves the differences in block order of the scan, 2 bytes each (reading them out of the records
     // costs a 128-byte line apiece: the records' size in traffic for 1/64 of their content)
     const int16_t *dcd = P.dcd ? P.dcd + (size_t)frame * P.blocks_per_frame : nullptr;
@@ -1073,7 +1092,8 @@ __global__ __launch_bounds__(1024) void k_hd_dc(HdParams P, int final_round) {
             if (o < n) {
                 const unsigned m = o / (unsigned)hv, r = o - m * (unsigned)hv;
                 const unsigned sy = r / (unsigned)C.h, sx = r - sy * (unsigned)C.h;
-                const unsigned my = m / (unsigned)P.mbs_wide, mx = m - my * (unsigned)P.mbs_wide;
+                const unsigned mf = m + R.mcu0; // the MCU's number in the file's scan
+                const unsigned my = mf / (unsigned)P.mbs_wide, mx = mf - my * (unsigned)P.mbs_wide;
                 dcp[e] = rec + ((size_t)(my * C.v + sy) * C.bw + (size_t)(mx * C.h + sx)) * 64;
                 v[e] = dcd ? dcd[(size_t)m * (unsigned)P.blocks_per_mcu + (unsigned)C.mcu_base + r] : *dcp[e];
             }
@@ -1097,7 +1117,7 @@ __global__ __launch_bounds__(1024) void k_hd_dc(HdParams P, int final_round) {
             const int dc = before + v[e];
             if (dc < -32768 || dc > 32767) bad = true;
             if (P.dc_plane) // 2 bytes into a compact array instead of 2 bytes into a 128-byte record (a partial-line write each)
-                P.dc_plane[(size_t)frame * P.dc_fs + (size_t)((dcp[e] - (P.coefs + (size_t)frame * P.coef_fs)) >> 6)] = (int16_t)dc;
+                P.dc_plane[(size_t)R.file * P.dc_fs + (size_t)((dcp[e] - (P.coefs + (size_t)R.file * P.coef_fs)) >> 6)] = (int16_t)dc;
             else
                 *dcp[e] = (int16_t)dc;
         }
@@ -1274,7 +1294,7 @@ hipError_t launch_hd_round(const HdParams &P, int round, hipStream_t s) {
 }
 
 // k_hd_write2 addresses the records in 16-byte units with 32 bits
-bool hd_write2_fits(const HdParams &P) { return (unsigned long long)P.n_frames * P.coef_fs < (1ull << 35); }
+bool hd_write2_fits(const HdParams &P) { return (unsigned long long)hd_files(P) * P.coef_fs < (1ull << 35); }
 
 hipError_t launch_hd_finish(const HdParams &P, int rounds_done, hipStream_t s) {
     if (P.total_sub == 0) return hipSuccess;
