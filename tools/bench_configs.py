@@ -58,7 +58,15 @@ def config3(args):
         u = synth_pixels(20 + f, 544, 960)[:H // 2]
         v = synth_pixels(30 + f, 544, 960)[:H // 2]
         jpegs.append(ctx.jpeg_encode(y, u, v, W, H, 420, 75))
-    if getattr(args, "own_tables", False):
+    ri = int(getattr(args, "restart_interval", 0) or 0)
+    if ri:
+        # every file re-written with a restart interval of ri MCUs (DRI + RSTn; 120 = a row of MCUs, what encoders write) and the
+        # readers told to honour them (hvc_set_restart_markers: the opt-in extension) -- same coefficients, same frames
+        from jpeg_opt_writer import jpeg_optimised_tables
+        qt = np.stack([hvc.hvc.quant_table(0, 75), hvc.hvc.quant_table(1, 75)])
+        jpegs = [jpeg_optimised_tables(W, H, 420, qt, hvc.hvc.jpeg_entropy_decode(j)[1], restart_interval=ri) for j in jpegs]
+        ctx.set_restart_markers(True)
+    elif getattr(args, "own_tables", False):
         # every distinct file re-written with Huffman tables optimised for its own statistics (what libjpeg -optimize
         # writes): other tables than the model's defaults AND other tables from file to file -- same coefficients,
         # same decoded frames, so the golden checksums still apply
@@ -88,7 +96,7 @@ def config3(args):
     result = {
         **verify(ctx, d_pix, info.pixel_bytes, args.frames, "configs_c3", args.distinct),
         "config": ("3-gpu-entropy" if gpu else "3") + ("-host-out" if args.host_out else "") +
-                  ("-own-tables" if getattr(args, "own_tables", False) else ""),
+                  ("-own-tables" if getattr(args, "own_tables", False) else "") + ("-restart-%d" % ri if ri else ""),
         "metric": "Mpixel/s decoded, " + ("host unstuffing + H2D of segments + GPU Huffman + GPU block stage"
                                           if gpu else "host Huffman + H2D + GPU block stage") + " overlapped",
         "host_prep_thread_ms_sum": round(st.host_prep_ms_sum, 1),
@@ -478,7 +486,7 @@ def config_convert(args):
 def make_args(**kw):
     """the argument object of the config functions for callers that are not this file's command line (bench.py)"""
     d = dict(frames=None, distinct=4, steps=None, warmup=10, threads=min(16, len(os.sched_getaffinity(0))), chunk=32,
-             gpu_entropy=False, host_out=False, own_tables=False, fused_only=False)
+             gpu_entropy=False, host_out=False, own_tables=False, fused_only=False, restart_interval=0)
     d.update(kw)
     return argparse.Namespace(**d)
 
@@ -496,6 +504,7 @@ def main():
     ap.add_argument("--host-out", action="store_true", help="config 3: decoded frames to host memory instead of HBM")
     ap.add_argument("--own-tables", action="store_true", help="config 3: every file with Huffman tables optimised for itself")
     ap.add_argument("--fused-only", action="store_true", help="config 7: skip the three-launch composition")
+    ap.add_argument("--restart-interval", type=int, default=0, help="config 3: the files carry DRI / RSTn every so many MCUs (own tables too) and the readers honour them")
     args = ap.parse_args()
     if args.config == 2:  # K2 upsample (optional output stage)
         args.frames = args.frames or 256

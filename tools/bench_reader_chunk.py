@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--files", type=int, default=256)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--own-tables", action="store_true")
+    ap.add_argument("--restart-interval", type=int, default=0, help="files with DRI / RSTn every so many MCUs (and their own tables), honoured")
     args = ap.parse_args()
     W, H = 1920, 1080
     ctx = hvc.Context(0)
@@ -33,13 +34,14 @@ def main():
         u = synth_pixels(20 + f, 544, 960)[:H // 2]
         v = synth_pixels(30 + f, 544, 960)[:H // 2]
         j = ctx.jpeg_encode(y, u, v, W, H, 420, 75)
-        if args.own_tables:
+        if args.own_tables or args.restart_interval:
             from jpeg_opt_writer import jpeg_optimised_tables
             qt = np.stack([hvc.hvc.quant_table(0, 75), hvc.hvc.quant_table(1, 75)])
-            j = jpeg_optimised_tables(W, H, 420, qt, hvc.hvc.jpeg_entropy_decode(j)[1])
+            j = jpeg_optimised_tables(W, H, 420, qt, hvc.hvc.jpeg_entropy_decode(j)[1], restart_interval=args.restart_interval)
         jpegs.append(j)
     batch = [jpegs[i % 4] for i in range(args.files)]
-    want = [hvc.hvc.jpeg_entropy_decode(j)[1] for j in jpegs]
+    want = [hvc.hvc.jpeg_entropy_decode(j, restart_markers=args.restart_interval > 0)[1] for j in jpegs]
+    ctx.set_restart_markers(args.restart_interval > 0)
     times = []
     for rep in range(args.reps + 1):
         t0 = time.perf_counter()
@@ -47,7 +49,7 @@ def main():
         times.append((time.perf_counter() - t0) * 1e3)
         assert used == 1, "the GPU reader declined the batch"
     ok = all(np.array_equal(recs[i], want[i % 4]) for i in range(args.files))
-    print(json.dumps({"files": args.files, "own_tables": args.own_tables, "call_ms_min": round(min(times[1:]), 3), "call_ms": [round(t, 2) for t in times[1:]],
+    print(json.dumps({"files": args.files, "own_tables": args.own_tables, "restart_interval": args.restart_interval, "call_ms_min": round(min(times[1:]), 3), "call_ms": [round(t, 2) for t in times[1:]],
                       "records_equal_host_reader": bool(ok)}))
     ctx.close()
     sys.exit(0 if ok else 1)

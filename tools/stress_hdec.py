@@ -44,7 +44,7 @@ def main():
     args = ap.parse_args()
     rng = np.random.Generator(np.random.PCG64(args.seed))
     ctx = hvc.Context(0)
-    used_gpu = fell_back = bad = refused = 0
+    used_gpu = fell_back = bad = refused = with_restart = 0
     keep = []
     for case in range(args.cases):
         chroma = int(rng.choice([420, 422, 444]))
@@ -67,41 +67,59 @@ def main():
             files = [jpeg_optimised_tables(w, h, chroma, qt, hvc.hvc.jpeg_entropy_decode(j)[1], int(rng.integers(1, 4)),
                                            ac_shape="many_prefixes" if rng.integers(0, 3) == 0 else None)  # (a third: tables past the sub-table limit)
                      if rng.integers(0, 5) else j for j in files]
+        rst = case % 4 == 1   # a quarter of the cases: the files carry restart intervals (one DRI for the batch) and both readers
+        if rst:               # honour them (the opt-in extension): every interval is a frame of its own to the GPU reader
+            qt = np.stack([hvc.hvc.quant_table(0, q), hvc.hvc.quant_table(1, q)])
+            ri = int(rng.integers(1, 2 * max(1, w // 16) + 2))
+            files = [jpeg_optimised_tables(w, h, chroma, qt, hvc.hvc.jpeg_entropy_decode(j)[1], int(rng.integers(1, 4)), restart_interval=ri)
+                     for j in files]
+            ctx.set_restart_markers(True)
+            with_restart += 1
         _, got, used = ctx.jpeg_entropy_decode_gpu(files, device=bool(case & 1))
+        ctx.set_restart_markers(False)
         used_gpu += used == 1
         fell_back += used != 1
         for f, j in enumerate(files):
-            _, want = hvc.hvc.jpeg_entropy_decode(j)
+            _, want = hvc.hvc.jpeg_entropy_decode(j, restart_markers=rst)
             if not np.array_equal(got[f], want):
                 bad += 1
                 print("MISMATCH case", case, "file", f, (w, h, chroma, q), file=sys.stderr)
         if len(keep) < 40:
-            keep.append(files[0])
+            keep.append((files[0], rst))
     agree = errs = 0
     for it in range(args.mutations):
-        b = bytearray(keep[it % len(keep)])
+        b, rst = keep[it % len(keep)]
+        b = bytearray(b)
         for _ in range(int(rng.integers(1, 4))):
             b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        if rst and it % 3 == 0:   # (markers lost, doubled, moved: the host reader's, with the same result)
+            marks = [i for i in range(len(b) - 1) if b[i] == 0xFF and 0xD0 <= b[i + 1] <= 0xD7]
+            if marks:
+                m = marks[int(rng.integers(0, len(marks)))]
+                kind = int(rng.integers(0, 3))
+                b = b[:m] + b[m + 2:] if kind == 0 else b[:m] + b[m:m + 2] + b[m:] if kind == 1 else b[:max(2, m - 5)] + b[m:]
         b = bytes(b)
         try:
             info = hvc.hvc.jpeg_read_header(b)
             if info.coef_count > 1 << 23:
                 continue
-            _, want = hvc.hvc.jpeg_entropy_decode(b, info)
+            _, want = hvc.hvc.jpeg_entropy_decode(b, info, restart_markers=rst)
             err = None
         except hvc.HvcError as e:
             want, err = None, e.code
+        ctx.set_restart_markers(rst)
         try:
             _, got, _ = ctx.jpeg_entropy_decode_gpu([b])
             gerr = None
         except hvc.HvcError as e:
             got, gerr = None, e.code
+        ctx.set_restart_markers(False)
         if err != gerr or (err is None and not np.array_equal(got[0], want)):
             bad += 1
             print("MISMATCH mutation", it, err, gerr, file=sys.stderr)
         agree += err is None
         errs += err is not None
-    print({"cases": args.cases, "encoder_refused_geometry": refused, "gpu_reader_used": used_gpu, "host_fallback": fell_back, "mutations_decoded": agree,
+    print({"cases": args.cases, "encoder_refused_geometry": refused, "with_restart_intervals": with_restart, "gpu_reader_used": used_gpu, "host_fallback": fell_back, "mutations_decoded": agree,
            "mutations_rejected": errs, "mismatches": bad})
     ctx.close()
     sys.exit(1 if bad else 0)

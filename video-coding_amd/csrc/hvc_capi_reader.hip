@@ -239,7 +239,7 @@ int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *si
                     const size_t u = (size_t)f * ipf + q;
                     ecs_off[u] = file_off[(size_t)f] + uoff[q];
                     sub_off[u] = (unsigned)subs;
-                    subs += (ulen[q] + SB - 1) / SB + 1;
+                    subs += hvc::hd_unit_subs(ulen[q]);
                 }
             } else {
                 r = hvc::prepare_gpu_decode_to(jpegs[f], sizes[f], &fi, t, fdst, room, &got, ok);
@@ -330,10 +330,10 @@ int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *si
         P.ftabs = (const hvc::HdFrameTabs *)c->gd_ftabs;
         P.tabset_of = (const unsigned *)((char *)c->gd_ftabs + tb);
         P.selmask = gd_component_selmask(P);
-        if (gd_lists_per_frame(P.total_sub, (int)nU)) {
+        if (gd_lists_per_frame(P.total_sub, n_frames)) {
             if ((r = grow(c, &c->gd_fcnt, &c->gd_fcnt_cap, (size_t)HVC_HD_LIST_N * nU * sizeof(unsigned)))) return r;
-            P.list_fn = (unsigned *)c->gd_fcnt; // work lists per frame (k_hd_sync_pf)
-            for (size_t f = 0; f < nU; f++) P.max_frame_sub = std::max(P.max_frame_sub, sub_off[f + 1] - sub_off[f]);
+            P.list_fn = (unsigned *)c->gd_fcnt; // work lists per file (k_hd_sync_pf)
+            for (size_t f = 0; f < (size_t)n_frames; f++) P.max_frame_sub = std::max(P.max_frame_sub, sub_off[(f + 1) * ipf] - sub_off[f * ipf]);
         }
     }
     P.ecs = (const uint8_t *)c->gd_ecs;
@@ -409,6 +409,7 @@ int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *si
         HIPCHK(c, hipStreamSynchronize(st));
     }
     const unsigned status = flags[1];
+    if (std::getenv("HVC_HD_DEBUG")) std::fprintf(stderr, "hd debug: frames %d subs %u changed %u status %u\n", P.n_frames, P.total_sub, flags[0], status);
     if (status) return HVC_OK; // the model raises / range / truncated stream: the host decoder reproduces it exactly
     *used_gpu = 1;
     if (after) after->speculated = consumer_enqueued;
@@ -875,7 +876,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
                 h_tabset_of[u] = frame_pf[(size_t)(first + f)] ? 1u + (unsigned)f : 0u;
                 h_ecs_off[u] = (unsigned)((size_t)f * R + (ipf > 1 ? unit_off[g] : 0u));
                 h_sub_off[u] = subs;
-                subs += (bytes + SB - 1) / SB + 1;
+                subs += ipf > 1 ? (unsigned)hvc::hd_unit_subs(bytes) : (bytes + SB - 1) / SB + 1;
             }
         }
         const size_t nu = (size_t)cnt * ipf;
@@ -894,7 +895,7 @@ static int decode_batch_gpu(hvc_ctx *c, const uint8_t *const *jpegs, const size_
             P.ftabs = (const hvc::HdFrameTabs *)c->gp_d_ftabs[slot];
             P.tabset_of = dm + CU + CU + 1;
             P.selmask = comp_selmask;
-            if (gd_lists_per_frame(subs, (int)nu)) {
+            if (gd_lists_per_frame(subs, cnt)) {
                 P.list_fn = (unsigned *)c->gd_fcnt + (size_t)(k % NRD) * HVC_HD_LIST_N * CU; // work lists per frame (k_hd_sync_pf)
                 P.max_frame_sub = (unsigned)nsub_max;
             }

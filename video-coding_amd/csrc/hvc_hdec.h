@@ -131,11 +131,11 @@ struct HdParams {
     // k_hd_sync only: second per-round exit buffer (exit_b is the first), the two work lists, list lengths per round
     unsigned long long *exit_c;
     unsigned *list0, *list1, *list_n; // [total_sub], [total_sub], [HVC_HD_LIST_N]
-    // PF mode with more than a handful of files: one work list per FRAME (frame f's entries sit at list0/1 + sub_off[f],
+    // PF mode with more than a handful of files: one work list per FILE (its entries sit at list0/1 + the sub_off of its first frame,
     // their number per round in list_fn[round * n_frames + f]), so that a workgroup's entries are all of one frame and
     // its tables can go to LDS.  list_fn: [HVC_HD_LIST_N * n_frames], or null (then the batch-wide lists are used).
     unsigned *list_fn;
-    unsigned max_frame_sub;    // the largest number of subsequences any frame has (the launches' grid)
+    unsigned max_frame_sub;    // the largest number of subsequences any FILE has (the launches' grid; restart intervals: all of a file's frames share a list)
     int16_t *dcd;              // [n_frames * blocks_per_frame] DC differences in scan order (k_hd_write2 -> k_hd_dc), or null
     int16_t *dc_plane;         // null: k_hd_dc puts the DC values into the records.  Otherwise into this compact array,
     size_t dc_fs;              //   dc_plane[frame * dc_fs + (block's coefficient offset in the frame record) / 64] -- what
@@ -169,9 +169,14 @@ struct RstUnits {
     unsigned interval, ipf;
     unsigned *off, *len; // [ipf]
 };
-// a reader frame's bytes in the segment buffer: its subsequences, one more of zeros (the reader sees zeros past the end)
-// and 16 bytes of overshoot -- a multiple of 16
-inline size_t hd_unit_slot(size_t len) { return ((len + HVC_HD_SUBSEQ_BITS / 8 - 1) / (HVC_HD_SUBSEQ_BITS / 8) + 1) * (HVC_HD_SUBSEQ_BITS / 8) + 16; }
+// An interval's place in the segment buffer: its subsequences -- the last one filled up with zeros -- and 16 bytes of
+// overshoot; a multiple of 16.  (A FILE's segment gets a whole subsequence of zeros more, so that a stream that ends a few
+// symbols early still finds its zeros on the GPU; per interval that subsequence -- a thousand zero bits are five hundred
+// of the shortest code: the slowest walk of its wavefront, in every round -- cost a third of the reader's time, and it is
+// not needed: a block the frame must have and that does not END inside the frame's own subsequences raises the
+// truncation flag (k_hd_scan), which sends the file to the host reader.)
+inline size_t hd_unit_subs(size_t len) { return len ? (len + HVC_HD_SUBSEQ_BITS / 8 - 1) / (HVC_HD_SUBSEQ_BITS / 8) : 1; }
+inline size_t hd_unit_slot(size_t len) { return hd_unit_subs(len) * (HVC_HD_SUBSEQ_BITS / 8) + 16; }
 int prepare_gpu_decode_to(const uint8_t *jpeg, size_t n, const ::hvc_jpeg_info *info, HdTables &t, uint8_t *dst, size_t cap,
                           size_t *ecs_size, bool &gpu_ok, RstUnits *units = nullptr);
 unsigned restart_interval_of(const uint8_t *jpeg, size_t n); // the file's DRI (0: none, or no header that parses)

@@ -66,6 +66,12 @@ __device__ __forceinline__ FrameRef frame_ref(const HdParams &P, unsigned f) {
     return r;
 }
 
+// frames f0 <= f1: of one FILE -- one set of per-file tables (PF mode: a workgroup whose subsequences lie between them can
+// keep that set in LDS)?  Frames are files, or with restart intervals a file's intervals, one after the other.
+__device__ __forceinline__ bool one_file(const HdParams &P, unsigned f0, unsigned f1) {
+    return f0 == f1 || (P.rst_ipf > 1u && f0 / P.rst_ipf == f1 / P.rst_ipf);
+}
+
 // A lane's bits come straight from global memory, one (byte-swapped) dword per 32 bits consumed, requested
 // two refills ahead -- a dozen symbols -- so their latency is covered.  (A first version staged each lane's
 // 144 bytes in LDS: 38 KB per workgroup, which held the kernel at 2 waves per SIMD; without it LDS holds only
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(256) void k_hd_round(HdParams P, int round) {
         if (PF) {
             const unsigned i0 = blockIdx.x * 256u, i1 = min(i0 + 256u, P.total_sub) - 1u;
             const unsigned f0 = P.frame_of[i0];
-            if (f0 == P.frame_of[i1]) {
+            if (one_file(P, f0, P.frame_of[i1])) {
                 const HdFrameTabs &ft = P.ftabs[P.tabset_of[f0]];
                 pf_lds = (ft.flags & 1u) != 0u;
                 src = reinterpret_cast<const unsigned *>(&ft.spec[0][0][0]);
@@ -564,7 +570,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_hd_sync(HdParams P, int round) {
     if (PF && round < 2) {
         const unsigned i0 = blockIdx.x * (unsigned)SYNC_WG, i1 = min(i0 + (unsigned)SYNC_WG, count) - 1u;
         const unsigned f0 = P.frame_of[i0];
-        if (f0 == P.frame_of[i1]) {
+        if (one_file(P, f0, P.frame_of[i1])) {
             const HdFrameTabs &ft = P.ftabs[P.tabset_of[f0]];
             pf_lds = (ft.flags & 1u) != 0u;
             src = reinterpret_cast<const unsigned *>(&ft.spec[0][0][0]);
@@ -615,8 +621,10 @@ __global__ __launch_bounds__(SYNC_WG) void k_hd_sync_pf(HdParams P, int round) {
     __shared__ uint16_t sp[2 * 2 * SPEC_T];
     __shared__ unsigned rows[SYNC_WG / 64][64 * SROW + 2]; // (+ 2: see spec_walk)
     __shared__ unsigned wcount[2][SYNC_WG / 64], wbase[2];
-    const unsigned f = blockIdx.y, s0 = P.sub_off[f];
-    const unsigned count = round < 2 ? P.sub_off[f + 1] - s0 : P.list_fn[(unsigned)round * (unsigned)P.n_frames + f];
+    // one list per FILE (blockIdx.y): its frame, or -- restart intervals -- its frames, which share its tables
+    const unsigned ipf = P.rst_ipf > 1u ? P.rst_ipf : 1u, g = blockIdx.y, n_groups = gridDim.y;
+    const unsigned f = g * ipf, f_end = min(f + ipf, (unsigned)P.n_frames), s0 = P.sub_off[f];
+    const unsigned count = round < 2 ? P.sub_off[f_end] - s0 : P.list_fn[(unsigned)round * n_groups + g];
     if (blockIdx.x * (unsigned)SYNC_WG >= count) return;
     const HdFrameTabs &ft = P.ftabs[P.tabset_of[f]];
     const bool pf_lds = (ft.flags & 1u) != 0u;
@@ -630,7 +638,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_hd_sync_pf(HdParams P, int round) {
     unsigned *row = rows[wave] + lane * SROW;
     const unsigned *list = ((round & 1) ? P.list1 : P.list0) + s0;
     unsigned *next = ((round & 1) ? P.list0 : P.list1) + s0;
-    unsigned *next_n = P.list_fn + (unsigned)(round + 1) * (unsigned)P.n_frames + f;
+    unsigned *next_n = P.list_fn + (unsigned)(round + 1) * n_groups + g;
     const unsigned long long *pe = (round & 1) ? P.exit_b : P.exit_c; // exits of round - 1
     unsigned long long *ce = (round & 1) ? P.exit_c : P.exit_b;       // exits of this round
     int trip = 0;
@@ -847,7 +855,7 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
     if (PF) {
         const unsigned i0 = blockIdx.x * (unsigned)WG, i1 = min(i0 + (unsigned)WG, P.total_sub) - 1u;
         const unsigned f0 = P.frame_of[i0];
-        if (f0 == P.frame_of[i1]) {
+        if (one_file(P, f0, P.frame_of[i1])) {
             const HdFrameTabs &ft = P.ftabs[P.tabset_of[f0]];
             if (ft.flags & 1u) {
                 pf_lds = true;
@@ -872,8 +880,13 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
     // the lane's subsequence in the segment buffer (the following ones come behind it; past the frame's last one
     // there is padding, another frame or the slack behind the buffer: nothing a block of this frame can reach)
     const unsigned *gbits = reinterpret_cast<const unsigned *>(P.ecs + P.ecs_off[f] + (size_t)j * (S / 8));
-    // dword q of the stream from this lane's subsequence on.  LDS: rows are consecutive subsequences, SROW = S / 32 + 1
-    auto rd = [&](unsigned q) -> unsigned { return GBITS ? __builtin_bswap32(gbits[q]) : row[q + (q >> 5)]; };
+    // dword q of the stream from this lane's subsequence on.  LDS: rows are consecutive subsequences, SROW = S / 32 + 1 --
+    // and dword S / 32, the one behind the subsequence IN MEMORY, comes from the lane's own row (its 33rd word), as the
+    // synchronisation walks read it: behind a frame's last subsequence that is the zero overshoot, not the first word of
+    // whichever frame comes next (a symbol that starts before the subsequence's end and looks past it must look at the
+    // same bits in both walks, or the exits they reach differ).  Dwords further on: the following rows.
+    auto rd = [&](unsigned q) -> unsigned { return GBITS ? __builtin_bswap32(gbits[q]) : row[q + (q ? (q - 1u) >> 5 : 0u)]; };
+    auto rd1 = [&](unsigned q) -> unsigned { return GBITS ? __builtin_bswap32(gbits[q]) : row[q + ((q - 1u) >> 5)]; }; // q >= 1
     static_assert(S == 1024, "rd(): S / 32 dwords per row");
     // where the coefficients of a block that is not this lane's go: the lane's own entry of the wavefront's store list
     // (written before it is read in every flush, and LDS operations of a wavefront keep their order)
@@ -973,11 +986,11 @@ __global__ __launch_bounds__(WG) void k_hd_write2(HdParams P, int final_round) {
             if (!GBITS) {
                 hi = refill ? lo : hi;
                 lo = refill ? nx : lo;
-                nx = rd((31u - mn) >> 5); // (a function of the position: read again rather than branched around)
+                nx = rd1((31u - mn) >> 5); // (a function of the position, >= 1: read again rather than branched around)
             } else if (refill) {
                 hi = lo;
                 lo = nx;
-                nx = rd((31u - mn) >> 5);
+                nx = rd1((31u - mn) >> 5);
             }
             if ((live && wrong) || mm <= watch) { // the rare things behind one branch
                 if (live && wrong) atomicOr(P.status, 1u);
@@ -1272,7 +1285,7 @@ static hipError_t launch_hd_round_t(const HdParams &P, int round, hipStream_t s)
         }();
         if (PF && P.list_fn && P.max_frame_sub) { // per-frame lists (k_hd_sync_pf)
             const unsigned per_frame = (P.max_frame_sub + (unsigned)SYNC_WG - 1u) / (unsigned)SYNC_WG;
-            for (int r = 0; r < rounds; r++) hipLaunchKernelGGL(k_hd_sync_pf, dim3(per_frame, (unsigned)P.n_frames), dim3(SYNC_WG), 0, s, P, r);
+            for (int r = 0; r < rounds; r++) hipLaunchKernelGGL(k_hd_sync_pf, dim3(per_frame, hd_files(P)), dim3(SYNC_WG), 0, s, P, r);
             return hipGetLastError();
         }
         for (int r = 0; r < rounds; r++) {
