@@ -409,7 +409,8 @@ int gpu_entropy_decode(hvc_ctx *c, const uint8_t *const *jpegs, const size_t *si
         HIPCHK(c, hipStreamSynchronize(st));
     }
     const unsigned status = flags[1];
-    if (std::getenv("HVC_HD_DEBUG")) std::fprintf(stderr, "hd debug: frames %d subs %u changed %u status %u\n", P.n_frames, P.total_sub, flags[0], status);
+    static const bool hd_debug = std::getenv("HVC_HD_DEBUG") != nullptr; // (diagnostics: why a call went to the host reader)
+    if (hd_debug) std::fprintf(stderr, "hd debug: frames %d subs %u changed %u status %u\n", P.n_frames, P.total_sub, flags[0], status);
     if (status) return HVC_OK; // the model raises / range / truncated stream: the host decoder reproduces it exactly
     *used_gpu = 1;
     if (after) after->speculated = consumer_enqueued;
