@@ -24,6 +24,7 @@ python tools/bench_configs.py --config 6 > gpurun_out/m_c6.json 2> gpurun_out/m_
 python tools/bench_configs.py --config 7 > gpurun_out/m_c7.json 2> gpurun_out/m_c7.err
 python tools/bench_configs.py --config 2 > gpurun_out/m_k2.json 2> gpurun_out/m_k2.err
 python tools/bench_configs.py --config 10 > gpurun_out/m_sub420.json 2> gpurun_out/m_sub420.err
+python tools/bench_configs.py --config 11 > gpurun_out/m_convert.json 2> gpurun_out/m_convert.err
 python tools/bench_configs.py --config 8 > gpurun_out/m_c5_files.json 2> gpurun_out/m_c5_files.err
 HVC_DECODE_KERNEL=q16 python bench.py --no-cpu-baseline > gpurun_out/m_bench_q16.json 2> gpurun_out/m_bench_q16.err
 # the file-level pipelines with the entropy stages on the GPU, the GPU Huffman coder alone, one file at a time
@@ -31,6 +32,9 @@ python tools/bench_configs.py --config 3 --frames 1024 --threads 16 --gpu-entrop
 python tools/bench_configs.py --config 3 --frames 4096 --threads 16 --gpu-entropy --chunk 256 > gpurun_out/m_c3_gpu_entropy_4096.json 2>> gpurun_out/m_c3g.err
 python tools/bench_configs.py --config 3 --frames 4096 --threads 16 --gpu-entropy --chunk 256 --own-tables > gpurun_out/m_c3_gpu_entropy_4096_own_tables.json 2>> gpurun_out/m_c3g.err
 python tools/bench_configs.py --config 3 --frames 4096 --threads 16 --gpu-entropy --chunk 256 --host-out > gpurun_out/m_c3_gpu_entropy_host_out.json 2>> gpurun_out/m_c3g.err
+# ... files with a restart interval of a row of MCUs (and their own tables), honoured: the GPU reader, the host reader
+python tools/bench_configs.py --config 3 --frames 4096 --threads 16 --gpu-entropy --chunk 256 --restart-interval 120 > gpurun_out/m_c3_gpu_entropy_4096_restart.json 2>> gpurun_out/m_c3g.err
+python tools/bench_configs.py --config 3 --frames 1024 --threads 16 --restart-interval 120 > gpurun_out/m_c3_restart.json 2>> gpurun_out/m_c3.err
 python tools/bench_configs.py --config 8 --gpu-entropy > gpurun_out/m_c5_files_gpu_entropy.json 2> gpurun_out/m_c5g.err
 python tools/bench_configs.py --config 9 > gpurun_out/m_huffman_gpu.json 2> gpurun_out/m_huffman_gpu.err
 python tools/bench_single.py > gpurun_out/m_single_file.jsonl 2> gpurun_out/m_single_file.err
@@ -46,8 +50,8 @@ python3 tools/trace_single_call.py --timeline $D > gpurun_out/m_single_call_time
 rm -rf $D
 # the GPU Huffman reader alone on one 256-file chunk, one stream: per-kernel durations that do not depend on what the
 # other reader stream of the pipeline is doing (model's tables; every file with its own optimised tables)
-for v in "" "--own-tables"; do
-  n=reader_chunk$(echo "$v" | sed 's/--own-tables/_own_tables/')
+for v in "" "--own-tables" "--restart-interval 120"; do
+  n=reader_chunk$(echo "$v" | sed 's/--own-tables/_own_tables/; s/--restart-interval 120/_restart/')
   D=$ROOT/gpurun_out/prof_${TAG}_$n; mkdir -p $D
   (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d $D/trace -o trace -- python3 $ROOT/tools/bench_reader_chunk.py --files 256 --reps 4 $v > $D/trace.log 2>&1) || true
   { grep records_equal $D/trace.log; python tools/reader_chunk_ms.py $D/trace; } > gpurun_out/m_$n.txt 2>&1 || true
