@@ -27,7 +27,8 @@ struct Params {
     int n_comp, work;
     Comp comp[3];
     unsigned *fix_count, *fix_list;
-    int pad[480]; // ~2 KB like DecodeParams (qt, qpair, thresholds)
+    int run_sh; // >= 0: every XCD takes runs of 2^run_sh consecutive tiles (csrc/hvc_kernels.h xcd_work); -1: as dispatched
+    int pad[479]; // ~2 KB like DecodeParams (qt, qpair, thresholds)
 };
 struct ParamsSmall {
     const uint4 *coefs;
@@ -36,12 +37,27 @@ struct ParamsSmall {
     int n_comp, work;
     Comp comp[3];
     unsigned *fix_count, *fix_list;
+    int run_sh;
 };
+
+// workgroup -> (frame, tile) as csrc/hvc_kernels.h xcd_work does it (round 4)
+__device__ __forceinline__ void xcd_remap(int sh, unsigned &frame, unsigned &tile) {
+    frame = blockIdx.y;
+    tile = blockIdx.x;
+    if (sh < 0) return;
+    const unsigned per = gridDim.x, id = frame * per + tile, group = 8u << sh, total = per * gridDim.y;
+    if (id >= total - total % group) return;
+    const unsigned k = id >> 3, lin = ((((k >> sh) << 3) + (id & 7u)) << sh) + (k & ((1u << sh) - 1u));
+    frame = lin / per;
+    tile = lin - frame * per;
+}
 
 template <class P, bool TAIL>
 __global__ __launch_bounds__(256) void k1(P p) {
     extern __shared__ unsigned char dyn_lds[]; // occupancy control only
-    const int lane = threadIdx.x, tile = blockIdx.x;
+    unsigned wframe, wtile;
+    xcd_remap(p.run_sh, wframe, wtile);
+    const int lane = threadIdx.x, tile = (int)wtile;
     int c = 0;
 #pragma unroll
     for (int i = 1; i < 3; i++)
@@ -51,7 +67,7 @@ __global__ __launch_bounds__(256) void k1(P p) {
     const bool active = b < K.nblk;
     b = active ? b : K.nblk - 1;
     const unsigned by = __umulhi((unsigned)b, K.magic), bx = (unsigned)b - by * (unsigned)K.bw;
-    const uint4 *src = p.coefs + (size_t)blockIdx.y * p.coef_fs + K.coef_off + (size_t)b * 8;
+    const uint4 *src = p.coefs + (size_t)wframe * p.coef_fs + K.coef_off + (size_t)b * 8;
     uint4 r[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) r[j] = src[j];
@@ -61,7 +77,7 @@ __global__ __launch_bounds__(256) void k1(P p) {
         for (int j = 0; j < 8; j++) acc += r[j].x ^ r[j].y ^ r[j].z ^ r[j].w;
         for (int i = 0; i < p.work; i += 3) acc = (acc ^ (acc << 5)) + 0x9e3779b9u; // three VALU instructions a trip
     }
-    unsigned char *dst = p.pixels + (size_t)blockIdx.y * p.pixel_fs + K.plane_off + (size_t)by * 8 * K.stride + (size_t)bx * 8;
+    unsigned char *dst = p.pixels + (size_t)wframe * p.pixel_fs + K.plane_off + (size_t)by * 8 * K.stride + (size_t)bx * 8;
     const bool bad = TAIL && acc == 0x12345u && p.work > 0;
     if (active && !bad) {
 #pragma unroll
@@ -89,7 +105,9 @@ __global__ __launch_bounds__(256) void k1(P p) {
 template <int LANES>
 __global__ __launch_bounds__(256) void k1_split(ParamsSmall p) {
     extern __shared__ unsigned char dyn_lds[];
-    const int lane = threadIdx.x, tile = blockIdx.x;
+    unsigned wframe, wtile;
+    xcd_remap(p.run_sh, wframe, wtile);
+    const int lane = threadIdx.x, tile = (int)wtile;
     constexpr int BPW = 256 / LANES; // blocks per workgroup
     int c = 0;
 #pragma unroll
@@ -101,11 +119,11 @@ __global__ __launch_bounds__(256) void k1_split(ParamsSmall p) {
     const bool active = b < K.nblk;
     b = active ? b : K.nblk - 1;
     const unsigned by = __umulhi((unsigned)b, K.magic), bx = (unsigned)b - by * (unsigned)K.bw;
-    const uint4 *src = p.coefs + (size_t)blockIdx.y * p.coef_fs + K.coef_off + (size_t)b * 8;
+    const uint4 *src = p.coefs + (size_t)wframe * p.coef_fs + K.coef_off + (size_t)b * 8;
     uint4 r[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) r[j] = src[j];
-    unsigned char *dst = p.pixels + (size_t)blockIdx.y * p.pixel_fs + K.plane_off + (size_t)by * 8 * K.stride + (size_t)bx * 8;
+    unsigned char *dst = p.pixels + (size_t)wframe * p.pixel_fs + K.plane_off + (size_t)by * 8 * K.stride + (size_t)bx * 8;
     if (active) {
 #pragma unroll
         for (int j = 0; j < 8 / LANES; j++) {
@@ -162,7 +180,13 @@ static void fill(P &p, bool chroma, const uint4 *a, unsigned char *b, unsigned *
     tiles = t;
 }
 
-int main() {
+int main(int argc, char **argv) {
+    // argv[1]: run length in 256-block tiles per XCD (0 = workgroups as dispatched), a power of two; the split kernels'
+    // smaller tiles take proportionally longer runs (the same bytes per run)
+    const int run = argc > 1 ? atoi(argv[1]) : 0;
+    int run_sh = -1;
+    if (run > 0) { run_sh = 0; while ((2 << run_sh) <= run) run_sh++; }
+    printf("workgroup order: %s\n", run_sh < 0 ? "as dispatched" : "runs per XCD");
     const size_t total = 9600ull * 1000000ull;
     uint4 *a;
     unsigned char *b;
@@ -187,6 +211,7 @@ int main() {
             size_t blocks;
             fill(ps, chroma, a, b, fix, tiles, blocks);
             fill(pl, chroma, a, b, fix, tiles, blocks);
+            ps.run_sh = pl.run_sh = run_sh;
             const int frames = (int)(total / (blocks * 192));
             const double bytes = (double)frames * blocks * 192;
             const dim3 grid(tiles, frames);
@@ -201,8 +226,10 @@ int main() {
             if (pr) report("  + 2 KB kernarg + fix-list tail", t, bytes);
             { // the granule halved / quartered: two / four lanes per block (tiles of 128 / 64 blocks)
                 fill(ps, chroma, a, b, fix, tiles, blocks);
+                ps.run_sh = run_sh;
                 for (int lanes : {2, 4}) {
                     ParamsSmall q2 = ps;
+                    q2.run_sh = run_sh < 0 ? -1 : run_sh + (lanes == 2 ? 1 : 2);
                     int t2 = 0;
                     for (int i = 0; i < q2.n_comp; i++) {
                         q2.comp[i].tile0 = t2;
