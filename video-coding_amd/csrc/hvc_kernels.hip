@@ -1314,6 +1314,12 @@ __device__ __forceinline__ int quant1(int f, float r) {
 #else
 #define HVC_ENCODE_ATTR
 #endif
+#ifndef HVC_ENCODE_NT_LOADS
+// ... and the pixel rows arrive as non-temporal loads: a wave's row load is 512 contiguous bytes of ONE instruction, so there
+// is nothing for the L1 to merge across instructions (unlike K1's eight 16-byte reads of a lane's 128-byte line), and the
+// pixels are read once: +0.3 ... +0.8 points of the HBM peak, three alternations (profiles/r04t_k3_nt_loads.txt)
+#define HVC_ENCODE_NT_LOADS 1
+#endif
 #ifndef HVC_ENCODE_NT
 // the 1 KiB runs leave as non-temporal stores: +2.5 % (1.754 -> 1.712 ms per 256 4K frames, same box, alternating
 // runs; profiles/r02e_ab.txt).  (For the lane-strided 16-byte pieces of the first version nt stores were 5x worse.)
@@ -1330,7 +1336,12 @@ __global__ __launch_bounds__(HVC_ENCODE_LB) HVC_ENCODE_ATTR void k_encode(Encode
     unsigned px[8][2];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
+#if HVC_ENCODE_NT_LOADS
+        typedef unsigned u2l __attribute__((ext_vector_type(2)));
+        const u2l w = __builtin_nontemporal_load(reinterpret_cast<const u2l *>(pix + (size_t)j * br.stride));
+#else
         const uint2 w = *reinterpret_cast<const uint2 *>(pix + (size_t)j * br.stride);
+#endif
         px[j][0] = w.x;
         px[j][1] = w.y;
     }
