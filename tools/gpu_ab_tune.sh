@@ -10,7 +10,7 @@ for rep in $(seq $ROUNDS); do
   for pad in 0 53000 64000; do   # K1: 116 VGPRs = 4 workgroups per CU; 3; 2
     echo -n "K1 HVC_DEC_LDS_PAD=$pad   "; HVC_DEC_LDS_PAD=$pad k1
   done
-  for pad in 0 40000 53000 64000; do   # K3: 88 VGPRs = 5 workgroups per CU; 4; 3; 2
+  for pad in 0 8000 20000 40000; do   # K3: 32 KB of LDS per workgroup = 5 workgroups per CU; + 8 KB: 4; + 20 KB: 3; + 40 KB: 2
     echo -n "K3 HVC_ENC_LDS_PAD=$pad   "; HVC_ENC_LDS_PAD=$pad k3
   done
   for pad in 0 16000 32000; do
