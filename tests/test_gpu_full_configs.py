@@ -43,3 +43,12 @@ def test_config4_one_gpus_whole_shard():
     assert rec["checksum"]["verified"] is True and rec["config"]["frames_per_gpu_per_step"] == 2048
     assert rec["config"]["frames_per_launch"] == 128 and rec["config"]["baseline_config"] == 4
     assert "resident" in rec["config"]["workload"]
+
+
+def test_convert_passes_on_resident_frames():
+    """tools/bench_configs.py --config 11: whole `oyuv convert` passes (4:2:0 <-> 4:4:4, to and from packed 4:2:2, a crop at an
+    offset) on 1080p frames resident in HBM -- every output frame's K5 checksum is the restated Oconv's"""
+    import bench_configs as bc
+    r = bc.config_convert(bc.make_args(frames=12, steps=1, warmup=0))
+    assert [p["pass"] for p in r["passes"]] == [k for k, *_ in bc.CONVERT_PASSES]
+    assert all(p["verified"] is True for p in r["passes"]) and r["checksum"]["verified"] is True
