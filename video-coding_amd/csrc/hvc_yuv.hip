@@ -242,15 +242,90 @@ hipError_t launch_packed_op(K kernel, PackedOp P, int n_frames, hipStream_t s) {
     return hipGetLastError();
 }
 
-enum OpKind { OP_SUB420, OP_SUB422, OP_UP422, OP_CROP };
+// ---- two compositions Oconv makes through the 4:4:4 frame, without the frame (same size, no offset): what the full-size chroma
+// plane would have held is formed in registers.  avg4 on four samples at once: avg4(a, b, c, d) = v_lerp_u8(avg2(a, b), (c + d)
+// >> 1, r) with r = ~(a ^ b) | (c ^ d) in bit 0 of every byte (tests/test_guard_bounds.py::test_avg4_by_lerp_identity).
+__device__ __forceinline__ unsigned avg4x4(unsigned a, unsigned b, unsigned c, unsigned d) {
+    return __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(a, b, 0x01010101u), __builtin_amdgcn_lerp(c, d, 0u), ~(a ^ b) | (c ^ d));
+}
+// every sample's right neighbour in the lane's two dwords; `next` = the sample behind them (the last column: itself)
+__device__ __forceinline__ void right_of(unsigned a0, unsigned a1, unsigned next, unsigned &b0, unsigned &b1) {
+    b0 = __builtin_amdgcn_alignbyte(a1, a0, 1);
+    b1 = (a1 >> 8) | (next << 24);
+}
+// 4:2:0 -> 4:2:2 chroma: subsample_h2 (supersample_hv2 src) (planar_444.ml:18-23 of :82-103): dst = sw x 2 sh
+//   dst[c, 2r]     = avg2 a (avg2 a b)                         a = src[c, r], b = src[c + 1, r], c' = src[c, r + 1],
+//   dst[c, 2r + 1] = avg2 (avg2 a c') (avg4 a b c' d)          d = src[c + 1, r + 1]; last column / row: the sample itself
+__global__ __launch_bounds__(256) void k_chroma_420_to_422(PlaneOp P) {
+    const unsigned groups = (unsigned)(P.sw + 7) >> 3;
+    unsigned wplane, wpiece;
+    hvc::xcd_work(P.xcd_map, P.xcd_magic, wplane, wpiece);
+    const unsigned t = wpiece * 256u + threadIdx.x;
+    if (t >= groups * (unsigned)P.sh) return;
+    const unsigned row = t / groups, g = t - row * groups, row2 = min(row + 1u, (unsigned)P.sh - 1u);
+    const uint8_t *s1 = P.src + (size_t)wplane * P.src_ps + (size_t)row * P.src_stride + 8 * g;
+    const uint8_t *s2 = P.src + (size_t)wplane * P.src_ps + (size_t)row2 * P.src_stride + 8 * g;
+    uint8_t *d1 = P.dst + (size_t)wplane * P.dst_ps + (size_t)(2 * row) * P.dst_stride + 8 * g, *d2 = d1 + P.dst_stride;
+    if (P.vec && (int)(8 * g + 8) <= P.sw) {
+        const u2v a = *reinterpret_cast<const u2v *>(s1), cc = *reinterpret_cast<const u2v *>(s2);
+        const bool last = (int)(8 * g + 8) == P.sw;
+        unsigned b0, b1, e0, e1;
+        right_of(a.x, a.y, last ? a.y >> 24 : (unsigned)s1[8], b0, b1);
+        right_of(cc.x, cc.y, last ? cc.y >> 24 : (unsigned)s2[8], e0, e1);
+        const u2v o1 = {avg2x4(a.x, avg2x4(a.x, b0)), avg2x4(a.y, avg2x4(a.y, b1))};
+        const u2v o2 = {avg2x4(avg2x4(a.x, cc.x), avg4x4(a.x, b0, cc.x, e0)), avg2x4(avg2x4(a.y, cc.y), avg4x4(a.y, b1, cc.y, e1))};
+        __builtin_nontemporal_store(o1, reinterpret_cast<u2v *>(d1));
+        __builtin_nontemporal_store(o2, reinterpret_cast<u2v *>(d2));
+        return;
+    }
+    for (int i = 0; i < 8 && (int)(8 * g) + i < P.sw; i++) {
+        const int c = (int)(8 * g) + i, cn = c + 1 < P.sw ? c + 1 : P.sw - 1;
+        const uint8_t *r1 = s1 - 8 * g, *r2 = s2 - 8 * g;
+        const unsigned a = r1[c], b = r1[cn], cv = r2[c], dv = r2[cn];
+        d1[i] = (uint8_t)((a + ((a + b + 1u) >> 1) + 1u) >> 1);
+        d2[i] = (uint8_t)((((a + cv + 1u) >> 1) + ((a + b + cv + dv + 2u) >> 2) + 1u) >> 1);
+    }
+}
+// 4:2:2 -> 4:2:0 chroma: subsample_hv2 (supersample_h2 src) (planar_444.ml:69-80 of :25-33): dst = sw x (sh / 2)
+//   dst[c, r] = avg4 a (avg2 a b) a' (avg2 a' b')    a, b = src[c, 2r], src[c + 1, 2r]; a', b' the same of row 2r + 1
+__global__ __launch_bounds__(256) void k_chroma_422_to_420(PlaneOp P) {
+    const unsigned groups = (unsigned)(P.sw + 7) >> 3;
+    unsigned wplane, wpiece;
+    hvc::xcd_work(P.xcd_map, P.xcd_magic, wplane, wpiece);
+    const unsigned t = wpiece * 256u + threadIdx.x;
+    if (t >= groups * (unsigned)P.dh) return;
+    const unsigned row = t / groups, g = t - row * groups;
+    const uint8_t *s1 = P.src + (size_t)wplane * P.src_ps + (size_t)(2 * row) * P.src_stride + 8 * g, *s2 = s1 + P.src_stride;
+    uint8_t *d = P.dst + (size_t)wplane * P.dst_ps + (size_t)row * P.dst_stride + 8 * g;
+    if (P.vec && (int)(8 * g + 8) <= P.sw) {
+        const u2v a = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(s1)), cc = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(s2));
+        const bool last = (int)(8 * g + 8) == P.sw;
+        unsigned b0, b1, e0, e1;
+        right_of(a.x, a.y, last ? a.y >> 24 : (unsigned)s1[8], b0, b1);
+        right_of(cc.x, cc.y, last ? cc.y >> 24 : (unsigned)s2[8], e0, e1);
+        const u2v o = {avg4x4(a.x, avg2x4(a.x, b0), cc.x, avg2x4(cc.x, e0)), avg4x4(a.y, avg2x4(a.y, b1), cc.y, avg2x4(cc.y, e1))};
+        __builtin_nontemporal_store(o, reinterpret_cast<u2v *>(d));
+        return;
+    }
+    for (int i = 0; i < 8 && (int)(8 * g) + i < P.sw; i++) {
+        const int c = (int)(8 * g) + i, cn = c + 1 < P.sw ? c + 1 : P.sw - 1;
+        const uint8_t *r1 = s1 - 8 * g, *r2 = s2 - 8 * g;
+        const unsigned a = r1[c], b = r1[cn], a2 = r2[c], b2 = r2[cn];
+        d[i] = (uint8_t)((a + ((a + b + 1u) >> 1) + a2 + ((a2 + b2 + 1u) >> 1) + 2u) >> 2);
+    }
+}
+
+enum OpKind { OP_SUB420, OP_SUB422, OP_UP422, OP_CROP, OP_C420_422, OP_C422_420 };
 
 // the lanes of one launch: groups of 8 samples per row
 hipError_t launch_plane_op(OpKind kind, PlaneOp P, int n_planes, hipStream_t s) {
-    const int cols = kind == OP_UP422 ? P.sw : P.dw, rows = kind == OP_UP422 ? P.sh : P.dh;
+    const bool by_source = kind == OP_UP422 || kind == OP_C420_422; // (a lane = 8 source samples; else 8 destination samples)
+    const int cols = by_source ? P.sw : P.dw, rows = by_source ? P.sh : P.dh;
     if (n_planes <= 0 || cols <= 0 || rows <= 0) return hipSuccess;
     const unsigned long long lanes = (unsigned long long)((cols + 7) >> 3) * (unsigned long long)rows;
     const dim3 grid((unsigned)((lanes + 255) / 256), (unsigned)n_planes, 1);
-    const size_t sa = kind == OP_UP422 ? 8 : 16, da = kind == OP_UP422 ? 16 : 8; // bytes a lane loads / stores at once
+    const bool same_w = kind == OP_C420_422 || kind == OP_C422_420; // (8 bytes in, 8 out)
+    const size_t sa = kind == OP_UP422 || same_w ? 8 : 16, da = kind == OP_UP422 ? 16 : 8; // bytes a lane loads / stores at once
     P.vec = kind == OP_CROP ? ((uintptr_t)P.dst % 8 == 0 && P.dst_stride % 8 == 0 && P.dst_ps % 8 == 0)
                             : ((uintptr_t)P.src % sa == 0 && P.src_stride % sa == 0 && P.src_ps % sa == 0 &&
                                (uintptr_t)P.dst % da == 0 && P.dst_stride % da == 0 && P.dst_ps % da == 0);
@@ -260,6 +335,8 @@ hipError_t launch_plane_op(OpKind kind, PlaneOp P, int n_planes, hipStream_t s) 
     case OP_SUB422: hipLaunchKernelGGL(k_subsample422, grid, dim3(256), 0, s, P); break;
     case OP_UP422: hipLaunchKernelGGL(k_upsample422, grid, dim3(256), 0, s, P); break;
     case OP_CROP: hipLaunchKernelGGL(k_crop, grid, dim3(256), 0, s, P); break;
+    case OP_C420_422: hipLaunchKernelGGL(k_chroma_420_to_422, grid, dim3(256), 0, s, P); break;
+    case OP_C422_420: hipLaunchKernelGGL(k_chroma_422_to_420, grid, dim3(256), 0, s, P); break;
     }
     return hipGetLastError();
 }
@@ -420,6 +497,9 @@ int hvc_yuv_convert(hvc_ctx *c, const uint8_t *src, int src_format, int src_w, i
     const int in_planar = is_packed(src_format) ? HVC_YUV_422 : src_format;
     const bool direct = same && out_planar == HVC_YUV_444 && in_planar != HVC_YUV_444; // the input stage's full-size chroma planes ARE the output's
     const bool luma_direct = same && is_packed(src_format) && !packed_out; // ... and the unpacked luma plane is
+    // 4:2:0 <-> 4:2:2 at the same size: the chroma planes go from one sampling to the other in one kernel, the full-size
+    // planes in between formed in registers (k_chroma_420_to_422 / _422_to_420)
+    const bool chroma_fused = same && ((in_planar == HVC_YUV_420 && out_planar == HVC_YUV_422) || (in_planar == HVC_YUV_422 && out_planar == HVC_YUV_420));
 
     // ---- Oconv.input (oconv.ml:12-28): the frame as three full-size planes
     Planes in;
@@ -439,7 +519,7 @@ int hvc_yuv_convert(hvc_ctx *c, const uint8_t *src, int src_format, int src_w, i
     }
     in.p[0] = py, in.w[0] = src_w, in.h[0] = src_h, in.fs[0] = p_fs;
     for (int k = 1; k < 3; k++) in.w[k] = src_w, in.h[k] = src_h;
-    if (planar == HVC_YUV_444) {
+    if (planar == HVC_YUV_444 || chroma_fused) { // (fused: the planes as they are, at their own sampling)
         in.p[1] = pu, in.p[2] = pv, in.fs[1] = in.fs[2] = p_fs;
     } else {
         uint8_t *const up[2] = {direct ? ou : A + 2 * sp, direct ? ov : A + 3 * sp};
@@ -470,7 +550,12 @@ int hvc_yuv_convert(hvc_ctx *c, const uint8_t *src, int src_format, int src_w, i
     // in place, with the source's row stride.
     const bool window = !same && out_planar != HVC_YUV_444 && x_off >= 0 && y_off >= 0 && x_off + dst_w <= src_w &&
                         y_off + dst_h <= src_h && x_off % 16 == 0 && src_w % 16 == 0;
-    for (int k = 1; k < 3 && !direct; k++) {
+    for (int k = 1; k < 3 && chroma_fused; k++) {
+        uint8_t *const od = k == 1 ? ou : ov;
+        if (in_planar == HVC_YUV_420) HIPCHK(c, op(OP_C420_422, in.p[k], src_w / 2, src_h / 2, in.fs[k], od, dst_w / 2, dst_h, o_fs));
+        else HIPCHK(c, op(OP_C422_420, in.p[k], src_w / 2, src_h, in.fs[k], od, dst_w / 2, dst_h / 2, o_fs));
+    }
+    for (int k = 1; k < 3 && !direct && !chroma_fused; k++) {
         uint8_t *const od = k == 1 ? ou : ov;
         const uint8_t *full = in.p[k];
         size_t full_fs = in.fs[k], full_stride = 0;
