@@ -70,3 +70,10 @@ def checksum_records(records):
     with np.errstate(over="ignore"):
         w = (np.arange(records.shape[1], dtype=np.uint64) * np.uint64(2) + np.uint64(1)) * CHECKSUM_MUL
         return ((records.astype(np.uint64) + np.uint64(1)) * w[None, :]).sum(axis=1, dtype=np.uint64)
+
+
+def config1_frame():
+    """BASELINE.json config 1's 128x128 4:2:0 frame: the reference's mini64x64.420 tiled 2x2"""
+    from conftest import golden_bytes
+    y, u, v = orc.split_yuv(golden_bytes("mini64x64.420"), 64, 64, 420)
+    return tuple(np.ascontiguousarray(np.tile(p, (2, 2))) for p in (y, u, v))

@@ -1,6 +1,6 @@
 """The host half of the GPU reader's restart-interval support, without a GPU: hvc::prepare_gpu_decode_to with `units` (every
 interval of a file unstuffed into a slot of its own, hvc_hdec.h RstUnits) through tests/host_harness/units_harness.cpp, built
-here with AddressSanitizer against csrc/hvc_entropy.cpp.  The intervals it cuts = this file's own cut of the same bytes;
+by tests/host_harness/Makefile (g++, CPU only) with AddressSanitizer against csrc/hvc_entropy.cpp.  The intervals it cuts = this file's own cut of the same bytes;
 mutated and truncated files never write past the buffers the callers give it."""
 import os
 import subprocess
@@ -13,19 +13,15 @@ from helpers import jpeg_optimised_tables
 from test_restart_intervals import QT, random_record
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HIPCC = "/opt/rocm/bin/hipcc"
+HARNESS_DIR = os.path.join(ROOT, "tests", "host_harness")
 
 
 @pytest.fixture(scope="module")
 def harness(tmp_path_factory):
-    if not os.path.exists(HIPCC):
-        pytest.skip("no hipcc")
+    """tests/host_harness/Makefile: a CPU-only g++ build (no device code) -- the sanitizer flags live there, and this file and
+    that directory are in .gpurunignore (the GPU run does not need them)"""
     exe = str(tmp_path_factory.mktemp("units") / "units_harness")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-Xarch_host", "-fsanitize=address", "-Xarch_host",
-           "-fno-omit-frame-pointer", "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "video-coding_amd", "csrc"),
-           "-o", exe, os.path.join(ROOT, "tests", "host_harness", "units_harness.cpp"),
-           os.path.join(ROOT, "video-coding_amd", "csrc", "hvc_entropy.cpp")]
-    subprocess.run(cmd, check=True, capture_output=True)
+    subprocess.run(["make", "-s", "-C", HARNESS_DIR, "OUT=" + exe], check=True, capture_output=True)
     return exe
 
 

@@ -2,7 +2,7 @@
 """Mutated and truncated reference files through the HOST header parser and Huffman reader (no GPU needed): meant
 to be run against an AddressSanitizer build of the library's host code,
 
-    make -C video-coding_amd/csrc asan
+    make -C video-coding_amd/csrc -f Makefile.asan asan
     ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 LD_PRELOAD=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so) \
         HVC_JPEG_LIB=video-coding_amd/libhvc_asan.so python tools/fuzz_host.py
 
