@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X JPEG block-transform path.
 
-    python bench.py --gpus N --steps K --warmup W [--config 2|4]
+    python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
 
 --config 2 (default; BASELINE.json configs[1], the configuration the metric is quoted on):
     1080p 4:2:0 baseline frames, synthetic *valid* coefficient blocks (Huffman bypassed), resident in
@@ -12,6 +12,15 @@
     one "step" = one pass over the rank's whole shard, --shard frames in launches of --frames (128) frames;
     the shard is resident in HBM (102 GB of coefficients + 51 GB of pixels per GPU) when the device has the
     room, otherwise one resident launch-sized chunk is processed shard / frames times (said in `config`).
+
+--config 3 (BASELINE.json configs[2]: 4096 x 1080p 4:2:0 baseline JPEG FILES, host Huffman || H2D || K1):
+    the 4096 files are split over the ranks (4096 / N each: strong scaling); one "step" = one hvc_jpeg_decode_batch call over
+    the rank's files -- host Huffman threads -> pinned ring -> hipMemcpyAsync on a side stream || k_decode_packed.  Each rank's
+    host threads run on its share of the CPUs of its GPU's NUMA node (node CPUs / ranks on that node, 16 at most): this is the
+    configuration where 8 ranks contend for the host.  Both readers are timed, K steps each: the host Huffman
+    reader (`value`: what BASELINE words) and the GPU Huffman reader (`gpu_reader` in the line).  Bound: host, not HBM.
+--config 5 (BASELINE.json configs[4]: encoder path, 4K 4:2:0 batch): one "step" = one hvc_encode_frames launch (level shift
+    -> forward Chen DCT -> quantise -> zig-zag, k_encode) over --frames (256) HBM-resident frames per GPU; weak scaling.
 
 N > 1: one process per GPU.  The driver starts the ranks with torch.distributed.run; typed by hand,
 `python bench.py --gpus N` starts them itself -- N fresh child processes, before this process has made any
@@ -70,6 +79,12 @@ WORKLOADS = {
     4: dict(name="4K 4:4:4 baseline, synthetic valid coefficient blocks, one GPU's 2048-frame shard of the 16384-frame batch",
             W=3840, H=2160, planes=[(480, 270, 0), (480, 270, 1), (480, 270, 1)],
             frames=128, shard=2048, steps=3, seed=0x4A504547 + 400, metric="Mpixel/s decoded (4K 4:4:4 batch)"),
+    3: dict(name="4096 x 1080p 4:2:0 baseline JPEG files, host Huffman || H2D || K1 (hvc_jpeg_decode_batch); the GPU Huffman reader beside it",
+            W=1920, H=1080, planes=[(240, 136, 0), (120, 68, 1), (120, 68, 1)], frames=4096, shard=None, steps=2, seed=None,
+            metric="Mpixel/s decoded (1080p 4:2:0 files, host Huffman + GPU block stage overlapped)"),
+    5: dict(name="4K 4:2:0 encoder path: level shift -> forward Chen DCT -> quantise -> zig-zag (k_encode), HBM-resident frames",
+            W=3840, H=2160, planes=[(480, 270, 0), (240, 135, 1), (240, 135, 1)], frames=256, shard=None, steps=40, seed=None,
+            metric="Mpixel/s encoded (4K 4:2:0 batch, fDCT + quantise)"),
 }
 # kept for callers of the N > 1 helpers (tests/test_distributed_cpu.py)
 W, H = WORKLOADS[2]["W"], WORKLOADS[2]["H"]
@@ -348,6 +363,57 @@ def bind_rank_to_gpu_node(ctx):
     return None
 
 
+def format_cpulist(cpus):
+    """[0, 1, 2, 8, 9] -> '0-2,8-9' (what hvc_set_host_cpus takes)"""
+    cpus, parts, i = sorted(cpus), [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        parts.append("%d" % cpus[i] if i == j else "%d-%d" % (cpus[i], cpus[j]))
+        i = j + 1
+    return ",".join(parts)
+
+
+def host_share(node_keys, rank, cpus, cap=16):
+    """config 3 at N > 1: the host Huffman threads of the ranks whose GPUs hang off one NUMA node share that node's CPUs.
+    node_keys[r] names rank r's node (its first CPU); `cpus` = this rank's node CPUs.  -> (this rank's CPUs, its thread count):
+    an equal contiguous slice per rank on the node, `cap` threads at most (a one-GPU box's CPU share), one at least."""
+    peers = [r for r, k in enumerate(node_keys) if k == node_keys[rank]]
+    cpus = sorted(cpus)
+    share = max(1, len(cpus) // len(peers))
+    i = peers.index(rank)
+    mine = cpus[i * share:(i + 1) * share] or cpus[-1:]
+    return mine, max(1, min(cap, len(mine)))
+
+
+def share_host_cpus(ctx, rank, world, dist, device, bind=True):
+    """-> (cpulist text or None, host threads): at N > 1 the rank's launch thread and its pipeline threads are put on the rank's
+    slice of its GPU's NUMA node (host_share); at N = 1 nothing is bound and the threads are min(16, CPUs of the mask)."""
+    mask = sorted(os.sched_getaffinity(0))
+    if world == 1:
+        return None, max(1, min(16, len(mask)))
+    cpus = mask
+    if ctx is not None and bind:
+        try:
+            ctx.set_host_cpus("auto")
+            text, n = ctx.get_host_cpus()
+            if n > 0:
+                cpus = parse_cpulist(text)
+        except Exception:
+            pass
+    keys = [int(k[0]) for k in gather_over_ranks([float(cpus[0])], world, dist, device)]
+    mine, threads = host_share(keys, rank, cpus)
+    text = format_cpulist(mine)
+    if ctx is not None and bind:
+        try:
+            ctx.set_host_cpus(text)
+            os.sched_setaffinity(0, mine)
+        except Exception:
+            text = None
+    return text, threads
+
+
 def whole_job_mpixels(world, frames_per_gpu, steps, dt, pixels_per_frame=W * H):
     """value = units ALL ranks processed / max-over-ranks time (weak scaling: per-GPU work fixed)."""
     return world * frames_per_gpu * steps * pixels_per_frame / dt / 1e6
@@ -379,7 +445,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=None)  # the first launches after idle run off-clock (DVFS)
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU per launch (9.6 GB of coefficients + pixels)")
     ap.add_argument("--shard", type=int, default=None, help="config 4: frames per GPU per step (launches of --frames)")
-    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames (replicated)")
+    ap.add_argument("--distinct", type=int, default=None, help="distinct synthetic frames (replicated): 8, configs 3 / 5: 4")
+    ap.add_argument("--threads", type=int, default=None, help="config 3: host threads per rank (default: the rank's share of its NUMA node, <= 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-others", action="store_true", help="skip `others` (configs 3 / 4 / 5 and the other kernels, after the timed region)")
@@ -389,11 +456,16 @@ def parse_args(argv=None):
     args = ap.parse_args(argv)
     wl = WORKLOADS[args.config]
     args.frames = args.frames or wl["frames"]
+    args.distinct = args.distinct or (4 if args.config in (3, 5) else 8)
+    if args.config == 3:
+        if args.frames % args.gpus:
+            ap.error("--config 3: --frames (files in total) must be a multiple of --gpus")
+        args.frames //= args.gpus   # files per rank: the batch is split, strong scaling
     args.shard = args.shard or wl["shard"] or args.frames
     if args.shard % args.frames:
         ap.error("--shard must be a multiple of --frames")
     args.steps = args.steps if args.steps is not None else wl["steps"]
-    args.warmup = args.warmup if args.warmup is not None else (10 if args.config == 2 else 1)
+    args.warmup = args.warmup if args.warmup is not None else (10 if args.config in (2, 5) else 1)
     return args
 
 
@@ -412,18 +484,214 @@ def run_without_gpu(args, rank, world):
     dt = max_over_ranks(dt_local, world, dist, "cpu")
     step_ms = 1.0 * (rank + 1)   # (what stands in for a rank's kernel time here: its sleep)
     per_rank = gather_over_ranks([step_ms, step_ms, step_ms], world, dist, "cpu")
+    # config 3: the ranks' host-thread shares, computed as on a GPU box (all ranks on this machine's one "node": its CPU mask)
+    cpus_text, threads = share_host_cpus(None, rank, world, dist, "cpu") if args.config == 3 else (None, None)
+    shares = gather_over_ranks([float(threads)], world, dist, "cpu") if args.config == 3 else None
     if rank == 0:
         wl = WORKLOADS[args.config]
-        print(json.dumps({"metric": wl["metric"], "value": round(whole_job_mpixels(world, args.shard, args.steps, dt, wl["W"] * wl["H"]), 1),
-                          "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "int32",
-                          "data": "none: launch-path rehearsal without a GPU (HVC_BENCH_NO_GPU=1), nothing decoded, not a measurement",
-                          "config": {"workload": wl["name"], "step_calls_rank0": len(calls)},
-                          "per_rank_kernel_ms": {"mean_min_max": [[round(x, 4) for x in r] for r in per_rank],
-                                                 "what": "launch-path rehearsal: each rank's sleep per step"}}), flush=True)
+        line = {"metric": wl["metric"], "value": round(whole_job_mpixels(world, args.shard, args.steps, dt, wl["W"] * wl["H"]), 1),
+                "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if args.config == 3 else "weak",
+                "vs_baseline": None, "dtype": "int32",
+                "data": "none: launch-path rehearsal without a GPU (HVC_BENCH_NO_GPU=1), nothing decoded, not a measurement",
+                "config": {"workload": wl["name"], "baseline_config": args.config, "step_calls_rank0": len(calls)},
+                "per_rank_kernel_ms": {"mean_min_max": [[round(x, 4) for x in r] for r in per_rank],
+                                       "what": "launch-path rehearsal: each rank's sleep per step"}}
+        if args.config == 3:
+            line["config"].update({"files_total": args.frames * world, "files_per_gpu_per_step": args.frames,
+                                   "host_threads_per_rank": [int(x[0]) for x in shares], "rank0_cpus": cpus_text})
+        print(json.dumps(line), flush=True)
     if use_group(world):
         dist.destroy_process_group()
+
+
+def all_ranks_ok(ok_local, world, dist, device):
+    """how many ranks verified their own output (every rank knows the answer: it comes out of an all-reduce)"""
+    if not use_group(world):
+        return int(bool(ok_local))
+    import torch
+    t = torch.tensor([1.0 if ok_local else 0.0], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+def cpu_baseline_files(jpegs, pixels_per_frame, min_seconds=10.0):
+    """config 3's CPU baseline: the model's whole CPU path on the same files -- Decoder.decode_a_frame as restated in
+    oracle/hvc_oracle.c (bit-at-a-time Huffman reader, block stage, crop), scalar, one thread, a bounded sample."""
+    from oracle import orc
+    done, t0 = 0, time.perf_counter()
+    while True:
+        orc.decode_a_frame(jpegs[done % len(jpegs)])
+        done += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds:
+            break
+    return {"value": round(done * pixels_per_frame / dt / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": "port",
+            "sample": "%d of the same 1080p files, %.1f s, oracle/hvc_oracle.c decode_a_frame (Huffman + block stage), 1 thread" % (done, dt)}
+
+
+def run_files(args, rank, world, local_rank, rehearsal):
+    """--config 3: BASELINE.json configs[2] over N ranks (decoder.ml:118-140, 261-281 stay on the host; :142-149, 213-224 and
+    dct.ml:11-107 on the GPU)."""
+    import torch
+    import video_coding_amd as hvc
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs as bc
+    wl = WORKLOADS[3]
+    PW, PH = wl["W"], wl["H"]
+    torch.cuda.set_device(local_rank)
+    dev = "cpu" if rehearsal else "cuda"
+    dist = dist_init(world, "gloo" if rehearsal else "nccl", torch.device("cuda", local_rank))
+    ctx = hvc.Context(local_rank)
+    cpus_text, threads = share_host_cpus(ctx, rank, world, dist, dev, bind=not rehearsal or world > 1)
+    if args.threads:
+        threads = args.threads
+    jpegs = bc.config3_files(ctx, args.distinct)   # the library's own encoder writes the input files, outside any timed region
+    n = args.frames
+    batch = [jpegs[i % len(jpegs)] for i in range(n)]
+    info = hvc.hvc.jpeg_read_header(batch[0])
+    d_pix = torch.zeros(n * info.pixel_bytes, dtype=torch.uint8, device="cuda")
+    blocks_per_frame = sum(bw * bh for bw, bh, _ in wl["planes"])
+    readers = {}
+    for reader in ("host", "gpu"):
+        gpu = reader == "gpu"
+        chunk = 0 if gpu else 32   # (0: the library's own choice for the GPU reader -- a quarter of the batch, 64..256)
+        d_pix.zero_()
+        ctx.jpeg_decode_batch(batch[:min(64, n)], d_pix, info.pixel_bytes, threads=threads, frames_per_chunk=chunk, gpu_entropy=gpu)
+        d_pix.zero_()
+        torch.cuda.synchronize()
+        stats = []
+
+        def step():
+            stats.append(ctx.jpeg_decode_batch(batch, d_pix, info.pixel_bytes, threads=threads, frames_per_chunk=chunk, gpu_entropy=gpu))
+
+        dt_local = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, world, dist)
+        dt = max_over_ranks(dt_local, world, dist, dev)
+        timed = stats[-args.steps:]
+        chk = bc.verify(ctx, d_pix, info.pixel_bytes, n, "configs_c3", args.distinct)["checksum"]
+        ranks_ok = all_ranks_ok(chk["verified"] is True, world, dist, dev)
+        k_ms = sum(st.kernel_ms_sum for st in timed) / len(timed)
+        e_ms = sum(st.entropy_ms_sum for st in timed) / len(timed)
+        h_ms = sum(st.h2d_ms_sum for st in timed) / len(timed)
+        per_rank = gather_over_ranks([dt_local / args.steps * 1e3, e_ms, h_ms, k_ms, float(threads)], world, dist, dev)
+        readers[reader] = {
+            "value": round(world * n * args.steps * PW * PH / dt / 1e6, 1), "unit": "Mpixel/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "timed_region_s": round(dt, 4), "frames_per_chunk": timed[-1].frames_per_chunk, "chunks": timed[-1].chunks,
+            "h2d_MB_per_step": round(timed[-1].coef_bytes / 1e6, 1), "verified": chk["verified"], "ranks_verified": ranks_ok,
+            "checksum_rank0": chk["distinct"],
+            "per_rank": {"wall_ms_entropy_thread_ms_sum_h2d_ms_kernel_ms_threads": [[round(x, 2) for x in r] for r in per_rank],
+                         "slowest_over_fastest": round(max(r[0] for r in per_rank) / min(r[0] for r in per_rank), 4)},
+            "gpu_busy_fraction": round(k_ms / (dt / args.steps * 1e3), 4),
+            "bound": ("pcie: unstuffed segments up + GPU reader kernels" if gpu else
+                      "host: Huffman thread time / threads ~ wall (%.0f ms / %d = %.0f ms)" % (e_ms, threads, e_ms / threads)),
+            "k_decode_packed_algorithmic_GBps": round(n * blocks_per_frame * ALGO_BYTES_PER_BLOCK / (max(k_ms, 1e-9) * 1e-3) / 1e9, 1)}
+    ok = all(r["ranks_verified"] == world for r in readers.values())
+    if rank == 0:
+        host, gpu_r = readers["host"], readers["gpu"]
+        out = {"metric": wl["metric"], "value": host["value"], "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": host["ms_per_step"], "timed_region_s": host["timed_region_s"],
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32",
+               "data": "synthetic: %d distinct seeded 1080p frames written as baseline JPEG files by hvc_jpeg_encode (q75), replicated"
+                       % args.distinct + (" (REHEARSAL: all ranks share cuda:0, gloo)" if rehearsal else ""),
+               "config": {"workload": "%s; %d files in total, %d per GPU per step" % (wl["name"], n * world, n), "baseline_config": 3,
+                          "files_total": n * world, "files_per_gpu_per_step": n, "host_threads_per_rank": threads,
+                          "rank0_cpus": cpus_text, "blocks_per_frame": blocks_per_frame,
+                          "parallelism": "the file batch split over the GPUs, no collective; host threads = the rank's share of its GPU's NUMA node"},
+               "roofline": {"bound": "hbm", "kernel": "k_decode_packed", "achieved": host["k_decode_packed_algorithmic_GBps"],
+                            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(host["k_decode_packed_algorithmic_GBps"] / HBM_PEAK_GBPS, 4),
+                            "traffic": None, "traffic_source": "no PMC pass of this configuration",
+                            "note": "chunk-sized launches inside a HOST-bound pipeline (GPU busy %.1f %% of the step): the kernel's own "
+                                    "roofline figure is config 2's line" % (100 * host["gpu_busy_fraction"])},
+               "checksum": {"kernel": "k_checksum (K5, hvc_checksum_records) over EVERY decoded frame", "verified": host["verified"],
+                            "ranks_verified": host["ranks_verified"], "expected": "tests/golden/bench_checksums.json:configs_c3"},
+               "host_reader": host, "gpu_reader": gpu_r}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_files(jpegs, PW * PH, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if use_group(world):
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
+
+
+def run_encode(args, rank, world, local_rank, rehearsal):
+    """--config 5: BASELINE.json configs[4], the encoder's block stage (encoder.ml:81-108, dct.ml:109-196) on HBM-resident frames"""
+    import torch
+    import video_coding_amd as hvc
+    from video_coding_amd.synth import synth_frame_pixels
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs as bc
+    wl = WORKLOADS[5]
+    planes, PW, PH = wl["planes"], wl["W"], wl["H"]
+    torch.cuda.set_device(local_rank)
+    dev = "cpu" if rehearsal else "cuda"
+    dist = dist_init(world, "gloo" if rehearsal else "nccl", torch.device("cuda", local_rank))
+    ctx = hvc.Context(local_rank)
+    node_cpus = bind_rank_to_gpu_node(ctx) if (world > 1 and not rehearsal) else None
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    qtabs = np.stack([hvc.hvc.quant_table(0, 75), hvc.hvc.quant_table(1, 75)])
+    specs, cfs, pfs = hvc.hvc.frame_layout(planes)
+    comps = hvc.hvc.components(specs)
+    recs = np.stack([synth_frame_pixels(60 + 8 * f, planes) for f in range(args.distinct)])   # (tools/bench_configs.py config5's seeds)
+    reps = (args.frames + args.distinct - 1) // args.distinct
+    d_pix = torch.from_numpy(recs).cuda().repeat(reps, 1)[:args.frames].contiguous()
+    d_coefs = torch.zeros((args.frames, cfs), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+
+    def step():
+        ctx.encode_frames(d_pix, pfs, qtabs, comps, args.frames, d_coefs, cfs)
+
+    for _ in range(8):   # setup, not measurement: pages touched, clock ramped
+        step()
+    torch.cuda.synchronize()
+    ctx.set_profiling(True)
+    dt = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, world, dist)
+    dt = max_over_ranks(dt, world, dist, dev)
+    kernel_ms = ctx.kernel_ms_history(min(args.steps, 64))
+    chk = bc.verify(ctx, d_coefs, cfs * 2, args.frames, "configs_c5", args.distinct)["checksum"]
+    ranks_ok = all_ranks_ok(chk["verified"] is True, world, dist, dev)
+    per_rank = gather_over_ranks([float(np.mean(kernel_ms)), float(np.min(kernel_ms)), float(np.max(kernel_ms))], world, dist, dev)
+    if rank == 0:
+        blocks_per_frame = sum(bw * bh for bw, bh, _ in planes)
+        k_ms = float(np.mean(kernel_ms))
+        algo_bytes = args.frames * blocks_per_frame * ALGO_BYTES_PER_BLOCK
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        traffic, traffic_source = measured_traffic(5, args.frames, "k_encode")
+        out = {"metric": wl["metric"], "value": round(whole_job_mpixels(world, args.frames, args.steps, dt, PW * PH), 1), "unit": "Mpixel/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+               "timed_region_s": round(dt, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+               "data": "synthetic" + (" (REHEARSAL: all ranks share cuda:0, gloo)" if rehearsal else ""),
+               "config": {"workload": "%s, %d frames/GPU/step" % (wl["name"], args.frames), "baseline_config": 5,
+                          "frames_per_gpu_per_step": args.frames, "blocks_per_frame": blocks_per_frame,
+                          "parallelism": "independent frame batch per GPU, no collective"},
+               "roofline": {"bound": "hbm", "kernel": "k_encode", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                            "kernel_ms": round(k_ms, 4), "launches_averaged": len(kernel_ms), "algorithmic_bytes_per_launch": algo_bytes},
+               "checksum": {"kernel": "k_checksum (K5) over EVERY coefficient record", "verified": chk["verified"], "ranks_verified": ranks_ok,
+                            "expected": "tests/golden/bench_checksums.json:configs_c5", "rank0": chk["distinct"]},
+               "per_rank_kernel_ms": {"mean_min_max": [[round(x, 4) for x in r] for r in per_rank], "rank0_cpus": node_cpus}}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import orc   # (the checker, timed as the baseline only)
+            frames, done, t0 = recs, 0, time.perf_counter()
+            while True:
+                off = 0
+                for bw, bh, qt in planes:
+                    nb = bw * bh * 64
+                    orc.fdct_quant(frames[done % len(frames)][off:off + nb].reshape(bh * 8, bw * 8), qtabs[qt], bw, bh)
+                    off += nb
+                done += 1
+                dtc = time.perf_counter() - t0
+                if dtc >= args.cpu_seconds:
+                    break
+            out["cpu_baseline"] = {"value": round(done * PW * PH / dtc / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": "port",
+                                   "sample": "%d frames of the same workload, %.1f s, oracle/hvc_oracle.c orc_fdct_quant, 1 thread" % (done, dtc)}
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if use_group(world):
+        dist.destroy_process_group()
+    if ranks_ok != world:
+        sys.exit(3)
 
 
 def main():
@@ -435,6 +703,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (set by the launcher): they must agree" % (args.gpus, world))
     if os.environ.get("HVC_BENCH_NO_GPU") == "1":
         return run_without_gpu(args, rank, world)
+    if args.config in (3, 5):
+        # (rehearsal on a one-GPU box: every rank on cuda:0, gloo -- never a measurement, the line says so)
+        rehearsal = os.environ.get("HVC_BENCH_REHEARSAL") == "1"
+        return (run_files if args.config == 3 else run_encode)(args, rank, world, 0 if rehearsal else local_rank, rehearsal)
 
     import torch
     import video_coding_amd as hvc

@@ -320,7 +320,12 @@ HVC_API int hvc_jpeg_entropy_decode(const uint8_t *jpeg, size_t n, const hvc_jpe
  * batch pipelines, hvc_jpeg_entropy_decode_gpu) do the same -- the host reader by walking from interval to interval, the GPU
  * reader by taking every interval as a stream of its own (an RSTn is a synchronisation point known in advance: a byte
  * boundary, the first block of an MCU, predictors at zero); files of one batch whose DRI differs from the first file's, or
- * whose markers are not the ones their DRI promises, are the host reader's.  A file without DRI decodes the same either way. */
+ * whose markers are not the ones their DRI promises, are the host reader's.  A file without DRI decodes the same either way.
+ * Which reader takes a call never changes its result, only its speed; the GPU reader's limits with the extension on are:
+ * intervals-per-file x files of one call <= 65535 (hvc_jpeg_entropy_decode_gpu: *used_gpu = 0 past that), intervals per
+ * file <= 4096 in the batch pipeline (the whole batch goes through the host-reader pipeline past that), and one DRI per
+ * chunk (a chunk holding a file with another DRI is redone by the host reader; stats->entropy_ms_sum > 0 says some were).
+ * A scan of a single interval (MCUs <= DRI) is read as the plain segment by both readers. */
 HVC_API int hvc_jpeg_entropy_decode_restart(const uint8_t *jpeg, size_t n, const hvc_jpeg_info *info, int16_t *coefs);
 HVC_API int hvc_set_restart_markers(hvc_ctx *ctx, int honour);
 /* The same for TWO files on the calling thread, their symbols decoded in turn: a file is one stream and its symbols one

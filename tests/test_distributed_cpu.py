@@ -155,3 +155,52 @@ def test_eight_ranks_as_the_driver_will_start_them():
                          timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     assert _json_line(out.stdout)["n_gpus"] == 8
+
+
+def test_host_share_splits_a_numa_node_between_the_ranks_on_it():
+    """config 3 at N > 1 (host Huffman threads are its scaling limit): ranks whose GPUs hang off one NUMA node
+    take equal, disjoint slices of that node's CPUs, 16 threads at most, one at least"""
+    sys.path.insert(0, ROOT)
+    import bench
+    node0, node1 = list(range(0, 64)), list(range(64, 128))
+    keys = [0, 0, 0, 0, 64, 64, 64, 64]                      # 8 GPUs, 4 per socket
+    got = [bench.host_share(keys, r, node0 if r < 4 else node1) for r in range(8)]
+    assert all(t == 16 for _, t in got)
+    for node, ranks in ((node0, range(0, 4)), (node1, range(4, 8))):
+        seen = [c for r in ranks for c in got[r][0]]
+        assert sorted(seen) == node                            # the node is covered, nobody shares a CPU
+    assert bench.host_share([0, 0], 1, list(range(16))) == (list(range(8, 16)), 8)
+    assert bench.host_share([0] * 8, 7, list(range(4))) == ([3], 1)          # fewer CPUs than ranks: one thread each, the last CPU
+    assert bench.host_share([0], 0, list(range(96))) == (list(range(96)), 16)
+    assert bench.format_cpulist([5, 0, 1, 2, 8, 9]) == "0-2,5,8-9" and bench.parse_cpulist(bench.format_cpulist(node1)) == node1
+
+
+def test_config3_and_5_over_n_ranks():
+    """`bench.py --config 3` splits BASELINE config 3's 4096 files over the ranks (strong scaling) and gives every rank its share
+    of the host's CPUs; `--config 5` is the encoder's block stage, weak.  Launch path only (HVC_BENCH_NO_GPU=1), world 2 and 8,
+    typed by hand and in the driver's form."""
+    cpus = len(os.sched_getaffinity(0))
+    for world in (2, 8):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+                              "--config", "3"], capture_output=True, text=True,
+                             env=_clean_env(HVC_BENCH_NO_GPU="1", OMP_NUM_THREADS="1"), timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-3000:]
+        rec = _json_line(out.stdout)
+        assert rec["n_gpus"] == world and rec["scaling"] == "strong" and rec["config"]["baseline_config"] == 3
+        assert rec["config"]["files_total"] == 4096 and rec["config"]["files_per_gpu_per_step"] == 4096 // world
+        assert "4096 x 1080p" in rec["config"]["workload"] and "host Huffman || H2D || K1" in rec["config"]["workload"]
+        assert rec["config"]["host_threads_per_rank"] == [max(1, min(16, cpus // world))] * world
+        # the whole job's files over the slowest rank's time
+        assert abs(rec["value"] - 4096 * 1920 * 1080 / (rec["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * rec["value"]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29551", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "0", "--config", "5"],
+                         capture_output=True, text=True, env=_clean_env(HVC_BENCH_NO_GPU="1"), timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = _json_line(out.stdout)
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["baseline_config"] == 5
+    assert abs(rec["value"] - 2 * 256 * 3840 * 2160 / (rec["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * rec["value"]
+    # 4096 files do not split over 3 ranks: an error, not a silent remainder
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--config", "3"],
+                         capture_output=True, text=True, env=_clean_env(HVC_BENCH_NO_GPU="1"), timeout=120, cwd=ROOT)
+    assert out.returncode != 0

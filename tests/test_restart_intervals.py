@@ -126,3 +126,25 @@ def test_streams_that_break_their_promise(hvc):
             hvc.jpeg_entropy_decode(bytes(data), restart_markers=True)
         except m.HvcError as e:
             assert e.code in (-8, -5)
+
+
+def test_a_single_interval_scan_is_cut_like_the_plain_segment(hvc):
+    """with the extension on, a scan of ONE interval (MCUs <= DRI) is the plain segment for both readers -- 0xFF 0xFF
+    ends it and a trailing lone 0xFF is data, exactly as without the extension (decoder.ml:261-281) -- so which reader takes
+    the file never changes the records."""
+    rec, n_mcu = random_record([(2, 2), (1, 1), (1, 1)], 96, 64, 21)
+    f = bytearray(jpeg_optimised_tables(96, 64, 420, QT, rec, restart_interval=n_mcu))
+    at = hvc.jpeg_read_header(bytes(f)).ecs_offset
+    eoi = bytes(f).rindex(b"\xff\xd9")
+    body = f[at:eoi]
+    for mutate in ("ffff_inside", "trailing_ff", "ff_then_eoi_removed"):
+        if mutate == "ffff_inside":
+            k = next(i for i in range(len(body) // 2, len(body) - 1) if body[i] != 0xFF and body[i + 1] != 0xFF and body[i - 1] != 0xFF)
+            g = bytes(f[:at] + body[:k] + b"\xff\xff" + body[k:] + f[eoi:])
+        elif mutate == "trailing_ff":
+            g = bytes(f[:at] + body + b"\xff")
+        else:
+            g = bytes(f[:at] + body + b"\xff\xff")
+        a = hvc.jpeg_entropy_decode(g)[1]
+        b = hvc.jpeg_entropy_decode(g, restart_markers=True)[1]
+        assert np.array_equal(a, b), mutate

@@ -45,6 +45,20 @@ def verify(ctx, data, record_bytes, n_records, key, distinct):
                          "verified": ok}}
 
 
+def config3_files(ctx, distinct):
+    """configuration 3's input: `distinct` seeded 1080p 4:2:0 frames as baseline JPEG files (q75), written by the library's own
+    encoder (hvc_jpeg_encode) -- tests/golden/bench_checksums.json `configs_c3` holds the model's decode of these"""
+    from video_coding_amd.synth import synth_pixels
+    W, H = 1920, 1080
+    jpegs = []
+    for f in range(distinct):
+        y = synth_pixels(10 + f, 1088, 1920)[:H]
+        u = synth_pixels(20 + f, 544, 960)[:H // 2]
+        v = synth_pixels(30 + f, 544, 960)[:H // 2]
+        jpegs.append(ctx.jpeg_encode(y, u, v, W, H, 420, 75))
+    return jpegs
+
+
 def config3(args):
     """-> the JSON object of configuration 3 (host or GPU reader)"""
     import torch
@@ -52,12 +66,7 @@ def config3(args):
     from video_coding_amd.synth import synth_pixels
     W, H = 1920, 1080
     ctx = hvc.Context(0)
-    jpegs = []
-    for f in range(args.distinct):  # the library's own encoder (hvc_jpeg_encode) makes the input files
-        y = synth_pixels(10 + f, 1088, 1920)[:H]
-        u = synth_pixels(20 + f, 544, 960)[:H // 2]
-        v = synth_pixels(30 + f, 544, 960)[:H // 2]
-        jpegs.append(ctx.jpeg_encode(y, u, v, W, H, 420, 75))
+    jpegs = config3_files(ctx, args.distinct)
     ri = int(getattr(args, "restart_interval", 0) or 0)
     if ri:
         # every file re-written with a restart interval of ri MCUs (DRI + RSTn; 120 = a row of MCUs, what encoders write) and the

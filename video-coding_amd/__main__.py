@@ -119,7 +119,7 @@ def oyuv_convert(a):
     with (sys.stdin.buffer if a.infile == "-" else open(a.infile, "rb")) as f:
         if first:
             f.read(first * n_in) if a.infile == "-" else f.seek(first * n_in)
-        raw = f.read((last - first + 1) * n_in)
+        raw = f.read(max(0, last - first + 1) * n_in)   # `for _ = 0 to end_ - start` (oconv.ml:120-131): a reversed range converts nothing
     n = len(raw) // n_in   # (whole frames only: Oconv.input returns false on a short one)
     out = np.zeros(n * n_out, dtype=np.uint8)
     if n:

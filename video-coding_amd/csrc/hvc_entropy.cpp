@@ -581,6 +581,15 @@ struct Walk {
         // ends the segment: the model would spin on zero bytes there.)
         const size_t pos = h.ecs_pos, room = (n > pos ? n - pos : 0) + 16 + BitReader::PAD;
         rst_interval = hvc::tl_honour_restart ? h.restart_interval : 0;
+        {   // a scan of one interval (MCUs <= DRI) holds no RSTn: it is read as the plain segment, the same cutter
+            // (extract_ecs_to) the GPU reader's rst_multi == false path takes -- so a fall-back from one reader to the other
+            // never changes the records (0xFF 0xFF and a trailing 0xFF were cut differently by the two cutters)
+            const hvc_jpeg_component &f = info->comp[0];
+            if (rst_interval && f.hscale && f.vscale) {
+                const unsigned long long mcus = (unsigned long long)(f.decoded_width / (8 * f.hscale)) * (f.decoded_height / (8 * f.vscale));
+                if (mcus <= (unsigned long long)rst_interval) rst_interval = 0;
+            }
+        }
         rst_k = 0;
         mcus_begun = 0;
         rst_at = rst_interval;

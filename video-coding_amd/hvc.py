@@ -122,8 +122,7 @@ def lib():
             L.hvc_fdct_quant.argtypes = [vp, vp, sz, sz, vp, i, i, i, vp, sz, i]
             L.hvc_encode_frames.argtypes = [vp, vp, sz, vp, i, C.POINTER(Component), i, i, vp, sz, i]
             L.hvc_upsample420.argtypes = [vp, vp, i, i, sz, vp, sz, i, sz, sz, i]
-            for f in ("hvc_jpeg_entropy_decode_restart", "hvc_set_restart_markers",
-    "hvc_subsample420", "hvc_subsample422", "hvc_upsample422"):
+            for f in ("hvc_subsample420", "hvc_subsample422", "hvc_upsample422"):
                 getattr(L, f).argtypes = [vp, vp, i, i, sz, vp, sz, i, sz, sz, i]
             L.hvc_crop_planes.argtypes = [vp, vp, i, i, sz, i, i, vp, i, i, sz, i, sz, sz, i]
             L.hvc_yuv_frame_bytes.argtypes = [i, i, i, C.POINTER(sz)]
