@@ -278,7 +278,7 @@ def config_444(args):
                       "fused_ms": round(res["fused"], 4), "separate_ms": round(res["separate"], 4) if "separate" in res else None,
                       "value": round(n * W * H / (res["fused"] * 1e-3) / 1e6, 1), "unit": "Mpixel/s",
                       "speedup_vs_separate": round(res["separate"] / res["fused"], 3) if "separate" in res else None,
-                      "algorithmic_GBps": round(algo / (res["fused"] * 1e-3) / 1e9, 1),
+                      "algorithmic_GBps": round(algo / (res["fused"] * 1e-3) / 1e9, 1), "algorithmic_bytes": algo,
                       "frac_of_8TBps": round(algo / (res["fused"] * 1e-3) / 8e12, 4),
                       "wide_path_blocks": int(ctx.last_wide_blocks())}
     ctx.close()
