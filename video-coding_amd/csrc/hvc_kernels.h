@@ -126,8 +126,13 @@ struct Decode444Params {
     size_t dc_fs;
     unsigned long long *wide_total; // as in DecodeParams
     int wide_first;
-    int xcd_map;                    // as in DecodeParams
+    int xcd_map;                    // as in DecodeParams; < 0: one of the other orders below (HVC_444_ORDER, A/B only)
     unsigned xcd_magic;
+    // HVC_444_ORDER (A/B only; profiles/r05c_fused_order.txt): -1 "stripe" = XCD x owns the x-th eighth of the batch's (frame,
+    // tile) list, i.e. a stretch of consecutive output rows of consecutive frames; -2 "run:R" = runs of any R tiles per XCD
+    // (98 = one 1080p frame); -3 "split" = every luma tile of the batch first (runs of 16), then the chroma tiles, one frame's
+    // two chroma planes per XCD
+    unsigned xo_run, xo_run_magic, xo_yt_magic, xo_c2_magic;
 };
 
 // HVC_XCD_RUN in the environment (A/B switch): 0 = workgroups as dispatched; R = runs of R tiles per XCD (a power of two).

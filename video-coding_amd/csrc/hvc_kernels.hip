@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "hvc_idct_spec.h"
 #include "hvc_kernels.h"
@@ -961,6 +962,49 @@ __device__ __forceinline__ void emit_rows444(uint8_t *row_even, size_t W, int x0
                      __builtin_amdgcn_perm(q1, v1, LO), __builtin_amdgcn_perm(q1, v1, HI));
 }
 
+// The other workgroup -> (frame, tile) orders of HVC_444_ORDER (Decode444Params::xcd_map < 0): each a permutation of the grid
+// (scalar arithmetic; divisions by host-made reciprocals, exact for grids of < 2^32 / 2^7 workgroups -- the host checks).
+__device__ __forceinline__ void xcd_work_444(const Decode444Params &P, unsigned &frame, unsigned &tile) {
+    const unsigned per = gridDim.x, total = per * gridDim.y, id = blockIdx.y * per + blockIdx.x;
+    const unsigned xcd = id & 7u, k = id >> 3;
+    frame = blockIdx.y;
+    tile = blockIdx.x;
+    if (P.xcd_map == -1) {
+        const unsigned eighth = total >> 3;
+        if (id < (eighth << 3)) {
+            const unsigned lin = xcd * eighth + k;
+            frame = __umulhi(lin, P.xcd_magic);
+            tile = lin - frame * per;
+        }
+    } else if (P.xcd_map == -2) {
+        const unsigned R = P.xo_run, group = 8u * R;
+        if (id < total - total % group) {
+            const unsigned kr = __umulhi(k, P.xo_run_magic);
+            const unsigned lin = (kr * 8u + xcd) * R + (k - kr * R);
+            frame = __umulhi(lin, P.xcd_magic);
+            tile = lin - frame * per;
+        }
+    } else if (P.xcd_map == -3) {
+        const unsigned yt = (unsigned)P.y_tiles, c2 = per - yt, A = yt * gridDim.y;
+        if (id < A) {
+            unsigned lin = id;
+            if (id < A - A % 128u) lin = ((((k >> 4) << 3) + xcd) << 4) + (k & 15u);
+            frame = __umulhi(lin, P.xo_yt_magic);
+            tile = lin - frame * yt;
+        } else {
+            const unsigned id2 = id - A, B = total - A, k2 = id2 >> 3;
+            if (id2 < B - B % (8u * c2)) {
+                const unsigned kr = __umulhi(k2, P.xo_c2_magic);
+                frame = kr * 8u + (id2 & 7u);
+                tile = yt + (k2 - kr * c2);
+            } else {
+                frame = __umulhi(id2, P.xo_c2_magic);
+                tile = yt + (id2 - frame * c2);
+            }
+        }
+    }
+}
+
 #ifdef HVC_444_WAVES /* experiments: -DHVC_444_WAVES=4 */
 #define HVC_444_ATTR __attribute__((amdgpu_waves_per_eu(HVC_444_WAVES, HVC_444_WAVES)))
 #else
@@ -973,7 +1017,10 @@ __global__ __launch_bounds__(HVC_TILE * NW, 4 / NW) HVC_444_ATTR void k_decode_4
     __shared__ uint4 edge[WGS]; // per lane: first row (x, y) and first column (z, w) of its chroma block
     const int lane = threadIdx.x;
     unsigned wframe, wtile;
-    xcd_work(P.xcd_map, P.xcd_magic, wframe, wtile);
+    if (P.xcd_map >= 0)
+        xcd_work(P.xcd_map, P.xcd_magic, wframe, wtile);
+    else
+        xcd_work_444(P, wframe, wtile);
     const int tile = (int)wtile + P.tile0;             // (tile0 = y_tiles when the luma planes went through k_decode_packed)
     const bool chroma = tile >= P.y_tiles;             // workgroup-uniform
     if (P.skip && P.skip == (chroma ? 2 : 1)) return;  // (measurements: one half of the kernel alone)
@@ -1224,6 +1271,18 @@ __device__ __forceinline__ int vmad24(int k, int x, int acc) {
 // (Round 4 tried the rotations as one v_dot2_i32_i16 per output on int16 operand pairs packed once per pair: 80 VALU
 // instructions per block fewer (1062 -> 982) and 72 VGPRs -- and 0.3 - 0.7 points SLOWER than this form on the same box,
 // three alternations: profiles/r04q_k3_dot2_ab.txt.  K3 does not wait for its VALU.)
+#ifndef HVC_ENCODE_MULHI
+#define HVC_ENCODE_MULHI 0
+#endif
+// c4 without its shift: (362 x) >> 9 = the high dword of (x << 9) * (362 << 14) as a 24 x 24 -> 48 bit product
+// (v_mul_hi_i32_i24: floor, like asr) -- exact while |x << 9| < 2^23, i.e. |x| < 2^14; the sums c4 sees are <= 1024 in the
+// column pass and <= 8 * 724 = 5792 in the row pass (tests/test_guard_bounds.py).  The << 9 rides in the producing add
+// (v_add_lshl_u32) or mad, so a c4 is 2 instructions instead of 3.
+__device__ __forceinline__ int vmulhi24(int k, int x) {
+    int d;
+    asm("v_mul_hi_i32_i24 %0, %1, %2" : "=v"(d) : "s"(k), "v"(x));
+    return d;
+}
 __device__ __forceinline__ int c4(int f, int g) { return vmul24(362, f + g) >> 9; }
 __device__ __forceinline__ int c4m(int f, int g) { return vmul24(362, f - g) >> 9; }
 __device__ __forceinline__ int c62(int f, int g) { return vmad24(473, g, vmul24(196, f)) >> 9; }
@@ -1240,6 +1299,17 @@ __device__ __forceinline__ int c35n(int f, int g) { return vmad24(-284, g, vmul2
 template <bool LS>
 __device__ __forceinline__ void fdct_tail(int a0, int a1, int a2, int a3, int c0, int c1, int c2, int c3, int &p0,
                                           int &p1, int &p2, int &p3, int &p4, int &p5, int &p6, int &p7) {
+#if HVC_ENCODE_MULHI
+    constexpr int C4S = 362 << 14;
+    const int b0s = (a0 + a3) << 9, b1s = (a1 + a2) << 9, b2 = a1 - a2, b3 = a0 - a3;
+    p0 = vmulhi24(C4S, LS ? b0s + b1s - (1024 << 9) : b0s + b1s);
+    p4 = vmulhi24(C4S, b0s - b1s);   // c4 b0 (-b1): the level shift cancels
+    p2 = c62(b2, b3);
+    p6 = c62n(b3, b2);     // c62 b3 (-b2)
+    const int c2s = c2 << 9;
+    int b0 = vmulhi24(C4S, vmad24(-512, c1, c2s));   // c4 c2 (-c1)
+    int b1 = vmulhi24(C4S, vmad24(512, c1, c2s));
+#else
     int b0 = LS ? a0 + a3 - 512 : a0 + a3, b1 = LS ? a1 + a2 - 512 : a1 + a2, b2 = a1 - a2, b3 = a0 - a3;
     p0 = c4(b0, b1);
     p4 = c4m(b0, b1);      // c4 b0 (-b1)
@@ -1247,6 +1317,7 @@ __device__ __forceinline__ void fdct_tail(int a0, int a1, int a2, int a3, int c0
     p6 = c62n(b3, b2);     // c62 b3 (-b2)
     b0 = c4m(c2, c1);      // c4 c2 (-c1)
     b1 = c4(c2, c1);
+#endif
     a0 = c0 + b0;
     a1 = c0 - b0;
     a2 = c3 - b1;
@@ -1387,8 +1458,18 @@ __global__ __launch_bounds__(HVC_ENCODE_LB) HVC_ENCODE_ATTR void k_encode(Encode
             const int lo = v[ZI[k]], hi = v[ZI[k + 1]];
             (void)qr;
 #else
+#if HVC_ENCODE_MULHI
+            // the two products of a pair as one v_pk_mul_f32 (the same IEEE single products as two v_mul_f32)
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            const f2v xf = {(float)v[ZI[k]], (float)v[ZI[k + 1]]}, rf = {qr[k], qr[k + 1]};
+            const f2v pr = xf * rf;
+            int lo, hi;
+            asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(lo) : "v"(pr.x));
+            asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(hi) : "v"(pr.y));
+#else
             const int lo = quant1(v[ZI[k]], qr[k]);
             const int hi = quant1(v[ZI[k + 1]], qr[k + 1]);
+#endif
 #endif
             w[h] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(lo, hi)); // |q| <= 2^13: no saturation
         }
@@ -1706,6 +1787,24 @@ hipError_t launch_decode_444(const Decode444Params &P, bool wide_only, hipStream
     Decode444Params Q = P;
     Q.skip = only;
     Q.xcd_map = xcd_map_for((unsigned)(P.tiles_per_frame - P.tile0), (unsigned)P.n_frames, Q.xcd_magic, true);
+    {   // HVC_444_ORDER=stripe | run:R | split (A/B only): see Decode444Params::xcd_map
+        static const char *const order = getenv("HVC_444_ORDER");
+        const unsigned per = (unsigned)(P.tiles_per_frame - P.tile0), c2 = per > (unsigned)P.y_tiles ? per - (unsigned)P.y_tiles : 0u;
+        auto rcp = [](unsigned d) { return d > 1 ? (unsigned)(((1ull << 32) + d - 1) / d) : 0u; };
+        if (order && Q.xcd_map > 0 && P.tile0 == 0 && (unsigned long long)per * P.n_frames * 128ull < (1ull << 32)) {
+            if (!strcmp(order, "stripe")) {
+                Q.xcd_map = -1;
+            } else if (!strncmp(order, "run:", 4) && atoi(order + 4) > 1) {
+                Q.xcd_map = -2;
+                Q.xo_run = (unsigned)atoi(order + 4);
+                Q.xo_run_magic = rcp(Q.xo_run);
+            } else if (!strcmp(order, "split") && P.y_tiles > 1 && c2 > 1) {
+                Q.xcd_map = -3;
+                Q.xo_yt_magic = rcp((unsigned)P.y_tiles);
+                Q.xo_c2_magic = rcp(c2);
+            }
+        }
+    }
     // HVC_444_LDS_PAD=bytes (experiments): dynamic LDS nobody uses, to hold the kernel to fewer workgroups per CU
     static const unsigned pad = [] { const char *v = getenv("HVC_444_LDS_PAD"); return v ? (unsigned)atoi(v) : 0u; }();
     if (!aligned && P.nw != 1) return hipErrorInvalidValue; // (plan_decode_444 was told otherwise)
