@@ -1271,8 +1271,22 @@ __device__ __forceinline__ int vmad24(int k, int x, int acc) {
 // (Round 4 tried the rotations as one v_dot2_i32_i16 per output on int16 operand pairs packed once per pair: 80 VALU
 // instructions per block fewer (1062 -> 982) and 72 VGPRs -- and 0.3 - 0.7 points SLOWER than this form on the same box,
 // three alternations: profiles/r04q_k3_dot2_ab.txt.  K3 does not wait for its VALU.)
+// K3 is bound by VALU issue, not by its LDS transpose or its memory shape: 827.6 M wave-instructions per 256-frame launch
+// at 4 cycles each = 97 % of the 1024 SIMDs' cycles (rocprofv3 SQ_INSTS_VALU / GRBM_GUI_ACTIVE; SQ_WAIT_INST_LDS 0.04 % of
+// the wave cycles, no bank conflicts: profiles/r05c_k3_pmc.txt) -- which is why it sat 1 - 2 points under its own
+// traffic-only build.  HVC_ENCODE_MULHI=1 (shipped) takes 80 of the 1062 instructions per block out -- c4 as one
+// v_mul_hi_i32_i24 on operands pre-shifted by the add or mad that makes them, the quantiser's products two at a time
+// (v_pk_mul_f32) -- and reads 75.3 - 76.7 % where the 0 form reads 73.5 - 74.1 %, its traffic-only build 74.9 - 77.4 %
+// (same box, three alternations: profiles/r05c_k3_ab.txt).
 #ifndef HVC_ENCODE_MULHI
-#define HVC_ENCODE_MULHI 0
+#define HVC_ENCODE_MULHI 1
+#endif
+// HVC_ENCODE_QMAGIC=1 (shipped): the quantiser as one v_fma_f32 per coefficient and one v_perm_b32 per pair (below): another
+// 31 instructions out, the slow-issue conversions among them (v_cvt_rpi_i32_f32, v_cvt_pk_i16_i32: 1.7 x the issue time of an
+// add or fma, profiles/r01_valu_ubench.txt).  Same box, four alternations (profiles/r05d_k3_variants.txt): 73.9 % without
+// either, 75.4 % with MULHI, 76.2 % with both (2 = the fma as v_pk_fma_f32: 76.0 %), traffic-only build 74.8 %.
+#ifndef HVC_ENCODE_QMAGIC
+#define HVC_ENCODE_QMAGIC 1
 #endif
 // c4 without its shift: (362 x) >> 9 = the high dword of (x << 9) * (362 << 14) as a 24 x 24 -> 48 bit product
 // (v_mul_hi_i32_i24: floor, like asr) -- exact while |x << 9| < 2^23, i.e. |x| < 2^14; the sums c4 sees are <= 1024 in the
@@ -1458,7 +1472,22 @@ __global__ __launch_bounds__(HVC_ENCODE_LB) HVC_ENCODE_ATTR void k_encode(Encode
             const int lo = v[ZI[k]], hi = v[ZI[k + 1]];
             (void)qr;
 #else
-#if HVC_ENCODE_MULHI
+#if HVC_ENCODE_QMAGIC
+            // quant_and_scale as ONE fused multiply-add per coefficient: float(f) * r + 1.5 * 2^23 rounds (to nearest, once, at
+            // an ulp of 1) to 1.5 * 2^23 + q, whose low 16 bits ARE q in two's complement -- no v_cvt_rpi, and the int16 pair is
+            // one v_perm_b32 of the two bit patterns.  The exact product f * r is never a tie and its nearest integer is the
+            // model's quotient for every t in 1..255 and |f| <= 2^15 (tests/test_quant_division.py, exhaustive).
+            typedef float f2v __attribute__((ext_vector_type(2)));
+#if HVC_ENCODE_QMAGIC == 2
+            const f2v xf = {(float)v[ZI[k]], (float)v[ZI[k + 1]]}, rf = {qr[k], qr[k + 1]}, mf = {12582912.f, 12582912.f};
+            const f2v pr = __builtin_elementwise_fma(xf, rf, mf);   // v_pk_fma_f32
+            const float plo = pr.x, phi = pr.y;
+#else
+            const float plo = __builtin_fmaf((float)v[ZI[k]], qr[k], 12582912.f);
+            const float phi = __builtin_fmaf((float)v[ZI[k + 1]], qr[k + 1], 12582912.f);
+#endif
+            w[h] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, phi), __builtin_bit_cast(unsigned, plo), 0x05040100u);
+#elif HVC_ENCODE_MULHI
             // the two products of a pair as one v_pk_mul_f32 (the same IEEE single products as two v_mul_f32)
             typedef float f2v __attribute__((ext_vector_type(2)));
             const f2v xf = {(float)v[ZI[k]], (float)v[ZI[k + 1]]}, rf = {qr[k], qr[k + 1]};
@@ -1471,7 +1500,9 @@ __global__ __launch_bounds__(HVC_ENCODE_LB) HVC_ENCODE_ATTR void k_encode(Encode
             const int hi = quant1(v[ZI[k + 1]], qr[k + 1]);
 #endif
 #endif
+#if HVC_TRAFFIC_ONLY || !HVC_ENCODE_QMAGIC
             w[h] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(lo, hi)); // |q| <= 2^13: no saturation
+#endif
         }
         const u4v t = {w[0], w[1], w[2], w[3]};
         lds[wv][l * 8 + (j ^ (l & 7))] = t;
