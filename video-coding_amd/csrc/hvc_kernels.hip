@@ -1477,8 +1477,8 @@ __global__ __launch_bounds__(HVC_ENCODE_LB) HVC_ENCODE_ATTR void k_encode(Encode
             // an ulp of 1) to 1.5 * 2^23 + q, whose low 16 bits ARE q in two's complement -- no v_cvt_rpi, and the int16 pair is
             // one v_perm_b32 of the two bit patterns.  The exact product f * r is never a tie and its nearest integer is the
             // model's quotient for every t in 1..255 and |f| <= 2^15 (tests/test_quant_division.py, exhaustive).
-            typedef float f2v __attribute__((ext_vector_type(2)));
 #if HVC_ENCODE_QMAGIC == 2
+            typedef float f2v __attribute__((ext_vector_type(2)));
             const f2v xf = {(float)v[ZI[k]], (float)v[ZI[k + 1]]}, rf = {qr[k], qr[k + 1]}, mf = {12582912.f, 12582912.f};
             const f2v pr = __builtin_elementwise_fma(xf, rf, mf);   // v_pk_fma_f32
             const float plo = pr.x, phi = pr.y;
