@@ -112,6 +112,28 @@ def test_bench_four_ranks_on_one_gpu():
     assert "sustained" not in rec
 
 
+def test_bench_config3_and_5_one_rank_and_two():
+    """bench.py --config 3 (BASELINE configs[2]: JPEG files, host Huffman || H2D || K1; the GPU reader beside it) and --config 5
+    (configs[4]: the encoder's block stage), small batches: alone with their CPU baselines, and over two ranks sharing the GPU
+    (the file batch split, every rank's output K5-verified, each rank on its share of the host's CPUs)."""
+    rec = _run_bench(["--config", "3", "--frames", "128", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1"])
+    assert rec["n_gpus"] == 1 and rec["scaling"] == "strong" and rec["config"]["baseline_config"] == 3
+    assert "host Huffman || H2D || K1" in rec["config"]["workload"] and rec["config"]["files_total"] == 128
+    for reader in ("host_reader", "gpu_reader"):
+        assert rec[reader]["verified"] is True and rec[reader]["ranks_verified"] == 1 and rec[reader]["value"] > 0
+    assert rec["value"] == rec["host_reader"]["value"] and rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["cores"] == 1
+    rec = _run_bench(["--gpus", "2", "--config", "3", "--frames", "128", "--steps", "2", "--warmup", "1"], HVC_BENCH_REHEARSAL="1")
+    assert rec["n_gpus"] == 2 and rec["config"]["files_per_gpu_per_step"] == 64 and "REHEARSAL" in rec["data"]
+    assert rec["host_reader"]["ranks_verified"] == 2 and rec["gpu_reader"]["ranks_verified"] == 2
+    walls = rec["host_reader"]["per_rank"]["wall_ms_entropy_thread_ms_sum_h2d_ms_kernel_ms_threads"]
+    assert len(walls) == 2 and all(w[0] > 0 and w[4] >= 1 for w in walls)
+    rec = _run_bench(["--config", "5", "--frames", "16", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1"])
+    assert rec["config"]["baseline_config"] == 5 and rec["roofline"]["kernel"] == "k_encode" and rec["checksum"]["verified"] is True
+    assert rec["cpu_baseline"]["value"] > 0 and 0 < rec["roofline"]["frac"] < 1
+    rec = _run_bench(["--gpus", "2", "--config", "5", "--frames", "16", "--steps", "2", "--warmup", "1"], HVC_BENCH_REHEARSAL="1")
+    assert rec["n_gpus"] == 2 and rec["checksum"]["ranks_verified"] == 2 and len(rec["per_rank_kernel_ms"]["mean_min_max"]) == 2
+
+
 def test_bench_fails_when_the_output_is_not_the_models(tmp_path):
     """A run whose checksums differ from the golden ones exits non-zero and says "verified": false: here
     the golden file is swapped for one with another rank's values."""
