@@ -578,6 +578,15 @@ __global__ __launch_bounds__(HVC_PACKED_LB) void k_decode_packed(DecodeParams P)
     if (hvc_full) src = src - 8 * (lane & 63) + (lane & 63);
 #endif
     HVC_DECODE_BLOCK_PACKED(src, qp, out, g, if (DCP) w[0] = with_dc(w[0], dcv););
+#ifdef HVC_K1_PAD_VALU /* probe only (profiles/r05g_k1_valu_probe.txt): N more slow-issue VALU instructions per lane -- how
+                          much of K1's time is its instruction issue? */
+    {
+        int pad = lane;
+#pragma unroll
+        for (int i = 0; i < HVC_K1_PAD_VALU; i++) asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(pad) : "v"(lane));
+        asm volatile("" ::"v"(pad));
+    }
+#endif
 
     const bool bad = packed_guard_failed(g, P.ethr_packed[br.qtab]);
     if (active && !bad) {
