@@ -202,3 +202,12 @@ def test_bench_rccl_calls_on_one_gpu():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert rec["n_gpus"] == 1 and rec["checksum"]["ranks_verified"] == 1 and "REHEARSAL" not in rec["data"]
+    # ... and the same calls (plus the all-gather of the per-rank figures) in the file pipeline's and the encoder's N-rank paths
+    for port, extra in (("29553", ["--config", "3", "--frames", "64", "--steps", "1", "--warmup", "1"]),
+                        ("29555", ["--config", "5", "--frames", "16", "--steps", "2", "--warmup", "1"])):
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                              "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
+                              "--gpus", "1", "--no-cpu-baseline"] + extra, capture_output=True, text=True, env=e, timeout=900, cwd=ROOT)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+        rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+        assert rec["n_gpus"] == 1 and rec["checksum"]["ranks_verified"] == 1 and "REHEARSAL" not in rec["data"]

@@ -65,7 +65,7 @@ def tables(tag):
     q16, q16src = R["bench_q16"]
     f4096, f4096src = R["bench_f4096"]
     k = []
-    k.append("| kernel | computes | algorithmic bytes / unit | % of 8 TB/s, session `%s` | counter traffic ÷ algorithmic |" % tag)
+    k.append("| kernel | computes | algorithmic bytes / unit | %% of 8 TB/s, session `%s` | counter traffic ÷ algorithmic |" % tag)
     k.append("|---|---|---|---|---|")
     rl = b["roofline"]
     k.append("| K1 `k_decode_packed`, config 2 (1024 × 1080p 4:2:0) | a1 – a6 | 192 B / block (128 in + 64 out) | **%s** (%.4f ms, %s) | %s |"
@@ -130,12 +130,14 @@ def tables(tag):
     if "huffman_gpu" in R:
         hg, hgsrc = R["huffman_gpu"]
         t.append("| GPU Huffman coder alone (4K 4:2:0, q75) | %.0f Gpixel/s | %s |" % (hg["value"] / 1e3, hgsrc))
-    for what, label in (("bench_rehearsal2", "2 ranks, config 2"), ("bench_rehearsal4_c4", "4 ranks, config 4"), ("bench_rehearsal2_c3", "2 ranks, config 3"),
-                        ("bench_rehearsal2_c5", "2 ranks, config 5")):
+    reh = []
+    for what, label in (("bench_rehearsal2", "2 ranks config 2"), ("bench_rehearsal4_c4", "4 ranks config 4"), ("bench_rehearsal2_c3", "2 ranks config 3"),
+                        ("bench_rehearsal2_c5", "2 ranks config 5")):
         if what in R:
             r, src = R[what]
-            ok = r["checksum"].get("ranks_verified")
-            t.append("| rehearsal on this one GPU (all ranks on cuda:0, gloo; never a measurement): %s | ran as typed, %s of %d ranks verified | %s |" % (label, ok, r["n_gpus"], src))
+            reh.append("%s: %s of %d verified (%s)" % (label, r["checksum"].get("ranks_verified"), r["n_gpus"], src.replace("profiles/%s_lines.jsonl" % tag, "")))
+    if reh:
+        t.append("| N-rank rehearsals on this one GPU (all ranks on cuda:0, gloo; never measurements) | %s | `profiles/%s_lines.jsonl`, lines as given |" % ("; ".join(reh), tag))
     prof = []
     for name, label in (("decode", "`python bench.py`, `k_decode_packed`"), ("decode_c4", "`--config 4`"), ("encode", "`k_encode`"), ("444", "`k_decode_444`")):
         ta = trace_avg(tag, name)
