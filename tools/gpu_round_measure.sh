@@ -44,9 +44,9 @@ bash tools/gpu_profile.sh ${TAG}_decode
 echo "decode profile done"
 bash tools/gpu_profile.sh ${TAG}_decode_c4 --config 4 --steps 2 --warmup 1
 echo "config-4 profile done"
-bash tools/gpu_profile_cmd.sh ${TAG}_444 tools/bench_configs.py --config 7 --steps 10 --fused-only
+bash tools/gpu_profile_cmd.sh ${TAG}_444 tools/bench_configs.py --config 7 --steps 40 --warmup 20 --fused-only
 echo "444 profile done"
-bash tools/gpu_profile_cmd.sh ${TAG}_encode tools/bench_configs.py --config 5 --steps 10
+bash tools/gpu_profile_cmd.sh ${TAG}_encode tools/bench_configs.py --config 5 --steps 40 --warmup 20
 echo "encode profile done"
 : > gpurun_out/traffic_${TAG}.jsonl
 python tools/rocpd_summary.py gpurun_out/prof_${TAG}_decode --traffic k_decode_packed 1024 2 ${TAG} | tr -d '\n' >> gpurun_out/traffic_${TAG}.jsonl; echo >> gpurun_out/traffic_${TAG}.jsonl
@@ -55,7 +55,7 @@ python tools/rocpd_summary.py gpurun_out/prof_${TAG}_encode --traffic k_encode 2
 python tools/rocpd_summary.py gpurun_out/prof_${TAG}_444 --traffic 'k_decode_444<' 512 7 ${TAG} | tr -d '\n' >> gpurun_out/traffic_${TAG}.jsonl; echo >> gpurun_out/traffic_${TAG}.jsonl
 # summaries here, databases deleted: gpurun only brings back 64 MiB
 for d in gpurun_out/prof_${TAG}_*; do
-    case $d in *_decode) W=18;; *_decode_c4) W=32;; *) W=10;; esac   # untimed launches of the profiled command (bench.py: 8 setup + 10 warm-up)
+    case $d in *_decode) W=18;; *_decode_c4) W=32;; *) W=20;; esac   # untimed launches of the profiled command (bench.py: 8 setup + 10 warm-up; bench_configs.py: --warmup 20)
     python tools/rocpd_summary.py $d $W > gpurun_out/$(basename $d | sed 's/^prof_//')_rocprofv3.txt 2>&1 || true
     find $d -name '*.db' -delete
 done
