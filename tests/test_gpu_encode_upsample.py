@@ -63,6 +63,36 @@ def test_ragged_sizes_and_extreme_pixels(ctx, bw, bh):
     assert np.array_equal(gpu_fdct_quant(ctx, pix, q), want)
 
 
+@pytest.mark.parametrize("t", [1, 2, 3, 16, 255])
+def test_forward_path_on_the_blocks_that_drive_it_hardest(ctx, t):
+    """K3's c4 by v_mul_hi_i32_i24 and its one-fma quantiser (round 5) on the inputs that push every intermediate to its bound:
+    all 64 two-level blocks whose signs follow one DCT basis function (each maximises one coefficient), both polarities, their
+    products with a second basis function, single pixels, and dense random two-level blocks -- under constant tables of the
+    smallest and largest divisors (quotients up to +-2^13 at t = 1) -- against the model restatement."""
+    yy, xx = np.mgrid[0:8, 0:8]
+    blocks = []
+    for v in range(8):
+        for u in range(8):
+            basis = np.cos((2 * xx + 1) * u * np.pi / 16) * np.cos((2 * yy + 1) * v * np.pi / 16)
+            for lo, hi in ((0, 255), (255, 0), (1, 254), (127, 128)):
+                blocks.append(np.where(basis >= 0, hi, lo))
+            blocks.append(np.where(basis * np.cos((2 * xx + 1) * ((u + 3) % 8) * np.pi / 16) >= 0, 255, 0))
+    for k in range(64):
+        b = np.zeros((8, 8), dtype=np.int64)
+        b[k // 8, k % 8] = 255
+        blocks += [b, 255 - b]
+    rng = np.random.Generator(np.random.PCG64(1000 + t))
+    blocks += [np.where(rng.random((8, 8)) < 0.5, 0, 255) for _ in range(192)]
+    n = len(blocks)
+    plane = np.concatenate([b.astype(np.uint8) for b in blocks], axis=1)   # one row of n blocks
+    q = np.full(64, t, dtype=np.uint16)
+    want = orc.fdct_quant(plane, q, n, 1)
+    got = np.zeros(n * 64, dtype=np.int16)
+    ctx.fdct_quant(np.ascontiguousarray(plane), q, n, 1, 1, got)
+    assert np.array_equal(got, want.reshape(-1))
+    assert np.abs(want).max() > (1000 if t <= 3 else 10)   # (the cases do reach large quotients)
+
+
 def test_frame_batch_encode_then_decode_roundtrip(ctx):
     """encode -> decode of a 4:2:0 frame batch on the GPU equals the oracle's
     encode -> decode (both directions exact => identical pixels)."""

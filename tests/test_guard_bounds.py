@@ -174,6 +174,50 @@ def fdct_1d(p):
     return o
 
 
+def mulhi24(c, x):
+    """v_mul_hi_i32_i24: the high dword of the signed 24 x 24 -> 48-bit product = floor(c x / 2^32); both operands must be
+    genuine 24-bit values"""
+    assert I24[0] <= c <= I24[1], "mulhi24 constant outside 24 bits"
+    assert I24[0] <= x.lo and x.hi <= I24[1], "mulhi24 operand outside 24 bits: [%d, %d]" % (x.lo, x.hi)
+    a, b = c * x.lo, c * x.hi
+    return Iv(min(a, b) >> 32, max(a, b) >> 32, "mulhi24")
+
+
+def fdct_1d_shipped(p, level_shift):
+    """the butterfly as k_encode issues it since round 5 (fdct_tail with HVC_ENCODE_MULHI, csrc/hvc_kernels.hip): c4 as one
+    v_mul_hi_i32_i24 of an operand pre-shifted by 9 with the constant 362 << 14 -- every pre-shifted operand must stay inside
+    24 bits.  level_shift: the sums still carry +256 each (column pass), taken out as -1024 << 9 in front of the one c4 that
+    sees them."""
+    C4S = 362 << 14
+    ref = fdct_1d([x - 128 for x in p] if level_shift else p)   # (the model's form: what the outputs are compared with)
+    a0, c3 = p[0] + p[7], p[0] - p[7]
+    a1, c2 = p[1] + p[6], p[1] - p[6]
+    a2, c1 = p[2] + p[5], p[2] - p[5]
+    a3, c0 = p[3] + p[4], p[3] - p[4]
+    b0s, b1s, b2, b3 = (a0 + a3).shl(9), (a1 + a2).shl(9), a1 - a2, a0 - a3
+    o = [None] * 8
+    o[0] = mulhi24(C4S, b0s + b1s - (1024 << 9) if level_shift else b0s + b1s)
+    o[4] = mulhi24(C4S, b0s - b1s)
+    c2s = c2.shl(9)
+    e0, e1 = mulhi24(C4S, mad24(-512, c1, c2s)), mulhi24(C4S, mad24(512, c1, c2s))
+    for k in (0, 4):   # same interval as the model's (362 x) >> 9 on the same sums
+        assert (o[k].lo, o[k].hi) == (ref[k].lo, ref[k].hi), k
+    return ref, (e0, e1)
+
+
+def test_c4_by_mul_hi_operands_fit_24_bits_in_both_passes():
+    """K3's c4 = v_mul_hi_i32_i24((x << 9), 362 << 14) is exact while |x << 9| < 2^23: replayed on intervals for the column pass
+    (un-shifted pixels 0..255, the -1024 << 9 folded in) and the row pass (whatever the column pass can produce); and pointwise,
+    (x << 9) * (362 << 14) >> 32 == (362 x) >> 9 over the whole range a sum can take"""
+    assert (362 << 14) <= I24[1]
+    cols, _ = fdct_1d_shipped([Iv(0, 255)] * 8, True)
+    m1 = max(c.absmax() for c in cols)
+    rows, _ = fdct_1d_shipped([Iv(-m1, m1)] * 8, False)
+    assert max(c.absmax() for c in rows) <= 1 << 15
+    for x in list(range(-(1 << 14) + 1, 1 << 14, 7)) + [-(1 << 14) + 1, (1 << 14) - 1, -1, 0, 1]:
+        assert ((x << 9) * (362 << 14)) >> 32 == (362 * x) >> 9, x
+
+
 def test_encode_path_needs_no_guard():
     p = Iv(-128, 127)
     cols = fdct_1d([p] * 8)
