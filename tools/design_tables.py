@@ -146,12 +146,31 @@ def tables(tag):
     return "\n".join(k), "\n".join(t), ("trace averages — " + "; ".join(prof) + "; counter bytes: `profiles/traffic.json`, session " + tag + ".") if prof else ""
 
 
+KERNEL_FILES = (("hvc_kernels.hip", ("k_decode_packed", "k_decode_wide", "k_decode_q16", "k_decode_444", "k_reinterp_444", "k_encode",
+                                      "k_upsample420", "k_upsample420_x8", "k_abs_error", "k_checksum")),
+                ("hvc_kernels.h", ("xcd_work",)), ("hvc_yuv.hip", ("k_subsample420",)), ("hvc_hdec.hip", ("k_hd_sync", "k_hd_write2")),
+                ("hvc_huff.hip", ("k_huff_len", "k_huff_emit")))
+
+
+def anchors():
+    """`name` file:line of every kernel DESIGN.md names: the line of its definition"""
+    out = []
+    for fn, names in KERNEL_FILES:
+        lines = open(os.path.join(ROOT, "video-coding_amd", "csrc", fn)).read().splitlines()
+        for name in names:
+            pat = re.compile(r"(__global__|__device__ __forceinline__ void).*\b%s\(" % re.escape(name))
+            hit = [n for n, ln in enumerate(lines, 1) if pat.search(ln)]
+            if hit:
+                out.append("`%s` `%s:%d`" % (name, fn, hit[0]))
+    return " · ".join(out)
+
+
 def main():
     tag = sys.argv[1]
     k, t, p = tables(tag)
     path = os.path.join(ROOT, "DESIGN.md")
     s = open(path).read()
-    for name, body in (("KERNELS", k), ("SESSION", t), ("PROFILES", p)):
+    for name, body in (("ANCHORS", anchors()), ("KERNELS", k), ("SESSION", t), ("PROFILES", p)):
         a, b = "<!-- %s:BEGIN -->" % name, "<!-- %s:END -->" % name
         i, j = s.index(a) + len(a), s.index(b)
         s = s[:i] + "\n" + body + "\n" + s[j:]
