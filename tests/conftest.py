@@ -17,7 +17,7 @@ def pytest_configure(config):
 # Under `pytest -x` one peripheral failure must not leave the hot path's parity unreached: the files that carry
 # SURVEY section 8(a)'s rows (decoder.ml:142-149, 213-224, 347-360; dct.ml:11-107; encoder.ml:81-108) run first, in this
 # order; everything else keeps pytest's own (alphabetical) order behind them.
-HOT_PATH_FIRST = ("test_gpu_decode", "test_gpu_encode_upsample", "test_gpu_jpeg_api", "test_gpu_config1_128", "test_gpu_full_configs",
+HOT_PATH_FIRST = ("test_gpu_decode", "test_gpu_encode_upsample", "test_gpu_jpeg_api", "test_cpp_model", "test_gpu_config1_128", "test_gpu_full_configs",
                   "test_gpu_yuv444", "test_gpu_huffman", "test_gpu_hdec")
 
 
