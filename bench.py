@@ -189,11 +189,8 @@ def other_measurements(threads):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_configs as bc
     cpus = len(os.sched_getaffinity(0))
-    try:  # the pod's CPU quota (cgroup v2 cpu.max: "quota period"): what the host stages really have, whatever the mask shows
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        cpu_quota = None if quota == "max" else round(int(quota) / int(period), 2)
-    except (OSError, ValueError):
-        cpu_quota = None
+    cpu_quota = cgroup_cpu_quota()
+    cpu_quota = None if cpu_quota is None else round(cpu_quota, 2)
     out = {"host": {"cpus_in_affinity_mask": cpus, "cgroup_cpu_quota": cpu_quota, "threads_used": threads}}
 
     def run(name, fn, bound, pick):
@@ -399,12 +396,24 @@ def host_share(node_keys, rank, cpus, cap=16):
     return mine, max(1, min(cap, len(mine)))
 
 
+def cgroup_cpu_quota():
+    """the container's CPU quota (cgroup v2 cpu.max: "quota period") as a number of CPUs, None where there is none: what the host
+    stages really have, whatever the affinity mask shows (a one-GPU box of the pool: a mask of 256 CPUs, a quota of 16)"""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else int(quota) / int(period)
+    except (OSError, ValueError):
+        return None
+
+
 def share_host_cpus(ctx, rank, world, dist, device, bind=True):
     """-> (cpulist text or None, host threads): at N > 1 the rank's launch thread and its pipeline threads are put on the rank's
     slice of its GPU's NUMA node (host_share); at N = 1 nothing is bound and the threads are min(16, CPUs of the mask)."""
     mask = sorted(os.sched_getaffinity(0))
+    quota = cgroup_cpu_quota()   # (the ranks of one node share one container: its quota is split between them)
+    cap = 16 if quota is None else max(1, min(16, int(quota / world)))
     if world == 1:
-        return None, max(1, min(16, len(mask)))
+        return None, max(1, min(cap, len(mask)))
     cpus = mask
     if ctx is not None and bind:
         try:
@@ -415,7 +424,7 @@ def share_host_cpus(ctx, rank, world, dist, device, bind=True):
         except Exception:
             pass
     keys = [int(k[0]) for k in gather_over_ranks([float(cpus[0])], world, dist, device)]
-    mine, threads = host_share(keys, rank, cpus)
+    mine, threads = host_share(keys, rank, cpus, cap)
     text = format_cpulist(mine)
     if ctx is not None and bind:
         try:
@@ -607,6 +616,7 @@ def run_files(args, rank, world, local_rank, rehearsal):
                        % args.distinct + (" (REHEARSAL: all ranks share cuda:0, gloo)" if rehearsal else ""),
                "config": {"workload": "%s; %d files in total, %d per GPU per step" % (wl["name"], n * world, n), "baseline_config": 3,
                           "files_total": n * world, "files_per_gpu_per_step": n, "host_threads_per_rank": threads,
+                          "cgroup_cpu_quota": cgroup_cpu_quota(),
                           "rank0_cpus": cpus_text, "blocks_per_frame": blocks_per_frame,
                           "parallelism": "the file batch split over the GPUs, no collective; host threads = the rank's share of its GPU's NUMA node"},
                "roofline": {"bound": "hbm", "kernel": "k_decode_packed", "achieved": host["k_decode_packed_algorithmic_GBps"],
