@@ -13,6 +13,7 @@
  *   jpeg/model/src/quant_tables.mli  Quant_tables::scale
  *   jpeg/model/src/dct.mli:8-11    Dct::Chen through the block stage it lives in (Decoder::recon_of_coefs, Encoder::quant_of_pixels)
  *   tools/src/ocompare.ml:8-59     Ocompare::max_difference, psnr; Float.to_string as the cram tests print it
+ *   tools/src/oconv.ml:111-133     Oconv::convert (one planar frame: size, offset, format)
  *
  * Everything computes on the GPU through libhvc_jpeg.so; where the model raises (`raise_s`), these throw hvc_model::Error
  * carrying the hvc_status.  There is no CPU fallback: Ctx's constructor throws without a gfx950 GPU. */
@@ -264,6 +265,26 @@ inline std::string encode_420(Ctx &ctx, const Frame &f, int quality) { return en
 inline std::string encode_422(Ctx &ctx, const Frame &f, int quality) { return encode(ctx, f, quality, Frame::Chroma_subsampling::C422); }
 inline std::string encode_444(Ctx &ctx, const Frame &f, int quality) { return encode(ctx, f, quality, Frame::Chroma_subsampling::C444); }
 } // namespace Encoder
+
+namespace Oconv { /* `oyuv convert IN WxH OUT W2xH2` for one planar frame (tools/src/oconv.ml:111-133): the frame to 4:4:4
+                     (Planar_444.convert_from_420 / _422), Yuv.crop at an offset into the new size, back to the output format */
+inline Frame convert(Ctx &ctx, const Frame &in, int out_width, int out_height, Frame::Chroma_subsampling out_format, int x_off = 0,
+                     int y_off = 0) {
+    std::vector<uint8_t> src;
+    for (const Plane *p : {&in.y(), &in.u(), &in.v()}) src.insert(src.end(), p->data(), p->data() + p->size());
+    Frame out = Frame::create(out_format, out_width, out_height);
+    std::vector<uint8_t> dst(out.y().size() + out.u().size() + out.v().size());
+    check(hvc_yuv_convert(ctx.get(), src.data(), (int)in.chroma_subsampling(), in.width(), in.height(), x_off, y_off, dst.data(),
+                          (int)out_format, out_width, out_height, 1, HVC_MEM_HOST),
+          "Oconv.convert");
+    size_t off = 0;
+    for (Plane *p : {&out.y(), &out.u(), &out.v()}) {
+        for (size_t k = 0; k < p->size(); k++) p->data()[k] = dst[off + k];
+        off += p->size();
+    }
+    return out;
+}
+} // namespace Oconv
 
 namespace Ocompare { /* tools/src/ocompare.ml:8-59 */
 inline void same_size(const Plane &a, const Plane &b) {

@@ -3,6 +3,7 @@
 //   test_chen_dct          jpeg/model/test/test_chen_dct.ml:47-87      (G1: the explicit block, its Chen fDCT / 4 rounded, the IDCT of that)
 //   test_quant_tables      jpeg/model/test/test_quant_tables.ml:4-62   (G5: scale luma q)
 //   model-encode-and-decode  jpeg/test/model-encode-and-decode.t:7-72  (the cram session, printed as `oyuv compare psnr` prints it)
+//   test-nonstandard-sizes   jpeg/test/test-nonstandard-sizes.t:3-15     (52 x 44 through `oyuv convert`, padding and crop)
 //   mini.jpg               jpeg/test_data: Encoder.encode_420 ~quality:75 of mini64x64.420 is that file (G3)
 // plus the error behaviour of the interfaces (what raises in the model throws here).
 //   model_tests host <golden dir> <fixtures.txt>      no GPU needed: Plane, Frame, Quant_tables, Header.decode
@@ -133,6 +134,17 @@ static int gpu_tests(const std::string &golden, std::map<std::string, std::vecto
                                                                          : Encoder::encode_444(ctx, src, k.quality);
         const Frame out = Decoder::decode_a_frame(ctx, jpg);
         std::cout << "$ model encode frame " << k.file << " 64x64 -quality " << k.quality << "; model decode frame; oyuv compare psnr\n";
+        std::cout << Ocompare::float_to_string(Ocompare::psnr(src.y(), out.y())) << "\n"
+                  << Ocompare::float_to_string(Ocompare::psnr(src.u(), out.u())) << "\n"
+                  << Ocompare::float_to_string(Ocompare::psnr(src.v(), out.v())) << "\n";
+    }
+    // ---- test-nonstandard-sizes.t:3-15: 64x64 -> 52x44 by `oyuv convert` (twice, as the session does), encode q95, decode, PSNR
+    {
+        const Frame full = input_yuv(golden + "/mini64x64.420", Frame::Chroma_subsampling::C420, 64, 64);
+        Frame src = Oconv::convert(ctx, full, 52, 44, Frame::Chroma_subsampling::C420);
+        src = Oconv::convert(ctx, full, 52, 44, Frame::Chroma_subsampling::C420);
+        const Frame out = Decoder::decode_a_frame(ctx, Encoder::encode_420(ctx, src, 95));
+        std::cout << "$ oyuv convert 64x64 -> 52x44; model encode frame -quality 95; model decode frame; oyuv compare psnr\n";
         std::cout << Ocompare::float_to_string(Ocompare::psnr(src.y(), out.y())) << "\n"
                   << Ocompare::float_to_string(Ocompare::psnr(src.u(), out.u())) << "\n"
                   << Ocompare::float_to_string(Ocompare::psnr(src.v(), out.v())) << "\n";
