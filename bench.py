@@ -468,6 +468,7 @@ def parse_args(argv=None):
     ap.add_argument("--shard", type=int, default=None, help="config 4: frames per GPU per step (launches of --frames)")
     ap.add_argument("--distinct", type=int, default=None, help="distinct synthetic frames (replicated): 8, configs 3 / 5: 4")
     ap.add_argument("--threads", type=int, default=None, help="config 3: host threads per rank (default: the rank's share of its NUMA node, <= 16)")
+    ap.add_argument("--tight", action="store_true", help="planes and frames back to back instead of on 64 KiB / 2 MiB boundaries (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-others", action="store_true", help="skip `others` (configs 3 / 4 / 5 and the other kernels, after the timed region)")
@@ -653,11 +654,13 @@ def run_encode(args, rank, world, local_rank, rehearsal):
     node_cpus = bind_rank_to_gpu_node(ctx) if (world > 1 and not rehearsal) else None
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     qtabs = np.stack([hvc.hvc.quant_table(0, 75), hvc.hvc.quant_table(1, 75)])
-    specs, cfs, pfs = hvc.hvc.frame_layout(planes)
+    tspecs, tcfs, tpfs = hvc.hvc.frame_layout(planes)
+    align = 1 if args.tight else hvc.hvc.layout_alignment(planes)   # (as in config 2: planes and frames on 2 MiB boundaries here)
+    specs, cfs, pfs = hvc.hvc.frame_layout(planes, align=align)
     comps = hvc.hvc.components(specs)
     recs = np.stack([synth_frame_pixels(60 + 8 * f, planes) for f in range(args.distinct)])   # (tools/bench_configs.py config5's seeds)
     reps = (args.frames + args.distinct - 1) // args.distinct
-    d_pix = torch.from_numpy(recs).cuda().repeat(reps, 1)[:args.frames].contiguous()
+    d_pix = hvc.hvc.spread_records(torch.from_numpy(recs).cuda(), tspecs, specs, pfs, "plane_offset").repeat(reps, 1)[:args.frames].contiguous()
     d_coefs = torch.zeros((args.frames, cfs), dtype=torch.int16, device="cuda")
     torch.cuda.synchronize()
 
@@ -671,7 +674,7 @@ def run_encode(args, rank, world, local_rank, rehearsal):
     dt = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, world, dist)
     dt = max_over_ranks(dt, world, dist, dev)
     kernel_ms = ctx.kernel_ms_history(min(args.steps, 64))
-    chk = bc.verify(ctx, d_coefs, cfs * 2, args.frames, "configs_c5", args.distinct)["checksum"]
+    chk = bc.verify(ctx, hvc.hvc.tight_records(d_coefs, specs, "coef_offset"), tcfs * 2, args.frames, "configs_c5", args.distinct)["checksum"]
     ranks_ok = all_ranks_ok(chk["verified"] is True, world, dist, dev)
     per_rank = gather_over_ranks([float(np.mean(kernel_ms)), float(np.min(kernel_ms)), float(np.max(kernel_ms))], world, dist, dev)
     if rank == 0:
@@ -686,6 +689,8 @@ def run_encode(args, rank, world, local_rank, rehearsal):
                "data": "synthetic" + (" (REHEARSAL: all ranks share cuda:0, gloo)" if rehearsal else ""),
                "config": {"workload": "%s, %d frames/GPU/step" % (wl["name"], args.frames), "baseline_config": 5,
                           "frames_per_gpu_per_step": args.frames, "blocks_per_frame": blocks_per_frame,
+                          "layout": "planes back to back (tight)" if align == 1 else
+                                    "every plane of every frame (pixels and coefficients) on a %d KiB boundary" % (align >> 10),
                           "parallelism": "independent frame batch per GPU, no collective"},
                "roofline": {"bound": "hbm", "kernel": "k_encode", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
@@ -747,9 +752,15 @@ def main():
     ctx = hvc.Context(local_rank)  # raises without a gfx950 GPU: there is no CPU fallback
     node_cpus = bind_rank_to_gpu_node(ctx) if (world > 1 and not rehearsal) else None
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    d_distinct, qtabs = make_distinct_frames(ctx, hvc, planes, args.distinct, wl["seed"], rank)
-    specs, cfs, pfs = hvc.hvc.frame_layout(planes)
+    d_distinct, qtabs = make_distinct_frames(ctx, hvc, planes, args.distinct, wl["seed"], rank)   # (tight records)
+    # The resident batch: every plane of every frame, coefficients and pixels, on a 64 KiB (1080p) / 2 MiB (4K) boundary -- the
+    # caller's choice of hvc_component offsets and frame strides; +0.4 ... +1.0 points over planes back to back
+    # (profiles/r05l_alignment_sweep.txt).  Padding is neither read nor written; K5 runs on the planes gathered tight.
+    tspecs, tcfs, tpfs = hvc.hvc.frame_layout(planes)
+    align = 1 if args.tight else hvc.hvc.layout_alignment(planes)
+    specs, cfs, pfs = hvc.hvc.frame_layout(planes, align=align)
     comps = hvc.hvc.components(specs)
+    d_distinct_laid = hvc.hvc.spread_records(d_distinct, tspecs, specs, cfs, "coef_offset")
     launches = args.shard // args.frames
     # the shard resident as a whole when the device has the room (config 4: 153 GB per GPU); otherwise one
     # launch-sized chunk, processed `launches` times per step
@@ -760,7 +771,7 @@ def main():
     d_coefs = torch.empty((held, cfs), dtype=torch.int16, device="cuda")
     for f0 in range(0, held, args.distinct):  # replicate the distinct frames
         n = min(args.distinct, held - f0)
-        d_coefs[f0:f0 + n] = d_distinct[:n]
+        d_coefs[f0:f0 + n] = d_distinct_laid[:n]
     d_pix = torch.zeros((held, pfs), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     ctx.set_profiling(True)
@@ -785,11 +796,15 @@ def main():
     kernel_ms = ctx.kernel_ms_history(min(args.steps * launches, 64))
     wide = ctx.last_wide_blocks()
     # K5: what was decoded -- the distinct frames' pixel records, checksummed where they are
-    sums = [int(x) for x in ctx.checksum_records(d_pix, pfs, min(args.distinct, held))]
+    def output_checksums():
+        k = min(args.distinct, held)
+        return [int(x) for x in ctx.checksum_records(hvc.hvc.tight_records(d_pix[:k], specs, "plane_offset"), tpfs, k)]
+
+    sums = output_checksums()
     want = expected_checksums(args.config, len(sums), rank) if args.distinct <= 8 else None
     sustained = sustained_run(step, args.sustain_seconds, launches)  # (after everything `value` is made of)
     if sustained is not None:  # ... and what the sustained run left behind is still the model's output
-        again = [int(x) for x in ctx.checksum_records(d_pix, pfs, min(args.distinct, held))]
+        again = output_checksums()
         sustained["output_unchanged"] = again == sums
     per_rank = gather_over_ranks([float(np.mean(kernel_ms)), float(np.min(kernel_ms)), float(np.max(kernel_ms))], world, dist,
                                  "cpu" if rehearsal else "cuda")
@@ -826,6 +841,8 @@ def main():
                        "frames_per_gpu_per_step": args.shard, "frames_per_launch": args.frames,
                        "blocks_per_frame": blocks_per_frame,
                        "parallelism": "independent frame batch per GPU, no collective",
+                       "layout": "planes back to back (tight)" if align == 1 else
+                                 "every plane of every frame (coefficients and pixels) on a %d KiB boundary" % (align >> 10),
                        "wide_path_blocks": int(wide)},
             "roofline": {"bound": "hbm", "kernel": "k_decode_packed", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),

@@ -124,6 +124,54 @@ def test_frame_batch_encode_then_decode_roundtrip(ctx):
             assert np.array_equal(recon[f * pfs + s["plane_offset"]:f * pfs + s["plane_offset"] + n], wp)
 
 
+@pytest.mark.parametrize("align", [4096, 65536, "auto"])
+def test_planes_and_frames_on_aligned_boundaries_give_the_same_records(ctx, align):
+    """the resident layout of bench.py (hvc.frame_layout(..., align): every plane of every frame -- pixels and coefficients -- on
+    an `align`-byte boundary) through both block stages on device memory: the planes gathered tight equal the tight layout's,
+    which equal the oracle's; the padding stays as it was"""
+    import torch
+    import video_coding_amd as hvc
+    planes = [(15, 9, 0), (8, 5, 1), (8, 5, 1)]
+    tspecs, tcfs, tpfs = hvc.hvc.frame_layout(planes)
+    specs, cfs, pfs = hvc.hvc.frame_layout(planes, align=align)
+    a = hvc.hvc.layout_alignment(planes) if align == "auto" else align
+    assert all(s["plane_offset"] % a == 0 and (2 * s["coef_offset"]) % a == 0 for s in specs) and pfs % a == 0 and (2 * cfs) % a == 0
+    n = 7
+    qtabs = np.stack([orc.quant_scale(orc.quant_luma(), 60), orc.quant_scale(orc.quant_chroma(), 60)]).astype(np.uint16)
+    tight = np.stack([np.concatenate([synth_pixels(f * 10 + bw, bh * 8, bw * 8).reshape(-1) for bw, bh, _ in planes]) for f in range(n)])
+    d_tight = torch.from_numpy(tight).cuda()
+    d_pix = hvc.hvc.spread_records(d_tight, tspecs, specs, pfs, "plane_offset")
+    d_pix[d_pix == 0] = 0   # (no-op: the padding is zero)
+    d_coefs = torch.full((n, cfs), 0x5a5a, dtype=torch.int16, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.encode_frames(d_pix, pfs, qtabs, hvc.hvc.components(specs), n, d_coefs, cfs)
+        d_out = torch.full((n, pfs), 0xa5, dtype=torch.uint8, device="cuda")
+        ctx.decode_frames(d_coefs, cfs, qtabs, hvc.hvc.components(specs), n, d_out, pfs)
+        ctx.synchronize()
+    finally:
+        ctx.reset_stream()
+    got_c = hvc.hvc.tight_records(d_coefs, specs, "coef_offset").cpu().numpy()
+    got_p = hvc.hvc.tight_records(d_out, specs, "plane_offset").cpu().numpy()
+    for f in range(n):
+        off = 0
+        for bw, bh, qt in planes:
+            m = bw * bh * 64
+            wc = orc.fdct_quant(tight[f, off:off + m].reshape(bh * 8, bw * 8), qtabs[qt], bw, bh).reshape(-1)
+            assert np.array_equal(got_c[f, off:off + m], wc)
+            assert np.array_equal(got_p[f, off:off + m], orc.dequant_idct_recon(wc, qtabs[qt], bw, bh).reshape(-1))
+            off += m
+    # what lies between the planes was not written: still the fill pattern
+    mask = np.ones(pfs, dtype=bool)
+    for s in specs:
+        mask[s["plane_offset"]:s["plane_offset"] + s["blocks_w"] * s["blocks_h"] * 64] = False
+    assert (d_out.cpu().numpy()[:, mask] == 0xa5).all()
+    cmask = np.ones(cfs, dtype=bool)
+    for s in specs:
+        cmask[s["coef_offset"]:s["coef_offset"] + s["blocks_w"] * s["blocks_h"] * 64] = False
+    assert (d_coefs.cpu().numpy()[:, cmask] == 0x5a5a).all()
+
+
 def test_g7_upsample_kat(ctx):
     g = golden_json("g7_upsample.json")["cases"]["444<->420"]
     f420, back = g[1], g[2]

@@ -91,3 +91,20 @@ def test_cli_convert_with_a_reversed_frame_range_writes_an_empty_file(tmp_path):
         dst.write_bytes(b"x")
         main(["oyuv", "convert", str(src), "48x32", str(dst), "-frames", r])
         assert dst.read_bytes() == b""
+
+
+def test_frame_layout_alignment_rule():
+    """hvc.frame_layout(planes, align): tight by default (the model's planes back to back); with an alignment every plane's
+    pixel and coefficient offset and both frame strides are multiples of it; "auto" = 64 KiB for 1080p frames, 2 MiB for 4K"""
+    import video_coding_amd as hvc
+    p1080 = [(240, 136, 0), (120, 68, 1), (120, 68, 1)]
+    specs, cfs, pfs = hvc.hvc.frame_layout(p1080)
+    assert (cfs, pfs) == (48960 * 64, 48960 * 64) and [s["plane_offset"] for s in specs] == [0, 2088960, 2611200]
+    assert hvc.hvc.layout_alignment(p1080) == 65536 and hvc.hvc.layout_alignment([(480, 270, 0)] * 3) == 2 << 20
+    for align in (4096, 65536, "auto"):
+        specs, cfs, pfs = hvc.hvc.frame_layout(p1080, align=align)
+        a = 65536 if align == "auto" else align
+        assert all(s["plane_offset"] % a == 0 and 2 * s["coef_offset"] % a == 0 for s in specs) and pfs % a == 0 and 2 * cfs % a == 0
+        for s, t in zip(specs, specs[1:]):   # planes do not overlap
+            assert t["plane_offset"] >= s["plane_offset"] + s["blocks_w"] * s["blocks_h"] * 64
+            assert t["coef_offset"] >= s["coef_offset"] + s["blocks_w"] * s["blocks_h"] * 64

@@ -130,16 +130,18 @@ def resident_decode(args, planes, W, H, tag):
     import video_coding_amd as hvc
     from video_coding_amd.synth import synth_frame_pixels
     qtabs = np.stack([hvc.hvc.quant_table(0, 75), hvc.hvc.quant_table(1, 75)])
-    specs, cfs, pfs = hvc.hvc.frame_layout(planes)
+    tspecs, tcfs, tpfs = hvc.hvc.frame_layout(planes)
+    # the resident batch as bench.py lays it out: planes and frames on 64 KiB / 2 MiB boundaries (hvc.layout_alignment)
+    specs, cfs, pfs = hvc.hvc.frame_layout(planes, align=1 if getattr(args, "tight", False) else "auto")
     comps = hvc.hvc.components(specs)
     ctx = hvc.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     # valid coefficients from the library's own forward path
     src = torch.from_numpy(np.stack([synth_frame_pixels(40 + 8 * f, planes) for f in range(args.distinct)])).cuda()
-    d_distinct = torch.zeros((args.distinct, cfs), dtype=torch.int16, device="cuda")
-    ctx.encode_frames(src, pfs, qtabs, comps, args.distinct, d_distinct, cfs)
+    d_distinct = torch.zeros((args.distinct, tcfs), dtype=torch.int16, device="cuda")
+    ctx.encode_frames(src, tpfs, qtabs, hvc.hvc.components(tspecs), args.distinct, d_distinct, tcfs)
     reps = (args.frames + args.distinct - 1) // args.distinct
-    d_coefs = d_distinct.repeat(reps, 1)[:args.frames].contiguous()
+    d_coefs = hvc.hvc.spread_records(d_distinct, tspecs, specs, cfs, "coef_offset").repeat(reps, 1)[:args.frames].contiguous()
     d_pix = torch.zeros((args.frames, pfs), dtype=torch.uint8, device="cuda")
     ctx.set_profiling(True)
     for _ in range(args.warmup):
@@ -153,7 +155,7 @@ def resident_decode(args, planes, W, H, tag):
     k_ms = float(np.mean(ctx.kernel_ms_history(min(args.steps, 64))))
     blocks = sum(bw * bh for bw, bh, _ in planes)
     algo = args.frames * blocks * 192
-    result = {**verify(ctx, d_pix, pfs, args.frames, "configs_c%d" % tag, args.distinct),
+    result = {**verify(ctx, hvc.hvc.tight_records(d_pix, specs, "plane_offset"), tpfs, args.frames, "configs_c%d" % tag, args.distinct),
                       "config": tag, "metric": "Mpixel/s decoded", "value": round(args.frames * args.steps * W * H / dt / 1e6, 1),
                       "unit": "Mpixel/s", "frames": args.frames, "blocks_per_frame": blocks, "kernel_ms": round(k_ms, 4),
                       "algorithmic_GBps": round(algo / (k_ms * 1e-3) / 1e9, 1), "frac_of_8TBps": round(algo / (k_ms * 1e-3) / 8e12, 4),
@@ -169,10 +171,11 @@ def config5(args):
     W, H = 3840, 2160
     planes = [(480, 270, 0), (240, 135, 1), (240, 135, 1)]
     ql, qc = hvc.hvc.quant_table(0, 75), hvc.hvc.quant_table(1, 75)
-    specs, cfs, pfs = hvc.hvc.frame_layout(planes)
+    tspecs, tcfs, tpfs = hvc.hvc.frame_layout(planes)
+    specs, cfs, pfs = hvc.hvc.frame_layout(planes, align=1 if getattr(args, "tight", False) else "auto")   # (as bench.py --config 5)
     recs = [synth_frame_pixels(60 + 8 * f, planes) for f in range(args.distinct)]
     reps = (args.frames + args.distinct - 1) // args.distinct
-    d_pix = torch.from_numpy(np.stack(recs)).cuda().repeat(reps, 1)[:args.frames].contiguous()
+    d_pix = hvc.hvc.spread_records(torch.from_numpy(np.stack(recs)).cuda(), tspecs, specs, pfs, "plane_offset").repeat(reps, 1)[:args.frames].contiguous()
     d_coefs = torch.zeros((args.frames, cfs), dtype=torch.int16, device="cuda")
     ctx = hvc.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -190,7 +193,7 @@ def config5(args):
     k_ms = float(np.mean(ctx.kernel_ms_history(min(args.steps, 64))))
     blocks = sum(bw * bh for bw, bh, _ in planes)
     algo = args.frames * blocks * 192
-    result = {**verify(ctx, d_coefs, cfs * 2, args.frames, "configs_c5", args.distinct),
+    result = {**verify(ctx, hvc.hvc.tight_records(d_coefs, specs, "coef_offset"), tcfs * 2, args.frames, "configs_c5", args.distinct),
                       "config": 5, "metric": "Mpixel/s encoded (fDCT + quantise, 4K 4:2:0)",
                       "value": round(args.frames * args.steps * W * H / dt / 1e6, 1), "unit": "Mpixel/s",
                       "frames": args.frames, "blocks_per_frame": blocks, "kernel_ms": round(k_ms, 4),
@@ -495,7 +498,7 @@ def config_convert(args):
 def make_args(**kw):
     """the argument object of the config functions for callers that are not this file's command line (bench.py)"""
     d = dict(frames=None, distinct=4, steps=None, warmup=10, threads=min(16, len(os.sched_getaffinity(0))), chunk=32,
-             gpu_entropy=False, host_out=False, own_tables=False, fused_only=False, restart_interval=0)
+             gpu_entropy=False, host_out=False, own_tables=False, fused_only=False, restart_interval=0, tight=False)
     d.update(kw)
     return argparse.Namespace(**d)
 
@@ -513,6 +516,7 @@ def main():
     ap.add_argument("--host-out", action="store_true", help="config 3: decoded frames to host memory instead of HBM")
     ap.add_argument("--own-tables", action="store_true", help="config 3: every file with Huffman tables optimised for itself")
     ap.add_argument("--fused-only", action="store_true", help="config 7: skip the three-launch composition")
+    ap.add_argument("--tight", action="store_true", help="configs 4 / 5: planes and frames back to back instead of on 64 KiB / 2 MiB boundaries (A/B)")
     ap.add_argument("--restart-interval", type=int, default=0, help="config 3: the files carry DRI / RSTn every so many MCUs (own tables too) and the readers honour them")
     args = ap.parse_args()
     if args.config == 2:  # K2 upsample (optional output stage)

@@ -192,15 +192,46 @@ def components(specs):
     return arr
 
 
-def frame_layout(planes_bw_bh_qtab):
-    """Tight frame record: component planes back to back.  Returns (specs,
-    coef elements per frame, pixel bytes per frame)."""
+def layout_alignment(planes_bw_bh_qtab):
+    """Where a resident batch's planes and frames should start (bytes): measured on MI355X, k_decode_packed and k_encode gain
+    0.4 ... 1.4 points of the HBM peak when every plane of every frame -- pixels and coefficients -- starts on a 64 KiB boundary
+    (frames below 8 MiB of pixels: 1080p) or a 2 MiB boundary (larger frames: 4K); 2 MiB costs 1080p frames 1.3 points
+    (profiles/r05l_alignment_sweep.txt, profiles/ANALYSIS.md section 7).  The padding is neither read nor written."""
+    return 65536 if sum(bw * bh * 64 for bw, bh, _ in planes_bw_bh_qtab) < (8 << 20) else (2 << 20)
+
+
+def frame_layout(planes_bw_bh_qtab, align=1):
+    """Frame record: component planes back to back, each starting on an `align`-byte boundary (1 = tight, the default;
+    "auto" = layout_alignment()), pixel planes and coefficient planes alike; the frame strides are rounded up the same way.
+    Returns (specs, coef elements per frame, pixel bytes per frame)."""
+    if align == "auto":
+        align = layout_alignment(planes_bw_bh_qtab)
+    up = lambda x: (x + align - 1) // align * align
     specs, co, po = [], 0, 0
     for bw, bh, qt in planes_bw_bh_qtab:
+        co, po = up(co * 2) // 2, up(po)
         specs.append(dict(blocks_w=bw, blocks_h=bh, qtab=qt, coef_offset=co, plane_offset=po, stride=bw * 8))
         co += bw * bh * 64
         po += bw * bh * 64
-    return specs, co, po
+    return specs, up(co * 2) // 2, up(po)
+
+
+def tight_records(t, specs, which):
+    """the planes of a batch laid out by frame_layout(..., align) gathered into tight records (torch tensor [n, stride] ->
+    [n, sum of the planes]): which = "plane_offset" (pixel bytes) or "coef_offset" (int16 elements) -- what the K5 golden
+    checksums are defined on, whatever the resident layout"""
+    import torch
+    return torch.cat([t[:, s[which]:s[which] + s["blocks_w"] * s["blocks_h"] * 64] for s in specs], dim=1).contiguous()
+
+
+def spread_records(tight, specs_tight, specs, stride, which):
+    """the inverse: tight records [n, ...] into a zeroed batch [n, stride] laid out by `specs`"""
+    import torch
+    out = torch.zeros((tight.shape[0], stride), dtype=tight.dtype, device=tight.device)
+    for a, b in zip(specs_tight, specs):
+        n = a["blocks_w"] * a["blocks_h"] * 64
+        out[:, b[which]:b[which] + n] = tight[:, a[which]:a[which] + n]
+    return out
 
 
 # -- host front end / back end (no GPU needed) ------------------------------------------------
