@@ -193,11 +193,17 @@ def components(specs):
 
 
 def layout_alignment(planes_bw_bh_qtab):
-    """Where a resident batch's planes and frames should start (bytes): measured on MI355X, k_decode_packed and k_encode gain
-    0.4 ... 1.4 points of the HBM peak when every plane of every frame -- pixels and coefficients -- starts on a 64 KiB boundary
-    (frames below 8 MiB of pixels: 1080p) or a 2 MiB boundary (larger frames: 4K); 2 MiB costs 1080p frames 1.3 points
-    (profiles/r05l_alignment_sweep.txt, profiles/ANALYSIS.md section 7).  The padding is neither read nor written."""
-    return 65536 if sum(bw * bh * 64 for bw, bh, _ in planes_bw_bh_qtab) < (8 << 20) else (2 << 20)
+    """Where a resident batch's planes and frames should start (bytes).  Measured on MI355X (profiles/r05l_alignment_sweep.txt,
+    r05m / r05n_layout_ab.txt, profiles/ANALYSIS.md section 7): with every plane of every frame -- pixels and coefficients -- on a
+    64 KiB boundary k_decode_packed gains 0.4 ... 1.0 points of the HBM peak on 1080p 4:2:0 frames, whose second chroma plane
+    otherwise starts 2 KiB off a 4 KiB boundary; 2 MiB boundaries give k_encode 0.6 ... 1.2 points on 4K 4:2:0 frames -- and cost 1080p
+    frames 1.3 points, because they nearly double that batch's footprint.  So: the larger of 2 MiB / 64 KiB whose padding stays
+    under 3 % of the frame.  The padding is neither read nor written."""
+    tight = sum(bw * bh * 64 for bw, bh, _ in planes_bw_bh_qtab)
+    for a in (2 << 20, 65536):
+        if sum((bw * bh * 64 + a - 1) // a * a for bw, bh, _ in planes_bw_bh_qtab) <= 1.03 * tight:
+            return a
+    return 65536
 
 
 def frame_layout(planes_bw_bh_qtab, align=1):
