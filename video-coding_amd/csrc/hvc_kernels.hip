@@ -1280,9 +1280,11 @@ __device__ __forceinline__ int vmad24(int k, int x, int acc) {
 // (Round 4 tried the rotations as one v_dot2_i32_i16 per output on int16 operand pairs packed once per pair: 80 VALU
 // instructions per block fewer (1062 -> 982) and 72 VGPRs -- and 0.3 - 0.7 points SLOWER than this form on the same box,
 // three alternations: profiles/r04q_k3_dot2_ab.txt.  K3 does not wait for its VALU.)
-// K3 is bound by VALU issue, not by its LDS transpose or its memory shape: 827.6 M wave-instructions per 256-frame launch
-// at 4 cycles each = 97 % of the 1024 SIMDs' cycles (rocprofv3 SQ_INSTS_VALU / GRBM_GUI_ACTIVE; SQ_WAIT_INST_LDS 0.04 % of
-// the wave cycles, no bank conflicts: profiles/r05c_k3_pmc.txt) -- which is why it sat 1 - 2 points under its own
+// What held K3 under its own traffic-only build was the time its instructions take to issue, not its LDS transpose: 827.6 M
+// wave-instructions per 256-frame launch -- 97 % of the 1024 SIMDs' cycles at the 4 cycles SQ_ACTIVE_INST_VALU books each at, about
+// 70 % by the measured issue times (profiles/r01_valu_ubench.txt) -- with SQ_WAIT_INST_LDS at 0.04 % of the wave cycles and no bank
+// conflicts (profiles/r05c_k3_pmc.txt): little slack for 5 waves per SIMD to hide a memory-bound kernel's latencies behind.  It sat 1 - 2
+// points under that
 // traffic-only build.  HVC_ENCODE_MULHI=1 (shipped) takes 80 of the 1062 instructions per block out -- c4 as one
 // v_mul_hi_i32_i24 on operands pre-shifted by the add or mad that makes them, the quantiser's products two at a time
 // (v_pk_mul_f32) -- and reads 75.3 - 76.7 % where the 0 form reads 73.5 - 74.1 %, its traffic-only build 74.9 - 77.4 %
