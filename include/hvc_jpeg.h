@@ -203,16 +203,6 @@ HVC_API int hvc_decode_frames_yuv444(hvc_ctx *ctx, const int16_t *coefs, size_t 
                                      const uint16_t *qtabs, int n_qtabs, const hvc_component *comps,
                                      int n_comp, int n_frames, int width, int height, uint8_t *frames,
                                      size_t frame_stride, int where);
-/* The same with the three output planes plane_stride bytes apart instead of back to back (plane p of frame f at
- * frames + f*frame_stride + p*plane_stride; plane_stride >= width*height, frame_stride >= 2*plane_stride + width*height):
- * for results that stay on the device.  A tight 1920 x 1080 x 3 frame leaves its planes on 1 KiB boundaries; with every plane
- * on a 64 KiB boundary the kernel gains about a point of the HBM peak (profiles/r05p_444_geometry.txt).  The gaps are
- * never written.  Device memory only (HVC_E_INVALID_ARG for host output with gaps: a host frame is the tight one).  The
- * 16-byte store form needs plane_stride % 16 == 0 (else the byte path, as for odd widths). */
-HVC_API int hvc_decode_frames_yuv444_planes(hvc_ctx *ctx, const int16_t *coefs, size_t coef_frame_stride,
-                                            const uint16_t *qtabs, int n_qtabs, const hvc_component *comps,
-                                            int n_comp, int n_frames, int width, int height, uint8_t *frames,
-                                            size_t frame_stride, size_t plane_stride, int where);
 
 /* Diagnostic: which implementation the decode entry points use.  0 = default (k_decode_packed, the
  * int16-pair block-per-lane kernel, with the int64 fix-up for blocks outside its proven range), 1 = the

@@ -113,17 +113,6 @@ let decode_frames_yuv444 =
     @-> int @-> ptr char @-> size_t @-> int @-> returning int)
 ;;
 
-(* int hvc_decode_frames_yuv444_planes(ctx, coefs, coef_frame_stride, qtabs, n_qtabs, comps, n_comp, n_frames,
-                                       width, height, frames, frame_stride, plane_stride, where)
-   the same with the output planes plane_stride bytes apart (device-resident results on aligned boundaries) *)
-let decode_frames_yuv444_planes =
-  foreign
-    "hvc_decode_frames_yuv444_planes"
-    ~release_runtime_lock:true
-    (ctx @-> ptr int16_t @-> size_t @-> ptr uint16_t @-> int @-> ptr Component.t @-> int @-> int @-> int
-    @-> int @-> ptr char @-> size_t @-> size_t @-> int @-> returning int)
-;;
-
 (* int hvc_fdct_quant(ctx, plane, stride, plane_stride, qtab, blocks_w, blocks_h, n_planes, coefs,
                       coef_plane_stride, where)                               encoder.ml:81-108; dct.ml:109-196 *)
 let fdct_quant =

@@ -255,44 +255,3 @@ def test_split_launch_modes_give_the_same_frames():
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu"], cwd=root,
                            env=dict(os.environ, HVC_444_MODE=mode), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and " passed" in r.stdout, (mode, r.stdout[-2000:], r.stderr[-2000:])
-
-
-@pytest.mark.parametrize("w,h,gap", [(1920, 1080, 65536), (64, 48, 16), (52, 44, 40), (130, 70, 7)])
-def test_output_planes_apart_give_the_same_planes_and_leave_the_gaps(w, h, gap):
-    """hvc_decode_frames_yuv444_planes: the three planes `plane_stride` bytes apart (aligned boundaries for device-resident results)
-    hold what the tight frame holds, and what lies between them is not written; host output with gaps is refused"""
-    import torch
-    import video_coding_amd as hvc
-    ctx = hvc.Context(0)
-    try:
-        bw, bh = (w + 15) // 16 * 2, (h + 15) // 16 * 2
-        planes = [(bw, bh, 0), (bw // 2, bh // 2, 1), (bw // 2, bh // 2, 1)]
-        specs, cfs, pfs = hvc.hvc.frame_layout(planes)
-        qtabs = np.stack([orc.quant_scale(orc.quant_luma(), 70), orc.quant_scale(orc.quant_chroma(), 70)]).astype(np.uint16)
-        n = 3
-        pix = np.stack([np.concatenate([synth_pixels(7 * f + b, hh * 8, ww * 8).reshape(-1) for b, (ww, hh, _) in enumerate(planes)]) for f in range(n)])
-        coefs = np.zeros((n, cfs), dtype=np.int16)
-        ctx.encode_frames(pix, pfs, qtabs, specs, n, coefs, cfs)
-        d_coefs = torch.from_numpy(coefs).cuda()
-        tight = torch.zeros((n, 3 * w * h), dtype=torch.uint8, device="cuda")
-        ps = (w * h + gap - 1) // gap * gap if gap >= 16 else w * h + gap
-        fs = 3 * ps + 5 * 16
-        apart = torch.full((n, fs), 0x3c, dtype=torch.uint8, device="cuda")
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        try:
-            ctx.decode_frames_yuv444(d_coefs, cfs, qtabs, specs, n, w, h, tight)
-            ctx.decode_frames_yuv444(d_coefs, cfs, qtabs, specs, n, w, h, apart, frame_stride=fs, plane_stride=ps)
-            ctx.synchronize()
-        finally:
-            ctx.reset_stream()
-        a, t = apart.cpu().numpy(), tight.cpu().numpy()
-        mask = np.ones(fs, dtype=bool)
-        for p in range(3):
-            assert np.array_equal(a[:, p * ps:p * ps + w * h], t[:, p * w * h:(p + 1) * w * h]), p
-            mask[p * ps:p * ps + w * h] = False
-        assert (a[:, mask] == 0x3c).all()
-        with pytest.raises(hvc.HvcError) as e:   # host output is the tight frame
-            ctx.decode_frames_yuv444(coefs, cfs, qtabs, specs, n, w, h, np.zeros((n, fs), dtype=np.uint8), frame_stride=fs, plane_stride=ps)
-        assert e.value.code == -1
-    finally:
-        ctx.close()

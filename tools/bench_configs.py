@@ -251,15 +251,12 @@ def config_444(args):
     ctx.encode_frames(src, pfs, qtabs, comps, args.distinct, d_distinct, cfs)
     n = args.frames
     d_coefs = d_distinct.repeat((n + args.distinct - 1) // args.distinct, 1)[:n].contiguous()
-    # the three output planes of every frame on 64 KiB boundaries (hvc_decode_frames_yuv444_planes): a tight 1920 x 1080 x 3 frame leaves
-    # them on 1 KiB boundaries, about a point of the HBM peak (profiles/r05p_444_geometry.txt); --tight = the tight frame
-    ps = W * H if getattr(args, "tight", False) else (W * H + 65535) // 65536 * 65536
-    d_out = torch.zeros((n, 3 * ps), dtype=torch.uint8, device="cuda")
+    d_out = torch.zeros((n, 3 * W * H), dtype=torch.uint8, device="cuda")
     d_pix = torch.zeros((n, pfs), dtype=torch.uint8, device="cuda")
     d_ref = torch.zeros((n, 3 * W * H), dtype=torch.uint8, device="cuda")
 
     def fused():
-        ctx.decode_frames_yuv444(d_coefs, cfs, qtabs, comps, n, W, H, d_out, frame_stride=3 * ps, plane_stride=ps)
+        ctx.decode_frames_yuv444(d_coefs, cfs, qtabs, comps, n, W, H, d_out)
 
     def separate():
         ctx.decode_frames(d_coefs, cfs, qtabs, comps, n, d_pix, pfs)
@@ -278,10 +275,8 @@ def config_444(args):
         res[name] = ctx.timer_end() / args.steps
     blocks_needed = 240 * 135 + 2 * 120 * 68
     algo = n * (blocks_needed * 128 + 3 * W * H)
-    fused()  # (the separate path ran last: the fused output once more)
-    tight = torch.cat([d_out[:, p * ps:p * ps + W * H] for p in range(3)], dim=1).contiguous()   # (K5 is defined on the tight frame)
-    result = {**verify(ctx, tight, 3 * W * H, n, "configs_c7", args.distinct),
-                      "output_plane_stride": ps,
+    ctx.decode_frames_yuv444(d_coefs, cfs, qtabs, comps, n, W, H, d_out)  # (the separate path ran last: the fused output once more)
+    result = {**verify(ctx, d_out, 3 * W * H, n, "configs_c7", args.distinct),
                       "config": "444", "metric": "Mpixel/s decoded to 4:4:4 (1080p 4:2:0 in)", "frames": n,
                       "fused_ms": round(res["fused"], 4), "separate_ms": round(res["separate"], 4) if "separate" in res else None,
                       "value": round(n * W * H / (res["fused"] * 1e-3) / 1e6, 1), "unit": "Mpixel/s",

@@ -795,7 +795,7 @@ int hvc_decode_frames(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const ui
 int decode_frames_yuv444_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const uint16_t *qtabs, int n_qtabs,
                               const hvc_component *comps, int n_comp, int n_frames, int width, int height, uint8_t *frames,
                               size_t frame_stride, int where, const int16_t *dc_plane, size_t dc_fs,
-                              const std::vector<WideFix> *wide, size_t plane_stride) {
+                              const std::vector<WideFix> *wide) {
     if (!c || !coefs || !frames || !comps || n_frames < 0) return HVC_E_INVALID_ARG;
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
     int r = check_qtabs(qtabs, n_qtabs, false);
@@ -815,11 +815,7 @@ int decode_frames_yuv444_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, 
     const int aw[3] = {width, width / 2, width / 2}, ah[3] = {height, height / 2, height / 2};
     for (int i = 0; i < 3; i++) // the crop must lie inside the decoded planes (decoder.ml:403-413)
         if (comps[i].blocks_w * 8 < aw[i] || comps[i].blocks_h * 8 < ah[i]) return HVC_E_INVALID_ARG;
-    const size_t plane_bytes = (size_t)width * (size_t)height;
-    if (plane_stride == 0) plane_stride = plane_bytes; // the tight frame: Y, U, V back to back
-    if (plane_stride < plane_bytes) return HVC_E_INVALID_ARG;
-    if (plane_stride != plane_bytes && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG; // (host output is the tight frame)
-    const size_t out_span = 2 * plane_stride + plane_bytes;
+    const size_t plane_bytes = (size_t)width * (size_t)height, out_span = 3 * plane_bytes;
     if (n_frames == 0) return HVC_OK;
     if (n_frames > 65535) return HVC_E_TOO_LARGE;
     if (n_frames > 1 && (coef_fs < L.coef_span || frame_stride < out_span)) return HVC_E_INVALID_ARG;
@@ -841,14 +837,13 @@ int decode_frames_yuv444_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, 
         K.ah = ah[i];
         K.qtab = comps[i].qtab;
         K.coef_off = comps[i].coef_offset;
-        K.out_off = (size_t)i * plane_stride;
+        K.out_off = (size_t)i * plane_bytes;
     }
     // umulhi(b, ceil(2^32 / d)) == b / d needs b * d < 2^32
     if ((unsigned long long)P.pl[0].cbw * P.pl[0].cbw * P.pl[0].cbh >= (1ull << 32)) return HVC_E_TOO_LARGE;
     // the 16-byte store form (and with it the wide chroma tiles) needs aligned rows: device output as the caller gave it,
     // host output through the library's own (256-byte aligned) scratch
-    const bool aligned = width % 16 == 0 && frame_stride % 16 == 0 && plane_stride % 16 == 0 &&
-                         (where == HVC_MEM_HOST || (uintptr_t)frames % 16 == 0);
+    const bool aligned = width % 16 == 0 && frame_stride % 16 == 0 && (where == HVC_MEM_HOST || (uintptr_t)frames % 16 == 0);
     hvc::plan_decode_444(P, aligned);
     const unsigned long long ids = (unsigned long long)n_frames * P.tiles_per_frame * HVC_TILE * P.nw;
     if (ids >= (1ull << 32)) return HVC_E_TOO_LARGE;
@@ -1028,14 +1023,6 @@ int hvc_decode_frames_yuv444(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, c
                              uint8_t *frames, size_t frame_stride, int where) try {
     return decode_frames_yuv444_impl(c, coefs, coef_fs, qtabs, n_qtabs, comps, n_comp, n_frames, width, height, frames,
                                      frame_stride, where, nullptr, 0);
-} HVC_ABI_CATCH
-
-int hvc_decode_frames_yuv444_planes(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const uint16_t *qtabs, int n_qtabs,
-                                    const hvc_component *comps, int n_comp, int n_frames, int width, int height,
-                                    uint8_t *frames, size_t frame_stride, size_t plane_stride, int where) try {
-    if (plane_stride == 0) return HVC_E_INVALID_ARG;
-    return decode_frames_yuv444_impl(c, coefs, coef_fs, qtabs, n_qtabs, comps, n_comp, n_frames, width, height, frames,
-                                     frame_stride, where, nullptr, 0, nullptr, plane_stride);
 } HVC_ABI_CATCH
 
 int hvc_dequant_idct_recon(hvc_ctx *c, const int16_t *coefs, size_t coef_plane_stride, const uint16_t *qtab,

@@ -280,7 +280,7 @@ int decode_frames_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const u
 int decode_frames_yuv444_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const uint16_t *qtabs, int n_qtabs,
                               const hvc_component *comps, int n_comp, int n_frames, int width, int height, uint8_t *frames,
                               size_t frame_stride, int where, const int16_t *dc_plane, size_t dc_fs,
-                              const std::vector<WideFix> *wide = nullptr, size_t plane_stride = 0 /* width * height */);
+                              const std::vector<WideFix> *wide = nullptr);
 
 // after_reader (optional): called once the reader's launches are enqueued and BEFORE its verdict is known -- the caller
 // enqueues what consumes the records (block stage, download) on the same stream, so that one call costs one host

@@ -20,7 +20,7 @@ SYMBOLS = [
     "hvc_device_free", "hvc_memcpy_h2d", "hvc_memcpy_d2h",
     "hvc_jpeg_read_header", "hvc_jpeg_entropy_decode", "hvc_jpeg_get_yuv_frame", "hvc_jpeg_decode",
     "hvc_jpeg_decode_batch", "hvc_quant_table", "hvc_jpeg_encoder_layout", "hvc_jpeg_entropy_encode",
-    "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444", "hvc_decode_frames_yuv444_planes", "hvc_jpeg_decode_yuv444", "hvc_compare_planes", "hvc_jpeg_encode_batch", "hvc_jpeg_decode_batch_yuv444", "hvc_jpeg_encoder_check", "hvc_huffman_encode_frames", "hvc_jpeg_header", "hvc_jpeg_encode_batch_gpu", "hvc_jpeg_entropy_decode_gpu", "hvc_jpeg_decode_batch_gpu",
+    "hvc_jpeg_encode", "hvc_set_decode_kernel", "hvc_reset_stream", "hvc_decode_frames_yuv444", "hvc_jpeg_decode_yuv444", "hvc_compare_planes", "hvc_jpeg_encode_batch", "hvc_jpeg_decode_batch_yuv444", "hvc_jpeg_encoder_check", "hvc_huffman_encode_frames", "hvc_jpeg_header", "hvc_jpeg_encode_batch_gpu", "hvc_jpeg_entropy_decode_gpu", "hvc_jpeg_decode_batch_gpu",
     "hvc_checksum_records", "hvc_encode_frames_recon", "hvc_set_host_cpus", "hvc_get_host_cpus",
     "hvc_host_threads", "hvc_host_threads_probe", "hvc_jpeg_entropy_decode2", "hvc_jpeg_get_cropped_planes",
     "hvc_jpeg_entropy_decode_restart", "hvc_set_restart_markers",
@@ -117,7 +117,6 @@ def lib():
         L.hvc_dequant_idct_recon.argtypes = [vp, vp, sz, vp, i, i, i, vp, sz, sz, i]
         L.hvc_decode_frames.argtypes = [vp, vp, sz, vp, i, C.POINTER(Component), i, i, vp, sz, i]
         L.hvc_decode_frames_yuv444.argtypes = [vp, vp, sz, vp, i, C.POINTER(Component), i, i, i, i, vp, sz, i]
-        L.hvc_decode_frames_yuv444_planes.argtypes = [vp, vp, sz, vp, i, C.POINTER(Component), i, i, i, i, vp, sz, sz, i]
         L.hvc_last_wide_blocks.argtypes = [vp, C.POINTER(C.c_uint64)]
         if hasattr(L, "hvc_fdct_quant"):
             L.hvc_fdct_quant.argtypes = [vp, vp, sz, sz, vp, i, i, i, vp, sz, i]
@@ -452,20 +451,13 @@ class Context:
                                      n_frames, pa, pixel_frame_stride, w1))
 
     def decode_frames_yuv444(self, coefs, coef_frame_stride, qtabs, comps, n_frames, width, height, frames,
-                             frame_stride=None, plane_stride=None):
-        """4:2:0 coefficient records -> tight 4:4:4 frames (block stage + crop + supersample_hv2 fused); plane_stride: the
-        three planes that many bytes apart instead of back to back (hvc_decode_frames_yuv444_planes)."""
+                             frame_stride=None):
+        """4:2:0 coefficient records -> tight 4:4:4 frames (block stage + crop + supersample_hv2 fused)."""
         ca, w1 = _addr(coefs)
         fa, w2 = _addr(frames)
         assert w1 == w2
         q = np.ascontiguousarray(qtabs, dtype=np.uint16).reshape(-1, 64)
         arr = comps if not isinstance(comps, list) else components(comps)
-        if plane_stride is not None:
-            fs = 2 * plane_stride + width * height if frame_stride is None else frame_stride
-            _chk(lib().hvc_decode_frames_yuv444_planes(self._h, ca, coef_frame_stride, q.ctypes.data, q.shape[0], arr, len(arr),
-                                                       n_frames, width, height, fa, fs, plane_stride, w1),
-                 "hvc_decode_frames_yuv444_planes")
-            return
         _chk(lib().hvc_decode_frames_yuv444(self._h, ca, coef_frame_stride, q.ctypes.data, q.shape[0], arr, len(arr),
                                             n_frames, width, height, fa,
                                             3 * width * height if frame_stride is None else frame_stride, w1),
