@@ -86,6 +86,17 @@ def test_bench_line_is_verified_against_the_golden_checksums():
     assert su["wall_s"] >= 0.5 and su["steps"] >= 64 and su["output_unchanged"] is True and 0 < su["first_decile_ms"] < 50
 
 
+def test_bench_layouts_aligned_and_tight_decode_the_same_frames():
+    """bench.py lays its resident batch out with every plane on a 64 KiB / 2 MiB boundary (hvc.layout_alignment); --tight = planes back
+    to back.  Both verify against the same golden checksums (K5 runs on the planes gathered tight), configs 2 and 5."""
+    for extra in ([], ["--config", "5"]):
+        recs = [_run_bench(extra + ["--steps", "2", "--warmup", "1", "--frames", "32", "--no-cpu-baseline", "--no-others", "--sustain-seconds", "0"] + t)
+                for t in ([], ["--tight"])]
+        assert "boundary" in recs[0]["config"]["layout"] and "tight" in recs[1]["config"]["layout"]
+        assert all(r["checksum"]["verified"] is True for r in recs)
+        assert recs[0]["checksum"]["rank0"] == recs[1]["checksum"]["rank0"]
+
+
 def test_bench_n_rank_path_on_one_gpu():
     """HVC_BENCH_REHEARSAL=1 python bench.py --gpus 2, as typed: bench.py starts the two ranks itself (both on
     cuda:0, gloo for the timing closure), each decodes its own shard, both outputs are verified."""
