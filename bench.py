@@ -156,13 +156,25 @@ def cpu_baseline(frames, qtabs, planes, pixels_per_frame, min_seconds=10.0):
 DOMINANT_KERNEL = "k_decode_packed"   # what this file's step launches (hvc_decode_frames, default kernel choice)
 
 
-def measured_traffic(config, frames, kernel=DOMINANT_KERNEL):
+def running_build():
+    """the kernel id of the library this process runs (hvc_version: the hash of the kernel sources it was built from)"""
+    try:
+        import video_coding_amd as hvc
+        return hvc.hvc.kernel_build_id()
+    except Exception:
+        return None
+
+
+def measured_traffic(config, frames, kernel=DOMINANT_KERNEL, build="running"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate --pmc runs of this very
     command and corrected as MI355X_MICROARCH.md prescribes).  bench.py cannot collect counters
     itself: (None, reason) when the profile is absent, was taken at another configuration or launch
-    size, or belongs to another kernel than the one this run launched (an entry names its kernel
-    symbol; one that does not is not trusted)."""
+    size, belongs to another kernel than the one this run launched (an entry names its kernel
+    symbol; one that does not is not trusted), or was taken on ANOTHER BUILD of the kernels than the
+    one running now (an entry carries the kernel id of hvc_version(); one without it is stale)."""
+    if build == "running":
+        build = running_build()
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
@@ -170,11 +182,14 @@ def measured_traffic(config, frames, kernel=DOMINANT_KERNEL):
         for e in t.get("entries", [t]):
             if e.get("frames_per_launch") == frames and e.get("config", 2) == config:
                 if not str(e.get("kernel", "")).startswith(kernel):
-                    stale = "profiles/traffic.json has a pass for this configuration, but of kernel %r, not %r: not reported" % (e.get("kernel"), kernel)
+                    stale = stale or "profiles/traffic.json has a pass for this configuration, but of kernel %r, not %r: not reported" % (e.get("kernel"), kernel)
                     continue
-                return round(e["hbm_bytes"]), "profiles/traffic.json (session %s, kernel %s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
-                                              "%s, not collected in this run" % (e.get("session") or "r01f", e["kernel"],
-                                                                                 "this command" if config in (2, 4) else e.get("source", "the same workload"))
+                if e.get("build") != build:
+                    stale = stale or "stale: profiled build %s (session %s), running build %s: not reported" % (e.get("build"), e.get("session"), build)
+                    continue
+                return round(e["hbm_bytes"]), "profiles/traffic.json (session %s, build %s, kernel %s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
+                                              "%s, not collected in this run" % (e.get("session"), e["build"], e["kernel"],
+                                                                                 "this command" if config in (2, 3, 4) else e.get("source", "the same workload"))
         return None, stale or "no committed PMC pass for config %d at %d frames per launch" % (config, frames)
     except (OSError, ValueError, KeyError):
         return None, "profiles/traffic.json absent"
@@ -227,10 +242,22 @@ def other_measurements(threads):
                                7, 512, "k_decode_444", r["algorithmic_bytes"]))
     run("k2_upsample420_512_planes", lambda: bc.config_k2(bc.make_args(frames=256, steps=100, warmup=50)), "hbm", kern)
     run("subsample420_512_planes", lambda: bc.config_sub420(bc.make_args(frames=256, steps=100, warmup=50)), "hbm", kern)
+    # the int64 kernel as a whole call: hvc_set_decode_kernel(ctx, 2), and a DQT entry above 255
+    wide = lambda r: dict(kern(r), Gpixel_s=round(r["value"] / 1e3, 2), frames=r["frames"], wide_path_blocks=r["wide_path_blocks"])
+    run("wide_only_64x1080p", lambda: bc.config_wide(bc.make_args(frames=64, steps=20, warmup=5, wide_mode="kernel2")), "valu (int64)", wide)
+    run("wide_dqt16_64x1080p", lambda: bc.config_wide(bc.make_args(frames=64, steps=20, warmup=5, wide_mode="dqt16")), "valu (int64)", wide)
+    # the asynchronous seam: the CALLER's reader fills pinned slots, hvc_decode_frames_submit / hvc_wait
+    seam = lambda r: dict(pipe(r), h2d_GBps=r["h2d_GBps"], d2h_GBps=r["d2h_GBps"], refill_GBps=r["refill_GBps"],
+                          overlap_fraction=r["overlap_fraction"], slots=r["slots"], frames_per_slot=r["frames_per_slot"],
+                          records_verified=r["checksum"]["records"])
+    run("async_seam_4096x1080p_to_hbm", lambda: bc.config_async(bc.make_args(frames=4096, steps=2, threads=threads, chunk=64)), "pcie", seam)
+    run("async_seam_2048x1080p_to_pinned_host", lambda: bc.config_async(bc.make_args(frames=2048, steps=2, threads=threads, chunk=64, host_out=True)),
+        "pcie", seam)
     # BASELINE config 3 at its own size (4096 x 1080p files), config 5 end to end on 256 x 4K frames
-    run("config3_host_reader_4096_files", lambda: bc.config3(bc.make_args(frames=4096, steps=2, threads=threads, chunk=32)), "host", pipe)
+    pipe3 = lambda r: dict(pipe(r), h2d_GBps=r["h2d_GBps"], overlap_fraction=r["overlap_fraction"])
+    run("config3_host_reader_4096_files", lambda: bc.config3(bc.make_args(frames=4096, steps=2, threads=threads, chunk=32)), "host", pipe3)
     run("config3_gpu_reader_4096_files", lambda: bc.config3(bc.make_args(frames=4096, steps=2, threads=threads, chunk=256, gpu_entropy=True)),
-        "pcie", pipe)
+        "pcie", pipe3)
     run("config5_files_host_coder_256_frames", lambda: bc.config5_files(bc.make_args(frames=256, steps=2, threads=threads, chunk=16)), "host", pipe)
     run("config5_files_gpu_coder_256_frames", lambda: bc.config5_files(bc.make_args(frames=256, steps=2, threads=threads, chunk=16, gpu_entropy=True)),
         "pcie", pipe)
@@ -599,7 +626,12 @@ def run_files(args, rank, world, local_rank, rehearsal):
         readers[reader] = {
             "value": round(world * n * args.steps * PW * PH / dt / 1e6, 1), "unit": "Mpixel/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
             "timed_region_s": round(dt, 4), "frames_per_chunk": timed[-1].frames_per_chunk, "chunks": timed[-1].chunks,
-            "h2d_MB_per_step": round(timed[-1].coef_bytes / 1e6, 1), "verified": chk["verified"], "ranks_verified": ranks_ok,
+            "h2d_MB_per_step": round(timed[-1].coef_bytes / 1e6, 1),
+            "h2d_GBps": round(timed[-1].coef_bytes / (max(h_ms, 1e-9) * 1e-3) / 1e9, 1),
+            # how much of the stages' time the pipeline hides: 1 - wall / (entropy / threads + upload + kernels)
+            "overlap_fraction": round(1.0 - (dt_local / args.steps * 1e3) / max(e_ms / threads + h_ms + k_ms, 1e-9), 3),
+            "kernel_launch_frames": timed[-1].frames_per_chunk,
+            "verified": chk["verified"], "ranks_verified": ranks_ok,
             "checksum_rank0": chk["distinct"],
             "per_rank": {"wall_ms_entropy_thread_ms_sum_h2d_ms_kernel_ms_threads": [[round(x, 2) for x in r] for r in per_rank],
                          "slowest_over_fastest": round(max(r[0] for r in per_rank) / min(r[0] for r in per_rank), 4)},
@@ -610,6 +642,9 @@ def run_files(args, rank, world, local_rank, rehearsal):
     ok = all(r["ranks_verified"] == world for r in readers.values())
     if rank == 0:
         host, gpu_r = readers["host"], readers["gpu"]
+        # the chunk-sized k_decode_packed launches of the host-reader pipeline: a committed PMC pass of this command
+        traffic, traffic_source = measured_traffic(3, host["kernel_launch_frames"], "k_decode_packed")
+        chunk_algo = host["kernel_launch_frames"] * blocks_per_frame * ALGO_BYTES_PER_BLOCK
         out = {"metric": wl["metric"], "value": host["value"], "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": host["ms_per_step"], "timed_region_s": host["timed_region_s"],
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32",
@@ -622,7 +657,10 @@ def run_files(args, rank, world, local_rank, rehearsal):
                           "parallelism": "the file batch split over the GPUs, no collective; host threads = the rank's share of its GPU's NUMA node"},
                "roofline": {"bound": "hbm", "kernel": "k_decode_packed", "achieved": host["k_decode_packed_algorithmic_GBps"],
                             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(host["k_decode_packed_algorithmic_GBps"] / HBM_PEAK_GBPS, 4),
-                            "traffic": None, "traffic_source": "no PMC pass of this configuration",
+                            "traffic": traffic, "traffic_source": traffic_source,
+                            "algorithmic_bytes_per_launch": chunk_algo,
+                            "traffic_over_algorithmic": round(traffic / chunk_algo, 4) if traffic else None,
+                            "h2d_GBps": host["h2d_GBps"], "overlap_fraction": host["overlap_fraction"],
                             "note": "chunk-sized launches inside a HOST-bound pipeline (GPU busy %.1f %% of the step): the kernel's own "
                                     "roofline figure is config 2's line" % (100 * host["gpu_busy_fraction"])},
                "checksum": {"kernel": "k_checksum (K5, hvc_checksum_records) over EVERY decoded frame", "verified": host["verified"],
@@ -796,16 +834,50 @@ def main():
     kernel_ms = ctx.kernel_ms_history(min(args.steps * launches, 64))
     wide = ctx.last_wide_blocks()
     # K5: what was decoded -- the distinct frames' pixel records, checksummed where they are
+    # ... EVERY record of the resident batch (record r holds distinct frame r % distinct), gathered tight a piece at a time
     def output_checksums():
-        k = min(args.distinct, held)
-        return [int(x) for x in ctx.checksum_records(hvc.hvc.tight_records(d_pix[:k], specs, "plane_offset"), tpfs, k)]
+        sums = []
+        for f0 in range(0, held, 128):
+            k = min(128, held - f0)
+            sums += [int(x) for x in ctx.checksum_records(hvc.hvc.tight_records(d_pix[f0:f0 + k], specs, "plane_offset"), tpfs, k)]
+        return sums
 
     sums = output_checksums()
-    want = expected_checksums(args.config, len(sums), rank) if args.distinct <= 8 else None
+    want_distinct = expected_checksums(args.config, min(args.distinct, held), rank) if args.distinct <= 8 else None
+    want = [want_distinct[r % args.distinct] for r in range(held)] if want_distinct is not None else None
     sustained = sustained_run(step, args.sustain_seconds, launches)  # (after everything `value` is made of)
     if sustained is not None:  # ... and what the sustained run left behind is still the model's output
         again = output_checksums()
         sustained["output_unchanged"] = again == sums
+    # The other layout beside the headline's: the same frames with planes and frames back to back -- what every
+    # library entry point that lays records out itself produces -- timed by the same events right after; never part of `value`.
+    other_layout = None
+    if launches == 1 and world == 1 and args.sustain_seconds > 0:
+        try:
+            o_align = hvc.hvc.layout_alignment(planes) if args.tight else 1
+            ospecs, ocfs, opfs = hvc.hvc.frame_layout(planes, align=o_align)
+            o_coefs = hvc.hvc.spread_records(d_distinct, tspecs, ospecs, ocfs, "coef_offset").repeat(
+                (held + args.distinct - 1) // args.distinct, 1)[:held].contiguous()
+            o_pix = torch.zeros((held, opfs), dtype=torch.uint8, device="cuda")
+            ocomps = hvc.hvc.components(ospecs)
+            for _ in range(10):
+                ctx.decode_frames(o_coefs, ocfs, qtabs, ocomps, held, o_pix, opfs)
+            torch.cuda.synchronize()
+            ctx.set_profiling(True)
+            for _ in range(30):
+                ctx.decode_frames(o_coefs, ocfs, qtabs, ocomps, held, o_pix, opfs)
+            o_ms = float(np.mean(ctx.kernel_ms_history(30)))
+            o_sums = []
+            for f0 in range(0, held, 128):
+                k = min(128, held - f0)
+                o_sums += [int(x) for x in ctx.checksum_records(hvc.hvc.tight_records(o_pix[f0:f0 + k], ospecs, "plane_offset"), tpfs, k)]
+            other_layout = {"layout": "planes back to back (tight)" if o_align == 1 else "planes on %d KiB boundaries" % (o_align >> 10),
+                            "kernel_ms": round(o_ms, 4), "launches_averaged": 30,
+                            "frac": round(args.frames * blocks_per_frame * ALGO_BYTES_PER_BLOCK / (o_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                            "verified": (o_sums == want) if want is not None else None}
+            del o_coefs, o_pix
+        except Exception as ex:   # (an A/B beside the headline must not take the line with it)
+            other_layout = {"error": "%s: %s" % (type(ex).__name__, ex)}
     per_rank = gather_over_ranks([float(np.mean(kernel_ms)), float(np.min(kernel_ms)), float(np.max(kernel_ms))], world, dist,
                                  "cpu" if rehearsal else "cuda")
     frames_host = d_distinct.cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
@@ -851,9 +923,10 @@ def main():
                          "launches_averaged": len(kernel_ms),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "arithmetic": "int32 with int16-pair dot products (v_dot2_i32_i16); int64 fix-up kernel "
-                                       "for blocks outside the proven range"},
-            "checksum": {"kernel": "k_checksum (K5, hvc_checksum_records)", "frames": len(sums),
-                         "rank0": ["%016x" % s for s in sums],
+                                       "for blocks outside the proven range",
+                         "other_layout": other_layout},
+            "checksum": {"kernel": "k_checksum (K5, hvc_checksum_records) over EVERY record of the resident batch", "frames": len(sums),
+                         "distinct": min(args.distinct, held), "rank0": ["%016x" % s for s in sums[:args.distinct]],
                          "expected": "tests/golden/bench_checksums.json" if want is not None else None,
                          "verified": bool(ok_local) if want is not None else None,
                          "ranks_verified": ranks_ok if want is not None else None,

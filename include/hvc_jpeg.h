@@ -89,7 +89,8 @@ typedef enum hvc_status {
     HVC_E_UNSUPPORTED_MARKER = -9, /* "unsupported marker code" (decoder.ml:67) */
     HVC_E_SYSTEM = -10,      /* the system refused a resource the call needs: a host thread of the batch pipelines
                                 could not be started (pids limit, RLIMIT_NPROC); the context stays usable */
-    HVC_E_INTERNAL = -11     /* an unexpected C++ exception was stopped at the boundary (never seen; reported, not thrown) */
+    HVC_E_INTERNAL = -11,    /* an unexpected C++ exception was stopped at the boundary (never seen; reported, not thrown) */
+    HVC_E_BUSY = -12         /* the slot of an asynchronous submission still holds one: hvc_wait(ctx, slot) first */
 } hvc_status;
 
 /* where the data pointers of a call live */
@@ -102,6 +103,8 @@ HVC_API int hvc_create(hvc_ctx **out, int device);
 HVC_API void hvc_destroy(hvc_ctx *ctx);
 HVC_API const char *hvc_strerror(int code);
 HVC_API int hvc_last_hip_error(const hvc_ctx *ctx);
+/* "hvc_jpeg <version> (gfx950) kernels <id>": <id> = the first 12 hex digits of the SHA-256 of the kernel sources the library
+ * was built from (csrc/Makefile KERNEL_ID) -- what ties a committed counter pass (profiles/traffic.json) to a build. */
 HVC_API const char *hvc_version(void);
 
 /* The host threads of the batch pipelines (hvc_jpeg_decode_batch*, hvc_jpeg_encode_batch*, the download threads of
@@ -475,6 +478,60 @@ HVC_API int hvc_jpeg_encode_batch_gpu(hvc_ctx *ctx, const uint8_t *const *frames
  * benchmarks' outputs to the model. */
 HVC_API int hvc_checksum_records(hvc_ctx *ctx, const void *data, size_t record_bytes, size_t record_stride,
                                  int n_records, uint64_t *sums, int where);
+
+/* ------------------------------------------------------------------------- */
+/* The asynchronous seam ("async batch API: submit(frame batch, stream slot) / wait(slot)"; BASELINE.json
+ * north_star: "host-side Huffman decode feeds pinned coefficient buffers via hipMemcpyAsync on a side stream overlapped
+ * with the IDCT kernel").  For the caller that keeps the reference's OWN sequential Huffman reader
+ * (decoder.ml:118-140, untouched) and wants what hvc_jpeg_decode_batch gives the library's reader: while the GPU works
+ * on batch k, the caller's reader fills batch k + 1.
+ *
+ * A context has HVC_SLOTS slots; a slot carries one batch in flight:
+ *     submit:  host coefficient records --hipMemcpyAsync, copy stream--> device --block stage, ctx's stream--> device pixels
+ *              --hipMemcpyAsync, download stream--> host pixel records          (decode; the encoder mirror runs the other way)
+ * and returns at once.  Three streams, so slot k + 1's upload, slot k's kernel and slot k - 1's download overlap, and the
+ * link carries both directions.  hvc_wait(ctx, slot) blocks until the slot's results are visible and frees the slot.
+ * The host buffers of a submission must stay valid and unmodified (coefficients) / unread (pixels) until its hvc_wait.
+ * They should be PINNED -- from hvc_host_alloc, or the caller's own memory (a Bigarray's data) passed once through
+ * hvc_host_register: from pageable memory hipMemcpyAsync stages through the runtime's bounce buffers and holds its
+ * caller (the result is the same, the overlap is gone).
+ * Like everything on a context the slot calls are not thread-safe among themselves; what the caller does meanwhile on
+ * its own memory (filling the next slot's buffer, on any number of threads) is its business.
+ * Errors: HVC_E_BUSY = the slot still holds a submission (hvc_wait first); everything hvc_decode_frames /
+ * hvc_encode_frames answer to the same arguments; a HIP failure inside the slot's work is reported by ITS hvc_wait. */
+enum { HVC_SLOTS = 4 };
+
+/* Pinned host memory (hipHostMalloc): 4 KiB-aligned, usable as a Bigarray (Ctypes.bigarray_of_ptr) or any byte buffer. */
+HVC_API int hvc_host_alloc(hvc_ctx *ctx, size_t bytes, void **out);
+HVC_API int hvc_host_free(hvc_ctx *ctx, void *p);
+/* Pins memory the caller already owns (hipHostRegister): [p, p + bytes) stays where it is and becomes a DMA source /
+ * target; hvc_host_unregister before freeing it.  A Bigarray.Array1 lives outside the OCaml heap and never moves. */
+HVC_API int hvc_host_register(hvc_ctx *ctx, void *p, size_t bytes);
+HVC_API int hvc_host_unregister(hvc_ctx *ctx, void *p);
+
+/* hvc_decode_frames (same arguments, same arithmetic: decoder.ml:142-149, 213-224; dct.ml:11-107) on host coefficient
+ * records, asynchronously in `slot`.  pixels_where = HVC_MEM_HOST: the pixel records are downloaded into `pixels`
+ * (only the bytes the kernels wrote: the component planes); HVC_MEM_DEVICE: `pixels` is device memory of ctx's GPU
+ * and the block stage writes it directly (hvc_wait then says the kernel is done). */
+HVC_API int hvc_decode_frames_submit(hvc_ctx *ctx, int slot, const int16_t *coefs, size_t coef_frame_stride,
+                                     const uint16_t *qtabs, int n_qtabs, const hvc_component *comps, int n_comp,
+                                     int n_frames, uint8_t *pixels, size_t pixel_frame_stride, int pixels_where);
+/* The encoder mirror: hvc_encode_frames (encoder.ml:81-108; dct.ml:109-196) on host pixel records; the coefficient
+ * records go to `coefs`, host (downloaded: the coefficient planes) or device as coefs_where says. */
+HVC_API int hvc_encode_frames_submit(hvc_ctx *ctx, int slot, const uint8_t *pixels, size_t pixel_frame_stride,
+                                     const uint16_t *qtabs, int n_qtabs, const hvc_component *comps, int n_comp,
+                                     int n_frames, int16_t *coefs, size_t coef_frame_stride, int coefs_where);
+/* Blocks until the slot's submission is complete (an idle slot: returns at once); the slot is free afterwards.
+ * hvc_slot_query: the same question without waiting (*done = 1: hvc_wait will not block). */
+HVC_API int hvc_wait(hvc_ctx *ctx, int slot);
+HVC_API int hvc_slot_query(hvc_ctx *ctx, int slot, int *done);
+/* What the slot's LAST completed submission cost, from HIP events on the three streams (valid after its hvc_wait):
+ * upload, block stage (incl. the fix-up kernels), download; 0 for a stage it did not have. */
+typedef struct hvc_slot_stats {
+    double h2d_ms, kernel_ms, d2h_ms;
+    uint64_t h2d_bytes, d2h_bytes;
+} hvc_slot_stats;
+HVC_API int hvc_slot_last_stats(hvc_ctx *ctx, int slot, hvc_slot_stats *stats);
 
 /* Device memory helpers so that a binding needs no HIP of its own. */
 HVC_API int hvc_device_alloc(hvc_ctx *ctx, size_t bytes, void **out);

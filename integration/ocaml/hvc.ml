@@ -437,6 +437,56 @@ let device_free = foreign "hvc_device_free" (ctx @-> ptr void @-> returning int)
 let memcpy_h2d = foreign "hvc_memcpy_h2d" ~release_runtime_lock:true (ctx @-> ptr void @-> ptr void @-> size_t @-> returning int)
 let memcpy_d2h = foreign "hvc_memcpy_d2h" ~release_runtime_lock:true (ctx @-> ptr void @-> ptr void @-> size_t @-> returning int)
 
+(* ---- the asynchronous seam: pinned host memory and slots (include/hvc_jpeg.h, "The asynchronous seam") ----
+   While the GPU works on the batch submitted to one slot, the caller -- this library's own sequential Huffman reader,
+   decoder.ml:118-140 -- fills the pinned record of the next one.  [Decoder.decode_frames_gpu] is built on these. *)
+let slots = 4 (* enum { HVC_SLOTS = 4 } *)
+
+(* int hvc_host_alloc(ctx, bytes, out); int hvc_host_free(ctx, p): pinned memory (hipHostMalloc)
+   int hvc_host_register(ctx, p, bytes); int hvc_host_unregister(ctx, p): the caller's own memory pinned in place *)
+let host_alloc = foreign "hvc_host_alloc" (ctx @-> size_t @-> ptr (ptr void) @-> returning int)
+let host_free = foreign "hvc_host_free" (ctx @-> ptr void @-> returning int)
+let host_register = foreign "hvc_host_register" (ctx @-> ptr void @-> size_t @-> returning int)
+let host_unregister = foreign "hvc_host_unregister" (ctx @-> ptr void @-> returning int)
+
+(* int hvc_decode_frames_submit(ctx, slot, coefs, coef_frame_stride, qtabs, n_qtabs, comps, n_comp, n_frames, pixels,
+                                pixel_frame_stride, pixels_where): hvc_decode_frames on host records, returns at once *)
+let decode_frames_submit =
+  foreign
+    "hvc_decode_frames_submit"
+    (ctx @-> int @-> ptr int16_t @-> size_t @-> ptr uint16_t @-> int @-> ptr Component.t @-> int @-> int
+    @-> ptr char @-> size_t @-> int @-> returning int)
+;;
+
+(* int hvc_encode_frames_submit(ctx, slot, pixels, pixel_frame_stride, qtabs, n_qtabs, comps, n_comp, n_frames, coefs,
+                                coef_frame_stride, coefs_where): the encoder mirror *)
+let encode_frames_submit =
+  foreign
+    "hvc_encode_frames_submit"
+    (ctx @-> int @-> ptr char @-> size_t @-> ptr uint16_t @-> int @-> ptr Component.t @-> int @-> int
+    @-> ptr int16_t @-> size_t @-> int @-> returning int)
+;;
+
+(* int hvc_wait(ctx, slot): blocks (runtime lock released) until the slot's results are visible; int hvc_slot_query(ctx, slot, done) *)
+let wait = foreign "hvc_wait" ~release_runtime_lock:true (ctx @-> int @-> returning int)
+let slot_query = foreign "hvc_slot_query" (ctx @-> int @-> ptr int @-> returning int)
+
+(* typedef struct hvc_slot_stats { double h2d_ms, kernel_ms, d2h_ms; uint64_t h2d_bytes, d2h_bytes; } *)
+module Slot_stats = struct
+  type t
+
+  let t : t structure typ = structure "hvc_slot_stats"
+  let h2d_ms = field t "h2d_ms" double
+  let kernel_ms = field t "kernel_ms" double
+  let d2h_ms = field t "d2h_ms" double
+  let h2d_bytes = field t "h2d_bytes" uint64_t
+  let d2h_bytes = field t "d2h_bytes" uint64_t
+  let () = seal t
+end
+
+(* int hvc_slot_last_stats(ctx, slot, stats) *)
+let slot_last_stats = foreign "hvc_slot_last_stats" (ctx @-> int @-> ptr Slot_stats.t @-> returning int)
+
 (* Plane.t (common/src/plane.ml:4-9) is a Base_bigstring = (char, int8_unsigned_elt, c_layout) Array1:
    its data pointer is passed zero-copy.  (Needs [Plane.plane : t -> Base_bigstring.t] exposed.) *)
 let plane_ptr (p : Hardcaml_video_common.Plane.t) =
@@ -446,6 +496,28 @@ let plane_ptr (p : Hardcaml_video_common.Plane.t) =
 type coefs = (int, Bigarray.int16_signed_elt, Bigarray.c_layout) Bigarray.Array1.t
 
 let coefs_ptr (c : coefs) = bigarray_start array1 c
+
+(* Pinned records as Bigarrays: [hvc_host_alloc]'s memory wrapped, not copied.  The Bigarray does not own it:
+   [free_pinned] gives it back (after the last [wait] on a submission that used it). *)
+let pinned_coefs (hvc : ctx) n : coefs =
+  let p = allocate (ptr void) null in
+  check "hvc_host_alloc" (host_alloc hvc (Unsigned.Size_t.of_int (2 * n)) p);
+  bigarray_of_ptr array1 n Bigarray.int16_signed (from_voidp int16_t !@p)
+;;
+
+let pinned_bytes (hvc : ctx) n : Base_bigstring.t =
+  let p = allocate (ptr void) null in
+  check "hvc_host_alloc" (host_alloc hvc (Unsigned.Size_t.of_int n) p);
+  bigarray_of_ptr array1 n Bigarray.char (from_voidp char !@p)
+;;
+
+let free_pinned_coefs (hvc : ctx) (c : coefs) =
+  check "hvc_host_free" (host_free hvc (to_voidp (bigarray_start array1 c)))
+;;
+
+let free_pinned_bytes (hvc : ctx) (b : Base_bigstring.t) =
+  check "hvc_host_free" (host_free hvc (to_voidp (bigarray_start array1 b)))
+;;
 
 (* Markers.Dqt.elements (zig-zag order) -> the uint16[64] the C side reads *)
 let qtab_of_int_array (q : int array) =

@@ -60,21 +60,49 @@ def test_single_rank_needs_no_process_group():
     assert bench.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and bench.parse_cpulist("") == []
 
 
-def test_traffic_entry_must_name_the_kernel_that_ran(tmp_path, monkeypatch):
+def test_traffic_entry_must_name_the_kernel_and_the_build_that_ran(tmp_path, monkeypatch):
     """roofline.traffic is a committed PMC pass, not a per-run measurement: bench.py quotes it only for the configuration,
-    the launch size AND the kernel symbol it has just run"""
+    the launch size, the kernel symbol AND the kernel build (hvc_version's id) it has just run"""
     sys.path.insert(0, ROOT)
     import bench
+    import video_coding_amd as hvc
+    build = hvc.hvc.kernel_build_id()
+    assert build == hvc.hvc.kernel_source_id() and len(build) == 12          # the library in the tree is built from the tree's kernels
+    assert build.encode() in hvc.lib().hvc_version()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    entry = {"kernel": "k_decode_packed", "config": 2, "session": "t", "build": build, "frames_per_launch": 1024, "hbm_bytes": 9.7e9}
+    (prof / "traffic.json").write_text(json.dumps({"entries": [entry]}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     got, src = bench.measured_traffic(2, 1024)
-    assert got is not None and "k_decode_packed" in src
+    assert got == 9700000000 and "k_decode_packed" in src and build in src
     assert bench.measured_traffic(2, 1000)[0] is None                      # another launch size
     got, why = bench.measured_traffic(2, 1024, kernel="k_decode_ldsdma")   # another kernel behind the same step
     assert got is None and "k_decode_packed" in why
-    prof = tmp_path / "profiles"
-    prof.mkdir()
-    (prof / "traffic.json").write_text(json.dumps({"entries": [{"config": 2, "frames_per_launch": 1024, "hbm_bytes": 1.0}]}))
-    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    assert bench.measured_traffic(2, 1024)[0] is None                      # an entry that does not say which kernel: not trusted
+    # a pass of another build of the kernels is stale, and says so
+    (prof / "traffic.json").write_text(json.dumps({"entries": [dict(entry, build="0123456789ab")]}))
+    got, why = bench.measured_traffic(2, 1024)
+    assert got is None and why.startswith("stale: profiled build 0123456789ab") and build in why
+    # ... a later entry of the running build still counts
+    (prof / "traffic.json").write_text(json.dumps({"entries": [dict(entry, build="0123456789ab"), dict(entry, hbm_bytes=5.0)]}))
+    assert bench.measured_traffic(2, 1024)[0] == 5
+    # an entry without a build id (sessions before round 6) or without a kernel name is not trusted
+    (prof / "traffic.json").write_text(json.dumps({"entries": [{k: v for k, v in entry.items() if k != "build"}]}))
+    assert bench.measured_traffic(2, 1024)[0] is None
+    (prof / "traffic.json").write_text(json.dumps({"entries": [{"config": 2, "frames_per_launch": 1024, "hbm_bytes": 1.0, "build": build}]}))
+    assert bench.measured_traffic(2, 1024)[0] is None
+
+
+def test_committed_traffic_entries_are_of_a_named_build():
+    """profiles/traffic.json as committed: every entry of the current session names the kernel build it profiled; what bench.py
+    makes of it for the headline is either that pass or an explicit "stale" (never a silent number of another build)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    newest = t["entries"][0]["session"]
+    assert all(len(e.get("build", "")) == 12 for e in t["entries"] if e["session"] == newest)
+    got, src = bench.measured_traffic(2, 1024)
+    assert (got is not None and "build" in src) or src.startswith("stale: profiled build")
 
 
 def _clean_env(**extra):

@@ -86,6 +86,19 @@ def test_bench_line_is_verified_against_the_golden_checksums():
     assert su["wall_s"] >= 0.5 and su["steps"] >= 64 and su["output_unchanged"] is True and 0 < su["first_decile_ms"] < 50
 
 
+def test_headline_launch_verifies_every_one_of_its_1024_frames():
+    """`python bench.py` at its default launch -- 1024 frames of 1080p 4:2:0 -- K5-checksums EVERY record of the
+    launch whose time is `value` (record r holds distinct frame r % 8), not the first eight; the tight layout beside the aligned
+    one is timed and verified in the same run (roofline.other_layout)."""
+    rec = _run_bench(["--steps", "2", "--no-others", "--cpu-seconds", "0", "--sustain-seconds", "0.3"])
+    assert rec["config"]["frames_per_launch"] == 1024 and rec["config"]["baseline_config"] == 2
+    assert rec["checksum"]["frames"] == 1024 and rec["checksum"]["distinct"] == 8 and rec["checksum"]["verified"] is True
+    assert rec["sustained"]["output_unchanged"] is True
+    o = rec["roofline"]["other_layout"]
+    assert "tight" in o["layout"] and o["verified"] is True and 0.3 < o["frac"] < 1.0
+    assert rec["roofline"]["traffic"] or rec["roofline"]["traffic_source"].startswith(("stale", "no committed"))
+
+
 def test_bench_layouts_aligned_and_tight_decode_the_same_frames():
     """bench.py lays its resident batch out with every plane on a 64 KiB / 2 MiB boundary (hvc.layout_alignment); --tight = planes back
     to back.  Both verify against the same golden checksums (K5 runs on the planes gathered tight), configs 2 and 5."""
@@ -133,6 +146,12 @@ def test_bench_config3_and_5_one_rank_and_two():
     for reader in ("host_reader", "gpu_reader"):
         assert rec[reader]["verified"] is True and rec[reader]["ranks_verified"] == 1 and rec[reader]["value"] > 0
     assert rec["value"] == rec["host_reader"]["value"] and rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["cores"] == 1
+    # upload rate, overlap fraction and the counter bytes of the pipeline's own launches
+    assert rec["host_reader"]["h2d_GBps"] > 1 and -1.0 < rec["host_reader"]["overlap_fraction"] < 1.0
+    rf = rec["roofline"]
+    assert rf["h2d_GBps"] == rec["host_reader"]["h2d_GBps"] and rf["overlap_fraction"] == rec["host_reader"]["overlap_fraction"]
+    assert rf["algorithmic_bytes_per_launch"] == rec["host_reader"]["kernel_launch_frames"] * 48960 * 192
+    assert rf["traffic"] or rf["traffic_source"].startswith(("stale", "no committed"))
     rec = _run_bench(["--gpus", "2", "--config", "3", "--frames", "128", "--steps", "2", "--warmup", "1"], HVC_BENCH_REHEARSAL="1")
     assert rec["n_gpus"] == 2 and rec["config"]["files_per_gpu_per_step"] == 64 and "REHEARSAL" in rec["data"]
     assert rec["host_reader"]["ranks_verified"] == 2 and rec["gpu_reader"]["ranks_verified"] == 2

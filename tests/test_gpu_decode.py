@@ -253,8 +253,8 @@ def test_empty_batches_are_no_ops(ctx):
 
 
 def test_frame_count_limits(ctx):
-    """grid.y carries the frame index: 65 535 frames per call work (here one block each), 65 536 are refused
-    with HVC_E_TOO_LARGE (hvc_dequant_idct_recon splits larger plane batches itself)."""
+    """grid.y carries the frame index, 65 535 per launch: a batch of any size is the library's to cut into launches, never
+    the caller's to split -- 65 535, 65 536 and 70 000 one-block frames, host memory both ways."""
     import video_coding_amd as hvc
     n = 65535
     rng = np.random.Generator(np.random.PCG64(99))
@@ -265,10 +265,12 @@ def test_frame_count_limits(ctx):
     ctx.decode_frames(coefs, cfs, q, specs, n, pix, pfs)
     want = orc.dequant_idct_recon(coefs.reshape(1, n, 64), q, n, 1).reshape(8, n, 8).transpose(1, 0, 2).reshape(n, 64)
     assert np.array_equal(pix, want)
-    with pytest.raises(hvc.HvcError) as e:
-        ctx.decode_frames(np.zeros((n + 1, 64), dtype=np.int16), cfs, q, specs, n + 1, np.zeros((n + 1, 64), dtype=np.uint8), pfs)
-    assert e.value.code == -7
-    # the per-plane entry point accepts more planes than one launch holds
+    c1 = np.concatenate([coefs, coefs[:1][:, ::-1]])   # one frame more than a launch holds
+    pix1 = np.zeros((n + 1, 64), dtype=np.uint8)
+    ctx.decode_frames(c1, cfs, q, specs, n + 1, pix1, pfs)
+    assert np.array_equal(pix1[:n], want)
+    assert np.array_equal(pix1[n], orc.dequant_idct_recon(c1[n].reshape(1, 1, 64), q, 1, 1).reshape(64))
+    # the per-plane entry point is the same call
     m = 70000
     c2 = rng.integers(-40, 41, size=(m, 64)).astype(np.int16)
     out = np.zeros((m, 64), dtype=np.uint8)

@@ -42,7 +42,8 @@ def test_checker_catches_drift(tmp_path, monkeypatch):
 def test_patch_uses_only_what_the_binding_defines(tmp_path):
     missing, used = chk.check_patch()
     assert missing == []
-    for name in ("ctx", "coefs", "coefs_ptr", "check", "decode_frames", "mem_host", "Component.t", "Component.stride"):
+    for name in ("ctx", "coefs", "coefs_ptr", "check", "decode_frames", "mem_host", "Component.t", "Component.stride",
+                 "decode_frames_submit", "wait", "pinned_coefs", "pinned_bytes", "free_pinned_coefs", "free_pinned_bytes"):
         assert name in used, name
     # ... and the check sees a name that is not there (round 2's sketch called helpers that existed nowhere)
     text = open(chk.PATCH).read().replace("Hvc.coefs_ptr record", "Hvc.coefs_pointer record")
@@ -73,9 +74,13 @@ def test_patch_applies_to_the_reference(tmp_path):
         assert r.returncode == 0 and "FAILED" not in r.stdout and "fuzz" not in r.stdout, r.stdout + r.stderr
     ml = (tmp_path / "jpeg/model/src/decoder.ml").read_text()
     mli = (tmp_path / "jpeg/model/src/decoder.mli").read_text()
-    for name in ("let decode_gpu ", "let decode_a_frame_gpu ", "module Gpu = struct", "?(decode_block = decode_block)"):
+    for name in ("let decode_gpu ", "let decode_a_frame_gpu ", "module Gpu = struct", "?(decode_block = decode_block)",
+                 "module Gpu_slot = struct", "let decode_frames_gpu (hvc : Hvc.ctx) (files : Bits.t list) : Frame.t list ="):
         assert name in ml, name
+    # the double-buffered form is defined after what it calls (OCaml reads top to bottom): get_yuv_frame, decode_seq, Gpu
+    assert ml.index("let get_yuv_frame decoder") < ml.index("let decode_frames_gpu") and ml.index("module Gpu = struct") < ml.index("module Gpu_slot")
     assert "val decode_gpu : Hvc.ctx -> t -> unit" in mli and "val decode_a_frame_gpu" in mli
+    assert "val decode_frames_gpu : Hvc.ctx -> Bits.t list -> Frame.t list" in mli
     enc, enci = (tmp_path / "jpeg/model/src/encoder.ml").read_text(), (tmp_path / "jpeg/model/src/encoder.mli").read_text()
     for name in ("let encode_seq_with ~encode_block (t : t) =", "let encode_seq (t : t) = encode_seq_with ~encode_block t",
                  "let encode_seq_gpu (hvc : Hvc.ctx) (t : t) =", "let encode_420_gpu hvc ~frame ~quality ~writer ="):

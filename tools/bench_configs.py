@@ -7,6 +7,8 @@
   --config 5   encoder: forward 8x8 DCT + quantise, 4K 4:2:0, HBM-resident (hvc_encode_frames)
   --config 2 / 10 / 7 / 8 / 9 / 6   K2 upsample / subsample_hv2 / fused 4:4:4 / config 5 to files / GPU Huffman coder / host buffers
   --config 11  whole `oyuv convert` passes (hvc_yuv_convert) on 1080p frames
+  --config 12  the asynchronous seam: caller-filled pinned slots -> hvc_decode_frames_submit / hvc_wait (--host-out: pixels back too)
+  --config 13  every block through the int64 kernel (--wide-mode kernel2 | dqt16)
 
 Every config function returns its JSON object (bench.py collects them as `others` in its one line); run as a command,
 this file prints it.
@@ -119,6 +121,8 @@ def config3(args):
         "kernel_ms_sum": round(st.kernel_ms_sum, 2),
         "overlap": "sum of stage times / wall = %.2f" % ((st.entropy_ms_sum / args.threads + st.h2d_ms_sum +
                                                           st.kernel_ms_sum) / (dt * 1e3)),
+        # the share of the stages' time the pipeline hides
+        "overlap_fraction": round(1.0 - dt * 1e3 / max(st.entropy_ms_sum / args.threads + st.h2d_ms_sum + st.kernel_ms_sum, 1e-9), 3),
         "bound": ("GPU reader kernels / upload" if gpu else "host Huffman (entropy time / threads ~ wall)") +
                  (", download of the frames" if args.host_out else "")}
     ctx.close()
@@ -229,6 +233,188 @@ def config_host(args):
                       "value": round(args.frames * 1920 * 1080 / dt / 1e6, 1), "unit": "Mpixel/s", "frames": args.frames,
                       "ms_per_call": round(dt * 1e3, 2), "bytes_over_pcie": moved,
                       "pcie_GBps": round(moved / dt / 1e9, 1)}
+    ctx.close()
+    return result
+
+
+def config_async(args):
+    """The asynchronous seam (include/hvc_jpeg.h: hvc_host_alloc, hvc_decode_frames_submit, hvc_wait): 1080p 4:2:0 coefficient
+    records handed over in PINNED slot buffers, HVC_SLOTS batches in flight.  The caller keeps its own entropy reader (the model's,
+    decoder.ml:118-140): here a pool of caller threads REFILLS slot k + 1's pinned buffer -- a copy of the next batch's records,
+    which is what a reader's output amounts to for the link -- while the GPU works on slot k.  Records: the library's host reader
+    on config 3's files (hvc_jpeg_entropy_decode), so the decoded frames are configs_c3's.
+    args.host_out: the pixel records come back into pinned host buffers as well (and every one is compared, byte for byte, with
+    the device-decoded frame of its distinct record); otherwise they stay in HBM and K5 verifies all of them.
+    Reports Gpixel/s over the whole loop (refills included), the upload rate, and the overlap fraction
+    1 - wall / (refill + upload + kernel + download), each summed over the submissions."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    import video_coding_amd as hvc
+    W, H = 1920, 1080
+    ctx = hvc.Context(0)
+    jpegs = config3_files(ctx, args.distinct)
+    info = hvc.hvc.jpeg_read_header(jpegs[0])
+    cfs, pfs = info.coef_count, info.pixel_bytes
+    planes = [(info.layout[i].blocks_w, info.layout[i].blocks_h, info.layout[i].qtab) for i in range(info.n_comp)]
+    specs, cfs2, pfs2 = hvc.hvc.frame_layout(planes)
+    assert (cfs2, pfs2) == (cfs, pfs)
+    comps = hvc.hvc.components(specs)
+    qtabs = info.qtab_array()
+    distinct = np.stack([hvc.hvc.jpeg_entropy_decode(j)[1] for j in jpegs])        # [D][cfs] int16, pageable
+    n, C, S, D = args.frames, args.chunk, hvc.hvc.HVC_SLOTS, args.distinct
+    n_chunks = (n + C - 1) // C
+    host_out = bool(getattr(args, "host_out", False))
+    bufs = [ctx.host_alloc((C, cfs), np.int16) for _ in range(S)]
+    outs = [ctx.host_alloc((C, pfs), np.uint8) for _ in range(S)] if host_out else None
+    d_pix = None if host_out else torch.zeros((n, pfs), dtype=torch.uint8, device="cuda")
+    expect = None
+    if host_out:   # the distinct frames decoded once through the blocking entry point (K5-verified below): what every record must equal
+        expect = np.zeros((D, pfs), dtype=np.uint8)
+        ctx.decode_frames(distinct, cfs, qtabs, comps, D, expect, pfs)
+    pool = ThreadPoolExecutor(args.threads)
+    T = max(1, args.threads)
+
+    def fill_part(s, first, cnt, t):     # thread t's share of slot s's refill
+        for f in range(t, cnt, T):
+            np.copyto(bufs[s][f], distinct[(first + f) % D])
+        return True
+
+    def check_part(s, first, cnt, t):
+        return all(np.array_equal(outs[s][f], expect[(first + f) % D]) for f in range(t, cnt, T))
+
+    def one_pass():
+        st = dict(fill=0.0, h2d=0.0, k=0.0, d2h=0.0, h2d_bytes=0, d2h_bytes=0, ok=True)
+        where = [None] * S
+
+        def retire(s):
+            ctx.wait(s)
+            x = ctx.slot_last_stats(s)
+            st["h2d"] += x.h2d_ms
+            st["k"] += x.kernel_ms
+            st["d2h"] += x.d2h_ms
+            st["h2d_bytes"] += x.h2d_bytes
+            st["d2h_bytes"] += x.d2h_bytes
+
+        t0 = time.perf_counter()
+        for k in range(n_chunks):
+            s, first = k % S, k * C
+            cnt = min(C, n - first)
+            checks = []
+            if where[s] is not None:
+                retire(s)
+                if host_out:   # the consumer of slot s's pixels runs beside the refill of its coefficient buffer
+                    pf, pc = where[s]
+                    checks = [pool.submit(check_part, s, pf, pc, t) for t in range(T)]
+            f0 = time.perf_counter()
+            for fu in [pool.submit(fill_part, s, first, cnt, t) for t in range(T)]:
+                fu.result()
+            st["fill"] += (time.perf_counter() - f0) * 1e3
+            st["ok"] &= all(c.result() for c in checks)
+            ctx.decode_frames_submit(s, bufs[s], cfs, qtabs, comps, cnt, outs[s] if host_out else d_pix[first:first + cnt], pfs)
+            where[s] = (first, cnt)
+        for k in range(n_chunks, n_chunks + S):   # drain in submission order
+            s = k % S
+            if where[s] is not None:
+                retire(s)
+                if host_out:
+                    pf, pc = where[s]
+                    st["ok"] &= all(c.result() for c in [pool.submit(check_part, s, pf, pc, t) for t in range(T)])
+                where[s] = None
+        st["wall"] = (time.perf_counter() - t0) * 1e3
+        return st
+
+    one_pass()   # warm-up: the slots' device buffers, the streams, the clock
+    best = None
+    for _ in range(args.steps):
+        st = one_pass()
+        if best is None or st["wall"] < best["wall"]:
+            best = st
+    st = best
+    if host_out:
+        v = verify(ctx, expect, pfs, D, "configs_c3", D)
+        v["checksum"]["records"] = n
+        v["checksum"]["verified"] = bool(v["checksum"]["verified"]) and bool(st["ok"])
+        v["checksum"]["how"] = "every downloaded record compared byte for byte with its distinct frame's, those K5-verified"
+    else:
+        v = verify(ctx, d_pix, pfs, n, "configs_c3", D)
+    stages = st["fill"] + st["h2d"] + st["k"] + st["d2h"]
+    result = {**v, "config": "async-seam" + ("-host-out" if host_out else ""),
+              "metric": "Mpixel/s decoded: caller-filled pinned coefficient slots -> hvc_decode_frames_submit / hvc_wait" +
+                        (" -> pinned pixel slots" if host_out else " -> HBM"),
+              "value": round(n * W * H / (st["wall"] * 1e-3) / 1e6, 1), "unit": "Mpixel/s", "frames": n, "frames_per_slot": C,
+              "slots": S, "host_threads": args.threads, "frames_per_chunk": C, "wall_ms": round(st["wall"], 2),
+              "refill_ms_sum": round(st["fill"], 2), "h2d_ms_sum": round(st["h2d"], 2), "kernel_ms_sum": round(st["k"], 2),
+              "d2h_ms_sum": round(st["d2h"], 2),
+              "h2d_GBps": round(st["h2d_bytes"] / (max(st["h2d"], 1e-9) * 1e-3) / 1e9, 1),
+              "d2h_GBps": round(st["d2h_bytes"] / (st["d2h"] * 1e-3) / 1e9, 1) if st["d2h"] > 0 else None,
+              "refill_GBps": round(st["h2d_bytes"] / (max(st["fill"], 1e-9) * 1e-3) / 1e9, 1),
+              "link_GBps_over_wall": round((st["h2d_bytes"] + st["d2h_bytes"]) / (st["wall"] * 1e-3) / 1e9, 1),
+              "overlap_fraction": round(1.0 - st["wall"] / max(stages, 1e-9), 3),
+              "bound": "pcie: 3.02 B of coefficients per pixel up" + (", 1.5 B of pixels down" if host_out else "")}
+    pool.shutdown()
+    for b in bufs + (outs or []):
+        ctx.host_free(b)
+    ctx.close()
+    return result
+
+
+def config_wide(args):
+    """k_decode_wide_all, the model's 63-bit arithmetic for every block of a call: what a DQT with an entry above 255 costs (mode
+    "dqt16": the luma table's first AC entry raised to 256, the coefficient there zeroed so that the frames -- and the golden
+    checksums -- stay config 2's) and what hvc_set_decode_kernel(ctx, 2) costs (mode "kernel2").  1080p 4:2:0, HBM-resident."""
+    import torch
+    import video_coding_amd as hvc
+    from video_coding_amd.synth import synth_frame_pixels
+    W, H = 1920, 1080
+    planes = [(240, 136, 0), (120, 68, 1), (120, 68, 1)]
+    qtabs = np.stack([hvc.hvc.quant_table(0, 75), hvc.hvc.quant_table(1, 75)])
+    specs, cfs, pfs = hvc.hvc.frame_layout(planes)
+    comps = hvc.hvc.components(specs)
+    ctx = hvc.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    src = torch.from_numpy(np.stack([synth_frame_pixels(40 + 8 * f, planes) for f in range(args.distinct)])).cuda()
+    d_distinct = torch.zeros((args.distinct, cfs), dtype=torch.int16, device="cuda")
+    ctx.encode_frames(src, pfs, qtabs, comps, args.distinct, d_distinct, cfs)
+    n = args.frames
+    d_coefs = d_distinct.repeat((n + args.distinct - 1) // args.distinct, 1)[:n].contiguous()
+    d_pix = torch.zeros((n, pfs), dtype=torch.uint8, device="cuda")
+    d_ref = torch.zeros((args.distinct, pfs), dtype=torch.uint8, device="cuda")
+    mode = getattr(args, "wide_mode", "kernel2")
+    q_run = qtabs.copy()
+    if mode == "dqt16":
+        # a 16-bit table: entry 63 (the last zig-zag position) of both tables becomes 40000 and the coefficient it scales is
+        # zeroed in every record, so the frames are the 8-bit tables' frames of the same (modified) records -- which the packed
+        # kernel decodes below as the reference.  (16-bit entries that DO scale something: tests/test_gpu_decode.py, oracle.)
+        q_run[:, 63] = 40000
+        d_coefs.view(n, -1, 64)[:, :, 63] = 0
+        d_distinct.view(args.distinct, -1, 64)[:, :, 63] = 0
+    else:
+        ctx.set_decode_kernel(2)
+    # reference: the same records through the default (packed) kernel with the 8-bit tables
+    ref = hvc.Context(0)
+    ref.set_stream(torch.cuda.current_stream().cuda_stream)
+    ref.decode_frames(d_distinct, cfs, qtabs, comps, args.distinct, d_ref, pfs)
+    ref.synchronize()
+    ref.close()
+    ctx.set_profiling(True)
+    for _ in range(args.warmup):
+        ctx.decode_frames(d_coefs, cfs, q_run, comps, n, d_pix, pfs)
+    torch.cuda.synchronize()
+    for _ in range(args.steps):
+        ctx.decode_frames(d_coefs, cfs, q_run, comps, n, d_pix, pfs)
+    torch.cuda.synchronize()
+    k_ms = float(np.mean(ctx.kernel_ms_history(min(args.steps, 64))))
+    wide = int(ctx.last_wide_blocks())
+    same = bool((d_pix.view(-1, args.distinct, pfs) == d_ref[None]).all()) if n % args.distinct == 0 else None
+    blocks = sum(bw * bh for bw, bh, _ in planes)
+    algo = n * blocks * 192
+    result = {"config": "wide-" + mode, "metric": "Mpixel/s decoded, every block through the int64 kernel", "frames": n,
+              "value": round(n * W * H / (k_ms * 1e-3) / 1e6, 1), "unit": "Mpixel/s", "kernel_ms": round(k_ms, 4),
+              "algorithmic_GBps": round(algo / (k_ms * 1e-3) / 1e9, 1), "frac_of_8TBps": round(algo / (k_ms * 1e-3) / 8e12, 4),
+              "wide_path_blocks": wide, "all_blocks": n * blocks,
+              "checksum": {"records": n, "verified": same and wide == n * blocks,
+                           "how": "every record equal to the packed kernel's decode of the same distinct record" +
+                                  (" (coefficient 63 zeroed: the 16-bit entry scales nothing)" if mode == "dqt16" else "")}}
     ctx.close()
     return result
 
@@ -498,14 +684,16 @@ def config_convert(args):
 def make_args(**kw):
     """the argument object of the config functions for callers that are not this file's command line (bench.py)"""
     d = dict(frames=None, distinct=4, steps=None, warmup=10, threads=min(16, len(os.sched_getaffinity(0))), chunk=32,
-             gpu_entropy=False, host_out=False, own_tables=False, fused_only=False, restart_interval=0, tight=False)
+             gpu_entropy=False, host_out=False, own_tables=False, fused_only=False, restart_interval=0, tight=False,
+             wide_mode="kernel2")
     d.update(kw)
     return argparse.Namespace(**d)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", type=int, required=True, choices=[2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+    ap.add_argument("--config", type=int, required=True, choices=[2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
+    ap.add_argument("--wide-mode", default="kernel2", choices=["kernel2", "dqt16"], help="config 13: what sends every block to the int64 kernel")
     ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--distinct", type=int, default=4)
     ap.add_argument("--steps", type=int, default=None)
@@ -519,7 +707,17 @@ def main():
     ap.add_argument("--tight", action="store_true", help="configs 4 / 5: planes and frames back to back instead of on 64 KiB / 2 MiB boundaries (A/B)")
     ap.add_argument("--restart-interval", type=int, default=0, help="config 3: the files carry DRI / RSTn every so many MCUs (own tables too) and the readers honour them")
     args = ap.parse_args()
-    if args.config == 2:  # K2 upsample (optional output stage)
+    if args.config == 12:  # the asynchronous seam: pinned slots, submit / wait
+        args.frames = args.frames or 4096
+        args.steps = args.steps or 2
+        if args.chunk == 32:
+            args.chunk = 64
+        r = config_async(args)
+    elif args.config == 13:  # every block through the int64 kernel
+        args.frames = args.frames or 64
+        args.steps = args.steps or 10
+        r = config_wide(args)
+    elif args.config == 2:  # K2 upsample (optional output stage)
         args.frames = args.frames or 256
         args.steps = args.steps or 20
         r = config_k2(args)

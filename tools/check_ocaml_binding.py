@@ -30,7 +30,7 @@ C_TO_ML = {
     "int*": {"ptr int"}, "size_t*": {"ptr size_t"}, "float*": {"ptr float"},
     "void*": {"ptr void"}, "void**": {"ptr (ptr void)"},
     "hvc_component*": {"ptr Component.t"}, "hvc_jpeg_info*": {"ptr Jpeg_info.t"},
-    "hvc_batch_stats*": {"ptr Batch_stats.t"},
+    "hvc_batch_stats*": {"ptr Batch_stats.t"}, "hvc_slot_stats*": {"ptr Slot_stats.t"},
     "uint8_t**": {"ptr (ptr char)", "ptr string"},  # const uint8_t *const *: an array of byte strings
 }
 FIELD_TO_ML = {"int": "int", "size_t": "size_t", "uint16_t": "uint16_t", "double": "double", "uint64_t": "uint64_t",

@@ -96,7 +96,10 @@ def traffic_json(d, kernel_substr, frames, config=2, session=""):
         out[name] = rows[0][0]
     fetch = out["FETCH_SIZE"] * 1024 * 2
     write = out["WRITE_SIZE"] * 1024
-    return {"kernel": kernel_substr, "config": config, "session": session, "frames_per_launch": frames, "fetch_bytes": fetch,
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import video_coding_amd as hvc   # the library the profiled commands loaded: the pass is of THIS build's kernels
+    return {"kernel": kernel_substr, "config": config, "session": session, "build": hvc.hvc.kernel_build_id(),
+            "frames_per_launch": frames, "fetch_bytes": fetch,
             "write_bytes": write, "hbm_bytes": fetch + write, "source": os.path.basename(os.path.normpath(d)),
             "corrections": "FETCH_SIZE KB x1024 x2 (gfx950 16 B/lane read undercount), WRITE_SIZE KB x1024"}
 

@@ -148,7 +148,10 @@ hipError_t wait_event(hipEvent_t e) {
 }
 
 
-const char *hvc_version(void) { return "hvc_jpeg 0.1 (gfx950)"; }
+#ifndef HVC_KERNEL_ID
+#define HVC_KERNEL_ID "unknown"
+#endif
+const char *hvc_version(void) { return "hvc_jpeg 0.2 (gfx950) kernels " HVC_KERNEL_ID; }
 
 const char *hvc_strerror(int code) {
     switch (code) {
@@ -164,6 +167,7 @@ const char *hvc_strerror(int code) {
     case HVC_E_UNSUPPORTED_MARKER: return "unsupported marker code";
     case HVC_E_SYSTEM: return "the system refused a host thread";
     case HVC_E_INTERNAL: return "internal error (C++ exception stopped at the boundary)";
+    case HVC_E_BUSY: return "the slot still holds a submission (hvc_wait first)";
     default: return "unknown hvc error";
     }
 }
@@ -253,6 +257,12 @@ void hvc_destroy(hvc_ctx *c) {
     }
     for (int i = 0; i < 4; i++)
         if (c->ev_t[i]) (void)hipEventDestroy(c->ev_t[i]);
+    for (hvc_ctx::Slot &s : c->slots) { // (a submission nobody waited for: the streams were drained above)
+        if (s.d_in) (void)hipFree(s.d_in);
+        if (s.d_out) (void)hipFree(s.d_out);
+        for (hipEvent_t e : {s.up0, s.up1, s.k0, s.k1, s.dn0, s.dn1})
+            if (e) (void)hipEventDestroy(e);
+    }
     if (c->gd_ecs) (void)hipFree(c->gd_ecs);
     if (c->gd_h_ecs) (void)hipHostFree(c->gd_h_ecs);
     if (c->gd_fcnt) (void)hipFree(c->gd_fcnt);
@@ -466,7 +476,6 @@ int hvc_checksum_records(hvc_ctx *c, const void *data, size_t record_bytes, size
     if (!c || !sums || n_records < 0 || (!data && n_records && record_bytes)) return HVC_E_INVALID_ARG;
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
     if (n_records == 0) return HVC_OK;
-    if (n_records > 65535) return HVC_E_TOO_LARGE;
     if (n_records > 1 && record_stride < record_bytes) return HVC_E_INVALID_ARG;
     DeviceGuard g(c->device);
     if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
@@ -480,7 +489,9 @@ int hvc_checksum_records(hvc_ctx *c, const void *data, size_t record_bytes, size
         d = (const uint8_t *)c->d_in;
     }
     if ((r = grow(c, &c->d_sums, &c->sums_cap, sum_bytes))) return r;
-    HIPCHK(c, hvc::launch_checksum(d, record_bytes, record_stride, n_records, (unsigned long long *)c->d_sums, c->stream));
+    for (int r0 = 0; r0 < n_records; r0 += 65535) // (the grid's y dimension holds 65535 records)
+        HIPCHK(c, hvc::launch_checksum(d + (size_t)r0 * record_stride, record_bytes, record_stride,
+                                       n_records - r0 < 65535 ? n_records - r0 : 65535, (unsigned long long *)c->d_sums + r0, c->stream));
     HIPCHK(c, hipMemcpyAsync(sums, c->d_sums, sum_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HVC_OK;
@@ -611,7 +622,7 @@ static int apply_wide_dc_444(hvc_ctx *c, const hvc::Decode444Params &P, const st
 // zero or a frame without width or height, the model's empty Plane.t (decoder.ml:304-345) -- has no part in the block
 // stage: decode_seq never calls decode_block for it.  The decoding entry points drop such components from the list
 // they work on (the others keep their offsets); *n_kept == 0: nothing to decode at all.
-static int drop_empty_components(const hvc_component *comps, int n_comp, hvc_component *kept, int *n_kept) {
+int drop_empty_components(const hvc_component *comps, int n_comp, hvc_component *kept, int *n_kept) {
     if (!comps || n_comp < 1 || n_comp > HVC_MAX_COMP) return HVC_E_INVALID_ARG;
     *n_kept = 0;
     for (int i = 0; i < n_comp; i++) {
@@ -619,6 +630,80 @@ static int drop_empty_components(const hvc_component *comps, int n_comp, hvc_com
         if (comps[i].blocks_w > 0 && comps[i].blocks_h > 0) kept[(*n_kept)++] = comps[i];
     }
     return HVC_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// Host callers get back what the kernels wrote and nothing else (hvc_ctx.h, RecordRun)
+static RecordRun record_run(const hvc_component *comps, int n_comp, bool pixels) {
+    int order[HVC_MAX_COMP] = {0, 1, 2, 3};
+    auto at_of = [&](int i) { return pixels ? comps[i].plane_offset : comps[i].coef_offset * sizeof(int16_t); };
+    for (int i = 0; i < n_comp; i++)
+        for (int j = i + 1; j < n_comp; j++)
+            if (at_of(order[j]) < at_of(order[i])) std::swap(order[i], order[j]);
+    RecordRun r;
+    size_t at = at_of(order[0]);
+    r.first = at;
+    for (int i = 0; i < n_comp; i++) {
+        const hvc_component &k = comps[order[i]];
+        if (at_of(order[i]) != at || (pixels && k.stride != (size_t)k.blocks_w * 8)) return RecordRun{};
+        at += (size_t)k.blocks_w * k.blocks_h * 64 * (pixels ? 1 : sizeof(int16_t));
+    }
+    r.len = at - r.first;
+    return r;
+}
+RecordRun pixel_run(const hvc_component *comps, int n_comp) { return record_run(comps, n_comp, true); }
+RecordRun coef_run(const hvc_component *comps, int n_comp) { return record_run(comps, n_comp, false); }
+
+hipError_t download_pixels(const hvc_component *comps, int n_comp, const RecordRun &run, int f0, int cnt, size_t fs,
+                           const uint8_t *d_base, uint8_t *h_base, hipStream_t st) {
+    if (cnt <= 0) return hipSuccess;
+    if (run.len) {
+        const size_t off = (size_t)f0 * fs + run.first;
+        if (cnt == 1 || fs == run.len)
+            return hipMemcpyAsync(h_base + off, d_base + off, (size_t)(cnt - 1) * fs + run.len, hipMemcpyDeviceToHost, st);
+        return hipMemcpy2DAsync(h_base + off, fs, d_base + off, fs, run.len, (size_t)cnt, hipMemcpyDeviceToHost, st);
+    }
+    for (int i = 0; i < n_comp; i++) { // every plane by itself: rows of blocks_w * 8 bytes, `stride` apart, all frames' rows
+        const hvc_component &k = comps[i];
+        const size_t w = (size_t)k.blocks_w * 8, h = (size_t)k.blocks_h * 8;
+        for (int f = f0; f < f0 + cnt; f++) {
+            const size_t off = (size_t)f * fs + k.plane_offset;
+            const hipError_t e = hipMemcpy2DAsync(h_base + off, k.stride, d_base + off, k.stride, w, h, hipMemcpyDeviceToHost, st);
+            if (e != hipSuccess) return e;
+        }
+    }
+    return hipSuccess;
+}
+
+hipError_t download_coefs(const hvc_component *comps, int n_comp, const RecordRun &run, int f0, int cnt, size_t fs,
+                          const uint8_t *d_base, uint8_t *h_base, hipStream_t st) {
+    if (cnt <= 0) return hipSuccess;
+    if (run.len) {
+        const size_t off = (size_t)f0 * fs + run.first;
+        if (cnt == 1 || fs == run.len)
+            return hipMemcpyAsync(h_base + off, d_base + off, (size_t)(cnt - 1) * fs + run.len, hipMemcpyDeviceToHost, st);
+        return hipMemcpy2DAsync(h_base + off, fs, d_base + off, fs, run.len, (size_t)cnt, hipMemcpyDeviceToHost, st);
+    }
+    for (int f = f0; f < f0 + cnt; f++)
+        for (int i = 0; i < n_comp; i++) {
+            const size_t off = (size_t)f * fs + comps[i].coef_offset * sizeof(int16_t);
+            const size_t n = (size_t)comps[i].blocks_w * comps[i].blocks_h * 64 * sizeof(int16_t);
+            const hipError_t e = hipMemcpyAsync(h_base + off, d_base + off, n, hipMemcpyDeviceToHost, st);
+            if (e != hipSuccess) return e;
+        }
+    return hipSuccess;
+}
+
+// A launch's grid is (tiles per frame, frames): at most 65535 frames, and the fix-up list names a block by a 32-bit id
+// (frame * tiles + tile) * lanes + lane.  A batch beyond either is the caller's business no more than the 10 GB rule
+// above: it is cut into launches (the largest number of frames per launch that respects all three).
+static int frames_per_launch_capped(int n_frames, unsigned long long blocks_per_frame, unsigned long long ids_per_frame) {
+    int per = frames_per_launch(n_frames, blocks_per_frame);
+    if (per > 65535) per = 65535;
+    const unsigned long long by_ids = ids_per_frame ? ((1ull << 32) - 1) / ids_per_frame : (unsigned long long)per;
+    if ((unsigned long long)per > by_ids) per = (int)by_ids;
+    return per < 1 ? 1 : per;
 }
 
 // dc_plane (device memory calls only, default kernels only): see hvc::DecodeParams::dc_plane
@@ -640,16 +725,18 @@ int decode_frames_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const u
     r = make_layout(comps, n_comp, n_qtabs, L);
     if (r) return r;
     if (n_frames == 0) return HVC_OK;
-    if (n_frames > 65535) return HVC_E_TOO_LARGE;
     if (n_frames > 1 && (coef_fs < L.coef_span || pixel_fs < L.pixel_span)) return HVC_E_INVALID_ARG;
     if ((coef_fs & 7) || (pixel_fs & 7)) return HVC_E_ALIGNMENT;
-    unsigned long long ids = (unsigned long long)n_frames * L.tiles_per_frame * HVC_TILE;
-    if (ids >= (1ull << 32)) return HVC_E_TOO_LARGE;
+    // frames per launch: the 10 GB rule, the grid's 65535 frames, 32-bit block ids (frames_per_launch_capped)
+    const unsigned long long ids_per_frame = (unsigned long long)L.tiles_per_frame * HVC_TILE;
+    const int per = frames_per_launch_capped(n_frames, L.blocks_per_frame, ids_per_frame);
+    // (a side list of wide DCs names its blocks by ids of the WHOLE batch: the chunked pipelines that make one stay far below this)
+    if (wide && !wide->empty() && (unsigned long long)n_frames * ids_per_frame >= (1ull << 32)) return HVC_E_TOO_LARGE;
     DeviceGuard g(c->device);
     if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
 
-    // fix-up list: one entry per block at most
-    size_t need = (size_t)ids;
+    // fix-up list: one entry per block of a LAUNCH at most (launches follow one another on the stream, each consumes its own)
+    size_t need = (size_t)((unsigned long long)per * ids_per_frame);
     if (need > c->fix_cap) {
         void *p = c->d_fix_list;
         size_t cap = c->fix_cap * sizeof(unsigned);
@@ -677,17 +764,29 @@ int decode_frames_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const u
     for (int i = 0; i < n_qtabs * 64; i++) wide_only |= qtabs[i] > 255;
     wide_only |= c->decode_kernel == 2;
     P.kernel_sel = (c->decode_kernel == 1 || c->decode_kernel == 3) ? c->decode_kernel : 0;
+    if (wide_only) c->wide_host = (long long)((unsigned long long)n_frames * L.blocks_per_frame);
     // one launch: consumes counter fix_phase, its wide kernel clears the other one (fix_assign / fix_commit above)
     auto launch = [&](hvc::DecodeParams &Q, hipEvent_t k0, hipEvent_t k1) -> hipError_t {
-        if (wide_only) {
-            c->wide_host = (long long)((unsigned long long)n_frames * L.blocks_per_frame);
-            return hvc::launch_decode_wide_only(Q, c->stream);
-        }
+        if (wide_only) return hvc::launch_decode_wide_only(Q, c->stream, k0, k1);
         fix_assign(c, Q);
         const hipError_t e = hvc::launch_decode(Q, c->stream, k0, k1);
         if (e == hipSuccess) fix_commit(c);
         else fix_reset(c);
         return e;
+    };
+    // frames [f0, f0 + cnt) of the batch at d_coefs / d_pixels, in launches of `per` frames; the event pair brackets the
+    // dominant kernel of all of them (and the few-microsecond fix-up kernels in between)
+    auto launch_range = [&](const int16_t *d_coefs, uint8_t *d_pixels, int f0, int cnt, hipEvent_t k0, hipEvent_t k1) -> hipError_t {
+        for (int f = f0; f < f0 + cnt; f += per) {
+            hvc::DecodeParams Pk = P;
+            Pk.n_frames = f0 + cnt - f < per ? f0 + cnt - f : per;
+            Pk.coefs = d_coefs + (size_t)f * coef_fs;
+            Pk.pixels = d_pixels + (size_t)f * pixel_fs;
+            if (dc_plane) Pk.dc_plane = dc_plane + (size_t)f * dc_fs;
+            const hipError_t e = launch(Pk, f == f0 ? k0 : nullptr, f + per >= f0 + cnt ? k1 : nullptr);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
     };
 
     if (where == HVC_MEM_DEVICE) {
@@ -697,18 +796,9 @@ int decode_frames_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const u
         P.pixels = pixels;
         P.dc_plane = dc_plane;
         P.dc_fs = dc_fs;
-        const bool prof = c->profiling && !wide_only;
+        const bool prof = c->profiling;
         const int slot = (int)(c->k_calls % HVC_PROF_RING);
-        const int per = frames_per_launch(n_frames, L.blocks_per_frame); // (see launch_bytes_limit)
-        for (int f0 = 0; f0 < n_frames; f0 += per) {
-            hvc::DecodeParams Pk = P;
-            Pk.n_frames = n_frames - f0 < per ? n_frames - f0 : per;
-            Pk.coefs = coefs + (size_t)f0 * coef_fs;
-            Pk.pixels = pixels + (size_t)f0 * pixel_fs;
-            if (dc_plane) Pk.dc_plane = dc_plane + (size_t)f0 * dc_fs;
-            // the event pair brackets the dominant kernel of all parts (and the few-microsecond fix-up kernels in between)
-            HIPCHK(c, launch(Pk, prof && f0 == 0 ? c->k0[slot] : nullptr, prof && f0 + per >= n_frames ? c->k1[slot] : nullptr));
-        }
+        HIPCHK(c, launch_range(coefs, pixels, 0, n_frames, prof ? c->k0[slot] : nullptr, prof ? c->k1[slot] : nullptr));
         if (prof) c->k_calls++;
         if (wide && !wide->empty()) return apply_wide_dc(c, P, *wide);
         return HVC_OK;
@@ -722,64 +812,22 @@ int decode_frames_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, const u
     if (r) return r;
     r = grow(c, &c->d_out, &c->out_cap, pbytes);
     if (r) return r;
-    // copy back only the pixels the kernels wrote (the caller's padding stays untouched).  Tight planes that
-    // follow one another -- the usual record -- are one stretch per frame, or one for the whole batch.
-    size_t run0 = 0, run = 0; // [run0, run0 + run): the planes as one byte range of the record, if they are one
-    {
-        bool tight = true;
-        int order[4] = {0, 1, 2, 3};
-        for (int i = 0; i < n_comp; i++)
-            for (int j = i + 1; j < n_comp; j++)
-                if (comps[order[j]].plane_offset < comps[order[i]].plane_offset) std::swap(order[i], order[j]);
-        size_t at = comps[order[0]].plane_offset;
-        run0 = at;
-        for (int i = 0; i < n_comp && tight; i++) {
-            const hvc_component &k = comps[order[i]];
-            tight = k.plane_offset == at && k.stride == (size_t)k.blocks_w * 8;
-            at += (size_t)k.blocks_w * 8 * (size_t)k.blocks_h * 8;
-        }
-        run = tight ? at - run0 : 0;
-    }
-    if (run && n_frames >= 8 && cbytes >= ((size_t)64 << 20)) // large batches in that usual form: see overlapped_parts
+    // copy back only the pixels the kernels wrote (the caller's padding stays untouched)
+    const RecordRun run = pixel_run(comps, n_comp);
+    if (run.len && n_frames >= 8 && cbytes >= ((size_t)64 << 20)) // large batches in the usual form: see overlapped_parts
         return overlapped_parts(
             c, n_frames,
             [&](int f0, int cnt) {
                 return hipMemcpyAsync((int16_t *)c->d_in + (size_t)f0 * coef_fs, coefs + (size_t)f0 * coef_fs,
                                       ((size_t)(cnt - 1) * coef_fs + L.coef_span) * sizeof(int16_t), hipMemcpyHostToDevice, c->stream);
             },
-            [&](int, int f0, int cnt) {
-                hvc::DecodeParams Pk = P;
-                Pk.coefs = (const int16_t *)c->d_in + (size_t)f0 * coef_fs;
-                Pk.pixels = (uint8_t *)c->d_out + (size_t)f0 * pixel_fs;
-                Pk.n_frames = cnt;
-                return launch(Pk, nullptr, nullptr);
-            },
+            [&](int, int f0, int cnt) { return launch_range((const int16_t *)c->d_in, (uint8_t *)c->d_out, f0, cnt, nullptr, nullptr); },
             [&](int f0, int cnt, hipStream_t st) {
-                const size_t off = (size_t)f0 * pixel_fs + run0;
-                return pixel_fs == run ? hipMemcpyAsync(pixels + off, (uint8_t *)c->d_out + off, (size_t)cnt * run,
-                                                        hipMemcpyDeviceToHost, st)
-                                       : hipMemcpy2DAsync(pixels + off, pixel_fs, (uint8_t *)c->d_out + off, pixel_fs, run, (size_t)cnt,
-                                                          hipMemcpyDeviceToHost, st);
+                return download_pixels(comps, n_comp, run, f0, cnt, pixel_fs, (const uint8_t *)c->d_out, pixels, st);
             });
     HIPCHK(c, hipMemcpyAsync(c->d_in, coefs, cbytes, hipMemcpyHostToDevice, c->stream));
-    P.coefs = (const int16_t *)c->d_in;
-    P.pixels = (uint8_t *)c->d_out;
-    HIPCHK(c, launch(P, nullptr, nullptr));
-    if (run && (n_frames == 1 || pixel_fs == run)) {
-        HIPCHK(c, hipMemcpyAsync(pixels + run0, (uint8_t *)c->d_out + run0, (size_t)(n_frames - 1) * pixel_fs + run,
-                                 hipMemcpyDeviceToHost, c->stream));
-    } else if (run) {
-        HIPCHK(c, hipMemcpy2DAsync(pixels + run0, pixel_fs, (uint8_t *)c->d_out + run0, pixel_fs, run, (size_t)n_frames,
-                                   hipMemcpyDeviceToHost, c->stream));
-    } else {
-        for (int f = 0; f < n_frames; f++)
-            for (int i = 0; i < n_comp; i++) {
-                size_t off = (size_t)f * pixel_fs + comps[i].plane_offset;
-                HIPCHK(c, hipMemcpy2DAsync(pixels + off, comps[i].stride, (uint8_t *)c->d_out + off, comps[i].stride,
-                                           (size_t)comps[i].blocks_w * 8, (size_t)comps[i].blocks_h * 8,
-                                           hipMemcpyDeviceToHost, c->stream));
-            }
-    }
+    HIPCHK(c, launch_range((const int16_t *)c->d_in, (uint8_t *)c->d_out, 0, n_frames, nullptr, nullptr));
+    HIPCHK(c, download_pixels(comps, n_comp, run, 0, n_frames, pixel_fs, (const uint8_t *)c->d_out, pixels, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HVC_OK;
 }
@@ -817,7 +865,6 @@ int decode_frames_yuv444_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, 
         if (comps[i].blocks_w * 8 < aw[i] || comps[i].blocks_h * 8 < ah[i]) return HVC_E_INVALID_ARG;
     const size_t plane_bytes = (size_t)width * (size_t)height, out_span = 3 * plane_bytes;
     if (n_frames == 0) return HVC_OK;
-    if (n_frames > 65535) return HVC_E_TOO_LARGE;
     if (n_frames > 1 && (coef_fs < L.coef_span || frame_stride < out_span)) return HVC_E_INVALID_ARG;
     if (coef_fs & 7) return HVC_E_ALIGNMENT;
 
@@ -845,8 +892,12 @@ int decode_frames_yuv444_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, 
     // host output through the library's own (256-byte aligned) scratch
     const bool aligned = width % 16 == 0 && frame_stride % 16 == 0 && (where == HVC_MEM_HOST || (uintptr_t)frames % 16 == 0);
     hvc::plan_decode_444(P, aligned);
-    const unsigned long long ids = (unsigned long long)n_frames * P.tiles_per_frame * HVC_TILE * P.nw;
-    if (ids >= (1ull << 32)) return HVC_E_TOO_LARGE;
+    // frames per launch: the 10 GB rule, the grid's 65535 frames, 32-bit block ids (frames_per_launch_capped); the fix-up
+    // lists are per launch
+    const unsigned long long ids_per_frame = (unsigned long long)P.tiles_per_frame * HVC_TILE * P.nw;
+    const int per = frames_per_launch_capped(n_frames, L.blocks_per_frame, ids_per_frame);
+    if (wide && !wide->empty() && (unsigned long long)n_frames * ids_per_frame >= (1ull << 32)) return HVC_E_TOO_LARGE;
+    const unsigned long long ids = (unsigned long long)per * ids_per_frame;
     DeviceGuard g(c->device);
     if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
     if ((size_t)ids > c->fix_cap) {
@@ -869,7 +920,7 @@ int decode_frames_yuv444_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, 
     // the fix-up kernel of hvc_decode_frames) and the chroma tiles alone in k_decode_444, one after the other or side
     // by side on two streams.
     const int split = (aligned && !wide_only && c->decode_kernel == 0 && height % 8 == 0 && P.pl[0].cbw == P.pl[0].bw) ? fused444_mode() : 0;
-    const size_t luma_ids = split ? (size_t)n_frames * (size_t)((P.pl[0].cbw * P.pl[0].cbh + HVC_TILE - 1) / HVC_TILE) * HVC_TILE : 0;
+    const size_t luma_ids = split ? (size_t)per * (size_t)((P.pl[0].cbw * P.pl[0].cbh + HVC_TILE - 1) / HVC_TILE) * HVC_TILE : 0;
     if (luma_ids + (size_t)ids > c->fix_cap) { // (the luma list sits behind the 4:4:4 kernels' list)
         void *p = c->d_fix_list;
         size_t cap = c->fix_cap * sizeof(unsigned);
@@ -958,6 +1009,20 @@ int decode_frames_yuv444_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, 
         return e;
     };
 
+    // frames [f0, f0 + cnt) of the batch at d_coefs / d_out, in launches of `per` frames
+    auto launch_range = [&](const int16_t *d_coefs, uint8_t *d_out, int f0, int cnt, hipEvent_t k0, hipEvent_t k1) -> hipError_t {
+        for (int f = f0; f < f0 + cnt; f += per) {
+            hvc::Decode444Params Pk = P;
+            Pk.n_frames = f0 + cnt - f < per ? f0 + cnt - f : per;
+            Pk.coefs = d_coefs + (size_t)f * coef_fs;
+            Pk.out = d_out + (size_t)f * frame_stride;
+            if (dc_plane) Pk.dc_plane = dc_plane + (size_t)f * dc_fs;
+            const hipError_t e = launch(Pk, f == f0 ? k0 : nullptr, f + per >= f0 + cnt ? k1 : nullptr);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    };
+
     if (where == HVC_MEM_HOST && (dc_plane || (wide && !wide->empty()))) return HVC_E_INVALID_ARG;
     if (where == HVC_MEM_DEVICE) {
         if ((uintptr_t)coefs & 15) return HVC_E_ALIGNMENT;
@@ -967,15 +1032,7 @@ int decode_frames_yuv444_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, 
         P.dc_fs = dc_fs;
         const bool prof = c->profiling && !wide_only;
         const int slot = (int)(c->k_calls % HVC_PROF_RING);
-        const int per = frames_per_launch(n_frames, L.blocks_per_frame); // (see launch_bytes_limit)
-        for (int f0 = 0; f0 < n_frames; f0 += per) {
-            hvc::Decode444Params Pk = P;
-            Pk.n_frames = n_frames - f0 < per ? n_frames - f0 : per;
-            Pk.coefs = coefs + (size_t)f0 * coef_fs;
-            Pk.out = frames + (size_t)f0 * frame_stride;
-            if (dc_plane) Pk.dc_plane = dc_plane + (size_t)f0 * dc_fs;
-            HIPCHK(c, launch(Pk, prof && f0 == 0 ? c->k0[slot] : nullptr, prof && f0 + per >= n_frames ? c->k1[slot] : nullptr));
-        }
+        HIPCHK(c, launch_range(coefs, frames, 0, n_frames, prof ? c->k0[slot] : nullptr, prof ? c->k1[slot] : nullptr));
         if (prof) c->k_calls++;
         if (wide && !wide->empty()) return apply_wide_dc_444(c, P, *wide);
         return HVC_OK;
@@ -993,22 +1050,14 @@ int decode_frames_yuv444_impl(hvc_ctx *c, const int16_t *coefs, size_t coef_fs, 
                 return hipMemcpyAsync((int16_t *)c->d_in + (size_t)f0 * coef_fs, coefs + (size_t)f0 * coef_fs,
                                       ((size_t)(cnt - 1) * coef_fs + L.coef_span) * sizeof(int16_t), hipMemcpyHostToDevice, c->stream);
             },
-            [&](int, int f0, int cnt) {
-                auto Pk = P;
-                Pk.coefs = (const int16_t *)c->d_in + (size_t)f0 * coef_fs;
-                Pk.out = (uint8_t *)c->d_out + (size_t)f0 * frame_stride;
-                Pk.n_frames = cnt;
-                return launch(Pk, nullptr, nullptr);
-            },
+            [&](int, int f0, int cnt) { return launch_range((const int16_t *)c->d_in, (uint8_t *)c->d_out, f0, cnt, nullptr, nullptr); },
             [&](int f0, int cnt, hipStream_t st) {
                 const size_t off = (size_t)f0 * frame_stride;
                 return hipMemcpy2DAsync(frames + off, frame_stride, (uint8_t *)c->d_out + off, frame_stride, out_span, (size_t)cnt,
                                         hipMemcpyDeviceToHost, st);
             });
     HIPCHK(c, hipMemcpyAsync(c->d_in, coefs, cbytes, hipMemcpyHostToDevice, c->stream));
-    P.coefs = (const int16_t *)c->d_in;
-    P.out = (uint8_t *)c->d_out;
-    HIPCHK(c, launch(P, nullptr, nullptr));
+    HIPCHK(c, launch_range((const int16_t *)c->d_in, (uint8_t *)c->d_out, 0, n_frames, nullptr, nullptr));
     if (n_frames == 1) // frame_stride is irrelevant for a single frame (and may be smaller than the frame)
         HIPCHK(c, hipMemcpyAsync(frames, c->d_out, out_span, hipMemcpyDeviceToHost, c->stream));
     else
@@ -1037,16 +1086,8 @@ int hvc_dequant_idct_recon(hvc_ctx *c, const int16_t *coefs, size_t coef_plane_s
     comp.stride = stride;
     if (!coef_plane_stride) coef_plane_stride = (size_t)blocks_w * blocks_h * 64;
     if (!plane_stride) plane_stride = stride * (size_t)blocks_h * 8;
-    // planes are "frames" of one component; split batches beyond the grid.y limit
-    int done = 0;
-    while (done < n_planes) {
-        int n = n_planes - done > 65535 ? 65535 : n_planes - done;
-        int r = hvc_decode_frames(c, coefs + (size_t)done * coef_plane_stride, coef_plane_stride, qtab, 1, &comp, 1,
-                                  n, plane + (size_t)done * plane_stride, plane_stride, where);
-        if (r) return r;
-        done += n;
-    }
-    return n_planes < 0 ? HVC_E_INVALID_ARG : HVC_OK;
+    // planes are "frames" of one component (a batch of any size: hvc_decode_frames cuts it into launches)
+    return hvc_decode_frames(c, coefs, coef_plane_stride, qtab, 1, &comp, 1, n_planes, plane, plane_stride, where);
 } HVC_ABI_CATCH
 
 // ---------------------------------------------------------------------------
@@ -1065,11 +1106,11 @@ int hvc_encode_frames(hvc_ctx *c, const uint8_t *pixels, size_t pixel_fs, const 
     r = make_layout(comps, n_comp, n_qtabs, L);
     if (r) return r;
     if (n_frames == 0) return HVC_OK;
-    if (n_frames > 65535) return HVC_E_TOO_LARGE;
     if (n_frames > 1 && (coef_fs < L.coef_span || pixel_fs < L.pixel_span)) return HVC_E_INVALID_ARG;
     if ((coef_fs & 7) || (pixel_fs & 7)) return HVC_E_ALIGNMENT;
     DeviceGuard g(c->device);
     if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
+    const int per = frames_per_launch_capped(n_frames, L.blocks_per_frame, 0); // the 10 GB rule and the grid's 65535 frames
 
     hvc::EncodeParams P;
     std::memset(&P, 0, sizeof P);
@@ -1082,19 +1123,23 @@ int hvc_encode_frames(hvc_ctx *c, const uint8_t *pixels, size_t pixel_fs, const 
     for (int i = 0; i < n_qtabs * 64; i++) // fl((1 + 2^-16) / (4t)): see quant1 in hvc_kernels.hip
         P.qrcp[i] = (float)((1.0 + 1.0 / 65536.0) / (4.0 * (double)qtabs[i]));
 
+    // frames [f0, f0 + cnt) of the batch at d_pixels / d_coefs, in launches of `per` frames
+    auto launch_range = [&](const uint8_t *d_pixels, int16_t *d_coefs, int f0, int cnt, hipEvent_t k0, hipEvent_t k1) -> hipError_t {
+        for (int f = f0; f < f0 + cnt; f += per) {
+            hvc::EncodeParams Pk = P;
+            Pk.n_frames = f0 + cnt - f < per ? f0 + cnt - f : per;
+            Pk.coefs = d_coefs + (size_t)f * coef_fs;
+            Pk.pixels = d_pixels + (size_t)f * pixel_fs;
+            const hipError_t e = hvc::launch_encode(Pk, c->stream, f == f0 ? k0 : nullptr, f + per >= f0 + cnt ? k1 : nullptr);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    };
     if (where == HVC_MEM_DEVICE) {
         if (((uintptr_t)coefs & 15) || ((uintptr_t)pixels & 7)) return HVC_E_ALIGNMENT;
         const bool prof = c->profiling;
         const int slot = (int)(c->k_calls % HVC_PROF_RING);
-        const int per = frames_per_launch(n_frames, L.blocks_per_frame); // (see launch_bytes_limit)
-        for (int f0 = 0; f0 < n_frames; f0 += per) {
-            hvc::EncodeParams Pk = P;
-            Pk.n_frames = n_frames - f0 < per ? n_frames - f0 : per;
-            Pk.coefs = coefs + (size_t)f0 * coef_fs;
-            Pk.pixels = pixels + (size_t)f0 * pixel_fs;
-            HIPCHK(c, hvc::launch_encode(Pk, c->stream, prof && f0 == 0 ? c->k0[slot] : nullptr,
-                                         prof && f0 + per >= n_frames ? c->k1[slot] : nullptr));
-        }
+        HIPCHK(c, launch_range(pixels, coefs, 0, n_frames, prof ? c->k0[slot] : nullptr, prof ? c->k1[slot] : nullptr));
         if (prof) c->k_calls++;
         return HVC_OK;
     }
@@ -1105,56 +1150,22 @@ int hvc_encode_frames(hvc_ctx *c, const uint8_t *pixels, size_t pixel_fs, const 
     if (r) return r;
     r = grow(c, &c->d_out, &c->out_cap, cbytes);
     if (r) return r;
-    // copy back only the coefficient planes (gaps in the caller's records stay untouched); planes that follow one
-    // another -- the usual record -- are one stretch per frame
-    size_t run0 = 0, run = 0; // in int16 elements
-    {
-        bool adjacent = true;
-        int order[4] = {0, 1, 2, 3};
-        for (int i = 0; i < n_comp; i++)
-            for (int j = i + 1; j < n_comp; j++)
-                if (comps[order[j]].coef_offset < comps[order[i]].coef_offset) std::swap(order[i], order[j]);
-        size_t at = comps[order[0]].coef_offset;
-        run0 = at;
-        for (int i = 0; i < n_comp && adjacent; i++) {
-            adjacent = comps[order[i]].coef_offset == at;
-            at += (size_t)comps[order[i]].blocks_w * comps[order[i]].blocks_h * 64;
-        }
-        run = adjacent ? at - run0 : 0;
-    }
-    if (run && n_frames >= 8 && cbytes >= ((size_t)64 << 20)) // large batches in that usual form: see overlapped_parts
+    // copy back only the coefficient planes (gaps in the caller's records stay untouched)
+    const RecordRun run = coef_run(comps, n_comp);
+    if (run.len && n_frames >= 8 && cbytes >= ((size_t)64 << 20)) // large batches in the usual form: see overlapped_parts
         return overlapped_parts(
             c, n_frames,
             [&](int f0, int cnt) {
                 return hipMemcpyAsync((uint8_t *)c->d_in + (size_t)f0 * pixel_fs, pixels + (size_t)f0 * pixel_fs,
                                       (size_t)(cnt - 1) * pixel_fs + L.pixel_span, hipMemcpyHostToDevice, c->stream);
             },
-            [&](int, int f0, int cnt) {
-                hvc::EncodeParams Pk = P;
-                Pk.pixels = (const uint8_t *)c->d_in + (size_t)f0 * pixel_fs;
-                Pk.coefs = (int16_t *)c->d_out + (size_t)f0 * coef_fs;
-                Pk.n_frames = cnt;
-                return hvc::launch_encode(Pk, c->stream);
-            },
+            [&](int, int f0, int cnt) { return launch_range((const uint8_t *)c->d_in, (int16_t *)c->d_out, f0, cnt, nullptr, nullptr); },
             [&](int f0, int cnt, hipStream_t st) {
-                const size_t off = (size_t)f0 * coef_fs + run0;
-                return coef_fs == run ? hipMemcpyAsync(coefs + off, (int16_t *)c->d_out + off, (size_t)cnt * run * sizeof(int16_t),
-                                                       hipMemcpyDeviceToHost, st)
-                                      : hipMemcpy2DAsync(coefs + off, coef_fs * sizeof(int16_t), (int16_t *)c->d_out + off,
-                                                         coef_fs * sizeof(int16_t), run * sizeof(int16_t), (size_t)cnt,
-                                                         hipMemcpyDeviceToHost, st);
+                return download_coefs(comps, n_comp, run, f0, cnt, coef_fs * sizeof(int16_t), (const uint8_t *)c->d_out, (uint8_t *)coefs, st);
             });
     HIPCHK(c, hipMemcpyAsync(c->d_in, pixels, pbytes, hipMemcpyHostToDevice, c->stream));
-    P.pixels = (const uint8_t *)c->d_in;
-    P.coefs = (int16_t *)c->d_out;
-    HIPCHK(c, hvc::launch_encode(P, c->stream));
-    for (int f = 0; f < n_frames; f++)
-        for (int i = 0; i < n_comp; i++) {
-            size_t off = (size_t)f * coef_fs + comps[i].coef_offset;
-            size_t n = (size_t)comps[i].blocks_w * comps[i].blocks_h * 64;
-            HIPCHK(c, hipMemcpyAsync(coefs + off, (int16_t *)c->d_out + off, n * sizeof(int16_t),
-                                     hipMemcpyDeviceToHost, c->stream));
-        }
+    HIPCHK(c, launch_range((const uint8_t *)c->d_in, (int16_t *)c->d_out, 0, n_frames, nullptr, nullptr));
+    HIPCHK(c, download_coefs(comps, n_comp, run, 0, n_frames, coef_fs * sizeof(int16_t), (const uint8_t *)c->d_out, (uint8_t *)coefs, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HVC_OK;
 } HVC_ABI_CATCH
@@ -1244,15 +1255,7 @@ int hvc_fdct_quant(hvc_ctx *c, const uint8_t *plane, size_t stride, size_t plane
     comp.stride = stride;
     if (!coef_plane_stride) coef_plane_stride = (size_t)blocks_w * blocks_h * 64;
     if (!plane_stride) plane_stride = stride * (size_t)blocks_h * 8;
-    int done = 0;
-    while (done < n_planes) {
-        int n = n_planes - done > 65535 ? 65535 : n_planes - done;
-        int r = hvc_encode_frames(c, plane + (size_t)done * plane_stride, plane_stride, qtab, 1, &comp, 1, n,
-                                  coefs + (size_t)done * coef_plane_stride, coef_plane_stride, where);
-        if (r) return r;
-        done += n;
-    }
-    return HVC_OK;
+    return hvc_encode_frames(c, plane, plane_stride, qtab, 1, &comp, 1, n_planes, coefs, coef_plane_stride, where);
 } HVC_ABI_CATCH
 
 int hvc_upsample420(hvc_ctx *c, const uint8_t *src, int cw, int ch, size_t src_stride, uint8_t *dst,
@@ -1261,7 +1264,6 @@ int hvc_upsample420(hvc_ctx *c, const uint8_t *src, int cw, int ch, size_t src_s
     if (where != HVC_MEM_HOST && where != HVC_MEM_DEVICE) return HVC_E_INVALID_ARG;
     if (src_stride < (size_t)cw || dst_stride < (size_t)cw * 2) return HVC_E_INVALID_ARG;
     if (n_planes == 0) return HVC_OK;
-    if (n_planes > 65535) return HVC_E_TOO_LARGE;
     if (!src_ps) src_ps = src_stride * (size_t)ch;
     if (!dst_ps) dst_ps = dst_stride * (size_t)ch * 2;
     DeviceGuard g(c->device);
@@ -1275,10 +1277,19 @@ int hvc_upsample420(hvc_ctx *c, const uint8_t *src, int cw, int ch, size_t src_s
     P.dst_stride = dst_stride;
     P.src_ps = src_ps;
     P.dst_ps = dst_ps;
+    auto launch_all = [&](const uint8_t *d_src, uint8_t *d_dst) -> hipError_t { // (the grid's y dimension holds 65535 planes)
+        for (int p0 = 0; p0 < n_planes; p0 += 65535) {
+            hvc::UpsampleParams Q = P;
+            Q.n_planes = n_planes - p0 < 65535 ? n_planes - p0 : 65535;
+            Q.src = d_src + (size_t)p0 * src_ps;
+            Q.dst = d_dst + (size_t)p0 * dst_ps;
+            const hipError_t e = hvc::launch_upsample420(Q, c->stream);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    };
     if (where == HVC_MEM_DEVICE) {
-        P.src = src;
-        P.dst = dst;
-        HIPCHK(c, hvc::launch_upsample420(P, c->stream));
+        HIPCHK(c, launch_all(src, dst));
         return HVC_OK;
     }
     size_t sbytes = (size_t)(n_planes - 1) * src_ps + (size_t)(ch - 1) * src_stride + (size_t)cw;
@@ -1288,9 +1299,7 @@ int hvc_upsample420(hvc_ctx *c, const uint8_t *src, int cw, int ch, size_t src_s
     r = grow(c, &c->d_out, &c->out_cap, dbytes);
     if (r) return r;
     HIPCHK(c, hipMemcpyAsync(c->d_in, src, sbytes, hipMemcpyHostToDevice, c->stream));
-    P.src = (const uint8_t *)c->d_in;
-    P.dst = (uint8_t *)c->d_out;
-    HIPCHK(c, hvc::launch_upsample420(P, c->stream));
+    HIPCHK(c, launch_all((const uint8_t *)c->d_in, (uint8_t *)c->d_out));
     for (int p = 0; p < n_planes; p++)
         HIPCHK(c, hipMemcpy2DAsync(dst + (size_t)p * dst_ps, dst_stride, (uint8_t *)c->d_out + (size_t)p * dst_ps,
                                    dst_stride, (size_t)cw * 2, (size_t)ch * 2, hipMemcpyDeviceToHost, c->stream));

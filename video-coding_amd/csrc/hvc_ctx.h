@@ -4,6 +4,7 @@
 //   hvc_capi_jpeg.hip    files: one at a time (hvc_jpeg_decode, hvc_jpeg_encode) and the batch pipeline with the host reader
 //   hvc_capi_reader.hip  the GPU Huffman reader's entry point and the batch pipeline built on it
 //   hvc_capi_files.hip   the GPU Huffman coder's entry point and the batch pipelines that write files
+//   hvc_capi_async.hip   pinned host memory and the slots of the asynchronous seam (hvc_decode_frames_submit / hvc_wait)
 #ifndef HVC_CTX_H
 #define HVC_CTX_H
 
@@ -106,6 +107,16 @@ struct hvc_ctx {
     unsigned *hd_tables = nullptr;
     void *hd_lens = nullptr, *hd_meta = nullptr, *hd_bitbuf = nullptr, *hd_ff = nullptr, *hd_out = nullptr;
     size_t hd_lens_cap = 0, hd_meta_cap = 0, hd_bitbuf_cap = 0, hd_ff_cap = 0, hd_out_cap = 0;
+    // The asynchronous seam (hvc_capi_async.hip): one batch in flight per slot.  Uploads run on copy_stream, the block stage
+    // on `stream`, downloads on down_stream; a slot's device buffers are its own (grown while the slot is free).
+    struct Slot {
+        void *d_in = nullptr, *d_out = nullptr;
+        size_t in_cap = 0, out_cap = 0;
+        // up0 / up1 around the upload, k0 / k1 around the block stage, dn0 / dn1 around the download; `done` = the last of them
+        hipEvent_t up0 = nullptr, up1 = nullptr, k0 = nullptr, k1 = nullptr, dn0 = nullptr, dn1 = nullptr;
+        bool busy = false, has_down = false, timed = false;
+        unsigned long long h2d_bytes = 0, d2h_bytes = 0;
+    } slots[HVC_SLOTS];
 };
 
 // pinned rings the host only ever writes (unstuffed segments, padded raw frames) and the copy engine reads
@@ -202,6 +213,25 @@ struct Layout {
 };
 int make_layout(const hvc_component *comps, int n_comp, int n_qtabs, Layout &L);
 int check_qtabs(const uint16_t *qtabs, int n_qtabs, bool divides); // divides: the encoder (an entry of zero is HVC_E_RANGE)
+
+// A component without a block (blocks_w or blocks_h of zero: the model's empty Plane.t) has no part in the block stage: the
+// decoding entry points drop such components from the list they work on; *n_kept == 0: nothing to decode at all.
+int drop_empty_components(const hvc_component *comps, int n_comp, hvc_component *kept, int *n_kept);
+
+// What comes back to a host caller is what the kernels wrote, never the padding between planes.  Planes (pixel planes:
+// decode; coefficient planes: encode) that follow one another tightly -- the usual record -- are ONE stretch per frame:
+// [first, first + len) in bytes from the frame record; len == 0: they are not, every plane is copied by itself.
+struct RecordRun {
+    size_t first = 0, len = 0;
+};
+RecordRun pixel_run(const hvc_component *comps, int n_comp);
+RecordRun coef_run(const hvc_component *comps, int n_comp); // (bytes, like pixel_run)
+// frames [f0, f0 + cnt) of a batch laid out alike on the device (d_base) and on the host (h_base), frame stride `fs` bytes,
+// device -> host on stream `st`: one copy (stretches that touch), one 2D copy, or one 2D copy per plane
+hipError_t download_pixels(const hvc_component *comps, int n_comp, const RecordRun &run, int f0, int cnt, size_t fs,
+                           const uint8_t *d_base, uint8_t *h_base, hipStream_t st);
+hipError_t download_coefs(const hvc_component *comps, int n_comp, const RecordRun &run, int f0, int cnt, size_t fs_bytes,
+                          const uint8_t *d_base, uint8_t *h_base, hipStream_t st);
 
 // The batch pipelines' orchestrating thread waits most of the call (an upload's end, a chunk's kernels).
 // hipEventSynchronize spins -- also on an event created with hipEventBlockingSync, on this ROCm (measured: CPU time =

@@ -126,13 +126,8 @@ struct Decode444Params {
     size_t dc_fs;
     unsigned long long *wide_total; // as in DecodeParams
     int wide_first;
-    int xcd_map;                    // as in DecodeParams; < 0: one of the other orders below (HVC_444_ORDER, A/B only)
+    int xcd_map;                    // as in DecodeParams (other workgroup orders were measured and closed: profiles/r05c_fused_order.txt)
     unsigned xcd_magic;
-    // HVC_444_ORDER (A/B only; profiles/r05c_fused_order.txt): -1 "stripe" = XCD x owns the x-th eighth of the batch's (frame,
-    // tile) list, i.e. a stretch of consecutive output rows of consecutive frames; -2 "run:R" = runs of any R tiles per XCD
-    // (98 = one 1080p frame); -3 "split" = every luma tile of the batch first (runs of 16), then the chroma tiles, one frame's
-    // two chroma planes per XCD
-    unsigned xo_run, xo_run_magic, xo_yt_magic, xo_c2_magic;
 };
 
 // HVC_XCD_RUN in the environment (A/B switch): 0 = workgroups as dispatched; R = runs of R tiles per XCD (a power of two).
@@ -189,7 +184,7 @@ hipError_t launch_decode_444(const Decode444Params &P, bool wide_only, hipStream
 // 16-byte store form can be used (width % 16 == 0, frame stride % 16 == 0, 16-byte aligned output)
 void plan_decode_444(Decode444Params &P, bool aligned);
 hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr);
-hipError_t launch_decode_wide_only(const DecodeParams &P, hipStream_t s);
+hipError_t launch_decode_wide_only(const DecodeParams &P, hipStream_t s, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr);
 // after a batch's launches: the listed blocks (fix-list ids of P's geometry) recomputed in int64 with the DC of dcs[]
 hipError_t launch_decode_dcfix(const DecodeParams &P, const unsigned *count, const unsigned *ids, const long long *dcs,
                                hipStream_t s);

@@ -188,13 +188,14 @@ __device__ __forceinline__ int64_t ocaml_int(uint64_t x) { return (int64_t)(x <<
 template <int S>
 __device__ __forceinline__ uint64_t asr63(uint64_t x) { return S ? (uint64_t)(ocaml_int(x) >> S) : x; }
 
+// Eight values in, eight out, all in registers: b[i] is the pass's input i (a row's or a column's i-th element).
 template <bool COL>
-__device__ __forceinline__ void idct_1d_wide(int64_t *b, int s) {
+__device__ __forceinline__ void idct8_wide(const uint64_t (&b)[8], int64_t (&o)[8]) {
     typedef uint64_t u64;
     constexpr u64 w1 = (u64)W1, w2 = (u64)W2, w3 = (u64)W3, w5 = (u64)W5, w6 = (u64)W6, w7 = (u64)W7;
-    u64 x0 = COL ? (u64)b[0] * 256u + 8192u : (u64)b[0] * 2048u + 128u;
-    u64 x1 = COL ? (u64)b[4 * s] * 256u : (u64)b[4 * s] * 2048u;
-    u64 x2 = (u64)b[6 * s], x3 = (u64)b[2 * s], x4 = (u64)b[1 * s], x5 = (u64)b[7 * s], x6 = (u64)b[5 * s], x7 = (u64)b[3 * s];
+    u64 x0 = COL ? b[0] * 256u + 8192u : b[0] * 2048u + 128u;
+    u64 x1 = COL ? b[4] * 256u : b[4] * 2048u;
+    u64 x2 = b[6], x3 = b[2], x4 = b[1], x5 = b[7], x6 = b[5], x7 = b[3];
     constexpr u64 R = COL ? 4 : 0;
     constexpr int RS = COL ? 3 : 0;
     u64 x8 = w7 * (x4 + x5) + R;
@@ -220,14 +221,14 @@ __device__ __forceinline__ void idct_1d_wide(int64_t *b, int s) {
     x2 = asr63<8>(181u * ys + 128u);
     x4 = asr63<8>(181u * yd + 128u);
     constexpr int S = COL ? 14 : 8;
-    b[0] = (int64_t)asr63<S>(x7 + x1);
-    b[1 * s] = (int64_t)asr63<S>(x3 + x2);
-    b[2 * s] = (int64_t)asr63<S>(x0 + x4);
-    b[3 * s] = (int64_t)asr63<S>(x8 + x6);
-    b[4 * s] = (int64_t)asr63<S>(x8 - x6);
-    b[5 * s] = (int64_t)asr63<S>(x0 - x4);
-    b[6 * s] = (int64_t)asr63<S>(x3 - x2);
-    b[7 * s] = (int64_t)asr63<S>(x7 - x1);
+    o[0] = (int64_t)asr63<S>(x7 + x1);
+    o[1] = (int64_t)asr63<S>(x3 + x2);
+    o[2] = (int64_t)asr63<S>(x0 + x4);
+    o[3] = (int64_t)asr63<S>(x8 + x6);
+    o[4] = (int64_t)asr63<S>(x8 - x6);
+    o[5] = (int64_t)asr63<S>(x0 - x4);
+    o[6] = (int64_t)asr63<S>(x3 - x2);
+    o[7] = (int64_t)asr63<S>(x7 - x1);
 }
 // decoder.ml:142-149 `coefs.(i) * qnt_tab.(i)` in the same arithmetic (the factors: an int16 or a 63-bit DC, a 16-bit entry)
 __device__ __forceinline__ int64_t mul63(int64_t a, int64_t b) { return (int64_t)((uint64_t)a * (uint64_t)b); }
@@ -800,49 +801,116 @@ __global__ __launch_bounds__(HVC_TILE) void k_decode_q16(DecodeParams P) {
     }
 }
 
-// K1 wide: int64, one flagged block per thread; also usable on its own for a
-// whole batch (list == nullptr: every block).
+// K1 wide: the model's own 63-bit arithmetic.  Two uses: the fix-up list of a launch (blocks the packed kernel's guard
+// sent here: normally none) and WHOLE calls -- a quantiser entry above 255 (16-bit DQT) or hvc_set_decode_kernel(ctx, 2)
+// sends every block through it -- so it is built on K1's skeleton: one block per lane, the block's 128 bytes as 8 x 16 B
+// loads, every intermediate in registers (the 64 int64 values of the transposed intermediate are 128 VGPRs; every index
+// below is a compile-time constant after unrolling, nothing goes to scratch), 8 x 8-byte row stores.
+//
+// One block: w = its 32 coefficient dwords (zig-zag order as loaded), q = its table (zig-zag order); has_dc: the DC is
+// `dc` (the model's 63-bit number: DecodeParams::dc_plane or the side list of DCs beyond int16) instead of coefficient 0.
+// decoder.ml:142-149 (dequantise + inverse zig-zag), dct.ml:11-107 (rows, then columns), decoder.ml:213-224 (clip, + 128).
+__device__ __forceinline__ void decode_block_wide(const unsigned (&w)[32], const int *__restrict__ q, bool has_dc, int64_t dc,
+                                                  unsigned (&out)[8][2]) {
+    int64_t v[64];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        uint64_t in[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int zz = ZF[8 * r + i]; // raster 8r + i sits at zig-zag position zz: dword zz / 2, half zz & 1
+            const int c = (zz & 1) ? (int)w[zz >> 1] >> 16 : (int)(short)(w[zz >> 1] & 0xffffu);
+            in[i] = (uint64_t)((int64_t)c * (int64_t)q[zz]);
+        }
+        if (r == 0 && has_dc) in[0] = (uint64_t)mul63(dc, (int64_t)q[0]);
+        int64_t o[8];
+        idct8_wide<false>(in, o);
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[8 * r + i] = o[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) out[j][0] = out[j][1] = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        uint64_t in[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) in[j] = (uint64_t)v[8 * j + c];
+        int64_t o[8];
+        idct8_wide<true>(in, o);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int64_t x = o[j] < -128 ? -128 : (o[j] > 127 ? 127 : o[j]);
+            out[j][c >> 2] |= (unsigned)(x + 128) << (8 * (c & 3));
+        }
+    }
+}
+
+__device__ __forceinline__ void load_block_dwords(const int16_t *cf, unsigned (&w)[32]) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(cf);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint4 t = src[j];
+        w[4 * j + 0] = t.x;
+        w[4 * j + 1] = t.y;
+        w[4 * j + 2] = t.z;
+        w[4 * j + 3] = t.w;
+    }
+}
+
+// The fix-up form: the listed blocks, one per lane, in a grid-stride loop over the (normally empty) list.
 // dc_list (optional, parallel to list): the listed block's true absolute DC where it does not fit the int16 record
 // (hvc_hdec.h WideDc: the model's 63-bit dc of decoder.ml:143)
 __global__ __launch_bounds__(64) void k_decode_wide(DecodeParams P, const unsigned *count, const unsigned *list,
-                                                    unsigned long long total, const long long *dc_list) {
-    unsigned long long n = list ? (unsigned long long)*count : total;
+                                                    const long long *dc_list) {
+    const unsigned long long n = (unsigned long long)*count;
     // The two fix-up counters alternate between calls: this launch reads the
     // current one and clears the other for the next call (no memset node).
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (P.fix_count_next) *P.fix_count_next = 0;
         // hvc_last_wide_blocks: the call's total (1 = this launch starts it, 0 = adds in stream order, 2 = adds beside
         // another stream's launch)
-        if (P.wide_total && list) {
+        if (P.wide_total) {
             if (P.wide_first == 2) atomicAdd(P.wide_total, n);
             else *P.wide_total = P.wide_first ? n : *P.wide_total + n;
         }
     }
     for (unsigned long long i = (unsigned long long)blockIdx.x * 64 + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * 64) {
-        unsigned long long id = list ? list[i] : i;
-        int lane = (int)(id % HVC_TILE);
-        unsigned long long t = id / HVC_TILE;
-        int tile = (int)(t % (unsigned)P.tiles_per_frame);
-        int frame = (int)(t / (unsigned)P.tiles_per_frame);
+        const unsigned long long id = list[i];
+        const int lane = (int)(id % HVC_TILE);
+        const unsigned long long t = id / HVC_TILE;
+        const int tile = (int)(t % (unsigned)P.tiles_per_frame);
+        const int frame = (int)(t / (unsigned)P.tiles_per_frame);
         if (frame >= P.n_frames) continue; // an id from another geometry must never turn into an address
         BlockRef br;
         if (!locate(P, frame, tile, lane, br)) continue;
-        const int *q = P.qt + br.qtab * 64;
-        int64_t v[64];
-        const int16_t *cf = P.coefs + br.coef_idx;
-        for (int k = 0; k < 64; k++) v[ZI[k]] = (int64_t)cf[k] * (int64_t)q[k];
+        unsigned w[32], out[8][2];
+        load_block_dwords(P.coefs + br.coef_idx, w);
+        int64_t dc = 0;
         if (P.dc_plane) // the DC lives in the compact array (DecodeParams::dc_plane)
-            v[0] = (int64_t)P.dc_plane[(size_t)frame * P.dc_fs + ((br.coef_idx - (size_t)frame * P.coef_fs) >> 6)] * (int64_t)q[0];
-        if (dc_list) v[0] = mul63((int64_t)dc_list[i], (int64_t)q[0]);
-        for (int r = 0; r < 8; r++) idct_1d_wide<false>(v + r * 8, 1);
-        for (int c = 0; c < 8; c++) idct_1d_wide<true>(v + c, 8);
-        for (int j = 0; j < 8; j++)
-            for (int i2 = 0; i2 < 8; i2++) {
-                int64_t x = v[j * 8 + i2];
-                x = x < -128 ? -128 : (x > 127 ? 127 : x);
-                P.pixels[br.pix_idx + (size_t)j * br.stride + i2] = (uint8_t)(x + 128);
-            }
+            dc = (int64_t)P.dc_plane[(size_t)frame * P.dc_fs + ((br.coef_idx - (size_t)frame * P.coef_fs) >> 6)];
+        if (dc_list) dc = (int64_t)dc_list[i];
+        decode_block_wide(w, P.qt + br.qtab * 64, P.dc_plane != nullptr || dc_list != nullptr, dc, out);
+#pragma unroll
+        for (int j = 0; j < 8; j++) store_row8(P.pixels + br.pix_idx + (size_t)j * br.stride, out[j][0], out[j][1]);
+    }
+}
+
+// Every block of a launch: K1's work decomposition (grid = tiles x frames, xcd_work, one block per lane).
+__global__ __launch_bounds__(HVC_TILE) void k_decode_wide_all(DecodeParams P) {
+    BlockRef br;
+    const int lane = threadIdx.x;
+    unsigned wframe, wtile;
+    xcd_work(P.xcd_map, P.xcd_magic, wframe, wtile);
+    const bool active = locate(P, (int)wframe, (int)wtile, lane, br);
+    unsigned w[32], out[8][2];
+    load_block_dwords(P.coefs + br.coef_idx, w);
+    int64_t dc = 0;
+    if (P.dc_plane) dc = (int64_t)P.dc_plane[(size_t)wframe * P.dc_fs + ((br.coef_idx - (size_t)wframe * P.coef_fs) >> 6)];
+    decode_block_wide(w, P.qt + br.qtab * 64, P.dc_plane != nullptr, dc, out);
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) store_row8(P.pixels + br.pix_idx + (size_t)j * br.stride, out[j][0], out[j][1]);
     }
 }
 
@@ -971,49 +1039,6 @@ __device__ __forceinline__ void emit_rows444(uint8_t *row_even, size_t W, int x0
                      __builtin_amdgcn_perm(q1, v1, LO), __builtin_amdgcn_perm(q1, v1, HI));
 }
 
-// The other workgroup -> (frame, tile) orders of HVC_444_ORDER (Decode444Params::xcd_map < 0): each a permutation of the grid
-// (scalar arithmetic; divisions by host-made reciprocals, exact for grids of < 2^32 / 2^7 workgroups -- the host checks).
-__device__ __forceinline__ void xcd_work_444(const Decode444Params &P, unsigned &frame, unsigned &tile) {
-    const unsigned per = gridDim.x, total = per * gridDim.y, id = blockIdx.y * per + blockIdx.x;
-    const unsigned xcd = id & 7u, k = id >> 3;
-    frame = blockIdx.y;
-    tile = blockIdx.x;
-    if (P.xcd_map == -1) {
-        const unsigned eighth = total >> 3;
-        if (id < (eighth << 3)) {
-            const unsigned lin = xcd * eighth + k;
-            frame = __umulhi(lin, P.xcd_magic);
-            tile = lin - frame * per;
-        }
-    } else if (P.xcd_map == -2) {
-        const unsigned R = P.xo_run, group = 8u * R;
-        if (id < total - total % group) {
-            const unsigned kr = __umulhi(k, P.xo_run_magic);
-            const unsigned lin = (kr * 8u + xcd) * R + (k - kr * R);
-            frame = __umulhi(lin, P.xcd_magic);
-            tile = lin - frame * per;
-        }
-    } else if (P.xcd_map == -3) {
-        const unsigned yt = (unsigned)P.y_tiles, c2 = per - yt, A = yt * gridDim.y;
-        if (id < A) {
-            unsigned lin = id;
-            if (id < A - A % 128u) lin = ((((k >> 4) << 3) + xcd) << 4) + (k & 15u);
-            frame = __umulhi(lin, P.xo_yt_magic);
-            tile = lin - frame * yt;
-        } else {
-            const unsigned id2 = id - A, B = total - A, k2 = id2 >> 3;
-            if (id2 < B - B % (8u * c2)) {
-                const unsigned kr = __umulhi(k2, P.xo_c2_magic);
-                frame = kr * 8u + (id2 & 7u);
-                tile = yt + (k2 - kr * c2);
-            } else {
-                frame = __umulhi(id2, P.xo_c2_magic);
-                tile = yt + (id2 - frame * c2);
-            }
-        }
-    }
-}
-
 #ifdef HVC_444_WAVES /* experiments: -DHVC_444_WAVES=4 */
 #define HVC_444_ATTR __attribute__((amdgpu_waves_per_eu(HVC_444_WAVES, HVC_444_WAVES)))
 #else
@@ -1026,10 +1051,7 @@ __global__ __launch_bounds__(HVC_TILE * NW, 4 / NW) HVC_444_ATTR void k_decode_4
     __shared__ uint4 edge[WGS]; // per lane: first row (x, y) and first column (z, w) of its chroma block
     const int lane = threadIdx.x;
     unsigned wframe, wtile;
-    if (P.xcd_map >= 0)
-        xcd_work(P.xcd_map, P.xcd_magic, wframe, wtile);
-    else
-        xcd_work_444(P, wframe, wtile);
+    xcd_work(P.xcd_map, P.xcd_magic, wframe, wtile);
     const int tile = (int)wtile + P.tile0;             // (tile0 = y_tiles when the luma planes went through k_decode_packed)
     const bool chroma = tile >= P.y_tiles;             // workgroup-uniform
     if (P.skip && P.skip == (chroma ? 2 : 1)) return;  // (measurements: one half of the kernel alone)
@@ -1143,24 +1165,22 @@ __global__ __launch_bounds__(64) void k_decode_wide_444(Decode444Params P, const
         const Ref444 r = locate444(P, tile, lane, (int)wgs, HVC_444_TILE_BW * P.nw);
         if (!r.store) continue;
         const Plane444K &K = P.pl[r.p];
-        const int *q = P.qt + K.qtab * 64;
-        int64_t v[64];
         const size_t in_frame = K.coef_off + ((size_t)r.by * K.bw + r.bx) * 64;
-        const int16_t *cf = P.coefs + frame * P.coef_fs + in_frame;
-        for (int k = 0; k < 64; k++) v[ZI[k]] = (int64_t)cf[k] * (int64_t)q[k];
-        if (P.dc_plane) v[0] = (int64_t)P.dc_plane[frame * P.dc_fs + (in_frame >> 6)] * (int64_t)q[0];
-        if (dc_list) v[0] = mul63((int64_t)dc_list[i], (int64_t)q[0]);
-        for (int rr = 0; rr < 8; rr++) idct_1d_wide<false>(v + rr * 8, 1);
-        for (int c = 0; c < 8; c++) idct_1d_wide<true>(v + c, 8);
+        unsigned w[32], out[8][2];
+        load_block_dwords(P.coefs + frame * P.coef_fs + in_frame, w);
+        int64_t dc = 0;
+        if (P.dc_plane) dc = (int64_t)P.dc_plane[frame * P.dc_fs + (in_frame >> 6)];
+        if (dc_list) dc = (int64_t)dc_list[i];
+        decode_block_wide(w, P.qt + K.qtab * 64, P.dc_plane != nullptr || dc_list != nullptr, dc, out);
         uint8_t *plane = P.out + frame * P.out_fs + K.out_off;
         const int step = r.p == 0 ? 1 : 2;
+#pragma unroll
         for (int j = 0; j < 8; j++)
+#pragma unroll
             for (int i2 = 0; i2 < 8; i2++) {
                 const int x = r.bx * 8 + i2, y = r.by * 8 + j;
                 if (x >= K.aw || y >= K.ah) continue;
-                int64_t s = v[j * 8 + i2];
-                s = s < -128 ? -128 : (s > 127 ? 127 : s);
-                plane[(size_t)(y * step) * (size_t)P.width + (size_t)(x * step)] = (uint8_t)(s + 128);
+                plane[(size_t)(y * step) * (size_t)P.width + (size_t)(x * step)] = (uint8_t)(out[j][i2 >> 2] >> (8 * (i2 & 3)));
             }
     }
 }
@@ -1741,7 +1761,7 @@ hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0, hi
     if (k1 && (e = hipEventRecord(k1, s)) != hipSuccess) return e;
     // Fixed small grid; every thread strides over the (normally empty) list and
     // exits as soon as its index passes *fix_count.
-    hipLaunchKernelGGL(k_decode_wide, dim3(256), dim3(64), 0, s, P, P.fix_count, P.fix_list, 0ull, (const long long *)nullptr);
+    hipLaunchKernelGGL(k_decode_wide, dim3(256), dim3(64), 0, s, P, P.fix_count, P.fix_list, (const long long *)nullptr);
     return hipGetLastError();
 }
 
@@ -1752,7 +1772,7 @@ hipError_t launch_decode_dcfix(const DecodeParams &P, const unsigned *count, con
     DecodeParams Q = P;
     Q.fix_count_next = nullptr; // (not part of the launches' counter ping-pong)
     Q.wide_total = nullptr;
-    hipLaunchKernelGGL(k_decode_wide, dim3(64), dim3(64), 0, s, Q, count, ids, 0ull, dcs);
+    hipLaunchKernelGGL(k_decode_wide, dim3(64), dim3(64), 0, s, Q, count, ids, dcs);
     return hipGetLastError();
 }
 
@@ -1777,12 +1797,17 @@ hipError_t launch_decode_444_dcfix(const Decode444Params &P, const unsigned *cou
     return hipGetLastError();
 }
 
-hipError_t launch_decode_wide_only(const DecodeParams &P, hipStream_t s) {
+hipError_t launch_decode_wide_only(const DecodeParams &P, hipStream_t s, hipEvent_t k0, hipEvent_t k1) {
     if (P.n_frames <= 0 || P.tiles_per_frame <= 0) return hipSuccess;
-    unsigned long long total = (unsigned long long)P.n_frames * P.tiles_per_frame * HVC_TILE;
-    hipLaunchKernelGGL(k_decode_wide, dim3(4096), dim3(64), 0, s, P, (const unsigned *)nullptr,
-                       (const unsigned *)nullptr, total, (const long long *)nullptr);
-    return hipGetLastError();
+    hipError_t e;
+    const dim3 grid((unsigned)P.tiles_per_frame, (unsigned)P.n_frames, 1);
+    DecodeParams Q = P;
+    Q.xcd_map = xcd_map_for(grid.x, grid.y, Q.xcd_magic);
+    if (k0 && (e = hipEventRecord(k0, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_decode_wide_all, grid, dim3(HVC_TILE), 0, s, Q);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (k1 && (e = hipEventRecord(k1, s)) != hipSuccess) return e;
+    return hipSuccess;
 }
 
 void plan_decode_444(Decode444Params &P, bool aligned) {
@@ -1829,24 +1854,6 @@ hipError_t launch_decode_444(const Decode444Params &P, bool wide_only, hipStream
     Decode444Params Q = P;
     Q.skip = only;
     Q.xcd_map = xcd_map_for((unsigned)(P.tiles_per_frame - P.tile0), (unsigned)P.n_frames, Q.xcd_magic, true);
-    {   // HVC_444_ORDER=stripe | run:R | split (A/B only): see Decode444Params::xcd_map
-        static const char *const order = getenv("HVC_444_ORDER");
-        const unsigned per = (unsigned)(P.tiles_per_frame - P.tile0), c2 = per > (unsigned)P.y_tiles ? per - (unsigned)P.y_tiles : 0u;
-        auto rcp = [](unsigned d) { return d > 1 ? (unsigned)(((1ull << 32) + d - 1) / d) : 0u; };
-        if (order && Q.xcd_map > 0 && P.tile0 == 0 && (unsigned long long)per * P.n_frames * 128ull < (1ull << 32)) {
-            if (!strcmp(order, "stripe")) {
-                Q.xcd_map = -1;
-            } else if (!strncmp(order, "run:", 4) && atoi(order + 4) > 1) {
-                Q.xcd_map = -2;
-                Q.xo_run = (unsigned)atoi(order + 4);
-                Q.xo_run_magic = rcp(Q.xo_run);
-            } else if (!strcmp(order, "split") && P.y_tiles > 1 && c2 > 1) {
-                Q.xcd_map = -3;
-                Q.xo_yt_magic = rcp((unsigned)P.y_tiles);
-                Q.xo_c2_magic = rcp(c2);
-            }
-        }
-    }
     // HVC_444_LDS_PAD=bytes (experiments): dynamic LDS nobody uses, to hold the kernel to fewer workgroups per CU
     static const unsigned pad = [] { const char *v = getenv("HVC_444_LDS_PAD"); return v ? (unsigned)atoi(v) : 0u; }();
     if (!aligned && P.nw != 1) return hipErrorInvalidValue; // (plan_decode_444 was told otherwise)

@@ -25,7 +25,11 @@ SYMBOLS = [
     "hvc_host_threads", "hvc_host_threads_probe", "hvc_jpeg_entropy_decode2", "hvc_jpeg_get_cropped_planes",
     "hvc_jpeg_entropy_decode_restart", "hvc_set_restart_markers",
     "hvc_subsample420", "hvc_subsample422", "hvc_upsample422", "hvc_crop_planes", "hvc_yuv_frame_bytes", "hvc_yuv_convert",
+    "hvc_host_alloc", "hvc_host_free", "hvc_host_register", "hvc_host_unregister", "hvc_decode_frames_submit",
+    "hvc_encode_frames_submit", "hvc_wait", "hvc_slot_query", "hvc_slot_last_stats",
 ]
+HVC_SLOTS = 4       # enum { HVC_SLOTS }
+HVC_E_BUSY = -12
 
 
 class HvcError(RuntimeError):
@@ -71,6 +75,12 @@ class BatchStats(C.Structure):
     _fields_ = [("wall_ms", C.c_double), ("entropy_ms_sum", C.c_double), ("h2d_ms_sum", C.c_double),
                 ("kernel_ms_sum", C.c_double), ("d2h_ms_sum", C.c_double), ("chunks", C.c_int), ("threads", C.c_int),
                 ("frames_per_chunk", C.c_int), ("coef_bytes", C.c_uint64), ("host_prep_ms_sum", C.c_double)]
+
+
+class SlotStats(C.Structure):
+    """struct hvc_slot_stats"""
+    _fields_ = [("h2d_ms", C.c_double), ("kernel_ms", C.c_double), ("d2h_ms", C.c_double), ("h2d_bytes", C.c_uint64),
+                ("d2h_bytes", C.c_uint64)]
 
 
 def build(force=False):
@@ -158,12 +168,42 @@ def lib():
         L.hvc_host_threads.argtypes = [vp, C.POINTER(i), C.POINTER(C.c_uint64)]
         L.hvc_host_threads_probe.argtypes = [i]
         L.hvc_encode_frames_recon.argtypes = [vp, vp, sz, vp, i, C.POINTER(Component), i, i, vp, sz, vp, vp, i]
+        L.hvc_host_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+        L.hvc_host_free.argtypes = [vp, vp]
+        L.hvc_host_register.argtypes = [vp, vp, sz]
+        L.hvc_host_unregister.argtypes = [vp, vp]
+        L.hvc_decode_frames_submit.argtypes = [vp, i, vp, sz, vp, i, C.POINTER(Component), i, i, vp, sz, i]
+        L.hvc_encode_frames_submit.argtypes = [vp, i, vp, sz, vp, i, C.POINTER(Component), i, i, vp, sz, i]
+        L.hvc_wait.argtypes = [vp, i]
+        L.hvc_slot_query.argtypes = [vp, i, C.POINTER(i)]
+        L.hvc_slot_last_stats.argtypes = [vp, i, C.POINTER(SlotStats)]
         L.hvc_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
         L.hvc_device_free.argtypes = [vp, vp]
         L.hvc_memcpy_h2d.argtypes = [vp, vp, vp, sz]
         L.hvc_memcpy_d2h.argtypes = [vp, vp, vp, sz]
         _LIB = L
     return _LIB
+
+
+KERNEL_SRCS = ("hvc_kernels.hip", "hvc_kernels.h", "hvc_idct_spec.h")   # csrc/Makefile KERNEL_SRCS, in that order
+
+
+def kernel_build_id():
+    """the kernel id the loaded library reports (hvc_version: "... kernels <id>")"""
+    return lib().hvc_version().decode().rsplit(" ", 1)[-1]
+
+
+def kernel_source_id():
+    """the same id computed from the sources in the tree (None where they are not there)"""
+    import hashlib
+    h = hashlib.sha256()
+    try:
+        for f in KERNEL_SRCS:
+            with open(os.path.join(_DIR, "csrc", f), "rb") as fh:
+                h.update(fh.read())
+    except OSError:
+        return None
+    return h.hexdigest()[:12]
 
 
 def _chk(code, what=""):
@@ -429,6 +469,59 @@ class Context:
         n = C.c_uint64()
         _chk(lib().hvc_last_wide_blocks(self._h, C.byref(n)))
         return n.value
+
+    # -- the asynchronous seam: pinned host memory + slots ---------------------
+    def host_alloc(self, shape, dtype=np.uint8):
+        """pinned host memory (hvc_host_alloc) as a numpy array; give it back with host_free(array)"""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        _chk(lib().hvc_host_alloc(self._h, n, C.byref(p)), "hvc_host_alloc(%d)" % n)
+        buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def host_free(self, arr):
+        _chk(lib().hvc_host_free(self._h, arr.ctypes.data), "hvc_host_free")
+
+    def host_register(self, arr):
+        """pins memory the caller owns (a numpy array's buffer) in place; host_unregister(arr) before it goes"""
+        _chk(lib().hvc_host_register(self._h, arr.ctypes.data, arr.nbytes), "hvc_host_register")
+
+    def host_unregister(self, arr):
+        _chk(lib().hvc_host_unregister(self._h, arr.ctypes.data), "hvc_host_unregister")
+
+    def decode_frames_submit(self, slot, coefs, coef_frame_stride, qtabs, comps, n_frames, pixels, pixel_frame_stride):
+        """hvc_decode_frames on HOST coefficient records (numpy; pinned for the overlap), asynchronously in `slot`;
+        pixels: numpy (host: downloaded) or a device tensor / address (written in place).  wait(slot) completes it."""
+        ca, w1 = _addr(coefs)
+        assert w1 == HVC_MEM_HOST, "the coefficient records of a submission are host memory"
+        pa, w2 = _addr(pixels)
+        q = np.ascontiguousarray(qtabs, dtype=np.uint16).reshape(-1, 64)
+        arr = comps if not isinstance(comps, list) else components(comps)
+        _chk(lib().hvc_decode_frames_submit(self._h, slot, ca, coef_frame_stride, q.ctypes.data, q.shape[0], arr, len(arr),
+                                            n_frames, pa, pixel_frame_stride, w2), "hvc_decode_frames_submit(slot %d)" % slot)
+
+    def encode_frames_submit(self, slot, pixels, pixel_frame_stride, qtabs, comps, n_frames, coefs, coef_frame_stride):
+        """the encoder mirror: HOST pixel records in, coefficient records to numpy (host) or a device tensor"""
+        pa, w1 = _addr(pixels)
+        assert w1 == HVC_MEM_HOST, "the pixel records of a submission are host memory"
+        ca, w2 = _addr(coefs)
+        q = np.ascontiguousarray(qtabs, dtype=np.uint16).reshape(-1, 64)
+        arr = comps if not isinstance(comps, list) else components(comps)
+        _chk(lib().hvc_encode_frames_submit(self._h, slot, pa, pixel_frame_stride, q.ctypes.data, q.shape[0], arr, len(arr),
+                                            n_frames, ca, coef_frame_stride, w2), "hvc_encode_frames_submit(slot %d)" % slot)
+
+    def wait(self, slot):
+        _chk(lib().hvc_wait(self._h, slot), "hvc_wait(slot %d)" % slot)
+
+    def slot_done(self, slot):
+        d = C.c_int()
+        _chk(lib().hvc_slot_query(self._h, slot, C.byref(d)), "hvc_slot_query")
+        return bool(d.value)
+
+    def slot_last_stats(self, slot):
+        st = SlotStats()
+        _chk(lib().hvc_slot_last_stats(self._h, slot, C.byref(st)), "hvc_slot_last_stats")
+        return st
 
     # -- decode -------------------------------------------------------------
     def dequant_idct_recon(self, coefs, qtab, blocks_w, blocks_h, n_planes, plane, stride=None,
