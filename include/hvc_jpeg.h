@@ -433,6 +433,13 @@ HVC_API int hvc_huffman_encode_frames(hvc_ctx *ctx, const hvc_jpeg_info *info, c
                                       size_t coef_frame_stride, int n_frames, uint8_t *out, size_t out_cap,
                                       uint64_t *offsets, int where);
 HVC_API int hvc_jpeg_header(const hvc_jpeg_info *info, uint8_t *out, size_t cap, size_t *len);
+/* Diagnostic: the code tables the encoder's back ends emit from -- Tables.Encoder.dc_table / ac_table of the default
+ * specifications (tables.ml:27-45 canonical assignment, :504-545; Tables.Default = ITU-T T.81 Annex K.3), which the
+ * reference's own test prints in full (jpeg/model/test/test_tables.ml:4-395 -> tests/golden/g8_code_tables.json).
+ * table_set: 0 luma, 1 chroma.  codes[i] = (code << 5) | length, 0 = no code: i < 16 the DC category i, i = 16 +
+ * ((run << 4) | size) the AC symbol.  where = HVC_MEM_HOST: the host coder's tables (ctx may be NULL); HVC_MEM_DEVICE:
+ * the GPU coder's tables as they sit in ctx's device memory (uploaded if no call has needed them yet, then read back). */
+HVC_API int hvc_huffman_code_tables(hvc_ctx *ctx, int table_set, int where, uint32_t *codes272);
 
 /* HVC_OK when Encoder.encode_seq can walk this geometry; HVC_E_INVALID_ARG where the model raises
  * "[Plane.get] out of bounds" (encoder.ml:476-505 with plane.ml:43-50): the MCU grid of the luma

@@ -412,6 +412,12 @@ let huffman_encode_frames =
     @-> returning int)
 ;;
 
+(* int hvc_huffman_code_tables(ctx, table_set, where, codes272): the encoder back ends' code tables (diagnostic;
+   Tables.Encoder.dc_table / ac_table, tables.ml:504-545) *)
+let huffman_code_tables =
+  foreign "hvc_huffman_code_tables" (ctx @-> int @-> int @-> ptr uint32_t @-> returning int)
+;;
+
 (* int hvc_jpeg_encode_batch(ctx, frames, n_frames, width, height, chroma, quality, threads, frames_per_chunk, jpegs, caps,
                              sizes, stats) and the same with the Huffman coder on the GPU      BASELINE config 5, files out *)
 let jpeg_encode_batch =

@@ -603,6 +603,46 @@ static void enc_tables_create(EncTables *t, const HuffSpec *dc, const HuffSpec *
     }
 }
 
+/* test hooks (G8: jpeg/model/test/test_tables.ml:4-395 prints these tables in full).
+ * orc_create_code_table: Specification.create_code_table of any specification, out[3 i + 0 / 1 / 2] = length, bits, data of
+ * code i in the order the model's list has them; returns the count.
+ * orc_enc_table: Tables.Encoder.dc_table (which 0 luma, 1 chroma) / ac_table (2 luma, 3 chroma) of the default specifications
+ * as enc_tables_create builds them.  dc: out[3 i + 0 / 1 / 2] = length, bits, data, returns the entries; ac: out[(16 run +
+ * size) * 4 + 0 / 1 / 2 / 3] = length, bits, run, size (a row's missing size-0 symbol is the model's placeholder 0, 0, run 0,
+ * size 0), rows[run] = entries of the row, returns 16. */
+ORC_API int orc_create_code_table(const int *lengths16, const int *values, int nvalues, int *out) {
+    HuffSpec s;
+    Code codes[256];
+    memset(&s, 0, sizeof s);
+    if (nvalues < 0 || nvalues > 256) return -1;
+    int total = 0;
+    for (int i = 0; i < 16; i++) { s.lengths[i] = lengths16[i]; total += lengths16[i]; }
+    if (total > nvalues) return -1;
+    for (int i = 0; i < nvalues; i++) s.values[i] = values[i];
+    s.nvalues = nvalues;
+    int n = create_code_table(&s, codes);
+    for (int i = 0; i < n; i++) { out[3 * i] = codes[i].length; out[3 * i + 1] = codes[i].bits; out[3 * i + 2] = codes[i].data; }
+    return n;
+}
+ORC_API int orc_enc_table(int which, int *out, int *rows) {
+    EncTables t;
+    if (which < 0 || which > 3) return -1;
+    enc_tables_create(&t, (which & 1) ? &DC_CHROMA : &DC_LUMA, (which & 1) ? &AC_CHROMA : &AC_LUMA);
+    if (which < 2) {
+        for (int i = 0; i < t.ndc; i++) { out[3 * i] = t.dc[i].length; out[3 * i + 1] = t.dc[i].bits; out[3 * i + 2] = t.dc[i].data; }
+        return t.ndc;
+    }
+    for (int run = 0; run < 16; run++) {
+        rows[run] = t.nac[run];
+        for (int size = 0; size < 16; size++) {
+            int *o = out + (16 * run + size) * 4;
+            o[0] = t.ac[run][size].length; o[1] = t.ac[run][size].bits;
+            o[2] = (t.ac[run][size].data >> 4) & 0xf; o[3] = t.ac[run][size].data & 0xf;
+        }
+    }
+    return 16;
+}
+
 /* ------------------------------------------------------------------------- */
 /* jpeg/model/src/markers.ml                                                  */
 typedef struct { int identifier, h, v, tq; } SofComponent;             /* :7-24 */

@@ -80,6 +80,29 @@ def _i64(a):
     return a, a.ctypes.data_as(i64p)
 
 
+def create_code_table(lengths16, values):
+    """Specification.create_code_table (tables.ml:27-45): [(length, bits, data)] in the model's list order"""
+    le = np.ascontiguousarray(lengths16, dtype=np.int32)
+    va = np.ascontiguousarray(values, dtype=np.int32)
+    out = np.zeros(3 * 256, dtype=np.int32)
+    n = lib().orc_create_code_table(_ptr(le), _ptr(va), int(va.size), _ptr(out))
+    assert n >= 0
+    return [tuple(int(x) for x in out[3 * i:3 * i + 3]) for i in range(n)]
+
+
+def enc_table(name):
+    """Tables.Encoder.dc_table / ac_table of a default specification ("dc_luma", "dc_chroma", "ac_luma", "ac_chroma") in the
+    shape tests/golden/g8_code_tables.json holds them: dc [category] -> [length, bits, data]; ac [run][size] -> [length, bits,
+    run, size]"""
+    which = ["dc_luma", "dc_chroma", "ac_luma", "ac_chroma"].index(name)
+    out = np.zeros(16 * 16 * 4, dtype=np.int32)
+    rows = np.zeros(16, dtype=np.int32)
+    n = lib().orc_enc_table(which, _ptr(out), _ptr(rows))
+    if which < 2:
+        return [[int(x) for x in out[3 * i:3 * i + 3]] for i in range(n)]
+    return [[[int(x) for x in out[(16 * r + k) * 4:(16 * r + k) * 4 + 4]] for k in range(int(rows[r]))] for r in range(16)]
+
+
 def zigzag_inverse():
     return np.array(lib().orc_zigzag_inverse()[:64])
 

@@ -166,6 +166,31 @@ def g8_rle():
     return {"source": "jpeg/model/test/test_rle.ml", "cases": cases}
 
 
+def g8_code_tables():
+    """jpeg/model/test/test_tables.ml:4-395: Tables.Encoder.dc_table / ac_table of the four default specifications
+    (Annex K), every symbol -- length / bits / data.  dc: [category] -> [length, bits, data]; ac: [run][size] ->
+    [length, bits, run, size] (rows that lack a size-0 symbol carry the model's placeholder (0, 0, run 0, size 0))."""
+    s = read("jpeg/model/test/test_tables.ml")
+    out = {"source": "jpeg/model/test/test_tables.ml:4-395"}
+    for name in ("dc_luma", "dc_chroma"):
+        t = s[s.index('("Tables.Encoder.dc_table Tables.Default.%s"' % name):]
+        t = t[:t.index("|}]")]
+        out[name] = [[int(x) for x in m.groups()] for m in re.finditer(r"\(\(length (\d+)\) \(bits (\d+)\) \(data (\d+)\)\)", t)]
+        assert len(out[name]) == 12, (name, len(out[name]))
+    for name in ("ac_luma", "ac_chroma"):
+        t = s[s.index('("Tables.Encoder.ac_table Tables.Default.%s"' % name):]
+        t = t[:t.index("|}]")]
+        entry = r"\(\(length (\d+)\) \(bits (\d+)\) \(data \(\(run (\d+)\) \(size (\d+)\)\)\)\)"
+        allv = [[int(x) for x in m.groups()] for m in re.finditer(entry, t)]
+        assert len(allv) == 16 * 11, (name, len(allv))
+        rows = [allv[11 * r:11 * r + 11] for r in range(16)]   # the printed table: 16 rows (runs) of 11 entries (sizes 0..10)
+        for r, row in enumerate(rows):   # ... each a run's symbols in size order behind a size-0 entry, real or placeholder
+            assert all(e[2] == r and e[3] == k for k, e in enumerate(row) if k), (name, r)
+            assert row[0][3] == 0 and (row[0][2] == r or row[0][:3] == [0, 0, 0]), (name, r)
+        out[name] = rows
+    return out
+
+
 def mouse_header():
     """jpeg/hardcaml/test/test_codeblock_decoder.ml prints the model's parsed
     header of Mouse480.jpg (Decoder.Header.t) and the first 64 bytes of the
@@ -201,7 +226,7 @@ def main():
         "g4_psnr_pins.json": g4_psnr(), "g5_quant_tables.json": g5_quant(),
         "g7_upsample.json": g7_upsample(), "g7_packed422.json": g7_packed422(),
         "g8_header_c420_480x320_q20.json": g8_header(),
-        "g8_codewords.json": g8_codewords(), "g8_rle.json": g8_rle(),
+        "g8_codewords.json": g8_codewords(), "g8_rle.json": g8_rle(), "g8_code_tables.json": g8_code_tables(),
         "mouse480_header.json": mouse_header(),
     }
     for name, obj in fixtures.items():

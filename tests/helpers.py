@@ -77,3 +77,35 @@ def config1_frame():
     from conftest import golden_bytes
     y, u, v = orc.split_yuv(golden_bytes("mini64x64.420"), 64, 64, 420)
     return tuple(np.ascontiguousarray(np.tile(p, (2, 2))) for p in (y, u, v))
+
+
+def every_symbol_record(info):
+    """A coefficient record (int16, info.coef_count) in which EVERY symbol of the default Huffman tables occurs in every
+    component: the 160 (run, size) AC symbols with size 1..10 (one block each: one coefficient of magnitude 2^(size-1) ...
+    2^size - 1 behind `run` zeros), EOB (every block that does not end at position 63), ZRL (runs of 16 ... 62 zeros), and the
+    twelve DC categories (differences of +-(2^(k-1)) ... between consecutive blocks of a component).  Needs >= 176 blocks per
+    component (a 4:4:4 frame of 128 x 88)."""
+    rec = np.zeros(info.coef_count, dtype=np.int16)
+    for i in range(info.n_comp):
+        L = info.layout[i]
+        n = L.blocks_w * L.blocks_h
+        assert n >= 176, n
+        blk = rec[L.coef_offset:L.coef_offset + n * 64].reshape(n, 64)
+        b = 0
+        for run in range(16):
+            for size in range(1, 11):
+                mag = (1 << (size - 1)) + (run * 7 + size) % (1 << (size - 1))      # any value of that size
+                blk[b, 1 + run] = mag if (run + size) & 1 else -mag
+                b += 1
+        for k, gap in enumerate((16, 17, 31, 32, 33, 47, 48, 61, 62)):                # ZRL chains; the last one ends at 63
+            blk[b, 1 + gap] = 3 + k
+            b += 1
+        # DC: category k difference between consecutive blocks, signs alternating so that the values stay small
+        dc, vals = 0, []
+        for j in range(n):
+            k = j % 12
+            d = 0 if k == 0 else (1 << (k - 1)) + (j % (1 << (k - 1)))
+            dc += d if dc <= 0 else -d
+            vals.append(dc)
+        blk[:, 0] = np.array(vals, dtype=np.int16)
+    return rec

@@ -45,3 +45,19 @@ def test_design_is_short_and_names_every_scope_row():
     assert s.count("\n") <= 350
     for row in ("a1", "a7", "a11", "a12", "a16", "| b |", "| c |", "| d |", "| e |", "next-1", "next-2", "next-3", "next-4"):
         assert row in s, row
+
+
+def test_tool_references_in_the_documents_exist():
+    """the documents cite tools by path; a tool that was purged with its closed study must not be cited as if it were
+    there.  Every `tools/...` path in DESIGN.md, README.md, profiles/ANALYSIS.md and profiles/README.md exists in the tree --
+    unless the sentence says it was removed (or the path is the reference's own tools/src/..., or a glob)."""
+    for doc in ("DESIGN.md", "README.md", os.path.join("profiles", "ANALYSIS.md"), os.path.join("profiles", "README.md")):
+        text = open(os.path.join(ROOT, doc)).read()
+        for m in re.finditer(r"tools/[A-Za-z0-9_./*-]+", text):
+            path = m.group(0).rstrip(".")
+            if path.startswith("tools/src/") or "*" in path or path.endswith(("_", "/")):
+                continue
+            if os.path.exists(os.path.join(ROOT, path)):
+                continue
+            tail = text[m.end():m.end() + 80]
+            assert "removed" in tail or "deleted" in tail or "is gone" in tail, "%s cites %s, which is not in the tree" % (doc, path)

@@ -4,8 +4,8 @@ to Model.Encoder: G3, G8, cram sessions), so header + segment + EOI is the model
 import numpy as np
 import pytest
 
-from conftest import golden_bytes
-from helpers import synth_pixels
+from conftest import golden_bytes, golden_json
+from helpers import every_symbol_record, synth_pixels
 from oracle import orc
 
 pytestmark = pytest.mark.gpu
@@ -115,3 +115,23 @@ def test_values_without_a_code_and_small_buffers_are_errors(ctx):
         ctx.huffman_encode_frames(info, rec, info.coef_count, 1, out_cap=4)
     assert e.value.code == -1
     assert ctx.huffman_encode_frames(info, rec, info.coef_count, 1)[0] == host_segment(hvc, info, rec)
+
+
+def test_g8_code_tables_on_the_device_every_symbol(ctx):
+    """The GPU coder's code tables, read back from the context's device memory, are Tables.Encoder.dc_table / ac_table as the
+    reference's own test prints them (jpeg/model/test/test_tables.ml:4-395 -> g8_code_tables.json), every symbol; and a record
+    that holds every symbol of both table sets comes out of k_huff_len / k_huff_emit as the host coder's bytes."""
+    import torch
+    import video_coding_amd as hvc
+    g = golden_json("g8_code_tables.json")
+    for t, name in ((0, "luma"), (1, "chroma")):
+        got = hvc.hvc.huffman_code_tables(t, ctx)
+        assert got["dc"] == g["dc_" + name] and got["ac"] == g["ac_" + name], name
+        assert got == hvc.hvc.huffman_code_tables(t)                 # ... and the host coder's
+    info = hvc.hvc.jpeg_encoder_layout(128, 88, 444, 50)
+    rec = every_symbol_record(info)
+    for arg in (rec.reshape(1, -1), torch.from_numpy(rec.reshape(1, -1)).cuda()):
+        seg = ctx.huffman_encode_frames(info, arg, info.coef_count, 1)[0]
+        assert seg == host_segment(hvc, info, rec)
+    d = orc.Decoder(hvc.hvc.jpeg_header(info) + seg + b"\xff\xd9")   # the model restatement reads it back
+    assert np.array_equal(d.coef_record().astype(np.int16), rec)

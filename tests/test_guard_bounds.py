@@ -439,7 +439,7 @@ def test_q16_exchange_step_is_covered_by_the_packed_proof():
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-coding_amd", "csrc",
                             "hvc_kernels.hip")).read()
     # the kernel uses the packed kernel's thresholds, not its own
-    q16 = src[src.index("void k_decode_q16("):src.index("// K1 wide: int64")]
+    q16 = src[src.index("void k_decode_q16("):src.index("// K1 wide: the model")]
     assert "P.ethr_packed[br.qtab]" in q16 and "GUARD_RE" in q16 and "GUARD_Y" in q16
 
 

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_bytes, golden_json
-from helpers import coef_planes_from_jpeg, synth_pixels
+from helpers import coef_planes_from_jpeg, every_symbol_record, synth_pixels
 from oracle import orc
 
 
@@ -722,3 +722,45 @@ def test_a_callers_info_is_not_trusted(hvc):
         inf = broken(change)
         assert L.hvc_jpeg_get_yuv_frame(C.byref(inf), pix.ctypes.data, out.ctypes.data, out.size, C.byref(n)) == -1
     assert L.hvc_jpeg_get_yuv_frame(C.byref(good), pix.ctypes.data, out.ctypes.data, out.size, C.byref(n)) == 0
+
+
+def test_g8_code_tables_of_the_host_coder_every_symbol(hvc):
+    """The host coder's code tables (hvc_huffman_code_tables, host side) are Tables.Encoder.dc_table / ac_table as the reference's
+    own test prints them (jpeg/model/test/test_tables.ml:4-395 -> g8_code_tables.json), every symbol -- and what the coder EMITS
+    for every symbol is what those tables say: a record holding all 160 (run, size) symbols, EOB, ZRL and the twelve DC
+    categories in every component goes through the back end and comes back, coefficient for coefficient, through the model
+    restatement's Huffman reader (whose look-up tables are built from the file's DHT segments by create_code_table)."""
+    g = golden_json("g8_code_tables.json")
+    for t, name in ((0, "luma"), (1, "chroma")):
+        got = hvc.huffman_code_tables(t)
+        assert got["dc"] == g["dc_" + name] and got["ac"] == g["ac_" + name], name
+    info = hvc.jpeg_encoder_layout(128, 88, 444, 50)
+    rec = every_symbol_record(info)
+    jpg = hvc.jpeg_entropy_encode(info, rec)
+    d = orc.Decoder(jpg)
+    assert np.array_equal(d.coef_record().astype(np.int16), rec)
+    assert np.array_equal(hvc.jpeg_entropy_decode(jpg)[1], rec)
+    # every symbol really is in there: the symbols of the record, counted the way Encoder.rle cuts a block
+    seen_ac, seen_dc = set(), set()
+    for i in range(3):
+        L = info.layout[i]
+        blk = rec[L.coef_offset:L.coef_offset + L.blocks_w * L.blocks_h * 64].reshape(-1, 64).astype(np.int64)
+        prev = 0
+        for b in blk:
+            seen_dc.add((i > 0, int(abs(int(b[0]) - prev)).bit_length()))
+            prev = int(b[0])
+            run = 0
+            for pos in range(1, 64):
+                if b[pos]:
+                    while run > 15:
+                        seen_ac.add((i > 0, 15, 0))
+                        run -= 16
+                    seen_ac.add((i > 0, run, int(abs(b[pos])).bit_length()))
+                    run = 0
+                else:
+                    run += 1
+            if run:
+                seen_ac.add((i > 0, 0, 0))
+    for chroma in (False, True):
+        assert {k for c, k in seen_dc if c == chroma} == set(range(12))
+        assert {(r, s) for c, r, s in seen_ac if c == chroma} == {(r, s) for r in range(16) for s in range(1, 11)} | {(0, 0), (15, 0)}

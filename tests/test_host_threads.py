@@ -64,7 +64,7 @@ def test_every_entry_point_is_a_function_try_block():
     hdr = open(os.path.join(ROOT, "include", "hvc_jpeg.h")).read()
     declared = set(re.findall(r"HVC_API\s+int\s+(hvc_\w+)\s*\(", hdr))
     guarded, forwarders = set(), set()
-    for fn in ("hvc_capi.hip", "hvc_capi_jpeg.hip", "hvc_capi_reader.hip", "hvc_capi_files.hip", "hvc_yuv.hip", "hvc_entropy.cpp"):
+    for fn in ("hvc_capi.hip", "hvc_capi_jpeg.hip", "hvc_capi_reader.hip", "hvc_capi_files.hip", "hvc_capi_async.hip", "hvc_yuv.hip", "hvc_entropy.cpp"):
         txt = open(os.path.join(ROOT, "video-coding_amd", "csrc", fn)).read()
         for m in re.finditer(r"^int (hvc_\w+)\(([^{;]*?)\)\s*(try\s*)?\{([^\n]*)", txt, re.M | re.S):
             name, is_try, rest = m.group(1), m.group(3), m.group(4)

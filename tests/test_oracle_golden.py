@@ -301,3 +301,22 @@ def test_oconv_reproduces_the_nonstandard_size_pin():
     jpg = orc.encode_yuv(y, u, v, c["width"], c["height"], 420, c["quality"])
     got = orc.decode_a_frame(jpg)
     assert [orc.ocaml_float_to_string(orc.psnr(a, b)) for a, b in zip((y, u, v), got)] == c["psnr"]
+
+
+def test_g8_code_tables_every_symbol():
+    """jpeg/model/test/test_tables.ml:4-395: Tables.Encoder.dc_table / ac_table of the four default specifications, every
+    symbol's length / bits / data -- create_code_table (tables.ml:27-45) and the encoder's table shaping (:504-545)."""
+    g = golden_json("g8_code_tables.json")
+    for name in ("dc_luma", "dc_chroma", "ac_luma", "ac_chroma"):
+        assert orc.enc_table(name) == g[name], name
+    assert sum(len(r) for r in g["ac_luma"]) == 176 and len(g["dc_luma"]) == 12
+    # the canonical assignment itself, on a specification that is not one of the defaults (Mouse480.jpg's own DHT segments:
+    # the reference prints them, test_codeblock_decoder.ml): prefix-free, lengths as specified, codes of one length consecutive
+    for ht in golden_json("mouse480_header.json")["huffman_tables"]:
+        codes = orc.create_code_table(ht["lengths"], ht["values"])
+        assert [c[2] for c in codes] == ht["values"][:len(codes)] and len(codes) == sum(ht["lengths"])
+        assert [sum(1 for c in codes if c[0] == k + 1) for k in range(16)] == ht["lengths"]
+        words = [format(c[1], "0%db" % c[0]) for c in codes]
+        assert len(set(words)) == len(words) and not any(a != b and b.startswith(a) for a in words for b in words)
+        for a, b in zip(codes, codes[1:]):
+            assert (b[1] == a[1] + 1) if a[0] == b[0] else (b[1] == (a[1] + 1) << (b[0] - a[0]))

@@ -24,7 +24,7 @@ BINDING = os.path.join(ROOT, "integration", "ocaml", "hvc.ml")
 C_TO_ML = {
     "int": {"int"}, "size_t": {"size_t"}, "void": {"void"}, "uint64_t": {"uint64_t"},
     "hvc_ctx*": {"ctx"}, "hvc_ctx**": {"ptr ctx"},
-    "int16_t*": {"ptr int16_t"}, "uint16_t*": {"ptr uint16_t"}, "uint64_t*": {"ptr uint64_t"},
+    "int16_t*": {"ptr int16_t"}, "uint16_t*": {"ptr uint16_t"}, "uint64_t*": {"ptr uint64_t"}, "uint32_t*": {"ptr uint32_t"},
     "uint8_t*": {"ptr char", "ptr uint8_t", "string"},  # Base_bigstring data / OCaml string for read-only bytes
     "char*": {"string", "ptr char"},  # a read-only C string / a buffer the callee fills
     "int*": {"ptr int"}, "size_t*": {"ptr size_t"}, "float*": {"ptr float"},

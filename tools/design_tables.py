@@ -146,7 +146,7 @@ def tables(tag):
     return "\n".join(k), "\n".join(t), ("trace averages — " + "; ".join(prof) + "; counter bytes: `profiles/traffic.json`, session " + tag + ".") if prof else ""
 
 
-KERNEL_FILES = (("hvc_kernels.hip", ("k_decode_packed", "k_decode_wide", "k_decode_q16", "k_decode_444", "k_reinterp_444", "k_encode",
+KERNEL_FILES = (("hvc_kernels.hip", ("k_decode_packed", "k_decode_wide", "k_decode_wide_all", "k_decode_q16", "k_decode_444", "k_reinterp_444", "k_encode",
                                       "k_upsample420", "k_upsample420_x8", "k_abs_error", "k_checksum")),
                 ("hvc_kernels.h", ("xcd_work",)), ("hvc_yuv.hip", ("k_subsample420",)), ("hvc_hdec.hip", ("k_hd_sync", "k_hd_write2")),
                 ("hvc_huff.hip", ("k_huff_len", "k_huff_emit")))

@@ -5,6 +5,33 @@
 // ---------------------------------------------------------------------------
 // Encoder back end on the GPU: RLE + Huffman + byte stuffing of coefficient records (hvc_huff.hip)
 
+// the default code tables on the device, once per context (hvc_huff.hip reads them through HuffParams::tables)
+static int upload_enc_tables(hvc_ctx *c) {
+    if (c->hd_tables) return HVC_OK;
+    uint32_t t[2][16 + 256];
+    hvc::default_enc_tables(t);
+    HIPCHK(c, hipMalloc((void **)&c->hd_tables, sizeof t));
+    HIPCHK(c, hipMemcpy(c->hd_tables, t, sizeof t, hipMemcpyHostToDevice));
+    return HVC_OK;
+}
+
+int hvc_huffman_code_tables(hvc_ctx *c, int table_set, int where, uint32_t *codes) try {
+    if (!codes || table_set < 0 || table_set > 1) return HVC_E_INVALID_ARG;
+    if (where == HVC_MEM_HOST) {
+        uint32_t t[2][16 + 256];
+        hvc::default_enc_tables(t);
+        std::memcpy(codes, t[table_set], sizeof t[0]);
+        return HVC_OK;
+    }
+    if (where != HVC_MEM_DEVICE || !c) return HVC_E_INVALID_ARG;
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
+    int r = upload_enc_tables(c);
+    if (r) return r;
+    HIPCHK(c, hipMemcpy(codes, c->hd_tables + (size_t)table_set * (16 + 256), (16 + 256) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return HVC_OK;
+} HVC_ABI_CATCH
+
 // Geometry + scratch of one call.  `out` / `offsets` are device pointers (the caller's, or NULL = scratch
 // inside ctx, see huffman_scratch_out).
 int huffman_prepare(hvc_ctx *c, const hvc_jpeg_info *info, const int16_t *d_coefs, size_t coef_fs, int n_frames, uint8_t *d_out,
@@ -42,12 +69,7 @@ int huffman_prepare(hvc_ctx *c, const hvc_jpeg_info *info, const int16_t *d_coef
     const size_t words = ((size_t)bpf * 216 + 3) / 4 + 2;
     P.bitbuf_words = (words + 15) / 16 * 16;
     P.ff_stride = P.bitbuf_words / 16;
-    if (!c->hd_tables) {
-        uint32_t t[2][16 + 256];
-        hvc::default_enc_tables(t);
-        HIPCHK(c, hipMalloc((void **)&c->hd_tables, sizeof t));
-        HIPCHK(c, hipMemcpy(c->hd_tables, t, sizeof t, hipMemcpyHostToDevice));
-    }
+    if ((r = upload_enc_tables(c))) return r;
     P.tables = c->hd_tables;
     const size_t nf = (size_t)n_frames;
     if ((r = grow(c, &c->hd_lens, &c->hd_lens_cap, nf * bpf * sizeof(unsigned)))) return r;

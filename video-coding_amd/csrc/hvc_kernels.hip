@@ -1303,9 +1303,8 @@ __device__ __forceinline__ int vmad24(int k, int x, int acc) {
 // What held K3 under its own traffic-only build was the time its instructions take to issue, not its LDS transpose: 827.6 M
 // wave-instructions per 256-frame launch -- 97 % of the 1024 SIMDs' cycles at the 4 cycles SQ_ACTIVE_INST_VALU books each at, about
 // 70 % by the measured issue times (profiles/r01_valu_ubench.txt) -- with SQ_WAIT_INST_LDS at 0.04 % of the wave cycles and no bank
-// conflicts (profiles/r05c_k3_pmc.txt): little slack for 5 waves per SIMD to hide a memory-bound kernel's latencies behind.  It sat 1 - 2
-// points under that
-// traffic-only build.  HVC_ENCODE_MULHI=1 (shipped) takes 80 of the 1062 instructions per block out -- c4 as one
+// conflicts (profiles/r05c_k3_pmc.txt): little slack for 5 waves per SIMD to hide a memory-bound kernel's latencies behind.  It
+// sat 1 - 2 points under that traffic-only build.  HVC_ENCODE_MULHI=1 (shipped) takes 80 of the 1062 instructions per block out -- c4 as one
 // v_mul_hi_i32_i24 on operands pre-shifted by the add or mad that makes them, the quantiser's products two at a time
 // (v_pk_mul_f32) -- and reads 75.3 - 76.7 % where the 0 form reads 73.5 - 74.1 %, its traffic-only build 74.9 - 77.4 %
 // (same box, three alternations: profiles/r05c_k3_ab.txt).

@@ -26,7 +26,7 @@ SYMBOLS = [
     "hvc_jpeg_entropy_decode_restart", "hvc_set_restart_markers",
     "hvc_subsample420", "hvc_subsample422", "hvc_upsample422", "hvc_crop_planes", "hvc_yuv_frame_bytes", "hvc_yuv_convert",
     "hvc_host_alloc", "hvc_host_free", "hvc_host_register", "hvc_host_unregister", "hvc_decode_frames_submit",
-    "hvc_encode_frames_submit", "hvc_wait", "hvc_slot_query", "hvc_slot_last_stats",
+    "hvc_encode_frames_submit", "hvc_wait", "hvc_slot_query", "hvc_slot_last_stats", "hvc_huffman_code_tables",
 ]
 HVC_SLOTS = 4       # enum { HVC_SLOTS }
 HVC_E_BUSY = -12
@@ -177,6 +177,7 @@ def lib():
         L.hvc_wait.argtypes = [vp, i]
         L.hvc_slot_query.argtypes = [vp, i, C.POINTER(i)]
         L.hvc_slot_last_stats.argtypes = [vp, i, C.POINTER(SlotStats)]
+        L.hvc_huffman_code_tables.argtypes = [vp, i, i, vp]
         L.hvc_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
         L.hvc_device_free.argtypes = [vp, vp]
         L.hvc_memcpy_h2d.argtypes = [vp, vp, vp, sz]
@@ -353,6 +354,25 @@ def compare_planes(a, b):
     mx, tot, se = C.c_int(), C.c_uint64(), C.c_uint64()
     _chk(lib().hvc_compare_planes(a.ctypes.data, b.ctypes.data, a.size, C.byref(mx), C.byref(tot), C.byref(se)))
     return mx.value, tot.value, se.value
+
+
+def huffman_code_tables(table_set, ctx=None):
+    """hvc_huffman_code_tables: the encoder back ends' code tables as {"dc": [[length, bits, category]], "ac": [[[length, bits,
+    run, size]]]} -- the shape of tests/golden/g8_code_tables.json (Tables.Encoder.dc_table / ac_table).  ctx = None: the host
+    coder's; a Context: the GPU coder's, read back from its device memory."""
+    codes = np.zeros(16 + 256, dtype=np.uint32)
+    _chk(lib().hvc_huffman_code_tables(ctx._h if ctx is not None else None, table_set, HVC_MEM_DEVICE if ctx is not None else HVC_MEM_HOST,
+                                       codes.ctypes.data), "hvc_huffman_code_tables")
+    dc = [[int(codes[i]) & 31, int(codes[i]) >> 5, i] for i in range(16) if codes[i]]
+    ac = []
+    for run in range(16):
+        row = [[int(codes[16 + (run << 4 | size)]) & 31, int(codes[16 + (run << 4 | size)]) >> 5, run, size] for size in range(16)]
+        while row and row[-1][0] == 0:
+            row.pop()
+        if row and row[0][0] == 0:     # no size-0 symbol for this run: the model's placeholder (tables.ml:536-543)
+            row[0] = [0, 0, 0, 0]
+        ac.append(row)
+    return {"dc": dc, "ac": ac}
 
 
 def jpeg_header(info):
