@@ -141,6 +141,53 @@ __global__ __launch_bounds__(512, 2) void k_chroma(const u4v *__restrict__ coefs
     }
 }
 
+// Two lanes per chroma block ("each lane stores half the bytes"): the per-lane granule halves to 64 B in +
+// 128 B out.  HALVES = 0: the pair sits side by side in the wave (lane 2k / 2k + 1 = block k's first / second 64 B of
+// coefficients and the left / right 8 output columns: 16 x 8 B row stores, a wave instruction = 512 B of an output row) -- what a
+// kernel that splits the passes between the two lanes and exchanges by DPP would do.  HALVES = 1: the two halves in different
+// waves (each lane 4 x 16 B of its block and the upper or lower 8 output rows as 16 B stores, a wave instruction = 1 KiB of a
+// row) -- the instruction shapes of the shipped kernel at half the granule.
+template <int HALVES>
+__global__ __launch_bounds__(512, 2) void k_chroma_pair(const u4v *__restrict__ coefs, unsigned char *__restrict__ out) {
+    const int lane = threadIdx.x;
+    const size_t plane = blockIdx.y;
+    const u4v *cp = coefs + plane * ((size_t)CBW * CBH * 8);
+    unsigned char *op = out + plane * ((size_t)CW * CBH * 16);
+    int bx, by, half;
+    if (HALVES == 0) {
+        bx = (lane & 255) >> 1;
+        half = lane & 1;
+        by = blockIdx.x * 2 + (lane >> 8);
+    } else {
+        bx = lane & 127;
+        by = blockIdx.x * 2 + ((lane >> 7) & 1);
+        half = lane >> 8;
+    }
+    const bool active = bx < CBW && by < CBH;
+    const int bxc = bx < CBW ? bx : CBW - 1, byc = by < CBH ? by : CBH - 1;
+    const u4v *src = cp + ((size_t)byc * CBW + bxc) * 8 + half * 4;
+    u4v r[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) r[j] = src[j];
+    if (!active) return;
+    if (HALVES == 0) {
+        unsigned char *p = op + (size_t)by * 16 * CW + (size_t)bx * 16 + half * 8;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            u2v t = {r[j & 3].x + (unsigned)j, r[j & 3].y ^ r[j & 3].w};
+            __builtin_nontemporal_store(t, reinterpret_cast<u2v *>(p + (size_t)j * CW));
+        }
+    } else {
+        unsigned char *p = op + ((size_t)by * 16 + half * 8) * CW + (size_t)bx * 16;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            u4v t = r[j & 3];
+            t.x += j;
+            __builtin_nontemporal_store(t, reinterpret_cast<u4v *>(p + (size_t)j * CW));
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------- fused luma half / K1
 constexpr int YBW = 240, YBH = 135, YNB = YBW * YBH;
 template <int MODE, int WGS> // 0 real, 1 ideal loads, 2 ideal stores
@@ -251,7 +298,12 @@ int main() {
             double t0 = timeit([&] { hipLaunchKernelGGL(k_chroma<0>, g, dim3(512), 0, 0, (const u4v *)a, b); }, reps);
             double t1 = timeit([&] { hipLaunchKernelGGL(k_chroma<1>, g, dim3(512), 0, 0, (const u4v *)a, b); }, reps);
             double t2 = timeit([&] { hipLaunchKernelGGL(k_chroma<2>, g, dim3(512), 0, 0, (const u4v *)a, b); }, reps);
+            const dim3 g2((CBH + 1) / 2, planes);
+            double t3 = timeit([&] { hipLaunchKernelGGL(k_chroma_pair<0>, g2, dim3(512), 0, 0, (const u4v *)a, b); }, reps);
+            double t4 = timeit([&] { hipLaunchKernelGGL(k_chroma_pair<1>, g2, dim3(512), 0, 0, (const u4v *)a, b); }, reps);
             if (pr) {
+                line("444 chroma c_pair   two lanes per block side by side: 4 x 16 B loads + 16 x 8 B stores", t3, bytes);
+                line("444 chroma c_halves two lanes per block in two waves: 4 x 16 B loads + 8 x 16 B stores", t4, bytes);
                 line("444 chroma c_real   K1-shape loads + 16 x 16 B row stores", t0, bytes);
                 line("444 chroma c_lideal ideal loads + the real stores", t1, bytes);
                 line("444 chroma c_sideal real loads + ideal stores", t2, bytes);
