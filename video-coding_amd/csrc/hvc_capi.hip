@@ -580,7 +580,7 @@ static int apply_wide_dc(hvc_ctx *c, const hvc::DecodeParams &P, const std::vect
 static int apply_wide_dc_444(hvc_ctx *c, const hvc::Decode444Params &P, const std::vector<WideFix> &wide) {
     std::vector<unsigned> ids;
     std::vector<long long> dcs;
-    const unsigned wgs = (unsigned)(HVC_TILE * P.nw), tw = (unsigned)hvc::tw444(P.nw);
+    const unsigned wgs = (unsigned)(HVC_TILE * P.nw), tw = (unsigned)(HVC_444_TILE_BW * P.nw);
     for (const WideFix &w : wide) {
         int p = -1; // the plane whose coefficient offset is the largest one not beyond the block
         for (int i = 0; i < 3; i++)

@@ -101,16 +101,6 @@ struct Plane444K {
 #define HVC_444_TILE_BW 64
 #define HVC_444_TILE_BH 4
 
-/* -DHVC_444_HALVES=1 (A/B builds only; profiles/ANALYSIS.md section 8): a chroma block is decoded by TWO lanes, in different
- * waves of the workgroup -- lane l and lane l + lanes / 2 -- each storing half of its 16 output rows: the per-lane granule of
- * the chroma half goes from 128 B in + 256 B out to (the same loads, served by the cache for the second wave) + 128 B out, at
- * the price of the block's arithmetic done twice.  Workgroups of 256 * nw lanes then carry chroma tiles of (32 * nw) x 4 blocks. */
-#ifndef HVC_444_HALVES
-#define HVC_444_HALVES 0
-#endif
-/* width in blocks of a chroma tile of the fused kernel for workgroups of 256 * nw lanes */
-constexpr int tw444(int nw) { return (HVC_444_HALVES && nw >= 2) ? HVC_444_TILE_BW * nw / 2 : HVC_444_TILE_BW * nw; }
-
 struct Decode444Params {
     const int16_t *coefs;
     uint8_t *out;

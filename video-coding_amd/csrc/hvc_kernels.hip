@@ -1047,17 +1047,14 @@ __device__ __forceinline__ void emit_rows444(uint8_t *row_even, size_t W, int x0
 // NW = P.nw: 256 * NW lanes per workgroup (16 waves per CU asked for in every form: NW = 1 -> 4 workgroups, ...)
 template <bool ALIGNED, bool DCP, int NW>
 __global__ __launch_bounds__(HVC_TILE * NW, 4 / NW) HVC_444_ATTR void k_decode_444(Decode444Params P) {
-    constexpr int WGS = HVC_TILE * NW, TW = tw444(NW);
-    constexpr int CL = TW * HVC_444_TILE_BH; // lanes that own a chroma block (WGS, or WGS / 2 under HVC_444_HALVES: see hvc_kernels.h)
+    constexpr int WGS = HVC_TILE * NW, TW = HVC_444_TILE_BW * NW;
     __shared__ uint4 edge[WGS]; // per lane: first row (x, y) and first column (z, w) of its chroma block
-    const int tlane = threadIdx.x;
+    const int lane = threadIdx.x;
     unsigned wframe, wtile;
     xcd_work(P.xcd_map, P.xcd_magic, wframe, wtile);
     const int tile = (int)wtile + P.tile0;             // (tile0 = y_tiles when the luma planes went through k_decode_packed)
     const bool chroma = tile >= P.y_tiles;             // workgroup-uniform
     if (P.skip && P.skip == (chroma ? 2 : 1)) return;  // (measurements: one half of the kernel alone)
-    const int half = (CL < WGS && chroma) ? tlane / CL : 0;   // wave-uniform
-    const int lane = (CL < WGS && chroma) ? tlane % CL : tlane;
     const Ref444 r = locate444(P, tile, lane, WGS, TW);
     const Plane444K &K = P.pl[r.p];
     const size_t in_frame = K.coef_off + ((size_t)r.by * K.bw + r.bx) * 64; // the block's place in the frame record
@@ -1098,12 +1095,12 @@ __global__ __launch_bounds__(HVC_TILE * NW, 4 / NW) HVC_444_ATTR void k_decode_4
                                                   __builtin_amdgcn_perm(out[1][0], out[0][0], B0), JOIN);
         const unsigned c1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(out[7][0], out[6][0], B0),
                                                   __builtin_amdgcn_perm(out[5][0], out[4][0], B0), JOIN);
-        if (half == 0) edge[lane] = make_uint4(out[0][0], out[0][1], c0, c1);
+        edge[lane] = make_uint4(out[0][0], out[0][1], c0, c1);
         __syncthreads();
         // right / lower / lower-right neighbours; past the tile the values are placeholders (seam pass)
-        const uint4 rt = edge[min(lane + 1, CL - 1)];
-        const uint4 dn = edge[min(lane + TW, CL - 1)];
-        const unsigned dg = edge[min(lane + TW + 1, CL - 1)].x;
+        const uint4 rt = edge[min(lane + 1, WGS - 1)];
+        const uint4 dn = edge[min(lane + TW, WGS - 1)];
+        const unsigned dg = edge[min(lane + TW + 1, WGS - 1)].x;
         const int lastx = K.aw - 1 - r.bx * 8; // samples at or beyond it take b = a
         const unsigned long long mm = lastx >= 8 ? 0ull : (~0ull << (8 * max(lastx, 0)));
         const unsigned m0 = (unsigned)mm, m1 = (unsigned)(mm >> 32);
@@ -1119,22 +1116,17 @@ __global__ __launch_bounds__(HVC_TILE * NW, 4 / NW) HVC_444_ATTR void k_decode_4
             const RowQ q6 = rowq<2>(out[6][0], out[6][1], rt.w, m0, m1);
             const RowQ q7 = rowq<3>(out[7][0], out[7][1], rt.w, m0, m1);
             const RowQ q8 = rowq<0>(dn.x, dn.y, dg, m0, m1);
-            const bool upper = CL == WGS || half == 0, lower = CL == WGS || half == 1;
-            if (upper) {
-                if (0 <= lasty) emit_rows444<ALIGNED>(p + 0 * W, W, x0, q0, q1, lasty == 0);
-                if (1 <= lasty) emit_rows444<ALIGNED>(p + 2 * W, W, x0, q1, q2, lasty == 1);
-                if (2 <= lasty) emit_rows444<ALIGNED>(p + 4 * W, W, x0, q2, q3, lasty == 2);
-                if (3 <= lasty) emit_rows444<ALIGNED>(p + 6 * W, W, x0, q3, q4, lasty == 3);
-            }
-            if (lower) {
-                if (4 <= lasty) emit_rows444<ALIGNED>(p + 8 * W, W, x0, q4, q5, lasty == 4);
-                if (5 <= lasty) emit_rows444<ALIGNED>(p + 10 * W, W, x0, q5, q6, lasty == 5);
-                if (6 <= lasty) emit_rows444<ALIGNED>(p + 12 * W, W, x0, q6, q7, lasty == 6);
-                if (7 <= lasty) emit_rows444<ALIGNED>(p + 14 * W, W, x0, q7, q8, lasty == 7);
-            }
+            if (0 <= lasty) emit_rows444<ALIGNED>(p + 0 * W, W, x0, q0, q1, lasty == 0);
+            if (1 <= lasty) emit_rows444<ALIGNED>(p + 2 * W, W, x0, q1, q2, lasty == 1);
+            if (2 <= lasty) emit_rows444<ALIGNED>(p + 4 * W, W, x0, q2, q3, lasty == 2);
+            if (3 <= lasty) emit_rows444<ALIGNED>(p + 6 * W, W, x0, q3, q4, lasty == 3);
+            if (4 <= lasty) emit_rows444<ALIGNED>(p + 8 * W, W, x0, q4, q5, lasty == 4);
+            if (5 <= lasty) emit_rows444<ALIGNED>(p + 10 * W, W, x0, q5, q6, lasty == 5);
+            if (6 <= lasty) emit_rows444<ALIGNED>(p + 12 * W, W, x0, q6, q7, lasty == 6);
+            if (7 <= lasty) emit_rows444<ALIGNED>(p + 14 * W, W, x0, q7, q8, lasty == 7);
         }
     }
-    const bool flag = r.store && bad && half == 0;
+    const bool flag = r.store && bad;
     const unsigned long long m = __ballot(flag);
     if (m) {
         const int wl = lane & 63;
@@ -1170,7 +1162,7 @@ __global__ __launch_bounds__(64) void k_decode_wide_444(Decode444Params P, const
         const int tile = (int)(t % (unsigned)P.tiles_per_frame);
         const size_t frame = (size_t)(t / (unsigned)P.tiles_per_frame);
         if (frame >= (size_t)P.n_frames) continue; // an id from another geometry must never turn into an address
-        const Ref444 r = locate444(P, tile, lane, (int)wgs, tw444(P.nw));
+        const Ref444 r = locate444(P, tile, lane, (int)wgs, HVC_444_TILE_BW * P.nw);
         if (!r.store) continue;
         const Plane444K &K = P.pl[r.p];
         const size_t in_frame = K.coef_off + ((size_t)r.by * K.bw + r.bx) * 64;
@@ -1276,7 +1268,7 @@ __global__ __launch_bounds__(256) void k_reinterp_444(Decode444Params P, const u
         const int tile = (int)(t % (unsigned)P.tiles_per_frame);
         const size_t f = (size_t)(t / (unsigned)P.tiles_per_frame);
         if (f >= (size_t)P.n_frames) continue;
-        const Ref444 rr = locate444(P, tile, lane, (int)wgs, tw444(P.nw));
+        const Ref444 rr = locate444(P, tile, lane, (int)wgs, HVC_444_TILE_BW * P.nw);
         if (!rr.store || rr.p == 0) continue;
         const int c = rr.bx * 8 - 1 + k % 9, r = rr.by * 8 - 1 + k / 9;
         if (c < 0 || r < 0 || c >= aw || r >= ah) continue;
@@ -1820,12 +1812,8 @@ hipError_t launch_decode_wide_only(const DecodeParams &P, hipStream_t s, hipEven
 void plan_decode_444(Decode444Params &P, bool aligned) {
     const int cbw = P.pl[1].cbw;
     // one chroma tile across the whole row where 256 blocks reach (the byte-store form for odd sizes keeps the small tile)
-#if HVC_444_HALVES
-    P.nw = !aligned || cbw <= HVC_444_TILE_BW / 2 ? 1 : cbw <= HVC_444_TILE_BW ? 2 : 4;
-#else
     P.nw = !aligned || cbw <= HVC_444_TILE_BW ? 1 : cbw <= 2 * HVC_444_TILE_BW ? 2 : 4;
-#endif
-    const int wgs = HVC_TILE * P.nw, tw = tw444(P.nw);
+    const int wgs = HVC_TILE * P.nw, tw = HVC_444_TILE_BW * P.nw;
     P.y_tiles = (P.pl[0].cbw * P.pl[0].cbh + wgs - 1) / wgs;
     P.y_magic = (unsigned)(((1ull << 32) + P.pl[0].cbw - 1) / P.pl[0].cbw);
     P.c_tiles_x = cbw <= tw ? 1 : (cbw - 1 + (tw - 1) - 1) / (tw - 1);
