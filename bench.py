@@ -189,7 +189,7 @@ def measured_traffic(config, frames, kernel=DOMINANT_KERNEL, build="running"):
                     continue
                 return round(e["hbm_bytes"]), "profiles/traffic.json (session %s, build %s, kernel %s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
                                               "%s, not collected in this run" % (e.get("session"), e["build"], e["kernel"],
-                                                                                 "this command" if config in (2, 3, 4) else e.get("source", "the same workload"))
+                                                                                 "this command" if config in (2, 4) else e.get("source", "the same workload"))
         return None, stale or "no committed PMC pass for config %d at %d frames per launch" % (config, frames)
     except (OSError, ValueError, KeyError):
         return None, "profiles/traffic.json absent"

@@ -37,7 +37,8 @@ def test_c_program_through_the_abi(tmp_path):
     w, h, frames = 208, 120, 3
     out = subprocess.run([str(exe), str(frames), "2", str(w), str(h)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    res = json.loads(out.stdout.strip().splitlines()[-1])
+    lines = [json.loads(ln) for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    res, seam = lines[0], lines[1]
     info = hvc.hvc.jpeg_encoder_layout(w, h, 420, 75)
     pix = lcg_pixels(info.pixel_bytes * frames)[:info.pixel_bytes]
     rec = np.zeros(info.pixel_bytes, dtype=np.uint8)
@@ -50,3 +51,6 @@ def test_c_program_through_the_abi(tmp_path):
         rec[L.plane_offset:L.plane_offset + n] = orc.dequant_idct_recon(coefs, q, L.blocks_w, L.blocks_h)
     assert res["crc32_frame0"] == zlib.crc32(rec.tobytes())
     assert res["Mpixel_s"] > 0
+    # the same frames through hvc_host_alloc / hvc_decode_frames_submit / hvc_wait, all slots in flight: the same pixels
+    assert seam["async_crc32_frame0"] == res["crc32_frame0"] and seam["slots"] == hvc.hvc.HVC_SLOTS
+    assert seam["async_batches"] >= seam["slots"] + 1 and seam["async_Mpixel_s"] > 0

@@ -473,3 +473,50 @@ def test_xcd_work_is_a_permutation_of_the_grid():
     for xcd in range(8):
         mine = lin[xcd::8][:96]
         assert np.array_equal(mine[:32], np.arange(32) + xcd * 32) and np.array_equal(mine[32:64], np.arange(32) + 256 + xcd * 32)
+
+
+def test_wide_kernel_without_the_63_bit_reading():
+    """k_decode_wide_all computes in plain int64 (asr63<S, false>: one shift, no 63-bit reading).  That equals the model's
+    63-bit arithmetic while every value of both passes stays below 2^62 in magnitude; replayed here on magnitudes (sums of
+    absolute values: conservative) for the kernel's inputs -- an int16 coefficient (or an int16 DC from the compact array) times
+    a 16-bit table entry.  The text of idct8_wide is parsed for the operations, so the replay follows the source."""
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-coding_amd", "csrc", "hvc_kernels.hip")).read()
+    body = src[src.index("void idct8_wide("):src.index("// decoder.ml:142-149 `coefs.(i) * qnt_tab.(i)`")]
+    # the statements the replay below restates, in the source's order (a change of the pass breaks this list first)
+    for stmt in ("u64 x8 = w7 * (x4 + x5) + R;", "x4 = asr63<RS, WRAP63>(x8 + (w1 - w7) * x4);", "x5 = asr63<RS, WRAP63>(x8 - (w1 + w7) * x5);",
+                 "x8 = w3 * (x6 + x7) + R;", "x6 = asr63<RS, WRAP63>(x8 - (w3 - w5) * x6);", "x7 = asr63<RS, WRAP63>(x8 - (w3 + w5) * x7);",
+                 "x1 = w6 * (x3 + x2) + R;", "x2 = asr63<RS, WRAP63>(x1 - (w2 + w6) * x2);", "x3 = asr63<RS, WRAP63>(x1 + (w2 - w6) * x3);",
+                 "x2 = asr63<8, WRAP63>(181u * ys + 128u);", "x4 = asr63<8, WRAP63>(181u * yd + 128u);",
+                 "o[0] = (int64_t)asr63<S, WRAP63>(x7 + x1);", "o[7] = (int64_t)asr63<S, WRAP63>(x7 - x1);"):
+        assert stmt in body, stmt
+    assert "decode_block_wide<false>(w, P.qt + br.qtab * 64, P.dc_plane != nullptr, dc, out);" in src      # the all-blocks kernel
+    assert src.count("decode_block_wide<true>(") == 2                                                          # the two list kernels
+
+    LIMIT = 1 << 62
+    seen = [0]
+
+    def chk(v):
+        assert v < LIMIT, v
+        seen[0] = max(seen[0], v)
+        return v
+
+    def one_pass(b, col):   # magnitudes in, magnitudes out
+        s_in, r0, r, rs, outshift = (256, 8192, 4, 3, 14) if col else (2048, 128, 0, 0, 8)
+        x0, x1 = chk(b[0] * s_in + r0), chk(b[4] * s_in)
+        x2, x3, x4, x5, x6, x7 = b[6], b[2], b[1], b[7], b[5], b[3]
+        t = chk(W7 * (x4 + x5) + r)
+        x4, x5 = chk(t + (W1 - W7) * x4) >> rs, chk(t + (W1 + W7) * x5) >> rs
+        t = chk(W3 * (x6 + x7) + r)
+        x6, x7 = chk(t + (W3 - W5) * x6) >> rs, chk(t + (W3 + W5) * x7) >> rs
+        x8, x0 = chk(x0 + x1), chk(x0 + x1)
+        t = chk(W6 * (x3 + x2) + r)
+        x2, x3 = chk(t + (W2 + W6) * x2) >> rs, chk(t + (W2 - W6) * x3) >> rs
+        x1, x4n, x6n, x5n = chk(x4 + x6), chk(x4 + x6), chk(x5 + x7), chk(x5 + x7)
+        x7n, x8n, x3n, x0n = chk(x8 + x3), chk(x8 + x3), chk(x0 + x2), chk(x0 + x2)
+        y = chk(181 * (x4n + x5n) + 128) >> 8
+        out = max(chk(x7n + x1), chk(x3n + y), chk(x0n + y), chk(x8n + x6n)) >> outshift
+        return [out + 1] * 8   # (+ 1: a floor of a negative value can be one larger in magnitude)
+
+    rows = one_pass([32768 * 65535] * 8, col=False)
+    one_pass(rows, col=True)
+    assert seen[0] < 1 << 57   # 32 times below the wrap-around: the plain shift is the model's asr

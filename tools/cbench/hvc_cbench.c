@@ -8,7 +8,14 @@
  * Frames of LCG pixels -> hvc_encode_frames (host buffers) -> coefficient records uploaded once with
  * hvc_device_alloc / hvc_memcpy_h2d -> `steps` x hvc_decode_frames on device memory, timed with
  * hvc_timer_* -> pixels downloaded; prints Mpixel/s, algorithmic GB/s and the CRC-32 of frame 0's
- * pixel record (tests/test_gpu_cbench.py recomputes it through the Python harness and the oracle). */
+ * pixel record (tests/test_gpu_cbench.py recomputes it through the Python harness and the oracle).
+ * Then the same frames through the ASYNCHRONOUS seam the way a single-threaded caller with its own entropy reader uses it
+ * (the OCaml patch's Decoder.decode_frames_gpu): pinned slot buffers from hvc_host_alloc; for every batch, "read" it into the
+ * next slot's pinned record (here: a memcpy) while the earlier submissions are in flight, hvc_decode_frames_submit, and
+ * hvc_wait on the slot only when its turn comes round again.  Prints the rate over the whole loop and the CRC-32 of frame 0 of
+ * the last batch's downloaded pixel record, which must equal the first one. */
+#define _POSIX_C_SOURCE 199309L
+#include <time.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -81,6 +88,41 @@ int main(int argc, char **argv) {
            (double)frames * (double)blocks * 192.0 / (ms / steps * 1e-3) / 1e9, crc32_bytes(pix, info.pixel_bytes));
     CHECK(hvc_device_free(ctx, d_coefs));
     CHECK(hvc_device_free(ctx, d_pix));
+    {
+        const size_t cbytes = info.coef_count * sizeof(int16_t) * (size_t)frames, pbytes = info.pixel_bytes * (size_t)frames;
+        int16_t *pin_c[HVC_SLOTS];
+        uint8_t *pin_p[HVC_SLOTS];
+        const int batches = steps < HVC_SLOTS + 1 ? HVC_SLOTS + 1 : steps;
+        struct timespec t0, t1;
+        double wall_ms;
+        hvc_slot_stats st;
+        int k;
+        for (k = 0; k < HVC_SLOTS; k++) {
+            CHECK(hvc_host_alloc(ctx, cbytes, (void **)&pin_c[k]));
+            CHECK(hvc_host_alloc(ctx, pbytes, (void **)&pin_p[k]));
+            memset(pin_p[k], 0, pbytes);
+        }
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (k = 0; k < batches; k++) {
+            const int slot = k % HVC_SLOTS;
+            CHECK(hvc_wait(ctx, slot));            /* batch k - HVC_SLOTS: its pixels are in pin_p[slot] now (idle slot: returns at once) */
+            memcpy(pin_c[slot], coefs, cbytes);    /* the caller's reader fills the pinned record -- batches k - 1, k - 2, ... are in flight */
+            CHECK(hvc_decode_frames_submit(ctx, slot, pin_c[slot], info.coef_count, &info.qtabs[0][0], info.n_qtabs, info.layout,
+                                           info.n_comp, frames, pin_p[slot], info.pixel_bytes, HVC_MEM_HOST));
+        }
+        for (k = 0; k < HVC_SLOTS; k++) CHECK(hvc_wait(ctx, k));
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        wall_ms = (double)(t1.tv_sec - t0.tv_sec) * 1e3 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-6;
+        CHECK(hvc_slot_last_stats(ctx, (batches - 1) % HVC_SLOTS, &st));
+        printf("{\"async_batches\": %d, \"slots\": %d, \"async_Mpixel_s\": %.1f, \"last_h2d_GBps\": %.1f, \"last_d2h_GBps\": %.1f, "
+               "\"async_crc32_frame0\": %u}\n", batches, (int)HVC_SLOTS, (double)batches * frames * width * height / (wall_ms * 1e-3) / 1e6,
+               (double)st.h2d_bytes / (st.h2d_ms * 1e-3) / 1e9, (double)st.d2h_bytes / (st.d2h_ms * 1e-3) / 1e9,
+               crc32_bytes(pin_p[(batches - 1) % HVC_SLOTS], info.pixel_bytes));
+        for (k = 0; k < HVC_SLOTS; k++) {
+            CHECK(hvc_host_free(ctx, pin_c[k]));
+            CHECK(hvc_host_free(ctx, pin_p[k]));
+        }
+    }
     hvc_destroy(ctx);
     free(pix);
     free(coefs);

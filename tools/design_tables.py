@@ -83,6 +83,10 @@ def tables(tag):
     k.append("| K2 `k_upsample420_x8`, 512 planes 960 × 540 → 1920 × 1080 | a11 | 5 B / source sample | %s (`others`; a 0.2 ms kernel) | — |" % pct(k2["frac_of_8TBps"]))
     k.append("| `k_subsample420` (`hvc_yuv.hip`), 512 planes 1920 × 1080 → 960 × 540 | `subsample_hv2` | 5 B / destination sample | %s (`others`) | — |" % pct(s2["frac_of_8TBps"]))
     k.append("| `k_decode_q16` (north star's mapping; A/B only) | a1 – a6 | 192 B / block | %s (%s) | — |" % (pct(q16["roofline"]["frac"]), q16src))
+    if "wide" in R:
+        wd, wdsrc = R["wide"]
+        k.append("| `k_decode_wide_all` (every block in the model's 63-bit arithmetic: a 16-bit DQT, `hvc_set_decode_kernel(ctx, 2)`), 64 × 1080p | a1 – a6 | 192 B / block | **%s** (%.4f ms, %s); VALU-bound | %s |"
+                 % (pct(wd["frac_of_8TBps"]), wd["kernel_ms"], wdsrc, ratio(tag, "k_decode_wide_all", 13, wd["all_blocks"] * 192)))
 
     t = []
     t.append("| what | measured | source |")
@@ -98,6 +102,12 @@ def tables(tag):
     if cb:
         t.append("| … CPU baseline: the oracle's scalar block stage, same frames (kind `port`) | %.0f Mpixel/s on 1 core; %.0f on %d threads | same line |"
                  % (cb["value"], cb["all_cores"]["value"], cb["all_cores"]["cores"]))
+    ol = rl.get("other_layout")
+    if ol and "frac" in ol:
+        t.append("| … the same frames, %s (what the library's own entry points lay out), same run | `k_decode_packed` %.4f ms = %s; K5 verified: %s | same line |"
+                 % (ol["layout"], ol["kernel_ms"], pct(ol["frac"]), ol["verified"]))
+    t.append("| … verification | K5 over **all %d records** of the launch (record r = distinct frame r mod %d) against `tests/golden/bench_checksums.json` | same line |"
+             % (b["checksum"]["frames"], b["checksum"].get("distinct", 8)))
     t.append("| … same workload, 4096 frames (38.5 GB) per call, cut into launches by the library | %s | %s |" % (pct(f4096["roofline"]["frac"]), f4096src))
     t.append("| … same workload through `k_decode_q16` | %s Mpixel/s = %s | %s |" % ("{:,.0f}".format(q16["value"]).replace(",", " "), pct(q16["roofline"]["frac"]), q16src))
     t.append("| **config 4** (`--config 4`): 4K 4:4:4, one GPU's 2048-frame shard, %s | **%s Mpixel/s**, %.2f ms per pass over the shard; kernel %.4f ms = **%s**; verified: %s | %s |"
@@ -106,8 +116,21 @@ def tables(tag):
     h, g = c3["host_reader"], c3["gpu_reader"]
     t.append("| **config 3** (`--config 3`): 4096 × 1080p JPEG files, host Huffman (%d threads) ‖ H2D ‖ K1 | **%.2f Gpixel/s** (%.1f ms per 4096 files; GPU busy %s: host-bound); verified: %s | %s |"
              % (c3["config"]["host_threads_per_rank"], h["value"] / 1e3, h["ms_per_step"], pct(h["gpu_busy_fraction"]), h["verified"], c3src))
+    if "h2d_GBps" in h:
+        c3r = c3["roofline"]
+        t.append("| … SURVEY §8(d) C3's figures of that line | upload %.1f GB/s; overlap fraction %.2f (1 − wall ÷ (Huffman ÷ threads + upload + kernels)); its 32-frame `k_decode_packed` launches: %.0f GB/s algorithmic, counter traffic ÷ algorithmic %s | same line |"
+                 % (h["h2d_GBps"], h["overlap_fraction"], c3r["achieved"], ("%.4f" % c3r["traffic_over_algorithmic"]) if c3r.get("traffic_over_algorithmic") else "— (%s)" % c3r["traffic_source"][:40]))
     t.append("| … the same files, Huffman reader on the GPU (`hvc_jpeg_decode_batch_gpu`) | **%.1f Gpixel/s** (%.1f ms; %.0f MB of unstuffed segments up instead of %.0f MB of coefficients: upload-bound); verified: %s | same line |"
              % (g["value"] / 1e3, g["ms_per_step"], g["h2d_MB_per_step"], h["h2d_MB_per_step"], g["verified"]))
+    if "seam" in R:
+        sm, smsrc = R["seam"]
+        t.append("| **the asynchronous seam** (`hvc_host_alloc`, `hvc_decode_frames_submit` / `hvc_wait`, %d slots of %d frames): 4096 × 1080p coefficient records, %d caller threads refilling the next slot's pinned record, pixels to HBM | **%.2f Gpixel/s** (%.1f ms); upload %.1f GB/s; overlap fraction %.2f; K5 over all %d records: %s | %s |"
+                 % (sm["slots"], sm["frames_per_slot"], sm["host_threads"], sm["value"] / 1e3, sm["wall_ms"], sm["h2d_GBps"], sm["overlap_fraction"],
+                    sm["checksum"]["records"], sm["checksum"]["verified"], smsrc))
+    if "seam_host" in R:
+        sh, shsrc = R["seam_host"]
+        t.append("| … pixels back into pinned host slots as well (%d records, every one compared byte for byte) | **%.2f Gpixel/s**; up %.1f GB/s ‖ down %.1f GB/s; overlap fraction %.2f; verified: %s | %s |"
+                 % (sh["frames"], sh["value"] / 1e3, sh["h2d_GBps"], sh["d2h_GBps"], sh["overlap_fraction"], sh["checksum"]["verified"], shsrc))
     if c3.get("cpu_baseline"):
         t.append("| … CPU baseline: the oracle's `decode_a_frame` (Huffman + block stage), 1 thread | %.1f Mpixel/s | same line |" % c3["cpu_baseline"]["value"])
     t.append("| **config 5** (`--config 5`): 4K 4:2:0 encode (fDCT + quantise), 256 frames (9.6 GB) per launch | **%s Mpixel/s**; `k_encode` %.4f ms = **%s**; verified: %s; CPU baseline %.0f Mpixel/s on 1 core | %s |"
@@ -127,6 +150,11 @@ def tables(tag):
     if "c6" in R:
         c6, c6src = R["c6"]
         t.append("| host-buffer boundary (`HVC_MEM_HOST`): PCIe-inclusive, never `value` | %.1f Gpixel/s | %s |" % (c6["value"] / 1e3, c6src))
+    if "wide" in R and "wide_dqt16" in R:
+        (wd, wdsrc), (w16, w16src) = R["wide"], R["wide_dqt16"]
+        t.append("| every block through `k_decode_wide_all` (64 × 1080p): `hvc_set_decode_kernel(ctx, 2)` / a DQT entry of 40000 | %.0f / %.0f Gpixel/s = %s / %s; equal to the packed kernel's frames: %s / %s | %s, %s |"
+                 % (wd["value"] / 1e3, w16["value"] / 1e3, pct(wd["frac_of_8TBps"]), pct(w16["frac_of_8TBps"]), wd["checksum"]["verified"],
+                    w16["checksum"]["verified"], wdsrc, w16src.replace("profiles/%s_lines.jsonl" % tag, "")))
     if "huffman_gpu" in R:
         hg, hgsrc = R["huffman_gpu"]
         t.append("| GPU Huffman coder alone (4K 4:2:0, q75) | %.0f Gpixel/s | %s |" % (hg["value"] / 1e3, hgsrc))
@@ -139,7 +167,8 @@ def tables(tag):
     if reh:
         t.append("| N-rank rehearsals on this one GPU (all ranks on cuda:0, gloo; never measurements) | %s | `profiles/%s_lines.jsonl`, lines as given |" % ("; ".join(reh), tag))
     prof = []
-    for name, label in (("decode", "`python bench.py`, `k_decode_packed`"), ("decode_c4", "`--config 4`"), ("encode", "`k_encode`"), ("444", "`k_decode_444`")):
+    for name, label in (("decode", "`python bench.py`, `k_decode_packed`"), ("decode_c4", "`--config 4`"), ("decode_c3", "config 3's 32-frame launches"),
+                        ("encode", "`k_encode`"), ("444", "`k_decode_444`"), ("wide", "`k_decode_wide_all`")):
         ta = trace_avg(tag, name)
         if ta:
             prof.append("%s %.4f ms (%s)" % (label, ta[0], ta[1]))

@@ -85,7 +85,7 @@ def main(d):
             print("  %-40s %-22s %16.1f  (n=%d)%s" % (kn[:40], cn, avg, n, extra))
 
 
-def traffic_json(d, kernel_substr, frames, config=2, session=""):
+def traffic_json(d, kernel_substr, frames, config=2, session="", what=""):
     """HBM bytes per launch of one kernel from the FETCH_SIZE / WRITE_SIZE passes, corrected as
     MI355X_MICROARCH.md prescribes (KB units; FETCH_SIZE x2 for 16 B/lane streaming reads on gfx950)."""
     out = {}
@@ -100,15 +100,16 @@ def traffic_json(d, kernel_substr, frames, config=2, session=""):
     import video_coding_amd as hvc   # the library the profiled commands loaded: the pass is of THIS build's kernels
     return {"kernel": kernel_substr, "config": config, "session": session, "build": hvc.hvc.kernel_build_id(),
             "frames_per_launch": frames, "fetch_bytes": fetch,
-            "write_bytes": write, "hbm_bytes": fetch + write, "source": os.path.basename(os.path.normpath(d)),
+            "write_bytes": write, "hbm_bytes": fetch + write,
+            "source": os.path.basename(os.path.normpath(d)) + (": " + what if what else ""),
             "corrections": "FETCH_SIZE KB x1024 x2 (gfx950 16 B/lane read undercount), WRITE_SIZE KB x1024"}
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 4 and sys.argv[2] == "--traffic":  # <dir> --traffic <kernel> <frames> [config] [session]
+    if len(sys.argv) > 4 and sys.argv[2] == "--traffic":  # <dir> --traffic <kernel> <frames> [config] [session] [the profiled command]
         import json
         print(json.dumps(traffic_json(sys.argv[1], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]) if len(sys.argv) > 5 else 2,
-                                      sys.argv[6] if len(sys.argv) > 6 else ""), indent=1))
+                                      sys.argv[6] if len(sys.argv) > 6 else "", sys.argv[7] if len(sys.argv) > 7 else ""), indent=1))
     else:
         if len(sys.argv) > 2:
             WARMUP = int(sys.argv[2])

@@ -185,11 +185,18 @@ __device__ __forceinline__ unsigned ashr14_sat_pack4(int a, int b, int c, int d)
 // an `asr`, the compare of clip.  For everything 16-bit coefficients and 16-bit tables can reach (< 2^47) the reading is
 // the identity; it matters for the DC values a table with 33...62-bit categories produces (include/hvc_jpeg.h).
 __device__ __forceinline__ int64_t ocaml_int(uint64_t x) { return (int64_t)(x << 1) >> 1; }
-template <int S>
-__device__ __forceinline__ uint64_t asr63(uint64_t x) { return S ? (uint64_t)(ocaml_int(x) >> S) : x; }
+// WRAP63 = false: the caller knows every value of the pass stays below 2^62 in magnitude, where the 63-bit reading is the
+// identity and `asr` is one 64-bit shift.  That is every block whose 64 inputs are an int16 coefficient times a 16-bit table
+// entry (|input| < 2^31: no value of either pass reaches 2^57 -- replayed on
+// magnitudes by tests/test_guard_bounds.py::test_wide_kernel_without_the_63_bit_reading); only a DC from the side list of
+// DCs beyond int16 (a 33 ... 62-bit DC category) can reach the wrap-around, and those blocks go through the WRAP63 form.
+template <int S, bool WRAP63>
+__device__ __forceinline__ uint64_t asr63(uint64_t x) {
+    return !S ? x : WRAP63 ? (uint64_t)(ocaml_int(x) >> S) : (uint64_t)((int64_t)x >> S);
+}
 
 // Eight values in, eight out, all in registers: b[i] is the pass's input i (a row's or a column's i-th element).
-template <bool COL>
+template <bool COL, bool WRAP63>
 __device__ __forceinline__ void idct8_wide(const uint64_t (&b)[8], int64_t (&o)[8]) {
     typedef uint64_t u64;
     constexpr u64 w1 = (u64)W1, w2 = (u64)W2, w3 = (u64)W3, w5 = (u64)W5, w6 = (u64)W6, w7 = (u64)W7;
@@ -199,16 +206,16 @@ __device__ __forceinline__ void idct8_wide(const uint64_t (&b)[8], int64_t (&o)[
     constexpr u64 R = COL ? 4 : 0;
     constexpr int RS = COL ? 3 : 0;
     u64 x8 = w7 * (x4 + x5) + R;
-    x4 = asr63<RS>(x8 + (w1 - w7) * x4);
-    x5 = asr63<RS>(x8 - (w1 + w7) * x5);
+    x4 = asr63<RS, WRAP63>(x8 + (w1 - w7) * x4);
+    x5 = asr63<RS, WRAP63>(x8 - (w1 + w7) * x5);
     x8 = w3 * (x6 + x7) + R;
-    x6 = asr63<RS>(x8 - (w3 - w5) * x6);
-    x7 = asr63<RS>(x8 - (w3 + w5) * x7);
+    x6 = asr63<RS, WRAP63>(x8 - (w3 - w5) * x6);
+    x7 = asr63<RS, WRAP63>(x8 - (w3 + w5) * x7);
     x8 = x0 + x1;
     x0 = x0 - x1;
     x1 = w6 * (x3 + x2) + R;
-    x2 = asr63<RS>(x1 - (w2 + w6) * x2);
-    x3 = asr63<RS>(x1 + (w2 - w6) * x3);
+    x2 = asr63<RS, WRAP63>(x1 - (w2 + w6) * x2);
+    x3 = asr63<RS, WRAP63>(x1 + (w2 - w6) * x3);
     x1 = x4 + x6;
     x4 = x4 - x6;
     x6 = x5 + x7;
@@ -218,17 +225,17 @@ __device__ __forceinline__ void idct8_wide(const uint64_t (&b)[8], int64_t (&o)[
     x3 = x0 + x2;
     x0 = x0 - x2;
     const u64 ys = x4 + x5, yd = x4 - x5;
-    x2 = asr63<8>(181u * ys + 128u);
-    x4 = asr63<8>(181u * yd + 128u);
+    x2 = asr63<8, WRAP63>(181u * ys + 128u);
+    x4 = asr63<8, WRAP63>(181u * yd + 128u);
     constexpr int S = COL ? 14 : 8;
-    o[0] = (int64_t)asr63<S>(x7 + x1);
-    o[1] = (int64_t)asr63<S>(x3 + x2);
-    o[2] = (int64_t)asr63<S>(x0 + x4);
-    o[3] = (int64_t)asr63<S>(x8 + x6);
-    o[4] = (int64_t)asr63<S>(x8 - x6);
-    o[5] = (int64_t)asr63<S>(x0 - x4);
-    o[6] = (int64_t)asr63<S>(x3 - x2);
-    o[7] = (int64_t)asr63<S>(x7 - x1);
+    o[0] = (int64_t)asr63<S, WRAP63>(x7 + x1);
+    o[1] = (int64_t)asr63<S, WRAP63>(x3 + x2);
+    o[2] = (int64_t)asr63<S, WRAP63>(x0 + x4);
+    o[3] = (int64_t)asr63<S, WRAP63>(x8 + x6);
+    o[4] = (int64_t)asr63<S, WRAP63>(x8 - x6);
+    o[5] = (int64_t)asr63<S, WRAP63>(x0 - x4);
+    o[6] = (int64_t)asr63<S, WRAP63>(x3 - x2);
+    o[7] = (int64_t)asr63<S, WRAP63>(x7 - x1);
 }
 // decoder.ml:142-149 `coefs.(i) * qnt_tab.(i)` in the same arithmetic (the factors: an int16 or a 63-bit DC, a 16-bit entry)
 __device__ __forceinline__ int64_t mul63(int64_t a, int64_t b) { return (int64_t)((uint64_t)a * (uint64_t)b); }
@@ -810,6 +817,7 @@ __global__ __launch_bounds__(HVC_TILE) void k_decode_q16(DecodeParams P) {
 // One block: w = its 32 coefficient dwords (zig-zag order as loaded), q = its table (zig-zag order); has_dc: the DC is
 // `dc` (the model's 63-bit number: DecodeParams::dc_plane or the side list of DCs beyond int16) instead of coefficient 0.
 // decoder.ml:142-149 (dequantise + inverse zig-zag), dct.ml:11-107 (rows, then columns), decoder.ml:213-224 (clip, + 128).
+template <bool WRAP63>
 __device__ __forceinline__ void decode_block_wide(const unsigned (&w)[32], const int *__restrict__ q, bool has_dc, int64_t dc,
                                                   unsigned (&out)[8][2]) {
     int64_t v[64];
@@ -824,7 +832,7 @@ __device__ __forceinline__ void decode_block_wide(const unsigned (&w)[32], const
         }
         if (r == 0 && has_dc) in[0] = (uint64_t)mul63(dc, (int64_t)q[0]);
         int64_t o[8];
-        idct8_wide<false>(in, o);
+        idct8_wide<false, WRAP63>(in, o);
 #pragma unroll
         for (int i = 0; i < 8; i++) v[8 * r + i] = o[i];
     }
@@ -836,11 +844,12 @@ __device__ __forceinline__ void decode_block_wide(const unsigned (&w)[32], const
 #pragma unroll
         for (int j = 0; j < 8; j++) in[j] = (uint64_t)v[8 * j + c];
         int64_t o[8];
-        idct8_wide<true>(in, o);
+        idct8_wide<true, WRAP63>(in, o);
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int64_t x = o[j] < -128 ? -128 : (o[j] > 127 ? 127 : o[j]);
-            out[j][c >> 2] |= (unsigned)(x + 128) << (8 * (c & 3));
+        for (int j = 0; j < 8; j++) { // clip to -128 .. 127, + 128 (decoder.ml:213-224) = the shifted value held to 0 .. 255
+            const uint64_t y = (uint64_t)o[j] + 128u;
+            const unsigned px = y <= 255u ? (unsigned)y : ((int64_t)y < 0 ? 0u : 255u);
+            out[j][c >> 2] |= px << (8 * (c & 3));
         }
     }
 }
@@ -890,7 +899,7 @@ __global__ __launch_bounds__(64) void k_decode_wide(DecodeParams P, const unsign
         if (P.dc_plane) // the DC lives in the compact array (DecodeParams::dc_plane)
             dc = (int64_t)P.dc_plane[(size_t)frame * P.dc_fs + ((br.coef_idx - (size_t)frame * P.coef_fs) >> 6)];
         if (dc_list) dc = (int64_t)dc_list[i];
-        decode_block_wide(w, P.qt + br.qtab * 64, P.dc_plane != nullptr || dc_list != nullptr, dc, out);
+        decode_block_wide<true>(w, P.qt + br.qtab * 64, P.dc_plane != nullptr || dc_list != nullptr, dc, out);
 #pragma unroll
         for (int j = 0; j < 8; j++) store_row8(P.pixels + br.pix_idx + (size_t)j * br.stride, out[j][0], out[j][1]);
     }
@@ -907,7 +916,7 @@ __global__ __launch_bounds__(HVC_TILE) void k_decode_wide_all(DecodeParams P) {
     load_block_dwords(P.coefs + br.coef_idx, w);
     int64_t dc = 0;
     if (P.dc_plane) dc = (int64_t)P.dc_plane[(size_t)wframe * P.dc_fs + ((br.coef_idx - (size_t)wframe * P.coef_fs) >> 6)];
-    decode_block_wide(w, P.qt + br.qtab * 64, P.dc_plane != nullptr, dc, out);
+    decode_block_wide<false>(w, P.qt + br.qtab * 64, P.dc_plane != nullptr, dc, out); // (int16 x 16-bit inputs: asr63's comment)
     if (active) {
 #pragma unroll
         for (int j = 0; j < 8; j++) store_row8(P.pixels + br.pix_idx + (size_t)j * br.stride, out[j][0], out[j][1]);
@@ -1171,7 +1180,7 @@ __global__ __launch_bounds__(64) void k_decode_wide_444(Decode444Params P, const
         int64_t dc = 0;
         if (P.dc_plane) dc = (int64_t)P.dc_plane[frame * P.dc_fs + (in_frame >> 6)];
         if (dc_list) dc = (int64_t)dc_list[i];
-        decode_block_wide(w, P.qt + K.qtab * 64, P.dc_plane != nullptr || dc_list != nullptr, dc, out);
+        decode_block_wide<true>(w, P.qt + K.qtab * 64, P.dc_plane != nullptr || dc_list != nullptr, dc, out);
         uint8_t *plane = P.out + frame * P.out_fs + K.out_off;
         const int step = r.p == 0 ? 1 : 2;
 #pragma unroll
