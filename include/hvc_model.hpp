@@ -8,7 +8,8 @@
  *
  *   common/src/plane.mli:6-41      Plane   create, width, height, .![] (bounds-checked), blit_available, output, input
  *   common/src/frame.mli:10-36     Frame   create, of_planes (chroma mode inferred; raises as frame.ml:42-61), y / u / v, output, input
- *   jpeg/model/src/decoder.mli:8-59  Decoder::Header::decode, init, decode, get_decoded_planes, get_yuv_frame, decode_a_frame
+ *   jpeg/model/src/decoder.mli:8-59  Decoder::Header::decode, init, decode, get_decoded_planes, get_yuv_frame, decode_a_frame;
+ *                                    decode_frames = the patch's decode_frames_gpu (the asynchronous seam, two slots)
  *   jpeg/model/src/encoder.mli:132-135  Encoder::encode_420 / encode_422 / encode_444
  *   jpeg/model/src/quant_tables.mli  Quant_tables::scale
  *   jpeg/model/src/dct.mli:8-11    Dct::Chen through the block stage it lives in (Decoder::recon_of_coefs, Encoder::quant_of_pixels)
@@ -25,6 +26,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <istream>
 #include <ostream>
 #include <stdexcept>
@@ -237,6 +239,80 @@ inline Frame decode_a_frame(Ctx &ctx, const std::string &bits) { /* decoder.ml:4
     t d = init(ctx, Header::decode(bits), bits);
     d.decode();
     return d.get_yuv_frame();
+}
+
+/* List.map ~f:decode_a_frame through the ABI's asynchronous seam -- the compiled twin of the OCaml patch's
+ * Decoder.decode_frames_gpu (integration/ocaml/hvc_backend.patch): two slots, each with a pinned coefficient
+ * record and a pinned pixel record that grow with the largest frame; while the GPU works on file k (upload, block stage,
+ * download: hvc_decode_frames_submit returns at once), the calling thread's Huffman reader (here hvc_jpeg_entropy_decode, the
+ * host half of Decoder.decode: decoder.ml:118-140, 143) is already filling file k + 1's record.  Same frames as decode_a_frame. */
+inline std::vector<Frame> decode_frames(Ctx &ctx, const std::vector<std::string> &files) {
+    struct Slot {
+        int16_t *record = nullptr;
+        uint8_t *pixels = nullptr;
+        size_t coef_cap = 0, pixel_cap = 0;
+        bool pending = false;
+        hvc_jpeg_info info{};
+    } slots[2];
+    std::vector<Frame> frames;
+    auto release = [&](Slot &s) {
+        if (s.record) hvc_host_free(ctx.get(), s.record);
+        if (s.pixels) hvc_host_free(ctx.get(), s.pixels);
+        s.record = nullptr;
+        s.pixels = nullptr;
+        s.coef_cap = s.pixel_cap = 0;
+    };
+    auto retire = [&](int index) { /* the file whose submission sits in the slot: wait, crop, Frame.of_planes */
+        Slot &s = slots[index];
+        if (!s.pending) return;
+        s.pending = false;
+        check(hvc_wait(ctx.get(), index), "hvc_wait");
+        size_t len = 0;
+        std::vector<uint8_t> buf(s.info.pixel_bytes + 1);
+        check(hvc_jpeg_get_yuv_frame(&s.info, s.pixels, buf.data(), buf.size(), &len), "Decoder.get_yuv_frame");
+        Plane pl[3];
+        size_t off = 0;
+        for (int i = 0; i < 3; i++) {
+            const hvc_jpeg_component &c = s.info.comp[i];
+            pl[i] = Plane::create(c.actual_width, c.actual_height);
+            for (size_t k = 0; k < pl[i].size(); k++) pl[i].data()[k] = buf[off + k];
+            off += pl[i].size();
+        }
+        frames.push_back(Frame::of_planes(std::move(pl[0]), std::move(pl[1]), std::move(pl[2])));
+    };
+    struct Finally { /* a failure half way: nothing may stay in flight on pinned memory that is about to be freed */
+        std::function<void()> f;
+        ~Finally() { f(); }
+    } finally{[&] {
+        for (int i = 0; i < 2; i++) {
+            if (slots[i].pending) (void)hvc_wait(ctx.get(), i);
+            release(slots[i]);
+        }
+    }};
+    for (size_t k = 0; k < files.size(); k++) {
+        const int index = (int)(k & 1);
+        retire(index); /* file k - 2 used this slot: its frame is due before the slot's records are written again */
+        Slot &s = slots[index];
+        const std::string &bits = files[k];
+        const uint8_t *data = reinterpret_cast<const uint8_t *>(bits.data());
+        check(hvc_jpeg_read_header(data, bits.size(), &s.info), "Decoder.Header.decode");
+        if (s.info.coef_count > s.coef_cap || s.info.pixel_bytes > s.pixel_cap) {
+            release(s);
+            check(hvc_host_alloc(ctx.get(), s.info.coef_count * sizeof(int16_t), reinterpret_cast<void **>(&s.record)), "hvc_host_alloc");
+            check(hvc_host_alloc(ctx.get(), s.info.pixel_bytes, reinterpret_cast<void **>(&s.pixels)), "hvc_host_alloc");
+            s.coef_cap = s.info.coef_count;
+            s.pixel_cap = s.info.pixel_bytes;
+        }
+        /* phase 1 on this thread -- while file k - 1 is in flight in the other slot */
+        check(hvc_jpeg_entropy_decode(data, bits.size(), &s.info, s.record), "Decoder.huffman_decode");
+        check(hvc_decode_frames_submit(ctx.get(), index, s.record, s.info.coef_count, &s.info.qtabs[0][0], s.info.n_qtabs, s.info.layout,
+                                       s.info.n_comp, 1, s.pixels, s.info.pixel_bytes, HVC_MEM_HOST),
+              "hvc_decode_frames_submit");
+        s.pending = true;
+    }
+    retire((int)(files.size() & 1)); /* drain in submission order: the older of the two first */
+    retire((int)((files.size() + 1) & 1));
+    return frames;
 }
 } // namespace Decoder
 

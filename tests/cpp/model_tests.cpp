@@ -163,6 +163,25 @@ static int gpu_tests(const std::string &golden, std::map<std::string, std::vecto
     ok = ok && planes.size() == 3 && planes[0].width() == 480 && planes[0].height() == 320 && planes[1].width() == 240 && fr.width() == 480 &&
          fr.chroma_subsampling() == Frame::Chroma_subsampling::C420 && Ocompare::max_difference(fr.y(), planes[0]) == 0;
     std::cout << "decoder init / decode / get_yuv_frame " << (ok ? "ok" : "MISMATCH") << "\n";
+    // ---- Decoder.decode_frames_gpu's twin: a list of files of several geometries through the asynchronous seam = List.map decode_a_frame
+    {
+        std::vector<std::string> files;
+        for (int k = 0; k < 7; k++) files.push_back(k % 3 == 1 ? mouse : mini);   // 64 x 64 and 480 x 320 in turn: the slots' records grow
+        files.push_back(Encoder::encode_444(ctx, input_yuv(golden + "/mini64x64.444", Frame::Chroma_subsampling::C444, 64, 64), 60));
+        const std::vector<Frame> got = Decoder::decode_frames(ctx, files);
+        ok = got.size() == files.size();
+        for (size_t k = 0; ok && k < files.size(); k++) {
+            const Frame want = Decoder::decode_a_frame(ctx, files[k]);
+            ok = want.width() == got[k].width() && want.chroma_subsampling() == got[k].chroma_subsampling() &&
+                 Ocompare::max_difference(want.y(), got[k].y()) == 0 && Ocompare::max_difference(want.u(), got[k].u()) == 0 &&
+                 Ocompare::max_difference(want.v(), got[k].v()) == 0;
+        }
+        ok = ok && Decoder::decode_frames(ctx, {}).empty() && Decoder::decode_frames(ctx, {mini}).size() == 1;
+        // a bad file in the middle: the exception leaves nothing in flight (the context is usable right after)
+        std::string cut_mid = mini.substr(0, 300);   // (header cut inside a table segment)
+        ok = ok && raises([&] { Decoder::decode_frames(ctx, {mini, cut_mid, mini}); }, HVC_E_BAD_JPEG) && Decoder::decode_frames(ctx, {mini, mini, mini}).size() == 3;
+        std::cout << "decode_frames through the asynchronous seam " << (ok ? "ok" : "MISMATCH") << "\n";
+    }
     // ---- what the model raises on
     std::string cut = mini.substr(0, 300);   // header cut inside a table segment
     ok = raises([&] { Decoder::decode_a_frame(ctx, cut); }, HVC_E_BAD_JPEG) && raises([&] { Decoder::decode_a_frame(ctx, "garbage"); }, HVC_E_BAD_JPEG) &&

@@ -261,3 +261,82 @@ def test_wide_kernel_bench_modes_verify():
         r = bc.config_wide(bc.make_args(frames=64, steps=3, warmup=2, wide_mode=mode))
         assert r["checksum"]["verified"] is True and r["wide_path_blocks"] == r["all_blocks"], r
         assert r["frac_of_8TBps"] > 0.02, r       # (the scratch-memory kernel of round 5 sat far below this)
+
+
+def test_randomised_submissions_interleaved_with_the_blocking_entry_points(ctx):
+    """Slots in any order, decode and encode submissions mixed, host and device destinations, pinned and pageable sources, other
+    entry points of the SAME context in between (blocking host calls, device calls, K5, a file decode): every result equals the
+    blocking call's on a second context (itself held to the oracle by tests/test_gpu_decode.py), and the first case of every
+    geometry the oracle's directly."""
+    import torch
+    import video_coding_amd as hvc
+    from conftest import golden_bytes
+    rng = np.random.Generator(np.random.PCG64(20261005))
+    ref = hvc.Context(0)
+    S = hvc.hvc.HVC_SLOTS
+    geoms = [[(3, 2, 0)], [(9, 7, 0), (5, 4, 1), (5, 4, 1)], [(30, 17, 0), (15, 9, 1), (15, 9, 1)], [(1, 1, 0), (1, 1, 1)]]
+    sets = []
+    for gi, planes in enumerate(geoms):
+        n = int(rng.integers(1, 6))
+        specs, cfs, pfs, q, coefs, want, pix = _frame_set(n, planes, 7000 + 100 * gi)
+        sets.append(dict(n=n, specs=specs, comps=hvc.hvc.components(specs), cfs=cfs, pfs=pfs, q=q, coefs=coefs, want=want, pix=pix))
+    pinned = []
+    in_flight = {}   # slot -> (kind, set, destination, keepalive)
+    mini = golden_bytes("mini.jpg")
+    mini_want = ref.jpeg_decode(mini)[1]
+
+    def retire(slot):
+        kind, st, dst, _ = in_flight.pop(slot)
+        ctx.wait(slot)
+        got = dst.cpu().numpy() if hasattr(dst, "cpu") else dst
+        assert np.array_equal(got, st["want"] if kind == "dec" else st["coefs"]), (kind, slot)
+
+    try:
+        for it in range(120):
+            slot = int(rng.integers(0, S))
+            if slot in in_flight:
+                retire(slot)
+            st = sets[int(rng.integers(0, len(sets)))]
+            kind = "dec" if rng.random() < 0.7 else "enc"
+            src = st["coefs"] if kind == "dec" else st["pix"]
+            if rng.random() < 0.5:   # a pinned copy of the source
+                p = ctx.host_alloc(src.shape, src.dtype)
+                p[:] = src
+                pinned.append(p)
+                src = p
+            shape, dt = ((st["n"], st["pfs"]), np.uint8) if kind == "dec" else ((st["n"], st["cfs"]), np.int16)
+            if rng.random() < 0.4:
+                dst = torch.zeros(shape, dtype=torch.uint8 if kind == "dec" else torch.int16, device="cuda")
+                torch.cuda.synchronize()
+            else:
+                dst = np.zeros(shape, dtype=dt)
+            if kind == "dec":
+                ctx.decode_frames_submit(slot, src, st["cfs"], st["q"], st["comps"], st["n"], dst, st["pfs"])
+            else:
+                ctx.encode_frames_submit(slot, src, st["pfs"], st["q"], st["comps"], st["n"], dst, st["cfs"])
+            in_flight[slot] = (kind, st, dst, src)
+            # something else on the same context while the slots are in flight
+            what = int(rng.integers(0, 5))
+            o = sets[int(rng.integers(0, len(sets)))]
+            if what == 0:      # a blocking host-memory decode
+                out = np.zeros((o["n"], o["pfs"]), dtype=np.uint8)
+                ctx.decode_frames(o["coefs"], o["cfs"], o["q"], o["comps"], o["n"], out, o["pfs"])
+                assert np.array_equal(out, o["want"])
+            elif what == 1:    # a device-memory encode + K5 of its result against the host array's
+                d_p = torch.from_numpy(o["pix"]).cuda()
+                d_c = torch.zeros((o["n"], o["cfs"]), dtype=torch.int16, device="cuda")
+                torch.cuda.synchronize()
+                ctx.encode_frames(d_p, o["pfs"], o["q"], o["comps"], o["n"], d_c, o["cfs"])
+                assert np.array_equal(ctx.checksum_records(d_c, o["cfs"] * 2, o["n"]), ctx.checksum_records(o["coefs"], o["cfs"] * 2, o["n"]))
+            elif what == 2:    # a whole file
+                assert np.array_equal(ctx.jpeg_decode(mini)[1], mini_want)
+            elif what == 3 and in_flight:   # an early retirement, any slot
+                retire(list(in_flight)[int(rng.integers(0, len(in_flight)))])
+        for slot in list(in_flight):
+            retire(slot)
+    finally:
+        for slot in list(in_flight):
+            ctx.wait(slot)
+        for p in pinned:
+            ctx.host_free(p)
+        ref.close()
