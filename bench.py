@@ -45,6 +45,8 @@ The JSON line also carries
                 values tests/golden/bench_checksums.json holds for these seeds -- which the CPU suite
                 reproduces from the model restatement (tests/test_bench_checksums.py): the timed output is
                 the model's output, not just fast;
+                roofline.other_layout: the same frames with planes back to back (what the library's own entry points lay out;
+                the headline batch starts every plane on a 64 KiB / 2 MiB boundary), timed and K5-verified after the timed region;
   sustained     >= --sustain-seconds (6 s) of the same step repeated AFTER the K timed steps, one event pair per step:
                 first / last decile of the step time (clock or thermal drift would show), the GPU-busy fraction; never
                 part of `value` / `ms_per_step`, which come from the K timed steps alone;
@@ -496,6 +498,7 @@ def parse_args(argv=None):
     ap.add_argument("--distinct", type=int, default=None, help="distinct synthetic frames (replicated): 8, configs 3 / 5: 4")
     ap.add_argument("--threads", type=int, default=None, help="config 3: host threads per rank (default: the rank's share of its NUMA node, <= 16)")
     ap.add_argument("--tight", action="store_true", help="planes and frames back to back instead of on 64 KiB / 2 MiB boundaries (A/B)")
+    ap.add_argument("--no-other-layout", action="store_true", help="skip roofline.other_layout (the same frames in the other layout, 40 launches after the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-others", action="store_true", help="skip `others` (configs 3 / 4 / 5 and the other kernels, after the timed region)")
@@ -852,7 +855,7 @@ def main():
     # The other layout beside the headline's: the same frames with planes and frames back to back -- what every
     # library entry point that lays records out itself produces -- timed by the same events right after; never part of `value`.
     other_layout = None
-    if launches == 1 and world == 1 and args.sustain_seconds > 0:
+    if launches == 1 and world == 1 and not args.no_other_layout:
         try:
             o_align = hvc.hvc.layout_alignment(planes) if args.tight else 1
             ospecs, ocfs, opfs = hvc.hvc.frame_layout(planes, align=o_align)

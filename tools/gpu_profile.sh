@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 40 --warmup 10 --no-cpu-baseline --no-others --sustain-seconds 2 $@"   # (the profile is of the headline step alone)
+ARGS="--steps 40 --warmup 10 --no-cpu-baseline --no-others --no-other-layout --sustain-seconds 2 $@"   # (the profile is of the headline step alone)
 # the kernel trace is of the command exactly as the driver runs it (`python bench.py`, or with the caller's arguments): the
 # dominant kernel's average over its TIMED dispatches (tools/rocpd_summary.py) is what bench.py's own event time must agree with
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python3 $ROOT/bench.py "$@" > $OUT/trace_bench.log 2>&1
