@@ -118,10 +118,13 @@ def tables(tag):
              % (c3["config"]["host_threads_per_rank"], h["value"] / 1e3, h["ms_per_step"], pct(h["gpu_busy_fraction"]), h["verified"], c3src))
     if "h2d_GBps" in h:
         c3r = c3["roofline"]
-        t.append("| … SURVEY §8(d) C3's figures of that line | upload %.1f GB/s; overlap fraction %.2f (1 − wall ÷ (Huffman ÷ threads + upload + kernels)); its 32-frame `k_decode_packed` launches: %.0f GB/s algorithmic, counter traffic ÷ algorithmic %s | same line |"
-                 % (h["h2d_GBps"], h["overlap_fraction"], c3r["achieved"], ("%.4f" % c3r["traffic_over_algorithmic"]) if c3r.get("traffic_over_algorithmic") else "— (%s)" % c3r["traffic_source"][:40]))
+        t.append("| … SURVEY §8(d) C3's figures of that line | upload %.1f GB/s; overlap fraction %.2f (1 − wall ÷ (Huffman ÷ threads + upload + kernels)); its %d-frame `k_decode_packed` launches: %.0f GB/s algorithmic, counter traffic ÷ algorithmic %s | same line |"
+                 % (h["h2d_GBps"], h["overlap_fraction"], h["kernel_launch_frames"], c3r["achieved"],
+                    ratio(tag, "k_decode_packed", 3, c3r["algorithmic_bytes_per_launch"])))
     t.append("| … the same files, Huffman reader on the GPU (`hvc_jpeg_decode_batch_gpu`) | **%.1f Gpixel/s** (%.1f ms; %.0f MB of unstuffed segments up instead of %.0f MB of coefficients: upload-bound); verified: %s | same line |"
              % (g["value"] / 1e3, g["ms_per_step"], g["h2d_MB_per_step"], h["h2d_MB_per_step"], g["verified"]))
+    if c3.get("cpu_baseline"):
+        t.append("| … CPU baseline: the oracle's `decode_a_frame` (Huffman + block stage), 1 thread | %.1f Mpixel/s | same line |" % c3["cpu_baseline"]["value"])
     if "seam" in R:
         sm, smsrc = R["seam"]
         t.append("| **the asynchronous seam** (`hvc_host_alloc`, `hvc_decode_frames_submit` / `hvc_wait`, %d slots of %d frames): 4096 × 1080p coefficient records, %d caller threads refilling the next slot's pinned record, pixels to HBM | **%.2f Gpixel/s** (%.1f ms); upload %.1f GB/s; overlap fraction %.2f; K5 over all %d records: %s | %s |"
@@ -131,8 +134,6 @@ def tables(tag):
         sh, shsrc = R["seam_host"]
         t.append("| … pixels back into pinned host slots as well (%d records, every one compared byte for byte) | **%.2f Gpixel/s**; up %.1f GB/s ‖ down %.1f GB/s; overlap fraction %.2f; verified: %s | %s |"
                  % (sh["frames"], sh["value"] / 1e3, sh["h2d_GBps"], sh["d2h_GBps"], sh["overlap_fraction"], sh["checksum"]["verified"], shsrc))
-    if c3.get("cpu_baseline"):
-        t.append("| … CPU baseline: the oracle's `decode_a_frame` (Huffman + block stage), 1 thread | %.1f Mpixel/s | same line |" % c3["cpu_baseline"]["value"])
     t.append("| **config 5** (`--config 5`): 4K 4:2:0 encode (fDCT + quantise), 256 frames (9.6 GB) per launch | **%s Mpixel/s**; `k_encode` %.4f ms = **%s**; verified: %s; CPU baseline %.0f Mpixel/s on 1 core | %s |"
              % ("{:,.0f}".format(c5["value"]).replace(",", " "), r5["kernel_ms"], pct(r5["frac"]), c5["checksum"]["verified"],
                 (c5.get("cpu_baseline") or {}).get("value", float("nan")), c5src))
