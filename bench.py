@@ -158,6 +158,13 @@ def cpu_baseline(frames, qtabs, planes, pixels_per_frame, min_seconds=10.0):
 DOMINANT_KERNEL = "k_decode_packed"   # what this file's step launches (hvc_decode_frames, default kernel choice)
 
 
+def step_kernel():
+    """the kernel symbol the config 2 / 4 step really launches: HVC_DECODE_KERNEL in the environment (A/B runs only) makes
+    hvc_decode_frames launch another one, and a counter pass of k_decode_packed is not that kernel's"""
+    v = os.environ.get("HVC_DECODE_KERNEL", "")
+    return "k_decode_q16" if v[:1] == "q" else "k_decode_fast" if v[:2] == "v2" else DOMINANT_KERNEL
+
+
 def running_build():
     """the kernel id of the library this process runs (hvc_version: the hash of the kernel sources it was built from)"""
     try:
@@ -896,7 +903,7 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         algo_bytes = args.frames * blocks_per_frame * ALGO_BYTES_PER_BLOCK
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
-        traffic, traffic_source = measured_traffic(args.config, args.frames)
+        traffic, traffic_source = measured_traffic(args.config, args.frames, step_kernel())
         out = {
             "metric": wl["metric"],
             "value": round(whole_job_mpixels(world, args.shard, args.steps, dt, PW * PH), 1),
@@ -919,7 +926,7 @@ def main():
                        "layout": "planes back to back (tight)" if align == 1 else
                                  "every plane of every frame (coefficients and pixels) on a %d KiB boundary" % (align >> 10),
                        "wide_path_blocks": int(wide)},
-            "roofline": {"bound": "hbm", "kernel": "k_decode_packed", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": step_kernel(), "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": round(k_ms, 4),
                          "kernel_ms_min_max": [round(float(np.min(kernel_ms)), 4), round(float(np.max(kernel_ms)), 4)],
