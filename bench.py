@@ -255,6 +255,11 @@ def other_measurements(threads):
     wide = lambda r: dict(kern(r), Gpixel_s=round(r["value"] / 1e3, 2), frames=r["frames"], wide_path_blocks=r["wide_path_blocks"])
     run("wide_only_64x1080p", lambda: bc.config_wide(bc.make_args(frames=64, steps=20, warmup=5, wide_mode="kernel2")), "valu (int64)", wide)
     run("wide_dqt16_64x1080p", lambda: bc.config_wide(bc.make_args(frames=64, steps=20, warmup=5, wide_mode="dqt16")), "valu (int64)", wide)
+    # ... and the exactness contract's worst case under 8-bit tables: adversarial records on which every block fails the packed
+    # kernel's guard and goes through the fix-up list (whole call: packed kernel + list + k_decode_wide)
+    run("fixup_worst_case_64x1080p", lambda: bc.config_fixup(bc.make_args(frames=64, steps=10, warmup=3)), "valu (int64) + one list",
+        lambda r: {"ms": r["ms_per_call"], "frac_of_8TBps": r["frac_of_8TBps"], "Gpixel_s": round(r["value"] / 1e3, 2), "frames": r["frames"],
+                   "wide_path_blocks": r["wide_path_blocks"]})
     # the asynchronous seam: the CALLER's reader fills pinned slots, hvc_decode_frames_submit / hvc_wait
     seam = lambda r: dict(pipe(r), h2d_GBps=r["h2d_GBps"], d2h_GBps=r["d2h_GBps"], refill_GBps=r["refill_GBps"],
                           overlap_fraction=r["overlap_fraction"], slots=r["slots"], frames_per_slot=r["frames_per_slot"],

@@ -340,3 +340,11 @@ def test_randomised_submissions_interleaved_with_the_blocking_entry_points(ctx):
         for p in pinned:
             ctx.host_free(p)
         ref.close()
+
+
+def test_every_block_through_the_fixup_list():
+    """the exactness contract's worst case: adversarial records on which every block fails the packed kernel's guard -- the
+    fix-up list holds every block of the launch (its fixed grid strides over it), the frames are the int64 kernel's"""
+    import bench_configs as bc
+    r = bc.config_fixup(bc.make_args(frames=16, steps=2, warmup=1))
+    assert r["checksum"]["verified"] is True and r["wide_path_blocks"] == r["all_blocks"] == 16 * 48960, r

@@ -156,6 +156,10 @@ def tables(tag):
         t.append("| every block through `k_decode_wide_all` (64 × 1080p): `hvc_set_decode_kernel(ctx, 2)` / a DQT entry of 40000 | %.0f / %.0f Gpixel/s = %s / %s; equal to the packed kernel's frames: %s / %s | %s, %s |"
                  % (wd["value"] / 1e3, w16["value"] / 1e3, pct(wd["frac_of_8TBps"]), pct(w16["frac_of_8TBps"]), wd["checksum"]["verified"],
                     w16["checksum"]["verified"], wdsrc, w16src.replace("profiles/%s_lines.jsonl" % tag, "")))
+    if "fixup" in R:
+        fx, fxsrc = R["fixup"]
+        t.append("| the exactness contract's worst case under 8-bit tables: adversarial ± 2047 records, every block fails the packed kernel's guard (packed kernel + fix-up list + `k_decode_wide`, whole call) | %.1f Gpixel/s = %s (%.4f ms per 64 frames; %d of %d blocks through the list); equal to `k_decode_wide_all`'s frames: %s | %s |"
+                 % (fx["value"] / 1e3, pct(fx["frac_of_8TBps"]), fx["ms_per_call"], fx["wide_path_blocks"], fx["all_blocks"], fx["checksum"]["verified"], fxsrc))
     if "huffman_gpu" in R:
         hg, hgsrc = R["huffman_gpu"]
         t.append("| GPU Huffman coder alone (4K 4:2:0, q75) | %.0f Gpixel/s | %s |" % (hg["value"] / 1e3, hgsrc))

@@ -36,6 +36,7 @@ python tools/bench_configs.py --config 12 --threads 16 > gpurun_out/m_seam.json 
 python tools/bench_configs.py --config 12 --threads 16 --host-out --frames 2048 > gpurun_out/m_seam_host.json 2> gpurun_out/m_seam_host.err   # ... pixels back into pinned slots
 python tools/bench_configs.py --config 13 > gpurun_out/m_wide.json 2> gpurun_out/m_wide.err                  # every block through the int64 kernel
 python tools/bench_configs.py --config 13 --wide-mode dqt16 > gpurun_out/m_wide_dqt16.json 2> gpurun_out/m_wide_dqt16.err
+python tools/bench_configs.py --config 14 > gpurun_out/m_fixup.json 2> gpurun_out/m_fixup.err                 # every block through the fix-up list (adversarial)
 echo "configs done"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mem_ubench3 tools/ubench/mem_ubench3.hip 2> /dev/null
 /tmp/mem_ubench3 > gpurun_out/m_mem_ubench3.txt 2>&1 || true

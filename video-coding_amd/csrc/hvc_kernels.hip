@@ -869,8 +869,20 @@ __device__ __forceinline__ void load_block_dwords(const int16_t *cf, unsigned (&
 // The fix-up form: the listed blocks, one per lane, in a grid-stride loop over the (normally empty) list.
 // dc_list (optional, parallel to list): the listed block's true absolute DC where it does not fit the int16 record
 // (hvc_hdec.h WideDc: the model's 63-bit dc of decoder.ml:143)
-__global__ __launch_bounds__(64) void k_decode_wide(DecodeParams P, const unsigned *count, const unsigned *list,
-                                                    const long long *dc_list) {
+// Launched with a fixed grid (the list's length is known on the device only): HVC_FIXUP_WGS workgroups of HVC_FIXUP_LANES
+// lanes.  Normally the list is empty and every lane leaves after one load; when an adversarial batch sends EVERY block here
+// (tools/bench_configs.py --config 14) the grid decides the cost: 256 x 64 lanes -- one wave per CU -- read 4.5 % of the HBM
+// peak on such a batch, 512 x 256 -- the two waves per SIMD the kernel's registers allow -- 9.1 %, with nothing to see in the
+// headline (profiles/r06f_fixup_grid.txt).  What is left there is the packed kernel's own worst case (one atomic per
+// wavefront on one counter, the list's stores), not this kernel's arithmetic (k_decode_wide_all: 31 - 34 %).
+#ifndef HVC_FIXUP_WGS
+#define HVC_FIXUP_WGS 512
+#endif
+#ifndef HVC_FIXUP_LANES
+#define HVC_FIXUP_LANES 256
+#endif
+__global__ __launch_bounds__(HVC_FIXUP_LANES) void k_decode_wide(DecodeParams P, const unsigned *count, const unsigned *list,
+                                                                 const long long *dc_list) {
     const unsigned long long n = (unsigned long long)*count;
     // The two fix-up counters alternate between calls: this launch reads the
     // current one and clears the other for the next call (no memset node).
@@ -883,8 +895,8 @@ __global__ __launch_bounds__(64) void k_decode_wide(DecodeParams P, const unsign
             else *P.wide_total = P.wide_first ? n : *P.wide_total + n;
         }
     }
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 64 + threadIdx.x; i < n;
-         i += (unsigned long long)gridDim.x * 64) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
         const unsigned long long id = list[i];
         const int lane = (int)(id % HVC_TILE);
         const unsigned long long t = id / HVC_TILE;
@@ -1769,7 +1781,7 @@ hipError_t launch_decode(const DecodeParams &P, hipStream_t s, hipEvent_t k0, hi
     if (k1 && (e = hipEventRecord(k1, s)) != hipSuccess) return e;
     // Fixed small grid; every thread strides over the (normally empty) list and
     // exits as soon as its index passes *fix_count.
-    hipLaunchKernelGGL(k_decode_wide, dim3(256), dim3(64), 0, s, P, P.fix_count, P.fix_list, (const long long *)nullptr);
+    hipLaunchKernelGGL(k_decode_wide, dim3(HVC_FIXUP_WGS), dim3(HVC_FIXUP_LANES), 0, s, P, P.fix_count, P.fix_list, (const long long *)nullptr);
     return hipGetLastError();
 }
 
