@@ -10,7 +10,8 @@
  *   common/src/frame.mli:10-36     Frame   create, of_planes (chroma mode inferred; raises as frame.ml:42-61), y / u / v, output, input
  *   jpeg/model/src/decoder.mli:8-59  Decoder::Header::decode, init, decode, get_decoded_planes, get_yuv_frame, decode_a_frame;
  *                                    decode_frames = the patch's decode_frames_gpu (the asynchronous seam, two slots)
- *   jpeg/model/src/encoder.mli:132-135  Encoder::encode_420 / encode_422 / encode_444
+ *   jpeg/model/src/encoder.mli:132-135  Encoder::encode_420 / encode_422 / encode_444; encode_frames = the patch's
+ *                                    encode_frames_gpu (the asynchronous seam the encoder's way round)
  *   jpeg/model/src/quant_tables.mli  Quant_tables::scale
  *   jpeg/model/src/dct.mli:8-11    Dct::Chen through the block stage it lives in (Decoder::recon_of_coefs, Encoder::quant_of_pixels)
  *   tools/src/ocompare.ml:8-59     Ocompare::max_difference, psnr; Float.to_string as the cram tests print it
@@ -340,6 +341,79 @@ inline std::string encode(Ctx &ctx, const Frame &frame, int quality, Frame::Chro
 inline std::string encode_420(Ctx &ctx, const Frame &f, int quality) { return encode(ctx, f, quality, Frame::Chroma_subsampling::C420); }
 inline std::string encode_422(Ctx &ctx, const Frame &f, int quality) { return encode(ctx, f, quality, Frame::Chroma_subsampling::C422); }
 inline std::string encode_444(Ctx &ctx, const Frame &f, int quality) { return encode(ctx, f, quality, Frame::Chroma_subsampling::C444); }
+
+/* List.map ~f:(encode_4xx ~quality) through the ABI's asynchronous seam, the encoder's way round (the patch's
+ * Encoder.encode_frames_gpu): the GPU does the FRONT half of encode_block for a whole frame -- level shift, forward DCT,
+ * quantiser (hvc_encode_frames_submit: encoder.ml:81-108, dct.ml:109-196) -- and while it works on frame k + 1 the calling
+ * thread runs the BACK half of frame k: rle + write_bits + headers (here hvc_jpeg_entropy_encode: encoder.ml:127-193, 371-418).
+ * Two slots with pinned pixel and coefficient records.  Same files as encode_4xx, byte for byte. */
+inline std::vector<std::string> encode_frames(Ctx &ctx, const std::vector<Frame> &frames, int quality) {
+    struct Slot {
+        uint8_t *pixels = nullptr;
+        int16_t *record = nullptr;
+        size_t pixel_cap = 0, coef_cap = 0;
+        bool pending = false;
+        hvc_jpeg_info info{};
+    } slots[2];
+    std::vector<std::string> files;
+    auto release = [&](Slot &s) {
+        if (s.pixels) hvc_host_free(ctx.get(), s.pixels);
+        if (s.record) hvc_host_free(ctx.get(), s.record);
+        s.pixels = nullptr;
+        s.record = nullptr;
+        s.pixel_cap = s.coef_cap = 0;
+    };
+    auto retire = [&](int index) { /* the frame whose coefficients the slot is waiting for: wait, then the host's half */
+        Slot &s = slots[index];
+        if (!s.pending) return;
+        s.pending = false;
+        check(hvc_wait(ctx.get(), index), "hvc_wait");
+        std::vector<uint8_t> out(8 * s.info.coef_count + 4096);
+        size_t len = 0;
+        check(hvc_jpeg_entropy_encode(&s.info, s.record, out.data(), out.size(), &len), "Encoder.rle / write_bits");
+        files.emplace_back(reinterpret_cast<const char *>(out.data()), len);
+    };
+    struct Finally {
+        std::function<void()> f;
+        ~Finally() { f(); }
+    } finally{[&] {
+        for (int i = 0; i < 2; i++) {
+            if (slots[i].pending) (void)hvc_wait(ctx.get(), i);
+            release(slots[i]);
+        }
+    }};
+    for (size_t k = 0; k < frames.size(); k++) {
+        const int index = (int)(k & 1);
+        retire(index);
+        Slot &s = slots[index];
+        const Frame &f = frames[k];
+        check(hvc_jpeg_encoder_layout(f.width(), f.height(), (int)f.chroma_subsampling(), quality, &s.info), "Encoder.create");
+        check(hvc_jpeg_encoder_check(&s.info), "Encoder.encode_seq");
+        if (s.info.pixel_bytes > s.pixel_cap || s.info.coef_count > s.coef_cap) {
+            release(s);
+            check(hvc_host_alloc(ctx.get(), s.info.pixel_bytes, reinterpret_cast<void **>(&s.pixels)), "hvc_host_alloc");
+            check(hvc_host_alloc(ctx.get(), s.info.coef_count * sizeof(int16_t), reinterpret_cast<void **>(&s.record)), "hvc_host_alloc");
+            s.pixel_cap = s.info.pixel_bytes;
+            s.coef_cap = s.info.coef_count;
+        }
+        /* Plane.blit_available into the scans' zero-padded planes (encoder.ml:451-458, 512-520) */
+        for (size_t b = 0; b < s.info.pixel_bytes; b++) s.pixels[b] = 0;
+        const Plane *planes[3] = {&f.y(), &f.u(), &f.v()};
+        for (int i = 0; i < 3; i++) {
+            const hvc_component &L = s.info.layout[i];
+            for (int y = 0; y < planes[i]->height(); y++)
+                for (int x = 0; x < planes[i]->width(); x++)
+                    s.pixels[L.plane_offset + (size_t)y * L.stride + x] = planes[i]->data()[(size_t)y * planes[i]->width() + x];
+        }
+        check(hvc_encode_frames_submit(ctx.get(), index, s.pixels, s.info.pixel_bytes, &s.info.qtabs[0][0], s.info.n_qtabs, s.info.layout,
+                                       s.info.n_comp, 1, s.record, s.info.coef_count, HVC_MEM_HOST),
+              "hvc_encode_frames_submit");
+        s.pending = true;
+    }
+    retire((int)(frames.size() & 1));
+    retire((int)((frames.size() + 1) & 1));
+    return files;
+}
 } // namespace Encoder
 
 namespace Oconv { /* `oyuv convert IN WxH OUT W2xH2` for one planar frame (tools/src/oconv.ml:111-133): the frame to 4:4:4

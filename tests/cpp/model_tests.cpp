@@ -182,6 +182,21 @@ static int gpu_tests(const std::string &golden, std::map<std::string, std::vecto
         ok = ok && raises([&] { Decoder::decode_frames(ctx, {mini, cut_mid, mini}); }, HVC_E_BAD_JPEG) && Decoder::decode_frames(ctx, {mini, mini, mini}).size() == 3;
         std::cout << "decode_frames through the asynchronous seam " << (ok ? "ok" : "MISMATCH") << "\n";
     }
+    // ---- Encoder.encode_frames_gpu's twin: frames of three samplings and two sizes through the seam = List.map encode_4xx, byte for byte
+    {
+        std::vector<Frame> fr;
+        const Frame f420 = input_yuv(golden + "/mini64x64.420", Frame::Chroma_subsampling::C420, 64, 64);
+        fr.push_back(f420);
+        fr.push_back(input_yuv(golden + "/mini64x64.444", Frame::Chroma_subsampling::C444, 64, 64));
+        fr.push_back(Oconv::convert(ctx, f420, 52, 44, Frame::Chroma_subsampling::C420));
+        fr.push_back(input_yuv(golden + "/mini64x64.422", Frame::Chroma_subsampling::C422, 64, 64));
+        fr.push_back(f420);
+        const std::vector<std::string> got = Encoder::encode_frames(ctx, fr, 75);
+        ok = got.size() == fr.size() && got[0] == mini && got[4] == mini;   // (mini.jpg: the model encoder's own file, G3)
+        for (size_t k = 0; ok && k < fr.size(); k++) ok = got[k] == Encoder::encode(ctx, fr[k], 75, fr[k].chroma_subsampling());
+        ok = ok && Encoder::encode_frames(ctx, {}, 75).empty();
+        std::cout << "encode_frames through the asynchronous seam " << (ok ? "ok" : "MISMATCH") << "\n";
+    }
     // ---- what the model raises on
     std::string cut = mini.substr(0, 300);   // header cut inside a table segment
     ok = raises([&] { Decoder::decode_a_frame(ctx, cut); }, HVC_E_BAD_JPEG) && raises([&] { Decoder::decode_a_frame(ctx, "garbage"); }, HVC_E_BAD_JPEG) &&

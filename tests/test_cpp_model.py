@@ -48,7 +48,7 @@ def test_the_references_tests_through_the_mirror_on_the_gpu(program):
     lines = run(program, "gpu")
     checks = [ln for ln in lines if ln.endswith(" ok") or "MISMATCH" in ln or ln.startswith("EXCEPTION")]
     assert checks == ["chen forward_8x8 ok", "chen inverse_8x8 ok", "encode_420 q75 = mini.jpg ok",
-                      "decoder init / decode / get_yuv_frame ok", "decode_frames through the asynchronous seam ok", "raises ok"], lines
+                      "decoder init / decode / get_yuv_frame ok", "decode_frames through the asynchronous seam ok", "encode_frames through the asynchronous seam ok", "raises ok"], lines
     # the cram session: three PSNR lines per case, digit for digit (jpeg/test/model-encode-and-decode.t:15-17, 27-29, 39-41, 56-58, 70-72)
     got, cur = [], None
     for ln in lines:

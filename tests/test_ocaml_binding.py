@@ -43,7 +43,8 @@ def test_patch_uses_only_what_the_binding_defines(tmp_path):
     missing, used = chk.check_patch()
     assert missing == []
     for name in ("ctx", "coefs", "coefs_ptr", "check", "decode_frames", "mem_host", "Component.t", "Component.stride",
-                 "decode_frames_submit", "wait", "pinned_coefs", "pinned_bytes", "free_pinned_coefs", "free_pinned_bytes"):
+                 "decode_frames_submit", "encode_frames_submit", "wait", "pinned_coefs", "pinned_bytes", "free_pinned_coefs",
+                 "free_pinned_bytes"):
         assert name in used, name
     # ... and the check sees a name that is not there (round 2's sketch called helpers that existed nowhere)
     text = open(chk.PATCH).read().replace("Hvc.coefs_ptr record", "Hvc.coefs_pointer record")
@@ -83,8 +84,11 @@ def test_patch_applies_to_the_reference(tmp_path):
     assert "val decode_frames_gpu : Hvc.ctx -> Bits.t list -> Frame.t list" in mli
     enc, enci = (tmp_path / "jpeg/model/src/encoder.ml").read_text(), (tmp_path / "jpeg/model/src/encoder.mli").read_text()
     for name in ("let encode_seq_with ~encode_block (t : t) =", "let encode_seq (t : t) = encode_seq_with ~encode_block t",
-                 "let encode_seq_gpu (hvc : Hvc.ctx) (t : t) =", "let encode_420_gpu hvc ~frame ~quality ~writer ="):
+                 "let encode_seq_gpu (hvc : Hvc.ctx) (t : t) =", "let encode_420_gpu hvc ~frame ~quality ~writer =",
+                 "let encode_420_frames_gpu (hvc : Hvc.ctx) ~quality jobs =", "module Gpu_slot = struct"):
         assert name in enc, name
+    assert enc.index("let complete_and_write_eoi") < enc.index("let encode_420_frames_gpu") and enc.index("module Gpu = struct") < enc.index("module Gpu_slot")
+    assert "val encode_420_frames_gpu : Hvc.ctx -> quality:int -> (Frame.t * Bitstream_writer.t) list -> unit" in enci
     # the exported signature of encode_seq is the reference's own (an optional argument would not match it)
     assert "val encode_seq : t -> Block.t Sequence.t" in enci and "val encode_seq_gpu : Hvc.ctx -> t -> Block.t Sequence.t" in enci
     assert "val plane : t -> Base_bigstring.t" in (tmp_path / "common/src/plane.mli").read_text()
