@@ -498,8 +498,10 @@ HVC_API int hvc_checksum_records(hvc_ctx *ctx, const void *data, size_t record_b
  *              --hipMemcpyAsync, download stream--> host pixel records          (decode; the encoder mirror runs the other way)
  * and returns at once.  Three streams, so slot k + 1's upload, slot k's kernel and slot k - 1's download overlap, and the
  * link carries both directions.  hvc_wait(ctx, slot) blocks until the slot's results are visible and frees the slot.
- * The host buffers of a submission must stay valid and unmodified (coefficients) / unread (pixels) until its hvc_wait.
- * They should be PINNED -- from hvc_host_alloc, or the caller's own memory (a Bigarray's data) passed once through
+ * The host buffers of a submission must stay valid and unmodified (coefficients) / unread (pixels) until its hvc_wait
+ * (or hvc_destroy): the copy engines read and write them on their own time, and memory freed under them is a GPU page
+ * fault, not a status code.
+ * They should be PINNED -- from hvc_host_alloc, or the caller's own page-aligned memory passed once through
  * hvc_host_register: from pageable memory hipMemcpyAsync stages through the runtime's bounce buffers and holds its
  * caller (the result is the same, the overlap is gone).
  * Like everything on a context the slot calls are not thread-safe among themselves; what the caller does meanwhile on
@@ -515,7 +517,11 @@ enum { HVC_SLOTS = 4 };
 HVC_API int hvc_host_alloc(hvc_ctx *ctx, size_t bytes, void **out);
 HVC_API int hvc_host_free(hvc_ctx *ctx, void *p);
 /* Pins memory the caller already owns (hipHostRegister): [p, p + bytes) stays where it is and becomes a DMA source /
- * target; hvc_host_unregister before freeing it.  A Bigarray.Array1 lives outside the OCaml heap and never moves. */
+ * target; hvc_host_unregister before freeing it.  WHOLE PAGES ONLY -- p and bytes multiples of the page size
+ * (posix_memalign / mmap / aligned_alloc; HVC_E_ALIGNMENT otherwise), pages that hold nothing but this buffer: the HIP
+ * runtime finds registered memory by page, and a pageable buffer that shares a registered range's last page is copied
+ * through that range's mapping until the GPU faults where it ends.  (A Bigarray.Array1 lives outside the OCaml heap and
+ * never moves, but Bigarray.create's memory is malloc's: take hvc_host_alloc for those, as the patch's Hvc.pinned_* do.) */
 HVC_API int hvc_host_register(hvc_ctx *ctx, void *p, size_t bytes);
 HVC_API int hvc_host_unregister(hvc_ctx *ctx, void *p);
 

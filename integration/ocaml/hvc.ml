@@ -449,7 +449,8 @@ let memcpy_d2h = foreign "hvc_memcpy_d2h" ~release_runtime_lock:true (ctx @-> pt
 let slots = 4 (* enum { HVC_SLOTS = 4 } *)
 
 (* int hvc_host_alloc(ctx, bytes, out); int hvc_host_free(ctx, p): pinned memory (hipHostMalloc)
-   int hvc_host_register(ctx, p, bytes); int hvc_host_unregister(ctx, p): the caller's own memory pinned in place *)
+   int hvc_host_register(ctx, p, bytes); int hvc_host_unregister(ctx, p): the caller's own memory pinned in place -- whole
+   pages only (posix_memalign'ed / mmap'ed memory; Bigarray.create's is malloc'ed: use [pinned_coefs] / [pinned_bytes]) *)
 let host_alloc = foreign "hvc_host_alloc" (ctx @-> size_t @-> ptr (ptr void) @-> returning int)
 let host_free = foreign "hvc_host_free" (ctx @-> ptr void @-> returning int)
 let host_register = foreign "hvc_host_register" (ctx @-> ptr void @-> size_t @-> returning int)

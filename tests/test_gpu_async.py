@@ -158,10 +158,15 @@ def test_registered_caller_memory_and_a_filling_thread(ctx):
     specs, cfs, pfs, q, coefs, want, _ = _frame_set(n, planes, 1234)
     comps = hvc.hvc.components(specs)
     S = hvc.hvc.HVC_SLOTS
-    bufs = [np.zeros((n, cfs), dtype=np.int16) for _ in range(S)]
-    outs = [np.zeros((n, pfs), dtype=np.uint8) for _ in range(S)]
+    bufs = [hvc.hvc.page_aligned_empty((n, cfs), np.int16) for _ in range(S)]     # whole pages of their own: what may be registered
+    outs = [hvc.hvc.page_aligned_empty((n, pfs), np.uint8) for _ in range(S)]
     for a in bufs + outs:
+        a[:] = 0
         ctx.host_register(a)
+    # memory that shares its pages with whatever malloc put beside it is refused (the runtime finds registered memory by page)
+    odd = np.zeros(3 * hvc.hvc.PAGE, dtype=np.uint8)
+    assert hvc.lib().hvc_host_register(ctx._h, odd.ctypes.data + 8, hvc.hvc.PAGE) == -4
+    assert hvc.lib().hvc_host_register(ctx._h, (odd.ctypes.data + hvc.hvc.PAGE - 1) // hvc.hvc.PAGE * hvc.hvc.PAGE, 100) == -4
     try:
         # batch k holds the frames rotated by k: a stale buffer would show
         def fill(s, k):

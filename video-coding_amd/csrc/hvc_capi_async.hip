@@ -13,6 +13,8 @@
 // download: both directions of the link and the kernel overlap.
 #include "hvc_ctx.h"
 
+#include <unistd.h>
+
 namespace {
 
 int slot_of(hvc_ctx *c, int slot, hvc_ctx::Slot **out) {
@@ -83,8 +85,15 @@ int hvc_host_free(hvc_ctx *c, void *p) try {
     return HVC_OK;
 } HVC_ABI_CATCH
 
+// Whole pages only.  The runtime resolves a host pointer to a registered range by PAGE: a pageable buffer that merely
+// starts in the last page of somebody's registered range is taken for part of it, copied through that range's mapping, and
+// faults on the GPU where the mapping ends (found by tools/stress_seam.py with registered and pageable arrays side by side
+// on the heap: the fault address was the first page behind a registered array, 3.6 KB past its end).  A range of whole
+// pages that the caller owns outright cannot be shared that way.
 int hvc_host_register(hvc_ctx *c, void *p, size_t bytes) try {
     if (!c || !p || !bytes) return HVC_E_INVALID_ARG;
+    const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+    if (((uintptr_t)p & (page - 1)) || (bytes & (page - 1))) return HVC_E_ALIGNMENT;
     DeviceGuard g(c->device);
     if (!g.ok) return fail_hip(c, hipErrorInvalidDevice);
     HIPCHK(c, hipHostRegister(p, bytes, hipHostRegisterDefault));

@@ -77,6 +77,17 @@ class BatchStats(C.Structure):
                 ("frames_per_chunk", C.c_int), ("coef_bytes", C.c_uint64), ("host_prep_ms_sum", C.c_double)]
 
 
+PAGE = os.sysconf("SC_PAGESIZE")
+
+
+def page_aligned_empty(shape, dtype=np.uint8):
+    """a numpy array on whole pages of its own (mmap): what hvc_host_register takes"""
+    import mmap
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    buf = mmap.mmap(-1, max((n + PAGE - 1) // PAGE * PAGE, PAGE))
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
 class SlotStats(C.Structure):
     """struct hvc_slot_stats"""
     _fields_ = [("h2d_ms", C.c_double), ("kernel_ms", C.c_double), ("d2h_ms", C.c_double), ("h2d_bytes", C.c_uint64),
@@ -409,8 +420,9 @@ class Context:
 
     def close(self):
         if self._h:
-            lib().hvc_destroy(self._h)
+            lib().hvc_destroy(self._h)   # (drains what is in flight: only then may a submission's buffers go)
             self._h = C.c_void_p()
+            getattr(self, "_slot_buffers", {}).clear()
 
     def __del__(self):
         try:
@@ -503,8 +515,10 @@ class Context:
         _chk(lib().hvc_host_free(self._h, arr.ctypes.data), "hvc_host_free")
 
     def host_register(self, arr):
-        """pins memory the caller owns (a numpy array's buffer) in place; host_unregister(arr) before it goes"""
-        _chk(lib().hvc_host_register(self._h, arr.ctypes.data, arr.nbytes), "hvc_host_register")
+        """pins memory the caller owns in place; host_unregister(arr) before it goes.  Whole pages only (include/hvc_jpeg.h):
+        arr from page_aligned_empty(), whose allocation is registered to its last page"""
+        size = (arr.nbytes + PAGE - 1) // PAGE * PAGE
+        _chk(lib().hvc_host_register(self._h, arr.ctypes.data, size), "hvc_host_register")
 
     def host_unregister(self, arr):
         _chk(lib().hvc_host_unregister(self._h, arr.ctypes.data), "hvc_host_unregister")
@@ -519,6 +533,7 @@ class Context:
         arr = comps if not isinstance(comps, list) else components(comps)
         _chk(lib().hvc_decode_frames_submit(self._h, slot, ca, coef_frame_stride, q.ctypes.data, q.shape[0], arr, len(arr),
                                             n_frames, pa, pixel_frame_stride, w2), "hvc_decode_frames_submit(slot %d)" % slot)
+        self._keep(slot, coefs, pixels)
 
     def encode_frames_submit(self, slot, pixels, pixel_frame_stride, qtabs, comps, n_frames, coefs, coef_frame_stride):
         """the encoder mirror: HOST pixel records in, coefficient records to numpy (host) or a device tensor"""
@@ -529,9 +544,20 @@ class Context:
         arr = comps if not isinstance(comps, list) else components(comps)
         _chk(lib().hvc_encode_frames_submit(self._h, slot, pa, pixel_frame_stride, q.ctypes.data, q.shape[0], arr, len(arr),
                                             n_frames, ca, coef_frame_stride, w2), "hvc_encode_frames_submit(slot %d)" % slot)
+        self._keep(slot, pixels, coefs)
+
+    def _keep(self, slot, *buffers):
+        """the ABI's rule: a submission's buffers stay valid until its hvc_wait -- an upload from memory the interpreter has
+        meanwhile freed is a GPU page fault (tools/stress_seam.py found it the hard way), so the binding holds on to them"""
+        if not hasattr(self, "_slot_buffers"):
+            self._slot_buffers = {}
+        self._slot_buffers[slot] = buffers
 
     def wait(self, slot):
-        _chk(lib().hvc_wait(self._h, slot), "hvc_wait(slot %d)" % slot)
+        try:
+            _chk(lib().hvc_wait(self._h, slot), "hvc_wait(slot %d)" % slot)
+        finally:
+            getattr(self, "_slot_buffers", {}).pop(slot, None)
 
     def slot_done(self, slot):
         d = C.c_int()
