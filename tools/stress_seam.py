@@ -3,7 +3,8 @@
 registered memory) against the BLOCKING entry points of a second context -- both product paths, the blocking ones pinned to
 the model restatement by the test suite: random geometries (1 ... 4 components, up to 1080p), batch sizes, padded strides and
 frame strides, 8- and 16-bit tables, adversarial coefficients (every block through the fix-up list), host and device
-destinations, pinned / registered / pageable sources, all slots in flight in any order, refill threads writing the NEXT
+destinations, pinned / registered / pageable sources, all slots in flight in any order, file-level batch decodes (both readers) of the
+same context in between, refill threads writing the NEXT
 submission's buffers while earlier ones run, the context's stream switched under way -- and invalid arguments, which must come
 back as the blocking call's status with the slot left free.  One summary line; exit code 1 on a mismatch.
 
@@ -178,6 +179,26 @@ def main():
             stats["decode"] += 1
         in_flight[slot] = ("enc" if encode else "dec", want, dst, cleanup, p)
         note("  submitted")
+        # another pipeline of the SAME context while the slots are in flight: the file-level batch decode (host or GPU Huffman
+        # reader: its own pinned ring, the same copy stream and fix-up list) against the other context's single-file decode
+        if rng.random() < 0.12:
+            from video_coding_amd.synth import synth_pixels
+            w, h = int(rng.integers(1, 20)) * 16, int(rng.integers(1, 12)) * 16
+            sd, quality = int(rng.integers(0, 1 << 30)), int(rng.choice([30, 75, 95]))   # (a batch shares one geometry and one set of tables)
+            files = [ref.jpeg_encode(synth_pixels(sd + 3 * k, h, w), synth_pixels(sd + 3 * k + 1, h // 2, w // 2), synth_pixels(sd + 3 * k + 2, h // 2, w // 2),
+                                     w, h, 420, quality) for k in range(int(rng.integers(1, 4)))]
+            batch = [files[k % len(files)] for k in range(int(rng.integers(1, 20)))]
+            info = hvc.hvc.jpeg_read_header(batch[0])
+            gpu_reader = bool(rng.integers(0, 2))
+            note("  batch decode of", len(batch), "files", w, "x", h, "gpu reader" if gpu_reader else "host reader")
+            out = np.zeros((len(batch), info.pixel_bytes), dtype=np.uint8)
+            ctx.jpeg_decode_batch(batch, out, info.pixel_bytes, threads=int(rng.integers(1, 5)), frames_per_chunk=int(rng.integers(1, 9)),
+                                  gpu_entropy=gpu_reader)
+            singles = {f: ref.jpeg_decode(f)[1] for f in set(batch)}
+            stats["batch_calls"] = stats.get("batch_calls", 0) + 1
+            if not all(np.array_equal(out[k], singles[f]) for k, f in enumerate(batch)):
+                stats["mismatches"] += 1
+                print("MISMATCH batch decode", file=sys.stderr)
         if rng.random() < 0.25 and in_flight:
             early = list(in_flight)[int(rng.integers(0, len(in_flight)))]
             note("  early retire", early)
