@@ -150,7 +150,7 @@ def test_encode_submit_matches_the_blocking_call_and_the_oracle(ctx):
 
 
 def test_registered_caller_memory_and_a_filling_thread(ctx):
-    """the caller's own arrays pinned in place (hvc_host_register: what an OCaml Bigarray gets), all slots in flight, a second
+    """the caller's own page-aligned arrays pinned in place (hvc_host_register: whole pages only), all slots in flight, a second
     thread writing the NEXT batch's records while the GPU works: every batch equals the oracle's frames"""
     import video_coding_amd as hvc
     planes = [(16, 12, 0), (8, 6, 1), (8, 6, 1)]
